@@ -1,0 +1,21 @@
+# Builds the gfx950 engine (libslacken_amd.so) in-tree, and the CPU oracle used by the tests.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+CSRC := slacken_amd/csrc
+LIB := slacken_amd/lib/libslacken_amd.so
+
+all: $(LIB) oracle
+
+$(LIB): $(CSRC)/kernels.hip $(CSRC)/capi.hip $(CSRC)/engine.h include/slacken_amd.h
+	@mkdir -p slacken_amd/lib
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/capi.hip
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

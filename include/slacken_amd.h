@@ -1,0 +1,176 @@
+/*
+ * slacken_amd.h -- C ABI of the MI355X-native classify engine (libslacken_amd.so).
+ *
+ * Drop-in boundary for the hot path of JNP-Solutions/Slacken:
+ *   minimizer scan -> minimizer->taxon lookup -> per-read LCA ("resolveTree") classification.
+ *
+ * The reference has NO native/FFI interface (it is Scala on Spark).  The seam this ABI sits
+ * behind is therefore method-level; each entry point cites the reference method(s) it replaces, relative to
+ * /root/reference/src/main/scala/com/jnpersson/ (abbreviated S/).  INTEGRATION.md shows the JNI binding a
+ * maintainer would add on the Scala side.
+ *
+ * Conventions
+ *   - every function returns int32 status: 0 = ok, negative = error (SLK_E_*); slk_last_error() gives the text
+ *     (thread-local);
+ *   - no exceptions, no callbacks, no ownership transfer: the caller owns every buffer it passes; the library owns
+ *     only the opaque handles it created;
+ *   - plain pointers and sizes only.  "host" entry points take host pointers and do their own H2D/D2H; "_device"
+ *     entry points take pointers to memory already resident on the index's GPU and are asynchronous on the
+ *     slk_stream (call slk_stream_synchronize before reading results);
+ *   - an slk_index is immutable after slk_index_finalize() and may be shared by many threads; an slk_stream holds
+ *     one HIP stream plus the scratch of ONE in-flight batch: use one per calling thread.
+ *   - minimizers wider than 32 nt (id_longs > 1) are not supported by this engine: slk_index_create fails loudly.
+ */
+#ifndef SLACKEN_AMD_H
+#define SLACKEN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLK_OK 0
+#define SLK_E_INVALID (-1)     /* bad argument */
+#define SLK_E_UNSUPPORTED (-2) /* e.g. m > 32 */
+#define SLK_E_HIP (-3)         /* HIP runtime error (text in slk_last_error) */
+#define SLK_E_NO_GPU (-4)      /* no usable gfx950 device: there is NO CPU fallback */
+#define SLK_E_CAPACITY (-5)    /* output buffer or table capacity exceeded */
+#define SLK_E_STATE (-6)       /* call order violated (e.g. classify before finalize / taxonomy) */
+
+/* S/slacken/package.scala:30-39 and S/slacken/Taxonomy.scala:30-31 */
+#define SLK_TAXON_NONE 0
+#define SLK_TAXON_ROOT 1
+#define SLK_TAXON_AMBIGUOUS (-1)
+#define SLK_TAXON_MATE_PAIR_BORDER (-2)
+#define SLK_FLAG_SEQUENCE 1
+#define SLK_FLAG_AMBIGUOUS 2
+#define SLK_FLAG_MATE_PAIR_BORDER 3
+/* S/kmers/minimizer/package.scala:32 */
+#define SLK_DEFAULT_TOGGLE_MASK 0xe37e28c4271b5a2dULL
+
+typedef struct slk_index slk_index;
+typedef struct slk_stream slk_stream;
+
+/* The splitter parameters of an index: S/kmers/IndexParams.scala:30-47 (k, m), S/kmers/SplitterFormat.scala:42-64
+ * (randomXOR mask, canonical, minimizerSpaces).  Defaults of `slacken build`: k=35, m=31, spaces=7,
+ * xor_mask=SLK_DEFAULT_TOGGLE_MASK, canonical=1 (S/slacken/Slacken.scala:126-136). */
+typedef struct {
+  int32_t k;
+  int32_t m;
+  int32_t spaces;
+  int32_t canonical;
+  uint64_t xor_mask;
+  int32_t id_longs; /* ceil(m/32), S/slacken/KeyValueIndex.scala:49; must be 1 */
+  int32_t reserved;
+} slk_params;
+
+/* Sizing of the HBM-resident record table (the engine's replacement for the bucketed Parquet table scanned by the
+ * join at S/slacken/Classifier.scala:84). */
+typedef struct {
+  uint64_t expected_records; /* upper bound on records that will be appended */
+  int32_t max_taxon;         /* largest taxon id that will be appended (0 = derive from nothing: 2^22-1) */
+  float load_factor;         /* target cells-used fraction, 0 = default 0.70 */
+} slk_table_config;
+
+typedef struct {
+  uint64_t records;       /* records stored (taxon != NONE) */
+  uint64_t buckets;       /* 64-byte buckets */
+  uint64_t table_bytes;
+  int32_t bucket_bits, taxon_bits, disp_bits;
+  int32_t max_displacement; /* largest bucket displacement in use (0 = every record in its home bucket) */
+  uint64_t duplicate_keys;  /* appended records whose key was already present (contract violation; first kept) */
+  int32_t taxonomy_size;
+  int32_t device;
+} slk_index_info;
+
+/* OrdinalSpan (S/slacken/package.scala:61-62) without the title; ordinal = position in the read's span list.
+ * For flag != SLK_FLAG_SEQUENCE the reference draws a random minimizer (S/slacken/Supermers.scala:34-42,53-56)
+ * that can never be observed; this engine writes key = 0. */
+typedef struct {
+  int64_t key; /* left-aligned, exactly the value of Parquet column id1 */
+  int32_t kmers;
+  int8_t flag;
+  uint8_t distinct;
+  uint16_t pad;
+} slk_span;
+
+/* TaxonHit (S/slacken/KeyValueIndex.scala:436-441); distinct/ordinal are implied by position. */
+typedef struct {
+  int32_t taxon;
+  int32_t count;
+} slk_hit;
+
+int32_t slk_device_count(void);
+const char *slk_last_error(void);
+const char *slk_version(void);
+
+/* ---- index: replaces KeyValueIndex.load / loadRecords (S/slacken/KeyValueIndex.scala:150-159,413-426) ---- */
+int32_t slk_index_create(const slk_params *params, const slk_table_config *cfg, int32_t device, slk_index **out);
+/* Append records (id1: int64 left-aligned minimizer, taxon: int32) -- the rows of the Parquet table, in any order
+ * and any chunking (one call per bucket file is the intended use).  Keys are unique (guaranteed by makeRecords'
+ * groupBy, KeyValueIndex.scala:85-93).  Records with taxon == NONE are skipped (indistinguishable from a miss). */
+int32_t slk_index_append(slk_index *ix, const int64_t *keys, const int32_t *taxa, uint64_t n);
+int32_t slk_index_append_device(slk_index *ix, const int64_t *d_keys, const int32_t *d_taxa, uint64_t n);
+/* parents[t] = parent taxon, parents[ROOT] = NONE, unused ids = NONE: Taxonomy.parents (S/slacken/Taxonomy.scala:81-109,159);
+ * replaces the bcTaxonomy broadcast (KeyValueIndex.scala:44-47). */
+int32_t slk_index_set_taxonomy(slk_index *ix, const int32_t *parents, int32_t T);
+int32_t slk_index_finalize(slk_index *ix);
+int32_t slk_index_get_info(const slk_index *ix, slk_index_info *out);
+/* Point lookups (host arrays), for tests and tooling: taxon or NONE per key -- the left join + spanToHit's
+ * otherwise(NONE) (KeyValueIndex.scala:176-185). */
+int32_t slk_index_lookup(const slk_index *ix, const int64_t *keys, uint64_t n, int32_t *out_taxa);
+void slk_index_destroy(slk_index *ix);
+
+int32_t slk_stream_create(slk_index *ix, slk_stream **out);
+int32_t slk_stream_synchronize(slk_stream *st);
+void *slk_stream_hip_stream(slk_stream *st); /* the hipStream_t, for event timing by the caller */
+void slk_stream_destroy(slk_stream *st);
+
+/* ---- kernel-1-only entry: replaces KeyValueIndex.getSpans (S/slacken/KeyValueIndex.scala:163-173), i.e.
+ * Supermers.splitFragment + Supermers.spans (S/slacken/Supermers.scala:49-97,113-125) over
+ * MinSplitter.splitEncode (S/kmers/minimizer/MinSplitter.scala:98-101).
+ * bases: concatenated ASCII reads WITHOUT whitespace (getSpans' precondition, KeyValueIndex.scala:162);
+ * offsets[R+1]; mate_bases/mate_offsets: second mates with the same indexing, or NULL for single-end.
+ * out_span_offsets[R+1]; out_spans[spans_capacity] in read order then ordinal order. */
+int32_t slk_spans_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, const uint64_t *offsets,
+                        const uint8_t *mate_bases, const uint64_t *mate_offsets, uint64_t R,
+                        uint64_t *out_span_offsets, slk_span *out_spans, uint64_t spans_capacity);
+
+/* ---- the hot path: replaces Classifier.classify (S/slacken/Classifier.scala:114-121) =
+ * collectHitsBySequence (:70-96: getSpans -> join -> spanToHit -> group) + classifyHits (:124-147) ->
+ * Classifier.classify (object, :439-454) -> TaxonCounts (S/slacken/TaxonCounts.scala:31-87) ->
+ * LowestCommonAncestor.resolveTree (S/slacken/LowestCommonAncestor.scala:91-146).
+ * One call = one batch of R fragments and C confidence thresholds.
+ *   out_taxon[C*R], out_classified[C*R]  (threshold-major): ClassifiedRead.taxon / .classified
+ *   out_num_distinct[R]  hits with distinct && taxon != NONE        (Classifier.scala:94)
+ *   out_total_kmers[R]   TaxonCounts.totalKmers                      (TaxonCounts.scala:84-87)
+ *   out_hit_offsets[R+1], out_hits[hits_capacity] (both nullable): un-merged TaxonHits in ordinal order incl.
+ *     the -1 / -2 entries.  A read with out_hit_offsets[r+1] == out_hit_offsets[r] produced no span: the reference
+ *     emits NO row for it (grouping is over span rows, Classifier.scala:92) -- the host must drop it.
+ * Sample-id regex, titles, duplicate-title merging and text formatting stay on the host. */
+int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, const uint64_t *offsets,
+                           const uint8_t *mate_bases, const uint64_t *mate_offsets, uint64_t R,
+                           int32_t min_hit_groups, const double *thresholds, int32_t C, int32_t *out_taxon,
+                           uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers,
+                           uint64_t *out_hit_offsets, slk_hit *out_hits, uint64_t hits_capacity);
+
+/* Same computation with every pointer (bases, offsets, mates, thresholds excepted: host) resident on the index's
+ * GPU; asynchronous on st.  d_out_num_hits[R] (nullable) receives the span count per read (0 => no row).
+ * total_bases / total_mate_bases = offsets[R] / mate_offsets[R] (the caller knows them; avoids a D2H sync). */
+int32_t slk_classify_batch_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
+                                  const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
+                                  uint64_t total_bases, uint64_t total_mate_bases, int32_t min_hit_groups,
+                                  const double *thresholds, int32_t C, int32_t *d_out_taxon,
+                                  uint8_t *d_out_classified, int32_t *d_out_num_distinct,
+                                  int32_t *d_out_total_kmers, int32_t *d_out_num_hits);
+
+/* Per-stage device timing of the last slk_classify_batch_device call on st, in milliseconds (HIP events on the
+ * stream the kernels ran on): [0]=scan, [1]=probe, [2]=classify.  Synchronises st. */
+int32_t slk_stream_last_stage_ms(slk_stream *st, float out_ms[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

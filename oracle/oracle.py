@@ -75,6 +75,8 @@ def lib():
         L.orc_split_encode.argtypes = [C.POINTER(Params), C.c_char_p, C.c_int, C.POINTER(Supermer), C.c_int]
         L.orc_split_by_ambiguity.argtypes = [C.c_char_p, C.c_int, C.c_int, i32p, i32p, i32p, C.c_int]
         L.orc_spans.argtypes = [C.POINTER(Params), C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(Span), C.c_int]
+        L.orc_minimizer_keys.argtypes = [C.POINTER(Params), C.c_char_p, C.c_long, i64p, C.c_long]
+        L.orc_minimizer_keys.restype = C.c_long
         L.orc_index_create.argtypes = [C.c_int, i64p, i32p, C.c_size_t]
         L.orc_index_create.restype = C.c_void_p
         L.orc_index_destroy.argtypes = [C.c_void_p]
@@ -175,6 +177,16 @@ def spans(p, seq1, seq2=None):
         raise ValueError(f"orc_spans failed: {n}")
     return [dict(key=tuple(out[i].key[:p.W]), kmers=out[i].kmers, flag=out[i].flag, ordinal=out[i].ordinal,
                  distinct=bool(out[i].distinct)) for i in range(n)]
+
+
+def minimizer_keys(p, seq):
+    """int64 array of the SEQUENCE-span minimizers (id1) of one sequence, in order."""
+    seq = _b(seq)
+    out = np.zeros(max(1, len(seq)), np.int64)
+    n = lib().orc_minimizer_keys(C.byref(p), seq, len(seq), _p(out, C.c_int64), len(out))
+    if n < 0:
+        raise ValueError(f"orc_minimizer_keys failed: {n}")
+    return out[:n]
 
 
 class Index:

@@ -396,6 +396,25 @@ int orc_spans(const orc_params *p, const char *seq1, int n1, const char *seq2, i
   return r;
 }
 
+long orc_minimizer_keys(const orc_params *p, const char *seq, long n, int64_t *out_keys, long cap) {
+  if (p->W != 1) return -2;
+  orc_span *sp = (orc_span *)malloc(sizeof(orc_span) * (size_t)(n + 2));
+  scratch_t s = {0};
+  int ns = spans_scratch(p, seq, (int)n, NULL, 0, &s, sp, (int)(n + 2));
+  long cnt = 0;
+  if (ns >= 0) {
+    for (int i = 0; i < ns; i++)
+      if (sp[i].flag == ORC_SEQUENCE_FLAG) {
+        if (cnt >= cap) { cnt = -5; break; }
+        out_keys[cnt++] = (int64_t)sp[i].key[0];
+      }
+  } else cnt = ns;
+  s.spans = NULL;
+  scratch_free(&s);
+  free(sp);
+  return cnt;
+}
+
 /* ---- index: the records side of `taggedSpans.join(index.records, idColumnNames, "left")`, Classifier.scala:84 ---- */
 struct orc_index {
   int W;

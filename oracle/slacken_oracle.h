@@ -99,6 +99,10 @@ int orc_split_by_ambiguity(const char *seq, int n, int k, int32_t *starts, int32
  * seq2 == NULL for single reads. Returns the number of spans or <0 on error. */
 int orc_spans(const orc_params *p, const char *seq1, int n1, const char *seq2, int n2, orc_span *out, int cap);
 
+/* All SEQUENCE_FLAG span keys (word 0 only, W must be 1) of one sequence, in order: the (id1) side of
+ * SplitterMinimizers.find (S/slacken/Minimizers.scala:43-76) used by the index build. Returns the count or <0. */
+long orc_minimizer_keys(const orc_params *p, const char *seq, long n, int64_t *out_keys, long cap);
+
 /* index ("records" table): keys are W words per record, left-aligned as in the Parquet id columns */
 orc_index *orc_index_create(int W, const int64_t *keys, const int32_t *taxa, size_t n);
 void orc_index_destroy(orc_index *ix);

@@ -1,0 +1,257 @@
+"""ctypes binding of include/slacken_amd.h (one Python method per C entry point; no compute happens in Python)."""
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+DEFAULT_TOGGLE_MASK = 0xE37E28C4271B5A2D
+TAXON_NONE, TAXON_ROOT, TAXON_AMBIGUOUS, TAXON_MATE_PAIR_BORDER = 0, 1, -1, -2
+FLAG_SEQUENCE, FLAG_AMBIGUOUS, FLAG_MATE_PAIR_BORDER = 1, 2, 3
+
+
+class SlackenError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"slacken_amd error {code}: {msg}")
+        self.code = code
+
+
+class _Params(C.Structure):
+    _fields_ = [("k", C.c_int32), ("m", C.c_int32), ("spaces", C.c_int32), ("canonical", C.c_int32),
+                ("xor_mask", C.c_uint64), ("id_longs", C.c_int32), ("reserved", C.c_int32)]
+
+
+class _TableConfig(C.Structure):
+    _fields_ = [("expected_records", C.c_uint64), ("max_taxon", C.c_int32), ("load_factor", C.c_float)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("records", C.c_uint64), ("buckets", C.c_uint64), ("table_bytes", C.c_uint64),
+                ("bucket_bits", C.c_int32), ("taxon_bits", C.c_int32), ("disp_bits", C.c_int32),
+                ("max_displacement", C.c_int32), ("duplicate_keys", C.c_uint64), ("taxonomy_size", C.c_int32),
+                ("device", C.c_int32)]
+
+
+SPAN_DTYPE = np.dtype([("key", "<i8"), ("kmers", "<i4"), ("flag", "i1"), ("distinct", "u1"), ("pad", "<u2")])
+HIT_DTYPE = np.dtype([("taxon", "<i4"), ("count", "<i4")])
+
+# every symbol include/slacken_amd.h declares
+EXPORTS = ["slk_device_count", "slk_last_error", "slk_version", "slk_index_create", "slk_index_append",
+           "slk_index_append_device", "slk_index_set_taxonomy", "slk_index_finalize", "slk_index_get_info",
+           "slk_index_lookup", "slk_index_destroy", "slk_stream_create", "slk_stream_synchronize",
+           "slk_stream_hip_stream", "slk_stream_destroy", "slk_spans_batch", "slk_classify_batch",
+           "slk_classify_batch_device", "slk_stream_last_stage_ms"]
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libslacken_amd.so")
+
+
+_lib = None
+
+
+def lib():
+    """Load libslacken_amd.so; raises loudly if it has not been built (there is no fallback implementation)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with `make` (or __graft_entry__.build()). "
+                          "slacken_amd has no CPU/Python fallback for the classify path.")
+    L = C.CDLL(path)
+    vp, u8p, i32p, i64p, u64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+    L.slk_device_count.restype = C.c_int32
+    L.slk_last_error.restype = C.c_char_p
+    L.slk_version.restype = C.c_char_p
+    L.slk_index_create.argtypes = [C.POINTER(_Params), C.POINTER(_TableConfig), C.c_int32, C.POINTER(vp)]
+    L.slk_index_append.argtypes = [vp, i64p, i32p, C.c_uint64]
+    L.slk_index_append_device.argtypes = [vp, i64p, i32p, C.c_uint64]
+    L.slk_index_set_taxonomy.argtypes = [vp, i32p, C.c_int32]
+    L.slk_index_finalize.argtypes = [vp]
+    L.slk_index_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
+    L.slk_index_lookup.argtypes = [vp, i64p, C.c_uint64, i32p]
+    L.slk_index_destroy.argtypes = [vp]
+    L.slk_index_destroy.restype = None
+    L.slk_stream_create.argtypes = [vp, C.POINTER(vp)]
+    L.slk_stream_synchronize.argtypes = [vp]
+    L.slk_stream_hip_stream.argtypes = [vp]
+    L.slk_stream_hip_stream.restype = C.c_void_p
+    L.slk_stream_destroy.argtypes = [vp]
+    L.slk_stream_destroy.restype = None
+    L.slk_spans_batch.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, u64p, vp, C.c_uint64]
+    L.slk_classify_batch.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_int32, C.POINTER(C.c_double),
+                                     C.c_int32, i32p, u8p, i32p, i32p, u64p, vp, C.c_uint64]
+    L.slk_classify_batch_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                            C.c_int32, C.POINTER(C.c_double), C.c_int32, i32p, u8p, i32p, i32p, i32p]
+    L.slk_stream_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int:  # default: int32 status
+            fn.restype = C.c_int32
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise SlackenError(rc, lib().slk_last_error().decode())
+
+
+def _np(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+@dataclass
+class ClassifyParams:
+    """Mirror of ClassifyParams (S/slacken/Classifier.scala:60-61)."""
+    minHitGroups: int = 2
+    withUnclassified: bool = True
+    thresholds: List[float] = field(default_factory=lambda: [0.0])
+    sampleRegex: Optional[str] = None
+    perReadOutput: bool = True
+
+
+class Index:
+    """HBM-resident minimizer->taxon records + taxonomy (the engine-side KeyValueIndex)."""
+
+    def __init__(self, k=35, m=31, spaces=7, xor_mask=DEFAULT_TOGGLE_MASK, canonical=True, expected_records=1 << 20,
+                 max_taxon=0, load_factor=0.0, device=0):
+        self.k, self.m, self.spaces = k, m, spaces
+        p = _Params(k, m, spaces, int(bool(canonical)), C.c_uint64(xor_mask & (2**64 - 1)), (m + 31) // 32, 0)
+        cfg = _TableConfig(int(expected_records), int(max_taxon), float(load_factor))
+        h = C.c_void_p()
+        _check(lib().slk_index_create(C.byref(p), C.byref(cfg), device, C.byref(h)))
+        self.h = h
+
+    def append(self, keys, taxa):
+        keys, taxa = _np(keys, np.int64), _np(taxa, np.int32)
+        assert keys.shape == taxa.shape
+        _check(lib().slk_index_append(self.h, _ptr(keys), _ptr(taxa), keys.size))
+
+    def append_device(self, d_keys_ptr, d_taxa_ptr, n):
+        _check(lib().slk_index_append_device(self.h, d_keys_ptr, d_taxa_ptr, n))
+
+    def set_taxonomy(self, parents):
+        parents = _np(parents, np.int32)
+        _check(lib().slk_index_set_taxonomy(self.h, _ptr(parents), parents.size))
+
+    def finalize(self):
+        _check(lib().slk_index_finalize(self.h))
+
+    def info(self):
+        out = IndexInfo()
+        _check(lib().slk_index_get_info(self.h, C.byref(out)))
+        return out
+
+    def lookup(self, keys):
+        keys = _np(keys, np.int64)
+        out = np.zeros(keys.size, np.int32)
+        _check(lib().slk_index_lookup(self.h, _ptr(keys), keys.size, _ptr(out)))
+        return out
+
+    def stream(self):
+        return Stream(self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().slk_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Stream:
+    def __init__(self, index):
+        self.index = index
+        h = C.c_void_p()
+        _check(lib().slk_stream_create(index.h, C.byref(h)))
+        self.h = h
+
+    @property
+    def hip_stream(self):
+        return lib().slk_stream_hip_stream(self.h)
+
+    def synchronize(self):
+        _check(lib().slk_stream_synchronize(self.h))
+
+    def spans_batch(self, bases, offsets, mate_bases=None, mate_offsets=None, capacity=None):
+        """-> (span_offsets u64[R+1], spans structured array SPAN_DTYPE)"""
+        bases, offsets = _np(bases, np.uint8), _np(offsets, np.uint64)
+        R = offsets.size - 1
+        if mate_bases is not None:
+            mate_bases, mate_offsets = _np(mate_bases, np.uint8), _np(mate_offsets, np.uint64)
+        if capacity is None:
+            capacity = int(bases.size + (mate_bases.size + R if mate_bases is not None else 0)) + 1
+        out_off = np.zeros(R + 1, np.uint64)
+        out = np.zeros(capacity, SPAN_DTYPE)
+        _check(lib().slk_spans_batch(self.index.h, self.h, _ptr(bases), _ptr(offsets), _ptr(mate_bases),
+                                     _ptr(mate_offsets), R, _ptr(out_off), _ptr(out), capacity))
+        return out_off, out[:int(out_off[R])]
+
+    def classify_batch(self, bases, offsets, mate_bases=None, mate_offsets=None, min_hit_groups=2,
+                       thresholds=(0.0,), with_hits=True, hits_capacity=None):
+        bases, offsets = _np(bases, np.uint8), _np(offsets, np.uint64)
+        R = offsets.size - 1
+        if mate_bases is not None:
+            mate_bases, mate_offsets = _np(mate_bases, np.uint8), _np(mate_offsets, np.uint64)
+        Cn = len(thresholds)
+        thr = (C.c_double * Cn)(*thresholds)
+        taxon = np.zeros((Cn, R), np.int32)
+        cls = np.zeros((Cn, R), np.uint8)
+        nd, tk = np.zeros(R, np.int32), np.zeros(R, np.int32)
+        hit_off = hits = None
+        cap = 0
+        if with_hits:
+            cap = hits_capacity if hits_capacity is not None else \
+                int(bases.size + (mate_bases.size + R if mate_bases is not None else 0)) + 1
+            hit_off = np.zeros(R + 1, np.uint64)
+            hits = np.zeros(cap, HIT_DTYPE)
+        _check(lib().slk_classify_batch(self.index.h, self.h, _ptr(bases), _ptr(offsets), _ptr(mate_bases),
+                                        _ptr(mate_offsets), R, min_hit_groups, thr, Cn, _ptr(taxon), _ptr(cls),
+                                        _ptr(nd), _ptr(tk), _ptr(hit_off), _ptr(hits), cap))
+        out = dict(taxon=taxon, classified=cls, num_distinct=nd, total_kmers=tk)
+        if with_hits:
+            out["hit_offsets"] = hit_off
+            out["hits"] = hits[:int(hit_off[R])]
+            out["num_hits"] = np.diff(hit_off.astype(np.int64)).astype(np.int32)
+        return out
+
+    def classify_batch_device(self, d_bases, d_offsets, R, total_bases, d_out_taxon, d_out_classified,
+                              d_out_num_distinct=None, d_out_total_kmers=None, d_out_num_hits=None,
+                              d_mate_bases=None, d_mate_offsets=None, total_mate_bases=0, min_hit_groups=2,
+                              thresholds=(0.0,)):
+        """All d_* are raw device addresses (ints), e.g. torch.Tensor.data_ptr(). Asynchronous on this stream."""
+        Cn = len(thresholds)
+        thr = (C.c_double * Cn)(*thresholds)
+        _check(lib().slk_classify_batch_device(self.index.h, self.h, d_bases, d_offsets, d_mate_bases,
+                                               d_mate_offsets, R, total_bases, total_mate_bases, min_hit_groups, thr,
+                                               Cn, d_out_taxon, d_out_classified, d_out_num_distinct,
+                                               d_out_total_kmers, d_out_num_hits))
+
+    def last_stage_ms(self):
+        out = (C.c_float * 3)()
+        _check(lib().slk_stream_last_stage_ms(self.h, out))
+        return list(out)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().slk_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,569 @@
+// capi.hip -- implementation of the C ABI declared in include/slacken_amd.h on top of the kernels in kernels.hip.
+// Host-side only: handle management, HBM table sizing, per-stream scratch, H2D/D2H for the host-pointer entry points.
+// There is NO CPU fallback: without a gfx950 device every compute entry point fails with SLK_E_NO_GPU / SLK_E_HIP.
+#include "../../include/slacken_amd.h"
+#include "engine.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace slk;
+
+static thread_local std::string g_err;
+
+static int32_t fail(int32_t code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return fail(SLK_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                      __FILE__, __LINE__);                                             \
+  } while (0)
+
+#define MAX_THRESHOLDS 16
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return (T *)p; }
+};
+
+struct slk_index {
+  int32_t device = 0;
+  slk_params params{};
+  ScanParams sp{};
+  uint64_t *cells = nullptr;
+  uint64_t nbuckets = 0;
+  int32_t bucket_bits = 0, taxon_bits = 0, disp_bits = 0;
+  int32_t *d_max_disp = nullptr;
+  unsigned long long *d_counters = nullptr;  // inserted, duplicate, overflow
+  int32_t *d_parents = nullptr;
+  int32_t T = 0;
+  bool finalized = false;
+  int32_t max_disp = 0;
+  uint64_t records = 0, dups = 0;
+  hipStream_t build_stream = nullptr;
+  DevBuf stage_keys, stage_taxa;
+
+  TableView view() const {
+    TableView v;
+    v.cells = cells;
+    v.bucket_mask = nbuckets - 1;
+    v.shift = 64 - bucket_bits;
+    v.rem_mask = (v.shift >= 64) ? ~0ULL : ((1ULL << v.shift) - 1);
+    v.taxon_bits = taxon_bits;
+    v.disp_bits = disp_bits;
+    v.max_disp = max_disp;
+    return v;
+  }
+};
+
+struct slk_stream {
+  slk_index *ix = nullptr;
+  hipStream_t s = nullptr;
+  DevBuf span_keys, span_meta, span_taxon, span_count;  // per-batch scratch (sparse per-read regions)
+  DevBuf bases, offsets, mate_bases, mate_offsets;      // staging for the host-pointer entry points
+  DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items;
+  double *d_thresholds = nullptr;
+  double *h_thresholds = nullptr;  // pinned
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool timed = false;
+};
+
+static int32_t set_device(const slk_index *ix) {
+  HIPCHK(hipSetDevice(ix->device));
+  return SLK_OK;
+}
+
+extern "C" {
+
+const char *slk_last_error(void) { return g_err.c_str(); }
+const char *slk_version(void) { return "slacken_amd 0.1 (gfx950)"; }
+
+int32_t slk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static int ceil_log2_u64(uint64_t x) {
+  int b = 0;
+  while (b < 63 && (1ULL << b) < x) b++;
+  return b;
+}
+
+int32_t slk_index_create(const slk_params *p, const slk_table_config *cfg, int32_t device, slk_index **out) {
+  if (!p || !cfg || !out) return fail(SLK_E_INVALID, "null argument");
+  *out = nullptr;
+  if (p->m < 1 || p->k < p->m || p->spaces < 0 || p->spaces > p->m / 2)
+    return fail(SLK_E_INVALID, "invalid splitter parameters k=%d m=%d spaces=%d", p->k, p->m, p->spaces);
+  if (p->m > 32 || p->id_longs != 1)
+    return fail(SLK_E_UNSUPPORTED, "minimizer width m=%d (id_longs=%d): this engine supports m <= 32 (one id column)",
+                p->m, p->id_longs);
+  if (p->k - p->m + 1 > 512) return fail(SLK_E_UNSUPPORTED, "k - m + 1 = %d > 512 m-mers per window", p->k - p->m + 1);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(SLK_E_NO_GPU, "no HIP device available; this engine has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(SLK_E_INVALID, "device %d out of range (%d devices)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(SLK_E_NO_GPU, "device %d is %s; this library holds gfx950 (MI355X) code objects only", device,
+                prop.gcnArchName);
+
+  slk_index *ix = new slk_index();
+  ix->device = device;
+  ix->params = *p;
+  ScanParams &sp = ix->sp;
+  sp.k = p->k; sp.m = p->m; sp.w = p->k - p->m + 1; sp.canonical = p->canonical ? 1 : 0;
+  sp.sh = (32 - p->m) * 2;
+  sp.keep = (sp.sh == 0) ? ~0ULL : (~0ULL << sp.sh);
+  // RandomXOR.mask (MinimizerPriorities.scala:146-160): one word; partial word => xorMask << (64 - (m%32)*2)
+  sp.xmask = (p->m % 32 != 0) ? (p->xor_mask << (64 - (p->m % 32) * 2)) : p->xor_mask;
+  // SpacedSeed.spaceMask (:285-300): fill(-1, m), then s times { <<= 4 ; |= 3 << (64 - (m%32)*2) }
+  uint64_t sm = sp.keep;
+  uint64_t finalBits = 3ULL << ((64 - (p->m % 32) * 2) & 63);
+  for (int i = 0; i < p->spaces; i++) sm = (sm << 4) | finalBits;
+  sp.smask = sm;
+
+  int32_t max_taxon = cfg->max_taxon > 0 ? cfg->max_taxon : ((1 << 22) - 1);
+  int tb = 1;
+  while (tb < 31 && (1LL << tb) <= (long long)max_taxon) tb++;
+  float lf = cfg->load_factor > 0 ? cfg->load_factor : 0.70f;
+  if (lf > 0.95f) lf = 0.95f;
+  uint64_t cells_needed = (uint64_t)((double)std::max<uint64_t>(cfg->expected_records, 1) / lf) + 8;
+  int bb = std::max(tb + 3, ceil_log2_u64((cells_needed + 7) / 8));
+  if (bb > 40) { delete ix; return fail(SLK_E_CAPACITY, "table of 2^%d buckets is too large", bb); }
+  ix->bucket_bits = bb;
+  ix->taxon_bits = tb;
+  ix->disp_bits = std::min(6, bb - tb);
+  ix->nbuckets = 1ULL << bb;
+  size_t bytes = (size_t)ix->nbuckets * 64;
+  hipError_t e = hipMalloc((void **)&ix->cells, bytes);
+  if (e != hipSuccess) {
+    delete ix;
+    return fail(SLK_E_HIP, "hipMalloc of %zu table bytes failed: %s", bytes, hipGetErrorString(e));
+  }
+  HIPCHK(hipStreamCreate(&ix->build_stream));
+  HIPCHK(hipMemsetAsync(ix->cells, 0, bytes, ix->build_stream));
+  HIPCHK(hipMalloc((void **)&ix->d_max_disp, sizeof(int32_t)));
+  HIPCHK(hipMalloc((void **)&ix->d_counters, 3 * sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(ix->d_max_disp, 0, sizeof(int32_t), ix->build_stream));
+  HIPCHK(hipMemsetAsync(ix->d_counters, 0, 3 * sizeof(unsigned long long), ix->build_stream));
+  HIPCHK(hipStreamSynchronize(ix->build_stream));
+  *out = ix;
+  return SLK_OK;
+}
+
+static int32_t read_build_counters(slk_index *ix) {
+  unsigned long long c[3];
+  int32_t md;
+  HIPCHK(hipStreamSynchronize(ix->build_stream));
+  HIPCHK(hipMemcpy(c, ix->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&md, ix->d_max_disp, sizeof(md), hipMemcpyDeviceToHost));
+  ix->records = c[0];
+  ix->dups = c[1];
+  ix->max_disp = md;
+  if (c[2] != 0)
+    return fail(SLK_E_CAPACITY,
+                "%llu records could not be placed within %d buckets of their home bucket: raise expected_records "
+                "or lower load_factor", c[2], (1 << ix->disp_bits) - 1);
+  return SLK_OK;
+}
+
+static TableBuild build_view(slk_index *ix) {
+  TableBuild t;
+  t.cells = ix->cells;
+  t.bucket_mask = ix->nbuckets - 1;
+  t.shift = 64 - ix->bucket_bits;
+  t.rem_mask = (1ULL << t.shift) - 1;
+  t.taxon_bits = ix->taxon_bits;
+  t.disp_bits = ix->disp_bits;
+  t.disp_limit = (1 << ix->disp_bits) - 1;
+  t.max_disp = ix->d_max_disp;
+  t.n_inserted = ix->d_counters;
+  t.n_duplicate = ix->d_counters + 1;
+  t.n_overflow = ix->d_counters + 2;
+  return t;
+}
+
+int32_t slk_index_append_device(slk_index *ix, const int64_t *d_keys, const int32_t *d_taxa, uint64_t n) {
+  if (!ix || (n && (!d_keys || !d_taxa))) return fail(SLK_E_INVALID, "null argument");
+  if (ix->finalized) return fail(SLK_E_STATE, "index is finalized");
+  int32_t rc = set_device(ix);
+  if (rc) return rc;
+  launch_table_insert(build_view(ix), d_keys, d_taxa, n, ix->build_stream);
+  HIPCHK(hipGetLastError());
+  return read_build_counters(ix);
+}
+
+int32_t slk_index_append(slk_index *ix, const int64_t *keys, const int32_t *taxa, uint64_t n) {
+  if (!ix || (n && (!keys || !taxa))) return fail(SLK_E_INVALID, "null argument");
+  if (ix->finalized) return fail(SLK_E_STATE, "index is finalized");
+  int32_t rc = set_device(ix);
+  if (rc) return rc;
+  const uint64_t CH = 1ULL << 24;
+  for (uint64_t o = 0; o < n; o += CH) {
+    uint64_t c = std::min(CH, n - o);
+    HIPCHK(ix->stage_keys.ensure(c * 8));
+    HIPCHK(ix->stage_taxa.ensure(c * 4));
+    int32_t max_t = (1 << ix->taxon_bits) - 1;
+    for (uint64_t i = 0; i < c; i++)
+      if (taxa[o + i] < 0 || taxa[o + i] > max_t)
+        return fail(SLK_E_INVALID, "record %llu: taxon %d outside [0, %d] (slk_table_config.max_taxon)",
+                    (unsigned long long)(o + i), taxa[o + i], max_t);
+    HIPCHK(hipMemcpyAsync(ix->stage_keys.p, keys + o, c * 8, hipMemcpyHostToDevice, ix->build_stream));
+    HIPCHK(hipMemcpyAsync(ix->stage_taxa.p, taxa + o, c * 4, hipMemcpyHostToDevice, ix->build_stream));
+    launch_table_insert(build_view(ix), ix->stage_keys.as<int64_t>(), ix->stage_taxa.as<int32_t>(), c,
+                        ix->build_stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ix->build_stream));
+  }
+  return read_build_counters(ix);
+}
+
+int32_t slk_index_set_taxonomy(slk_index *ix, const int32_t *parents, int32_t T) {
+  if (!ix || !parents || T < 2) return fail(SLK_E_INVALID, "taxonomy needs parents[] with at least ROOT (T >= 2)");
+  int32_t rc = set_device(ix);
+  if (rc) return rc;
+  // The reference's parent walks terminate only on a forest (Taxonomy.scala:151-156); reject cycles up front.
+  {
+    std::vector<uint8_t> state((size_t)T, 0);  // 0 new, 1 on the current path, 2 done
+    std::vector<int32_t> path;
+    for (int32_t t = 1; t < T; t++) {
+      int32_t x = t;
+      path.clear();
+      while (x != 0 && state[x] == 0) {
+        if (parents[x] < 0 || parents[x] >= T) return fail(SLK_E_INVALID, "parents[%d] = %d out of range", x, parents[x]);
+        state[x] = 1;
+        path.push_back(x);
+        x = parents[x];
+      }
+      if (x != 0 && state[x] == 1) return fail(SLK_E_INVALID, "taxonomy has a cycle through taxon %d", x);
+      for (int32_t y : path) state[y] = 2;
+    }
+  }
+  if (ix->d_parents) { HIPCHK(hipFree(ix->d_parents)); ix->d_parents = nullptr; }
+  HIPCHK(hipMalloc((void **)&ix->d_parents, (size_t)T * sizeof(int32_t)));
+  HIPCHK(hipMemcpy(ix->d_parents, parents, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice));
+  ix->T = T;
+  return SLK_OK;
+}
+
+int32_t slk_index_finalize(slk_index *ix) {
+  if (!ix) return fail(SLK_E_INVALID, "null argument");
+  int32_t rc = set_device(ix);
+  if (rc) return rc;
+  rc = read_build_counters(ix);
+  if (rc) return rc;
+  ix->stage_keys.release();
+  ix->stage_taxa.release();
+  ix->finalized = true;
+  return SLK_OK;
+}
+
+int32_t slk_index_get_info(const slk_index *ix, slk_index_info *out) {
+  if (!ix || !out) return fail(SLK_E_INVALID, "null argument");
+  memset(out, 0, sizeof(*out));
+  out->records = ix->records;
+  out->buckets = ix->nbuckets;
+  out->table_bytes = ix->nbuckets * 64;
+  out->bucket_bits = ix->bucket_bits;
+  out->taxon_bits = ix->taxon_bits;
+  out->disp_bits = ix->disp_bits;
+  out->max_displacement = ix->max_disp;
+  out->duplicate_keys = ix->dups;
+  out->taxonomy_size = ix->T;
+  out->device = ix->device;
+  return SLK_OK;
+}
+
+int32_t slk_index_lookup(const slk_index *ix, const int64_t *keys, uint64_t n, int32_t *out_taxa) {
+  if (!ix || (n && (!keys || !out_taxa))) return fail(SLK_E_INVALID, "null argument");
+  if (!ix->finalized) return fail(SLK_E_STATE, "index is not finalized");
+  int32_t rc = set_device(ix);
+  if (rc) return rc;
+  if (n == 0) return SLK_OK;
+  DevBuf k, o;
+  HIPCHK(k.ensure(n * 8));
+  HIPCHK(o.ensure(n * 4));
+  HIPCHK(hipMemcpy(k.p, keys, n * 8, hipMemcpyHostToDevice));
+  launch_table_lookup(ix->view(), k.as<int64_t>(), n, o.as<int32_t>(), nullptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out_taxa, o.p, n * 4, hipMemcpyDeviceToHost));
+  k.release();
+  o.release();
+  return SLK_OK;
+}
+
+void slk_index_destroy(slk_index *ix) {
+  if (!ix) return;
+  (void)hipSetDevice(ix->device);
+  if (ix->cells) (void)hipFree(ix->cells);
+  if (ix->d_max_disp) (void)hipFree(ix->d_max_disp);
+  if (ix->d_counters) (void)hipFree(ix->d_counters);
+  if (ix->d_parents) (void)hipFree(ix->d_parents);
+  ix->stage_keys.release();
+  ix->stage_taxa.release();
+  if (ix->build_stream) (void)hipStreamDestroy(ix->build_stream);
+  delete ix;
+}
+
+int32_t slk_stream_create(slk_index *ix, slk_stream **out) {
+  if (!ix || !out) return fail(SLK_E_INVALID, "null argument");
+  *out = nullptr;
+  int32_t rc = set_device(ix);
+  if (rc) return rc;
+  slk_stream *st = new slk_stream();
+  st->ix = ix;
+  HIPCHK(hipStreamCreate(&st->s));
+  HIPCHK(hipMalloc((void **)&st->d_thresholds, MAX_THRESHOLDS * sizeof(double)));
+  HIPCHK(hipHostMalloc((void **)&st->h_thresholds, MAX_THRESHOLDS * sizeof(double), hipHostMallocDefault));
+  for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&st->ev[i]));
+  *out = st;
+  return SLK_OK;
+}
+
+int32_t slk_stream_synchronize(slk_stream *st) {
+  if (!st) return fail(SLK_E_INVALID, "null argument");
+  HIPCHK(hipSetDevice(st->ix->device));
+  HIPCHK(hipStreamSynchronize(st->s));
+  return SLK_OK;
+}
+
+void *slk_stream_hip_stream(slk_stream *st) { return st ? (void *)st->s : nullptr; }
+
+void slk_stream_destroy(slk_stream *st) {
+  if (!st) return;
+  (void)hipSetDevice(st->ix->device);
+  (void)hipStreamSynchronize(st->s);
+  DevBuf *bufs[] = {&st->span_keys, &st->span_meta, &st->span_taxon, &st->span_count, &st->bases, &st->offsets,
+                    &st->mate_bases, &st->mate_offsets, &st->out_taxon, &st->out_cls, &st->out_nd, &st->out_tk,
+                    &st->out_nh, &st->out_offsets, &st->out_items};
+  for (DevBuf *b : bufs) b->release();
+  if (st->d_thresholds) (void)hipFree(st->d_thresholds);
+  if (st->h_thresholds) (void)hipHostFree(st->h_thresholds);
+  for (int i = 0; i < 4; i++) if (st->ev[i]) (void)hipEventDestroy(st->ev[i]);
+  if (st->s) (void)hipStreamDestroy(st->s);
+  delete st;
+}
+
+// span slots needed by a batch (see span_region in engine.h)
+static uint64_t span_slots(uint64_t total_bases, uint64_t total_mate_bases, uint64_t R, bool paired) {
+  return total_bases + (paired ? total_mate_bases + R : 0) + 1;
+}
+
+static int32_t ensure_scratch(slk_stream *st, uint64_t slots, uint64_t R) {
+  HIPCHK(st->span_keys.ensure(slots * 8));
+  HIPCHK(st->span_meta.ensure(slots * 4));
+  HIPCHK(st->span_taxon.ensure(slots * 4));
+  HIPCHK(st->span_count.ensure((R + 1) * 4));
+  return SLK_OK;
+}
+
+static int32_t check_ready(const slk_index *ix, const slk_stream *st, bool need_tax) {
+  if (!ix || !st) return fail(SLK_E_INVALID, "null handle");
+  if (st->ix != ix) return fail(SLK_E_INVALID, "stream belongs to a different index");
+  if (!ix->finalized) return fail(SLK_E_STATE, "index is not finalized");
+  if (need_tax && !ix->d_parents) return fail(SLK_E_STATE, "taxonomy not set");
+  return SLK_OK;
+}
+
+int32_t slk_classify_batch_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
+                                  const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
+                                  uint64_t total_bases, uint64_t total_mate_bases, int32_t min_hit_groups,
+                                  const double *thresholds, int32_t C, int32_t *d_out_taxon,
+                                  uint8_t *d_out_classified, int32_t *d_out_num_distinct,
+                                  int32_t *d_out_total_kmers, int32_t *d_out_num_hits) {
+  int32_t rc = check_ready(ix, st, true);
+  if (rc) return rc;
+  if (C < 1 || C > MAX_THRESHOLDS || !thresholds) return fail(SLK_E_INVALID, "need 1..%d thresholds", MAX_THRESHOLDS);
+  if (R && (!d_bases || !d_offsets || !d_out_taxon || !d_out_classified)) return fail(SLK_E_INVALID, "null argument");
+  if ((d_mate_bases == nullptr) != (d_mate_offsets == nullptr))
+    return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
+  rc = set_device(ix);
+  if (rc) return rc;
+  bool paired = d_mate_bases != nullptr;
+  rc = ensure_scratch(st, span_slots(total_bases, total_mate_bases, R, paired), R);
+  if (rc) return rc;
+  memcpy(st->h_thresholds, thresholds, C * sizeof(double));
+  HIPCHK(hipMemcpyAsync(st->d_thresholds, st->h_thresholds, C * sizeof(double), hipMemcpyHostToDevice, st->s));
+  HIPCHK(hipEventRecord(st->ev[0], st->s));
+  launch_scan(ix->sp, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, st->span_keys.as<uint64_t>(),
+              st->span_meta.as<int32_t>(), st->span_count.as<int32_t>(), st->s);
+  HIPCHK(hipEventRecord(st->ev[1], st->s));
+  launch_probe(ix->view(), d_offsets, d_mate_offsets, R, st->span_keys.as<uint64_t>(), st->span_meta.as<int32_t>(),
+               st->span_count.as<int32_t>(), st->span_taxon.as<int32_t>(), st->s);
+  HIPCHK(hipEventRecord(st->ev[2], st->s));
+  // the key slots are dead after the probe: the per-read taxon->count map reuses them
+  launch_classify(ix->d_parents, ix->T, d_offsets, d_mate_offsets, R, st->span_meta.as<int32_t>(),
+                  st->span_taxon.as<int32_t>(), st->span_count.as<int32_t>(), st->span_keys.as<uint64_t>(),
+                  min_hit_groups, st->d_thresholds, C, d_out_taxon, d_out_classified, d_out_num_distinct,
+                  d_out_total_kmers, d_out_num_hits, st->s);
+  HIPCHK(hipEventRecord(st->ev[3], st->s));
+  HIPCHK(hipGetLastError());
+  st->timed = true;
+  return SLK_OK;
+}
+
+int32_t slk_stream_last_stage_ms(slk_stream *st, float out_ms[3]) {
+  if (!st || !out_ms) return fail(SLK_E_INVALID, "null argument");
+  if (!st->timed) return fail(SLK_E_STATE, "no classify call has been issued on this stream");
+  HIPCHK(hipSetDevice(st->ix->device));
+  HIPCHK(hipEventSynchronize(st->ev[3]));
+  for (int i = 0; i < 3; i++) HIPCHK(hipEventElapsedTime(&out_ms[i], st->ev[i], st->ev[i + 1]));
+  return SLK_OK;
+}
+
+static int32_t upload_reads(slk_stream *st, const uint8_t *bases, const uint64_t *offsets, const uint8_t *mate_bases,
+                            const uint64_t *mate_offsets, uint64_t R, uint64_t *total, uint64_t *mate_total) {
+  for (uint64_t r = 0; r < R; r++) {
+    if (offsets[r + 1] < offsets[r] || offsets[r + 1] - offsets[r] > 0x7fffffffULL)
+      return fail(SLK_E_INVALID, "offsets must be non-decreasing with reads shorter than 2^31 (read %llu)",
+                  (unsigned long long)r);
+    if (mate_offsets && (mate_offsets[r + 1] < mate_offsets[r] || mate_offsets[r + 1] - mate_offsets[r] > 0x7fffffffULL))
+      return fail(SLK_E_INVALID, "mate_offsets must be non-decreasing (read %llu)", (unsigned long long)r);
+  }
+  *total = offsets[R];
+  *mate_total = mate_offsets ? mate_offsets[R] : 0;
+  HIPCHK(st->bases.ensure(*total + 16));
+  HIPCHK(st->offsets.ensure((R + 1) * 8));
+  if (*total) HIPCHK(hipMemcpyAsync(st->bases.p, bases, *total, hipMemcpyHostToDevice, st->s));
+  HIPCHK(hipMemcpyAsync(st->offsets.p, offsets, (R + 1) * 8, hipMemcpyHostToDevice, st->s));
+  if (mate_offsets) {
+    HIPCHK(st->mate_bases.ensure(*mate_total + 16));
+    HIPCHK(st->mate_offsets.ensure((R + 1) * 8));
+    if (*mate_total) HIPCHK(hipMemcpyAsync(st->mate_bases.p, mate_bases, *mate_total, hipMemcpyHostToDevice, st->s));
+    HIPCHK(hipMemcpyAsync(st->mate_offsets.p, mate_offsets, (R + 1) * 8, hipMemcpyHostToDevice, st->s));
+  }
+  return SLK_OK;
+}
+
+// counts (device, int32[R]) -> out_offsets (host, u64[R+1]); uploads the offsets for a gather kernel
+static int32_t counts_to_offsets(slk_stream *st, const int32_t *d_counts, uint64_t R, uint64_t *out_offsets,
+                                 uint64_t capacity) {
+  std::vector<int32_t> counts(R);
+  HIPCHK(hipMemcpyAsync(counts.data(), d_counts, R * 4, hipMemcpyDeviceToHost, st->s));
+  HIPCHK(hipStreamSynchronize(st->s));
+  out_offsets[0] = 0;
+  for (uint64_t r = 0; r < R; r++) out_offsets[r + 1] = out_offsets[r] + (uint64_t)counts[r];
+  if (out_offsets[R] > capacity)
+    return fail(SLK_E_CAPACITY, "output needs %llu entries, capacity is %llu", (unsigned long long)out_offsets[R],
+                (unsigned long long)capacity);
+  HIPCHK(st->out_offsets.ensure((R + 1) * 8));
+  HIPCHK(hipMemcpyAsync(st->out_offsets.p, out_offsets, (R + 1) * 8, hipMemcpyHostToDevice, st->s));
+  return SLK_OK;
+}
+
+int32_t slk_spans_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, const uint64_t *offsets,
+                        const uint8_t *mate_bases, const uint64_t *mate_offsets, uint64_t R,
+                        uint64_t *out_span_offsets, slk_span *out_spans, uint64_t spans_capacity) {
+  int32_t rc = check_ready(ix, st, false);
+  if (rc) return rc;
+  if (!offsets || !out_span_offsets || (R && !bases)) return fail(SLK_E_INVALID, "null argument");
+  if ((mate_bases == nullptr) != (mate_offsets == nullptr))
+    return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
+  rc = set_device(ix);
+  if (rc) return rc;
+  out_span_offsets[0] = 0;
+  if (R == 0) return SLK_OK;
+  uint64_t total, mate_total;
+  rc = upload_reads(st, bases, offsets, mate_bases, mate_offsets, R, &total, &mate_total);
+  if (rc) return rc;
+  bool paired = mate_offsets != nullptr;
+  rc = ensure_scratch(st, span_slots(total, mate_total, R, paired), R);
+  if (rc) return rc;
+  const uint64_t *d_off = st->offsets.as<uint64_t>();
+  const uint64_t *d_moff = paired ? st->mate_offsets.as<uint64_t>() : nullptr;
+  launch_scan(ix->sp, st->bases.as<uint8_t>(), d_off, paired ? st->mate_bases.as<uint8_t>() : nullptr, d_moff, R,
+              st->span_keys.as<uint64_t>(), st->span_meta.as<int32_t>(), st->span_count.as<int32_t>(), st->s);
+  HIPCHK(hipGetLastError());
+  rc = counts_to_offsets(st, st->span_count.as<int32_t>(), R, out_span_offsets, spans_capacity);
+  if (rc) return rc;
+  uint64_t n = out_span_offsets[R];
+  if (n) {
+    if (!out_spans) return fail(SLK_E_INVALID, "out_spans is null");
+    HIPCHK(st->out_items.ensure(n * sizeof(slk_span)));
+    launch_gather_spans(d_off, d_moff, R, st->span_keys.as<uint64_t>(), st->span_meta.as<int32_t>(),
+                        st->out_offsets.as<uint64_t>(), st->out_items.p, st->s);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_spans, st->out_items.p, n * sizeof(slk_span), hipMemcpyDeviceToHost, st->s));
+  }
+  HIPCHK(hipStreamSynchronize(st->s));
+  return SLK_OK;
+}
+
+int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, const uint64_t *offsets,
+                           const uint8_t *mate_bases, const uint64_t *mate_offsets, uint64_t R,
+                           int32_t min_hit_groups, const double *thresholds, int32_t C, int32_t *out_taxon,
+                           uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers,
+                           uint64_t *out_hit_offsets, slk_hit *out_hits, uint64_t hits_capacity) {
+  int32_t rc = check_ready(ix, st, true);
+  if (rc) return rc;
+  if (!offsets || (R && (!bases || !out_taxon || !out_classified))) return fail(SLK_E_INVALID, "null argument");
+  if (C < 1 || C > MAX_THRESHOLDS || !thresholds) return fail(SLK_E_INVALID, "need 1..%d thresholds", MAX_THRESHOLDS);
+  if ((mate_bases == nullptr) != (mate_offsets == nullptr))
+    return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
+  rc = set_device(ix);
+  if (rc) return rc;
+  if (out_hit_offsets) out_hit_offsets[0] = 0;
+  if (R == 0) return SLK_OK;
+  uint64_t total, mate_total;
+  rc = upload_reads(st, bases, offsets, mate_bases, mate_offsets, R, &total, &mate_total);
+  if (rc) return rc;
+  bool paired = mate_offsets != nullptr;
+  HIPCHK(st->out_taxon.ensure((size_t)C * R * 4));
+  HIPCHK(st->out_cls.ensure((size_t)C * R));
+  HIPCHK(st->out_nd.ensure(R * 4));
+  HIPCHK(st->out_tk.ensure(R * 4));
+  HIPCHK(st->out_nh.ensure(R * 4));
+  const uint64_t *d_off = st->offsets.as<uint64_t>();
+  const uint64_t *d_moff = paired ? st->mate_offsets.as<uint64_t>() : nullptr;
+  rc = slk_classify_batch_device(ix, st, st->bases.as<uint8_t>(), d_off,
+                                 paired ? st->mate_bases.as<uint8_t>() : nullptr, d_moff, R, total, mate_total,
+                                 min_hit_groups, thresholds, C, st->out_taxon.as<int32_t>(), st->out_cls.as<uint8_t>(),
+                                 st->out_nd.as<int32_t>(), st->out_tk.as<int32_t>(), st->out_nh.as<int32_t>());
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out_taxon, st->out_taxon.p, (size_t)C * R * 4, hipMemcpyDeviceToHost, st->s));
+  HIPCHK(hipMemcpyAsync(out_classified, st->out_cls.p, (size_t)C * R, hipMemcpyDeviceToHost, st->s));
+  if (out_num_distinct) HIPCHK(hipMemcpyAsync(out_num_distinct, st->out_nd.p, R * 4, hipMemcpyDeviceToHost, st->s));
+  if (out_total_kmers) HIPCHK(hipMemcpyAsync(out_total_kmers, st->out_tk.p, R * 4, hipMemcpyDeviceToHost, st->s));
+  if (out_hit_offsets) {
+    rc = counts_to_offsets(st, st->out_nh.as<int32_t>(), R, out_hit_offsets, out_hits ? hits_capacity : ~0ULL);
+    if (rc) return rc;
+    uint64_t n = out_hit_offsets[R];
+    if (n && out_hits) {
+      HIPCHK(st->out_items.ensure(n * sizeof(slk_hit)));
+      launch_gather_hits(d_off, d_moff, R, st->span_meta.as<int32_t>(), st->span_taxon.as<int32_t>(),
+                         st->out_offsets.as<uint64_t>(), st->out_items.p, st->s);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(out_hits, st->out_items.p, n * sizeof(slk_hit), hipMemcpyDeviceToHost, st->s));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(st->s));
+  return SLK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+// engine.h -- internal device/host structures of the classify engine (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace slk {
+
+// Splitter constants in the reference's left-aligned key space.
+struct ScanParams {
+  int32_t k, m, w;    // w = k - m + 1 = m-mers per k-mer window (PosRankWindow.scala:43-45,70)
+  int32_t canonical;
+  int32_t sh;         // (32 - m) * 2: left shift that aligns a right-aligned m-mer to the MSB
+  uint64_t xmask;     // RandomXOR.mask word 0 (MinimizerPriorities.scala:146-160)
+  uint64_t smask;     // SpacedSeed.spaceMask word 0 (:285-300)
+  uint64_t keep;      // ~0 << sh: the 2m bits an m-mer occupies
+};
+
+// HBM-resident record table: 64-byte buckets of eight 8-byte cells, bucket-level linear probing.
+//   h      = fmix64(key)                       (bijective, so (home bucket, remainder) identifies the key: lossless)
+//   home   = h >> (64 - bucket_bits)
+//   cell   = (((h & rem_mask) << disp_bits | displacement) << taxon_bits) | taxon        (0 = empty; taxon != 0)
+// A record lives in the first bucket home+d (d <= max_disp) that had a free cell when it was inserted; cells are never
+// freed, so a lookup may stop at the first bucket that still has an empty cell.
+struct TableView {
+  const uint64_t *cells;
+  uint64_t bucket_mask;
+  uint64_t rem_mask;
+  int32_t shift;      // 64 - bucket_bits
+  int32_t taxon_bits;
+  int32_t disp_bits;
+  int32_t max_disp;   // largest displacement in use
+};
+
+__host__ __device__ inline uint64_t fmix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+// span_meta packing: kmers (signed) << 4 | flag << 1 | distinct
+__host__ __device__ inline int32_t pack_meta(int32_t kmers, int32_t flag, int32_t distinct) {
+  return (int32_t)(((uint32_t)kmers << 4) | ((uint32_t)flag << 1) | (uint32_t)distinct);
+}
+__host__ __device__ inline int32_t meta_kmers(int32_t m) { return m >> 4; }
+__host__ __device__ inline int32_t meta_flag(int32_t m) { return (m >> 1) & 7; }
+__host__ __device__ inline int32_t meta_distinct(int32_t m) { return m & 1; }
+
+// Where read r's span slots start in the per-batch scratch.  A fragment yields at most
+// max(0, L1-k+1) [+ 1 + max(0, L2-k+1)] spans, so [offsets[r] (+ mate_offsets[r] + r)] regions never overlap.
+__device__ inline uint64_t span_region(const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t r) {
+  return offsets[r] + (mate_offsets ? mate_offsets[r] + r : 0);
+}
+
+// build-time view of the table (table_insert_kernel)
+struct TableBuild {
+  uint64_t *cells;
+  uint64_t bucket_mask, rem_mask;
+  int32_t shift, taxon_bits, disp_bits;
+  int32_t disp_limit;          // (1 << disp_bits) - 1
+  int32_t *max_disp;           // device: running maximum displacement
+  unsigned long long *n_inserted, *n_duplicate, *n_overflow;
+};
+
+// launchers (kernels.hip)
+void launch_table_insert(const TableBuild &t, const int64_t *keys, const int32_t *taxa, uint64_t n, hipStream_t s);
+void launch_table_lookup(const TableView &t, const int64_t *keys, uint64_t n, int32_t *out, hipStream_t s);
+void launch_scan(const ScanParams &P, const uint8_t *bases, const uint64_t *offsets, const uint8_t *mate_bases,
+                 const uint64_t *mate_offsets, uint64_t R, uint64_t *span_keys, int32_t *span_meta, int32_t *span_count,
+                 hipStream_t s);
+void launch_probe(const TableView &T, const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R,
+                  const uint64_t *span_keys, const int32_t *span_meta, const int32_t *span_count, int32_t *span_taxon,
+                  hipStream_t s);
+void launch_classify(const int32_t *parents, int32_t T, const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R,
+                     const int32_t *span_meta, const int32_t *span_taxon, const int32_t *span_count,
+                     uint64_t *map_scratch, int32_t min_hit_groups, const double *d_thresholds, int32_t C,
+                     int32_t *out_taxon, uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers,
+                     int32_t *out_num_hits, hipStream_t s);
+void launch_gather_spans(const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, const uint64_t *span_keys,
+                         const int32_t *span_meta, const uint64_t *out_offsets, void *out, hipStream_t s);
+void launch_gather_hits(const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, const int32_t *span_meta,
+                        const int32_t *span_taxon, const uint64_t *out_offsets, void *out, hipStream_t s);
+
+}  // namespace slk

@@ -1,0 +1,453 @@
+// kernels.hip -- CDNA4 (gfx950) kernels of the classify path, baseline generation ("v1": one lane per read for the
+// scan and for the per-read LCA, one wave per read for the table probes).  Integer / byte work, HBM-bound: no MFMA.
+//
+// Stage <-> reference map (S/ = src/main/scala/com/jnpersson/ under /root/reference):
+//   scan_kernel      KeyValueIndex.getSpans (S/slacken/KeyValueIndex.scala:163-173): Supermers.splitByAmbiguity /
+//                    splitFragment / spans (S/slacken/Supermers.scala:49-125,150-189) over ShiftScanner.allMatches
+//                    (S/kmers/minimizer/ShiftScanner.scala:90-159), SpacedSeed/RandomXOR priorities
+//                    (S/kmers/minimizer/MinimizerPriorities.scala:144-179,282-321), PosRankWindow + MinSplitter.splitRead
+//                    (PosRankWindow.scala:33-97, MinSplitter.scala:133-172) in their observable form: window minimum by
+//                    value + run-length merge of equal minima (the equivalence is a property test under tests/).
+//   probe_kernel     the left equi-join + spanToHit (S/slacken/Classifier.scala:84-88, KeyValueIndex.scala:176-185).
+//   classify_kernel  Classifier.classify (Classifier.scala:439-454), TaxonCounts.toMap/totalKmers
+//                    (S/slacken/TaxonCounts.scala:70-87), LowestCommonAncestor.apply/resolveTree
+//                    (S/slacken/LowestCommonAncestor.scala:49-146), Taxonomy.hasAncestor (S/slacken/Taxonomy.scala:236-244).
+#include "engine.h"
+
+namespace slk {
+
+// ---------------------------------------------------------------------------------------------------------------
+// table build / lookup
+// ---------------------------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) table_insert_kernel(TableBuild t, const int64_t *__restrict__ keys,
+                                                           const int32_t *__restrict__ taxa, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    int32_t taxon = taxa[i];
+    if (taxon == 0) continue;  // a record with taxon NONE is indistinguishable from a miss
+    uint64_t h = fmix64((uint64_t)keys[i]);
+    uint64_t home = h >> t.shift;
+    uint64_t rem_hi = (h & t.rem_mask) << t.disp_bits;
+    bool done = false;
+    for (int d = 0; d <= t.disp_limit && !done; d++) {
+      unsigned long long *bucket = (unsigned long long *)(t.cells + (((home + d) & t.bucket_mask) << 3));
+      uint64_t tag = rem_hi | (uint64_t)d;
+      unsigned long long val = (tag << t.taxon_bits) | (uint32_t)taxon;
+      for (int c = 0; c < 8 && !done; c++) {
+        unsigned long long cur = __hip_atomic_load(&bucket[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == 0) {
+          unsigned long long old = atomicCAS(&bucket[c], 0ULL, val);
+          if (old == 0) {
+            done = true;
+            atomicAdd(t.n_inserted, 1ULL);
+            if (d > 0) atomicMax(t.max_disp, d);
+            break;
+          }
+          cur = old;
+        }
+        if ((cur >> t.taxon_bits) == tag) {  // same key already present: contract violation, keep the first
+          done = true;
+          atomicAdd(t.n_duplicate, 1ULL);
+        }
+      }
+    }
+    if (!done) atomicAdd(t.n_overflow, 1ULL);
+  }
+}
+
+// One 64-byte bucket per probe step; returns the stored taxon or 0 (NONE).
+__device__ __forceinline__ int32_t table_lookup(const TableView &t, uint64_t key) {
+  uint64_t h = fmix64(key);
+  uint64_t home = h >> t.shift;
+  uint64_t rem_hi = (h & t.rem_mask) << t.disp_bits;
+  uint64_t tmask = (1ULL << t.taxon_bits) - 1;
+  for (int d = 0; d <= t.max_disp; d++) {
+    const ulonglong2 *b = (const ulonglong2 *)(t.cells + (((home + d) & t.bucket_mask) << 3));
+    ulonglong2 c0 = b[0], c1 = b[1], c2 = b[2], c3 = b[3];
+    uint64_t tag = rem_hi | (uint64_t)d;
+    uint64_t cells[8] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y, c3.x, c3.y};
+    bool has_empty = false;
+    int32_t found = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      has_empty |= (cells[c] == 0);
+      if (cells[c] != 0 && (cells[c] >> t.taxon_bits) == tag) found = (int32_t)(cells[c] & tmask);
+    }
+    if (found) return found;
+    if (has_empty) return 0;
+  }
+  return 0;
+}
+
+__global__ void __launch_bounds__(256) table_lookup_kernel(TableView t, const int64_t *__restrict__ keys, uint64_t n,
+                                                           int32_t *__restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = table_lookup(t, (uint64_t)keys[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stage 1: scan (one lane per fragment)
+// ---------------------------------------------------------------------------------------------------------------
+
+// BitRepresentation.charToTwobitWithInvalid (S/kmers/util/BitRepresentation.scala:150-158): 0..3, 4 = whitespace, 5 = invalid
+__device__ __forceinline__ int char_code(uint8_t c) {
+  if (c == '\n' || c == '\r') return 4;
+  switch (c | 0x20) {
+    case 'a': return 0;
+    case 'c': return 1;
+    case 'g': return 2;
+    case 't': return 3;
+    case 'u': return 3;
+    default: return 5;
+  }
+}
+
+struct SpanWriter {
+  uint64_t *keys;
+  int32_t *meta;
+  uint64_t base;
+  int32_t n;
+  bool first;       // Supermers.spans :72
+  bool have_last;   // lastMinimizer = Array[Long]() initially (:73)
+  uint64_t last;
+
+  __device__ __forceinline__ void emit(uint64_t key, int32_t kmers, int32_t flag) {
+    bool seqlike = (flag == 1);
+    bool distinct = seqlike && (first || !(have_last && key == last));  // :84-86
+    if (seqlike) { last = key; have_last = true; }                      // :88-90
+    first = false;
+    keys[base + n] = seqlike ? key : 0;
+    meta[base + n] = pack_meta(kmers, flag, distinct ? 1 : 0);
+    n++;
+  }
+};
+
+// One mate: Supermers.splitFragment(NTSeq) :113-125 fused with splitByAmbiguity :150-178 and the m-mer scan.
+// ring: this lane's last w keys, ring[slot * blockDim.x + threadIdx.x].
+__device__ void scan_mate(const ScanParams &P, const uint8_t *__restrict__ seq, uint32_t n, uint64_t *ring, SpanWriter &out) {
+  const int k = P.k, m = P.m, w = P.w;
+  const uint32_t stride = blockDim.x;
+  int run_class = 0;        // 1 = characters of [actguACTGU\n\r], 0 = anything else
+  uint32_t run_len = 0;     // string length of the current run (incl. whitespace)
+  uint32_t nvalid = 0;      // valid nucleotides in the current run
+  uint64_t fwd = 0, rc = 0;
+  int head = 0;             // ring slot of the newest key
+  uint64_t minv = 0;        // minimum of the last <= w keys
+  int minage = 0;           // pushes since the newest key equal to minv
+  uint64_t cur_val = 0;     // value of the open super-mer
+  int32_t cur_run = 0;      // its number of k-mer windows (0 = none open)
+
+  for (uint32_t i = 0; i <= n; i++) {
+    int t = 5, cls = -1;
+    if (i < n) {
+      t = char_code(seq[i]);
+      cls = (t < 5) ? 1 : 0;
+    }
+    if (run_len > 0 && cls != run_class) {  // the run [.., i) ends
+      if (run_class == 1 && nvalid >= (uint32_t)k) {
+        out.emit(cur_val, cur_run, 1);      // last super-mer of a SEQUENCE_FLAG run
+      } else if (run_len >= (uint32_t)k) {
+        // AMBIGUOUS_FLAG run of string length >= k: ONE span with kmers = length - (k-1) (Supermers.scala:116-119)
+        out.emit(0, (int32_t)run_len - (k - 1), 2);
+      }                                     // runs shorter than k vanish (:116)
+      run_len = 0;
+    }
+    if (i == n) break;
+    if (run_len == 0) {
+      run_class = cls;
+      nvalid = 0; fwd = 0; rc = 0; head = w - 1; minage = 0; minv = ~0ULL; cur_run = 0;
+    }
+    run_len++;
+    if (t < 4) {
+      nvalid++;
+      // left-aligned rolling m-mer (NTBitArray.shiftLongArrayKmerLeft, NTBitArray.scala:140-150) and its reverse complement
+      fwd = (fwd << 2) | ((uint64_t)t << P.sh);
+      rc = ((rc >> 2) | ((uint64_t)(3 - t) << 62)) & P.keep;
+      if (nvalid >= (uint32_t)m) {
+        uint64_t canon = (P.canonical && rc < fwd) ? rc : fwd;  // NTBitArray.writeCanonical :258-266 == unsigned min
+        uint64_t key = (canon ^ P.xmask) & P.smask;            // RandomXOR then SpacedSeed (MinimizerPriorities.scala:165-175,308-312)
+        head = (head + 1 == w) ? 0 : head + 1;
+        ring[(uint32_t)head * stride + threadIdx.x] = key;
+        if (key <= minv) { minv = key; minage = 0; }
+        else if (++minage >= w) {  // the minimum left the window: rescan the last w keys (oldest first)
+          int slot = (head + 1 == w) ? 0 : head + 1;
+          minv = ~0ULL;
+          for (int a = w - 1; a >= 0; a--) {
+            uint64_t v = ring[(uint32_t)slot * stride + threadIdx.x];
+            if (v <= minv) { minv = v; minage = a; }
+            slot = (slot + 1 == w) ? 0 : slot + 1;
+          }
+        }
+        if (nvalid >= (uint32_t)k) {  // one k-mer window is complete: its minimizer VALUE is minv
+          if (cur_run == 0) { cur_val = minv; cur_run = 1; }
+          else if (minv == cur_val) cur_run++;                 // MinSplitter.splitRead :154-158 (equal value, any position)
+          else { out.emit(cur_val, cur_run, 1); cur_val = minv; cur_run = 1; }
+        }
+      }
+    }
+  }
+}
+
+__global__ void scan_kernel(ScanParams P, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets,
+                            const uint8_t *__restrict__ mate_bases, const uint64_t *__restrict__ mate_offsets, uint64_t R,
+                            uint64_t *__restrict__ span_keys, int32_t *__restrict__ span_meta,
+                            int32_t *__restrict__ span_count) {
+  extern __shared__ uint64_t ring[];
+  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  SpanWriter out;
+  out.keys = span_keys; out.meta = span_meta;
+  out.base = span_region(offsets, mate_offsets, r);
+  out.n = 0; out.first = true; out.have_last = false; out.last = 0;
+  uint64_t o0 = offsets[r];
+  scan_mate(P, bases + o0, (uint32_t)(offsets[r + 1] - o0), ring, out);
+  if (mate_bases) {
+    out.emit(0, -(P.k - 1), 3);  // MATE_PAIR_BORDER pseudo-span: empty super-mer, kmers = 0 - (k-1) (Supermers.scala:53-57)
+    uint64_t m0 = mate_offsets[r];
+    scan_mate(P, mate_bases + m0, (uint32_t)(mate_offsets[r + 1] - m0), ring, out);
+  }
+  span_count[r] = out.n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stage 2: probe (one wave per fragment, one lane per span)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) probe_kernel(TableView T, const uint64_t *__restrict__ offsets,
+                                                    const uint64_t *__restrict__ mate_offsets, uint64_t R,
+                                                    const uint64_t *__restrict__ span_keys,
+                                                    const int32_t *__restrict__ span_meta,
+                                                    const int32_t *__restrict__ span_count,
+                                                    int32_t *__restrict__ span_taxon) {
+  const uint32_t lane = threadIdx.x & 63;
+  uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (uint64_t r = wave; r < R; r += nwaves) {
+    uint64_t base = span_region(offsets, mate_offsets, r);
+    int32_t n = span_count[r];
+    for (int32_t j = lane; j < n; j += 64) {
+      int32_t flag = meta_flag(span_meta[base + j]);
+      int32_t taxon;
+      // spanToHit (KeyValueIndex.scala:176-185): flag wins over any record; unmatched -> NONE
+      if (flag == 2) taxon = -1;
+      else if (flag == 3) taxon = -2;
+      else taxon = table_lookup(T, span_keys[base + j]);
+      span_taxon[base + j] = taxon;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stage 3: classify (one lane per fragment)
+// ---------------------------------------------------------------------------------------------------------------
+struct Tax {
+  const int32_t *parents;
+  int32_t T;
+  __device__ __forceinline__ int32_t parent(int32_t t) const { return ((uint32_t)t < (uint32_t)T) ? parents[t] : 0; }
+};
+
+// LowestCommonAncestor.apply :49-78 without the path buffer: first node on b's path that lies on a's path.
+__device__ int32_t lca_pair(const Tax &tx, int32_t a, int32_t b) {
+  if (a == 0 || b == 0) return b == 0 ? a : b;
+  for (int32_t y = b; y != 0; y = tx.parent(y))
+    for (int32_t x = a; x != 0; x = tx.parent(x))
+      if (x == y) return y;
+  return 1;  // ROOT
+}
+
+struct MapView {  // insertion-ordered taxon -> count map (Int2IntArrayMap) in this fragment's scratch slots
+  int2 *e;
+  int32_t n;
+  __device__ __forceinline__ int32_t get(int32_t t) const {
+    for (int32_t i = 0; i < n; i++) { int2 v = e[i]; if (v.x == t) return v.y; }
+    return 0;
+  }
+};
+
+__global__ void __launch_bounds__(256) classify_kernel(Tax tx, const uint64_t *__restrict__ offsets,
+                                                       const uint64_t *__restrict__ mate_offsets, uint64_t R,
+                                                       const int32_t *__restrict__ span_meta,
+                                                       const int32_t *__restrict__ span_taxon,
+                                                       const int32_t *__restrict__ span_count,
+                                                       uint64_t *__restrict__ map_scratch, int32_t min_hit_groups,
+                                                       const double *__restrict__ thresholds, int32_t C,
+                                                       int32_t *__restrict__ out_taxon, uint8_t *__restrict__ out_classified,
+                                                       int32_t *__restrict__ out_num_distinct,
+                                                       int32_t *__restrict__ out_total_kmers,
+                                                       int32_t *__restrict__ out_num_hits) {
+  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  uint64_t base = span_region(offsets, mate_offsets, r);
+  int32_t n = span_count[r];
+  MapView map;
+  map.e = (int2 *)(map_scratch + base);
+  map.n = 0;
+  int32_t total = 0, nd = 0;
+  for (int32_t j = 0; j < n; j++) {
+    int32_t meta = span_meta[base + j];
+    int32_t taxon = span_taxon[base + j];
+    int32_t count = meta_kmers(meta);
+    if (taxon != -2) total += count;                         // TaxonCounts.totalKmers :84-87
+    if (meta_distinct(meta) && taxon != 0) nd++;              // Classifier.scala:94 (distinct is false for flagged spans)
+    if (taxon == -1 || taxon == -2) continue;                 // TaxonCounts.toMap :70-81
+    int32_t i = 0;
+    for (; i < map.n; i++) if (map.e[i].x == taxon) break;
+    if (i == map.n) { map.e[i] = make_int2(taxon, count); map.n++; }
+    else map.e[i].y += count;
+  }
+
+  // resolveTree step 1 (:101-123): LCA of all taxa with the maximal root-path score; threshold independent
+  int32_t maxTaxon = 0, maxScore = 0;
+  for (int32_t it = 0; it < map.n; it++) {
+    int32_t taxon = map.e[it].x;
+    int32_t score = 0;
+    for (int32_t node = taxon; node != 0; node = tx.parent(node)) score += map.get(node);
+    if (score > maxScore) { maxTaxon = taxon; maxScore = score; }
+    else if (score == maxScore) maxTaxon = lca_pair(tx, maxTaxon, taxon);
+  }
+
+  for (int32_t c = 0; c < C; c++) {
+    // Math.ceil(confidenceThreshold * totalKmers) in binary64 (:94)
+    double required = ceil(__dmul_rn(thresholds[c], (double)total));
+    int32_t mt = maxTaxon;
+    int32_t ms = map.get(mt);                                // :125
+    while (mt != 0 && (double)ms < required) {               // :126-144
+      ms = 0;
+      for (int32_t it = 0; it < map.n; it++) {
+        int2 v = map.e[it];
+        bool in_clade = false;                               // Taxonomy.hasAncestor(v.x, mt) :236-244
+        for (int32_t x = v.x; x != 0; x = tx.parent(x)) if (x == mt) { in_clade = true; break; }
+        if (in_clade) ms += v.y;
+      }
+      if ((double)ms >= required) break;
+      mt = tx.parent(mt);
+    }
+    bool classified = (mt != 0) && (nd >= min_hit_groups);   // Classifier.scala:445
+    out_taxon[(uint64_t)c * R + r] = classified ? mt : 0;
+    out_classified[(uint64_t)c * R + r] = classified ? 1 : 0;
+  }
+  if (out_num_distinct) out_num_distinct[r] = nd;
+  if (out_total_kmers) out_total_kmers[r] = total;
+  if (out_num_hits) out_num_hits[r] = n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// compaction of the sparse per-read regions for the host-facing outputs
+// ---------------------------------------------------------------------------------------------------------------
+struct SpanOut { int64_t key; int32_t kmers; int8_t flag; uint8_t distinct; uint16_t pad; };
+struct HitOut { int32_t taxon; int32_t count; };
+
+__global__ void __launch_bounds__(256) gather_spans_kernel(const uint64_t *__restrict__ offsets,
+                                                           const uint64_t *__restrict__ mate_offsets, uint64_t R,
+                                                           const uint64_t *__restrict__ span_keys,
+                                                           const int32_t *__restrict__ span_meta,
+                                                           const uint64_t *__restrict__ out_offsets,
+                                                           SpanOut *__restrict__ out) {
+  const uint32_t lane = threadIdx.x & 63;
+  uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (uint64_t r = wave; r < R; r += nwaves) {
+    uint64_t base = span_region(offsets, mate_offsets, r);
+    uint64_t o = out_offsets[r];
+    int32_t n = (int32_t)(out_offsets[r + 1] - o);
+    for (int32_t j = lane; j < n; j += 64) {
+      int32_t meta = span_meta[base + j];
+      SpanOut s;
+      s.key = (int64_t)span_keys[base + j];
+      s.kmers = meta_kmers(meta);
+      s.flag = (int8_t)meta_flag(meta);
+      s.distinct = (uint8_t)meta_distinct(meta);
+      s.pad = 0;
+      out[o + j] = s;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) gather_hits_kernel(const uint64_t *__restrict__ offsets,
+                                                          const uint64_t *__restrict__ mate_offsets, uint64_t R,
+                                                          const int32_t *__restrict__ span_meta,
+                                                          const int32_t *__restrict__ span_taxon,
+                                                          const uint64_t *__restrict__ out_offsets,
+                                                          HitOut *__restrict__ out) {
+  const uint32_t lane = threadIdx.x & 63;
+  uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (uint64_t r = wave; r < R; r += nwaves) {
+    uint64_t base = span_region(offsets, mate_offsets, r);
+    uint64_t o = out_offsets[r];
+    int32_t n = (int32_t)(out_offsets[r + 1] - o);
+    for (int32_t j = lane; j < n; j += 64) {
+      HitOut h;
+      h.taxon = span_taxon[base + j];
+      h.count = meta_kmers(span_meta[base + j]);
+      out[o + j] = h;
+    }
+  }
+}
+
+// ---- launchers (called from capi.hip) ----
+void launch_table_insert(const TableBuild &t, const int64_t *keys, const int32_t *taxa, uint64_t n, hipStream_t s) {
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks == 0) return;
+  hipLaunchKernelGGL(table_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t, keys, taxa, n);
+}
+void launch_table_lookup(const TableView &t, const int64_t *keys, uint64_t n, int32_t *out, hipStream_t s) {
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks == 0) return;
+  hipLaunchKernelGGL(table_lookup_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t, keys, n, out);
+}
+void launch_scan(const ScanParams &P, const uint8_t *bases, const uint64_t *offsets, const uint8_t *mate_bases,
+                 const uint64_t *mate_offsets, uint64_t R, uint64_t *span_keys, int32_t *span_meta, int32_t *span_count,
+                 hipStream_t s) {
+  if (R == 0) return;
+  // one lane per fragment; the w-key ring lives in LDS: blockDim * w * 8 bytes <= 64 KiB
+  int block = 256;
+  while (block > 64 && (size_t)block * P.w * 8 > 65536) block >>= 1;
+  size_t lds = (size_t)block * P.w * 8;
+  uint64_t blocks = (R + block - 1) / block;
+  hipLaunchKernelGGL(scan_kernel, dim3((unsigned)blocks), dim3(block), lds, s, P, bases, offsets, mate_bases,
+                     mate_offsets, R, span_keys, span_meta, span_count);
+}
+void launch_probe(const TableView &T, const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R,
+                  const uint64_t *span_keys, const int32_t *span_meta, const int32_t *span_count, int32_t *span_taxon,
+                  hipStream_t s) {
+  if (R == 0) return;
+  uint64_t blocks = (R + 3) / 4;  // 4 waves per block, one fragment per wave per iteration
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(probe_kernel, dim3((unsigned)blocks), dim3(256), 0, s, T, offsets, mate_offsets, R, span_keys,
+                     span_meta, span_count, span_taxon);
+}
+void launch_classify(const int32_t *parents, int32_t T, const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R,
+                     const int32_t *span_meta, const int32_t *span_taxon, const int32_t *span_count,
+                     uint64_t *map_scratch, int32_t min_hit_groups, const double *d_thresholds, int32_t C,
+                     int32_t *out_taxon, uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers,
+                     int32_t *out_num_hits, hipStream_t s) {
+  if (R == 0) return;
+  Tax tx{parents, T};
+  uint64_t blocks = (R + 255) / 256;
+  hipLaunchKernelGGL(classify_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tx, offsets, mate_offsets, R, span_meta,
+                     span_taxon, span_count, map_scratch, min_hit_groups, d_thresholds, C, out_taxon, out_classified,
+                     out_num_distinct, out_total_kmers, out_num_hits);
+}
+void launch_gather_spans(const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, const uint64_t *span_keys,
+                         const int32_t *span_meta, const uint64_t *out_offsets, void *out, hipStream_t s) {
+  if (R == 0) return;
+  uint64_t blocks = (R + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gather_spans_kernel, dim3((unsigned)blocks), dim3(256), 0, s, offsets, mate_offsets, R, span_keys,
+                     span_meta, out_offsets, (SpanOut *)out);
+}
+void launch_gather_hits(const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, const int32_t *span_meta,
+                        const int32_t *span_taxon, const uint64_t *out_offsets, void *out, hipStream_t s) {
+  if (R == 0) return;
+  uint64_t blocks = (R + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gather_hits_kernel, dim3((unsigned)blocks), dim3(256), 0, s, offsets, mate_offsets, R, span_meta,
+                     span_taxon, out_offsets, (HitOut *)out);
+}
+
+}  // namespace slk

@@ -1,0 +1,186 @@
+"""GPU parity: every result of the HIP engine, obtained through the C ABI, is compared bit for bit with the CPU oracle
+on the same seeded inputs (integer/byte/index work => exact equality; the only floating point is one binary64
+multiply + ceil per read and threshold, also compared exactly)."""
+import numpy as np
+import pytest
+
+import synth
+import taxgen
+
+pytestmark = pytest.mark.gpu
+
+PARAM_SETS = [
+    dict(k=35, m=31, spaces=7),                                   # `slacken build` defaults (Slacken.scala:126-136)
+    dict(k=35, m=31, spaces=0),
+    dict(k=31, m=31, spaces=0),                                   # window of one m-mer
+    dict(k=5, m=2, spaces=0, xor_mask=0, canonical=False),        # the reference's KAT configuration
+    dict(k=21, m=12, spaces=5),
+    dict(k=45, m=32, spaces=16),                                  # full 64-bit key, widest space mask
+    dict(k=63, m=9, spaces=2, canonical=False),                   # wide window (55 m-mers)
+]
+
+
+def full(ps):
+    d = dict(xor_mask=0xe37e28c4271b5a2d, canonical=True)
+    d.update(ps)
+    return d
+
+
+@pytest.fixture(scope="module")
+def world(orc):
+    """A small synthetic library + taxonomy + engine index for the default parameters."""
+    import slacken_amd
+    rng = np.random.default_rng(2240)
+    parents = taxgen.taxonomy(8 * 128, rng)
+    p = orc.params()
+    lib = synth.Library(orc, p, parents, n_genomes=12, genome_len=20000, pad_records=50000)
+    ix = slacken_amd.Index(expected_records=len(lib.keys), max_taxon=len(parents) - 1)
+    half = len(lib.keys) // 2
+    ix.append(lib.keys[:half], lib.taxa[:half])          # chunked append, as one call per Parquet bucket file would
+    ix.append(lib.keys[half:], lib.taxa[half:])
+    ix.set_taxonomy(parents)
+    ix.finalize()
+    oix = orc.Index(1, lib.keys, lib.taxa)
+    return dict(p=p, lib=lib, ix=ix, oix=oix, parents=parents, st=ix.stream())
+
+
+def test_index_lookup_is_lossless(world):
+    lib, ix = world["lib"], world["ix"]
+    info = ix.info()
+    assert info.records == len(lib.keys) and info.duplicate_keys == 0
+    assert np.array_equal(ix.lookup(lib.keys), lib.taxa)
+    rng = np.random.default_rng(1)
+    # near misses: flip one bit of stored keys (must not alias: the table is lossless, unlike a Kraken 2 CHT)
+    probe = lib.keys[rng.integers(0, len(lib.keys), 20000)] ^ (np.int64(1) << rng.integers(2, 62, 20000))
+    expect = np.array([world["oix"].lookup([int(k) & (2**64 - 1)]) for k in probe], np.int32)
+    assert np.array_equal(ix.lookup(probe), expect)
+    assert ix.lookup(np.zeros(0, np.int64)).size == 0
+
+
+def oracle_spans(orc, p, reads, mates=None):
+    out, off = [], [0]
+    for i, r in enumerate(reads):
+        sp = orc.spans(p, r.tobytes(), None if mates is None else mates[i].tobytes())
+        out += [(np.int64(np.uint64(s["key"][0])), s["kmers"], s["flag"], int(s["distinct"])) for s in sp]
+        off.append(len(out))
+    return off, out
+
+
+@pytest.mark.parametrize("ps", PARAM_SETS, ids=lambda ps: f"k{ps['k']}m{ps['m']}s{ps['spaces']}")
+def test_spans_parity(orc, ps):
+    import slacken_amd
+    ps = full(ps)
+    p = orc.params(**ps)
+    rng = np.random.default_rng(ps["k"] * 100 + ps["m"])
+    parents = taxgen.taxonomy(64, rng)
+    lib = synth.Library(orc, p, parents, n_genomes=3, genome_len=3000) if p.W == 1 else None
+    reads = synth.make_reads(lib, 700, rng, vary_length=True, n_single=0.15, n_run=0.1, lowercase=0.1, short=0.05)
+    reads += [np.frombuffer(s, np.uint8) for s in
+              (b"", b"N", b"ACGT" * 50, b"A" * 200, b"ACGTU" * 30, b"ACGT" * 9 + b"-" + b"TTGCA" * 20,
+               b"N" * 100, b"AATTTACTTTAGTTAC")]
+    ix = slacken_amd.Index(expected_records=16, max_taxon=7, **ps)
+    ix.finalize()
+    st = ix.stream()
+    bases, offsets = synth.pack(reads)
+    got_off, got = st.spans_batch(bases, offsets)
+    want_off, want = oracle_spans(orc, p, reads)
+    assert got_off.tolist() == want_off
+    assert [(int(s["key"]), int(s["kmers"]), int(s["flag"]), int(s["distinct"])) for s in got] == \
+           [(int(a), b, c, d) for a, b, c, d in want]
+    # paired: mate border span + distinct tracking across mates
+    mates = [reads[(i * 7 + 3) % len(reads)] for i in range(len(reads))]
+    mb, mo = synth.pack(mates)
+    got_off, got = st.spans_batch(bases, offsets, mb, mo)
+    want_off, want = oracle_spans(orc, p, reads, mates)
+    assert got_off.tolist() == want_off
+    assert [(int(s["key"]), int(s["kmers"]), int(s["flag"]), int(s["distinct"])) for s in got] == \
+           [(int(a), b, c, d) for a, b, c, d in want]
+
+
+def test_reference_kat_on_gpu():
+    # T/kmers/minimizer/MinSplitterTest.scala:25-33 through the C ABI
+    import slacken_amd
+    ix = slacken_amd.Index(k=5, m=2, spaces=0, xor_mask=0, canonical=False, expected_records=16, max_taxon=7)
+    ix.finalize()
+    seq = b"AATTTACTTTAGTTAC"
+    off, sp = ix.stream().spans_batch(np.frombuffer(seq, np.uint8), np.array([0, len(seq)], np.uint64))
+    starts = np.concatenate([[0], np.cumsum(sp["kmers"])[:-1]])
+    assert [seq[s:s + n + 4].decode() for s, n in zip(starts, sp["kmers"])] == \
+           ["AATTT", "ATTTA", "TTTACTTT", "CTTTA", "TTTAGTTA", "GTTAC"]
+
+
+def check_classify(orc, world, reads, mates=None, thresholds=(0.0, 0.07, 0.15, 0.5, 1.0), min_hit_groups=2):
+    p, st = world["p"], world["st"]
+    bases, offsets = synth.pack(reads)
+    mb = mo = None
+    if mates is not None:
+        mb, mo = synth.pack(mates)
+    got = st.classify_batch(bases, offsets, mb, mo, min_hit_groups=min_hit_groups, thresholds=thresholds)
+    want = orc.classify_batch(p, world["oix"], world["parents"], bases, offsets, mb, mo,
+                              min_hit_groups=min_hit_groups, thresholds=thresholds)
+    for key in ("taxon", "classified", "num_distinct", "total_kmers", "num_hits"):
+        assert np.array_equal(got[key], want[key]), key
+    # un-merged hit lists (what hitDetails / lengthString are formatted from)
+    ho = got["hit_offsets"].astype(np.int64)
+    for i in range(0, len(reads), max(1, len(reads) // 300)):
+        _, hits = orc.classify_read(p, world["oix"], world["parents"], reads[i].tobytes(),
+                                    None if mates is None else mates[i].tobytes(), min_hit_groups, thresholds[0])
+        g = got["hits"][ho[i]:ho[i + 1]]
+        assert [(int(t), int(c)) for t, c in zip(g["taxon"], g["count"])] == hits
+    return got
+
+
+def test_classify_parity_single(orc, world):
+    rng = np.random.default_rng(150)
+    reads = synth.make_reads(world["lib"], 6000, rng)
+    got = check_classify(orc, world, reads)
+    assert got["classified"][0].mean() > 0.5          # most genome-derived reads classify at confidence 0
+    assert (got["num_hits"] == 0).any()                # some reads vanish (SURVEY 3.3 i)
+
+
+def test_classify_parity_varied_lengths(orc, world):
+    rng = np.random.default_rng(151)
+    reads = synth.make_reads(world["lib"], 3000, rng, vary_length=True, n_single=0.2, n_run=0.1)
+    check_classify(orc, world, reads, min_hit_groups=1)
+    check_classify(orc, world, reads, min_hit_groups=3, thresholds=(0.3,))
+
+
+def test_classify_parity_paired(orc, world):
+    rng = np.random.default_rng(152)
+    r1 = synth.make_reads(world["lib"], 3000, rng)
+    r2 = synth.make_reads(world["lib"], 3000, rng, vary_length=True)
+    got = check_classify(orc, world, r1, r2)
+    assert (got["num_hits"] >= 1).all()                # the mate border span always exists
+
+
+def test_classify_edge_batches(orc, world):
+    st = world["st"]
+    empty = st.classify_batch(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert empty["taxon"].shape == (1, 0) and empty["hit_offsets"].tolist() == [0]
+    reads = [np.zeros(0, np.uint8)] * 5 + [np.frombuffer(b"N" * 150, np.uint8)] + [np.frombuffer(b"ACGT" * 8, np.uint8)]
+    check_classify(orc, world, reads)
+    check_classify(orc, world, reads, reads[::-1])
+    long_read = synth.make_reads(world["lib"], 1, np.random.default_rng(9), length=15000, short=0)
+    check_classify(orc, world, long_read * 3)
+
+
+def test_api_errors(world):
+    import slacken_amd
+    with pytest.raises(slacken_amd.SlackenError) as e:
+        slacken_amd.Index(k=63, m=33, spaces=0)
+    assert e.value.code == -2
+    with pytest.raises(slacken_amd.SlackenError):
+        slacken_amd.Index(k=10, m=12)
+    ix = slacken_amd.Index(expected_records=16, max_taxon=7)
+    with pytest.raises(slacken_amd.SlackenError):  # not finalized
+        ix.stream().classify_batch(np.frombuffer(b"ACGT", np.uint8), np.array([0, 4], np.uint64))
+    with pytest.raises(slacken_amd.SlackenError):  # taxon above max_taxon
+        ix.append(np.array([1], np.int64), np.array([9], np.int32))
+    with pytest.raises(slacken_amd.SlackenError):  # cycle
+        ix.set_taxonomy(np.array([0, 0, 3, 2], np.int32))
+    st = world["st"]
+    reads = synth.make_reads(world["lib"], 50, np.random.default_rng(3))
+    bases, offsets = synth.pack(reads)
+    with pytest.raises(slacken_amd.SlackenError) as e:
+        st.classify_batch(bases, offsets, hits_capacity=3)
+    assert e.value.code == -5
