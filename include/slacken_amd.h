@@ -157,14 +157,16 @@ int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, 
                            uint64_t *out_hit_offsets, slk_hit *out_hits, uint64_t hits_capacity);
 
 /* Same computation with every pointer (bases, offsets, mates, thresholds excepted: host) resident on the index's
- * GPU; asynchronous on st.  d_out_num_hits[R] (nullable) receives the span count per read (0 => no row).
+ * GPU; asynchronous on st.  d_out_num_hits[R] (nullable) receives the span count per read (0 => no row);
+ * d_out_num_probes[R] (nullable) the number of SEQUENCE_FLAG spans = table lookups (the P_r of SURVEY.md 8d).
  * total_bases / total_mate_bases = offsets[R] / mate_offsets[R] (the caller knows them; avoids a D2H sync). */
 int32_t slk_classify_batch_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
                                   const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
                                   uint64_t total_bases, uint64_t total_mate_bases, int32_t min_hit_groups,
                                   const double *thresholds, int32_t C, int32_t *d_out_taxon,
                                   uint8_t *d_out_classified, int32_t *d_out_num_distinct,
-                                  int32_t *d_out_total_kmers, int32_t *d_out_num_hits);
+                                  int32_t *d_out_total_kmers, int32_t *d_out_num_hits,
+                                  int32_t *d_out_num_probes);
 
 /* Per-stage device timing of the last slk_classify_batch_device call on st, in milliseconds (HIP events on the
  * stream the kernels ran on): [0]=scan, [1]=probe, [2]=classify.  Synchronises st. */

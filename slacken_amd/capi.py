@@ -86,7 +86,7 @@ def lib():
     L.slk_classify_batch.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_int32, C.POINTER(C.c_double),
                                      C.c_int32, i32p, u8p, i32p, i32p, u64p, vp, C.c_uint64]
     L.slk_classify_batch_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_uint64, C.c_uint64,
-                                            C.c_int32, C.POINTER(C.c_double), C.c_int32, i32p, u8p, i32p, i32p, i32p]
+                                            C.c_int32, C.POINTER(C.c_double), C.c_int32, i32p, u8p, i32p, i32p, i32p, i32p]
     L.slk_stream_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
     for name in EXPORTS:
         fn = getattr(L, name)
@@ -229,7 +229,7 @@ class Stream:
         return out
 
     def classify_batch_device(self, d_bases, d_offsets, R, total_bases, d_out_taxon, d_out_classified,
-                              d_out_num_distinct=None, d_out_total_kmers=None, d_out_num_hits=None,
+                              d_out_num_distinct=None, d_out_total_kmers=None, d_out_num_hits=None, d_out_num_probes=None,
                               d_mate_bases=None, d_mate_offsets=None, total_mate_bases=0, min_hit_groups=2,
                               thresholds=(0.0,)):
         """All d_* are raw device addresses (ints), e.g. torch.Tensor.data_ptr(). Asynchronous on this stream."""
@@ -238,7 +238,7 @@ class Stream:
         _check(lib().slk_classify_batch_device(self.index.h, self.h, d_bases, d_offsets, d_mate_bases,
                                                d_mate_offsets, R, total_bases, total_mate_bases, min_hit_groups, thr,
                                                Cn, d_out_taxon, d_out_classified, d_out_num_distinct,
-                                               d_out_total_kmers, d_out_num_hits))
+                                               d_out_total_kmers, d_out_num_hits, d_out_num_probes))
 
     def last_stage_ms(self):
         out = (C.c_float * 3)()

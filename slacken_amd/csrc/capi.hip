@@ -396,7 +396,8 @@ int32_t slk_classify_batch_device(slk_index *ix, slk_stream *st, const uint8_t *
                                   uint64_t total_bases, uint64_t total_mate_bases, int32_t min_hit_groups,
                                   const double *thresholds, int32_t C, int32_t *d_out_taxon,
                                   uint8_t *d_out_classified, int32_t *d_out_num_distinct,
-                                  int32_t *d_out_total_kmers, int32_t *d_out_num_hits) {
+                                  int32_t *d_out_total_kmers, int32_t *d_out_num_hits,
+                                  int32_t *d_out_num_probes) {
   int32_t rc = check_ready(ix, st, true);
   if (rc) return rc;
   if (C < 1 || C > MAX_THRESHOLDS || !thresholds) return fail(SLK_E_INVALID, "need 1..%d thresholds", MAX_THRESHOLDS);
@@ -421,7 +422,7 @@ int32_t slk_classify_batch_device(slk_index *ix, slk_stream *st, const uint8_t *
   launch_classify(ix->d_parents, ix->T, d_offsets, d_mate_offsets, R, st->span_meta.as<int32_t>(),
                   st->span_taxon.as<int32_t>(), st->span_count.as<int32_t>(), st->span_keys.as<uint64_t>(),
                   min_hit_groups, st->d_thresholds, C, d_out_taxon, d_out_classified, d_out_num_distinct,
-                  d_out_total_kmers, d_out_num_hits, st->s);
+                  d_out_total_kmers, d_out_num_hits, d_out_num_probes, st->s);
   HIPCHK(hipEventRecord(st->ev[3], st->s));
   HIPCHK(hipGetLastError());
   st->timed = true;
@@ -544,7 +545,7 @@ int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, 
   rc = slk_classify_batch_device(ix, st, st->bases.as<uint8_t>(), d_off,
                                  paired ? st->mate_bases.as<uint8_t>() : nullptr, d_moff, R, total, mate_total,
                                  min_hit_groups, thresholds, C, st->out_taxon.as<int32_t>(), st->out_cls.as<uint8_t>(),
-                                 st->out_nd.as<int32_t>(), st->out_tk.as<int32_t>(), st->out_nh.as<int32_t>());
+                                 st->out_nd.as<int32_t>(), st->out_tk.as<int32_t>(), st->out_nh.as<int32_t>(), nullptr);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(out_taxon, st->out_taxon.p, (size_t)C * R * 4, hipMemcpyDeviceToHost, st->s));
   HIPCHK(hipMemcpyAsync(out_classified, st->out_cls.p, (size_t)C * R, hipMemcpyDeviceToHost, st->s));

@@ -75,7 +75,7 @@ void launch_classify(const int32_t *parents, int32_t T, const uint64_t *offsets,
                      const int32_t *span_meta, const int32_t *span_taxon, const int32_t *span_count,
                      uint64_t *map_scratch, int32_t min_hit_groups, const double *d_thresholds, int32_t C,
                      int32_t *out_taxon, uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers,
-                     int32_t *out_num_hits, hipStream_t s);
+                     int32_t *out_num_hits, int32_t *out_num_probes, hipStream_t s);
 void launch_gather_spans(const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, const uint64_t *span_keys,
                          const int32_t *span_meta, const uint64_t *out_offsets, void *out, hipStream_t s);
 void launch_gather_hits(const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, const int32_t *span_meta,

@@ -276,7 +276,8 @@ __global__ void __launch_bounds__(256) classify_kernel(Tax tx, const uint64_t *_
                                                        int32_t *__restrict__ out_taxon, uint8_t *__restrict__ out_classified,
                                                        int32_t *__restrict__ out_num_distinct,
                                                        int32_t *__restrict__ out_total_kmers,
-                                                       int32_t *__restrict__ out_num_hits) {
+                                                       int32_t *__restrict__ out_num_hits,
+                                                       int32_t *__restrict__ out_num_probes) {
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   uint64_t base = span_region(offsets, mate_offsets, r);
@@ -284,7 +285,7 @@ __global__ void __launch_bounds__(256) classify_kernel(Tax tx, const uint64_t *_
   MapView map;
   map.e = (int2 *)(map_scratch + base);
   map.n = 0;
-  int32_t total = 0, nd = 0;
+  int32_t total = 0, nd = 0, nprobe = 0;
   for (int32_t j = 0; j < n; j++) {
     int32_t meta = span_meta[base + j];
     int32_t taxon = span_taxon[base + j];
@@ -292,6 +293,7 @@ __global__ void __launch_bounds__(256) classify_kernel(Tax tx, const uint64_t *_
     if (taxon != -2) total += count;                         // TaxonCounts.totalKmers :84-87
     if (meta_distinct(meta) && taxon != 0) nd++;              // Classifier.scala:94 (distinct is false for flagged spans)
     if (taxon == -1 || taxon == -2) continue;                 // TaxonCounts.toMap :70-81
+    nprobe++;
     int32_t i = 0;
     for (; i < map.n; i++) if (map.e[i].x == taxon) break;
     if (i == map.n) { map.e[i] = make_int2(taxon, count); map.n++; }
@@ -331,6 +333,7 @@ __global__ void __launch_bounds__(256) classify_kernel(Tax tx, const uint64_t *_
   if (out_num_distinct) out_num_distinct[r] = nd;
   if (out_total_kmers) out_total_kmers[r] = total;
   if (out_num_hits) out_num_hits[r] = n;
+  if (out_num_probes) out_num_probes[r] = nprobe;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -425,13 +428,13 @@ void launch_classify(const int32_t *parents, int32_t T, const uint64_t *offsets,
                      const int32_t *span_meta, const int32_t *span_taxon, const int32_t *span_count,
                      uint64_t *map_scratch, int32_t min_hit_groups, const double *d_thresholds, int32_t C,
                      int32_t *out_taxon, uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers,
-                     int32_t *out_num_hits, hipStream_t s) {
+                     int32_t *out_num_hits, int32_t *out_num_probes, hipStream_t s) {
   if (R == 0) return;
   Tax tx{parents, T};
   uint64_t blocks = (R + 255) / 256;
   hipLaunchKernelGGL(classify_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tx, offsets, mate_offsets, R, span_meta,
                      span_taxon, span_count, map_scratch, min_hit_groups, d_thresholds, C, out_taxon, out_classified,
-                     out_num_distinct, out_total_kmers, out_num_hits);
+                     out_num_distinct, out_total_kmers, out_num_hits, out_num_probes);
 }
 void launch_gather_spans(const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, const uint64_t *span_keys,
                          const int32_t *span_meta, const uint64_t *out_offsets, void *out, hipStream_t s) {
