@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -87,9 +88,13 @@ struct slk_stream {
   DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items;
   double *d_thresholds = nullptr;
   double *h_thresholds = nullptr;  // pinned
+  int32_t *d_status = nullptr;     // device error bits of the fused kernels
+  int32_t *h_status = nullptr;     // pinned copy, refreshed after every classify launch
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool timed = false;
 };
+
+static int32_t check_status(slk_stream *st);
 
 static int32_t set_device(const slk_index *ix) {
   HIPCHK(hipSetDevice(ix->device));
@@ -342,6 +347,10 @@ int32_t slk_stream_create(slk_index *ix, slk_stream **out) {
   HIPCHK(hipMalloc((void **)&st->d_thresholds, MAX_THRESHOLDS * sizeof(double)));
   HIPCHK(hipHostMalloc((void **)&st->h_thresholds, MAX_THRESHOLDS * sizeof(double), hipHostMallocDefault));
   for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&st->ev[i]));
+  HIPCHK(hipMalloc((void **)&st->d_status, sizeof(int32_t)));
+  HIPCHK(hipMemset(st->d_status, 0, sizeof(int32_t)));
+  HIPCHK(hipHostMalloc((void **)&st->h_status, sizeof(int32_t), hipHostMallocDefault));
+  *st->h_status = 0;
   *out = st;
   return SLK_OK;
 }
@@ -350,7 +359,7 @@ int32_t slk_stream_synchronize(slk_stream *st) {
   if (!st) return fail(SLK_E_INVALID, "null argument");
   HIPCHK(hipSetDevice(st->ix->device));
   HIPCHK(hipStreamSynchronize(st->s));
-  return SLK_OK;
+  return check_status(st);
 }
 
 void *slk_stream_hip_stream(slk_stream *st) { return st ? (void *)st->s : nullptr; }
@@ -365,6 +374,8 @@ void slk_stream_destroy(slk_stream *st) {
   for (DevBuf *b : bufs) b->release();
   if (st->d_thresholds) (void)hipFree(st->d_thresholds);
   if (st->h_thresholds) (void)hipHostFree(st->h_thresholds);
+  if (st->d_status) (void)hipFree(st->d_status);
+  if (st->h_status) (void)hipHostFree(st->h_status);
   for (int i = 0; i < 4; i++) if (st->ev[i]) (void)hipEventDestroy(st->ev[i]);
   if (st->s) (void)hipStreamDestroy(st->s);
   delete st;
@@ -391,6 +402,75 @@ static int32_t check_ready(const slk_index *ix, const slk_stream *st, bool need_
   return SLK_OK;
 }
 
+// The fused wave-per-read kernels (fused.hip) cover windows of up to 32 m-mers; wider windows (and SLK_FORCE_V1=1, an
+// A/B switch for tests) run the three separate lane-per-read kernels of kernels.hip.  Both are HIP: no CPU path.
+static bool use_fused(const slk_index *ix) {
+  static const bool force_v1 = getenv("SLK_FORCE_V1") != nullptr && getenv("SLK_FORCE_V1")[0] == '1';
+  return !force_v1 && ix->sp.w <= 32;
+}
+
+static int32_t check_status(slk_stream *st) {  // call after the stream has been synchronised
+  int32_t v = *st->h_status;
+  if (v != 0) {
+    *st->h_status = 0;
+    HIPCHK(hipMemsetAsync(st->d_status, 0, sizeof(int32_t), st->s));
+    if (v & 1) return fail(SLK_E_CAPACITY, "a fragment hit more than %d distinct taxa; the per-read taxon map overflowed", 128);
+    return fail(SLK_E_HIP, "device status %d", v);
+  }
+  return SLK_OK;
+}
+
+static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
+                            const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
+                            uint64_t total_bases, uint64_t total_mate_bases, int32_t min_hit_groups,
+                            const double *thresholds, int32_t C, int32_t *d_out_taxon, uint8_t *d_out_classified,
+                            int32_t *d_out_num_distinct, int32_t *d_out_total_kmers, int32_t *d_out_num_hits,
+                            int32_t *d_out_num_probes, bool want_hits) {
+  bool paired = d_mate_bases != nullptr;
+  bool fused = use_fused(ix);
+  int32_t rc;
+  if (!fused || want_hits) {
+    rc = ensure_scratch(st, span_slots(total_bases, total_mate_bases, R, paired), R);
+    if (rc) return rc;
+  }
+  memcpy(st->h_thresholds, thresholds, C * sizeof(double));
+  HIPCHK(hipMemcpyAsync(st->d_thresholds, st->h_thresholds, C * sizeof(double), hipMemcpyHostToDevice, st->s));
+  HIPCHK(hipEventRecord(st->ev[0], st->s));
+  if (fused) {
+    FusedArgs A{};
+    A.P = ix->sp; A.T = ix->view(); A.parents = ix->d_parents; A.ntax = ix->T;
+    A.bases = d_bases; A.offsets = d_offsets; A.mate_bases = d_mate_bases; A.mate_offsets = d_mate_offsets; A.R = R;
+    A.min_hit_groups = min_hit_groups; A.thresholds = st->d_thresholds; A.C = C;
+    A.out_taxon = d_out_taxon; A.out_classified = d_out_classified;
+    A.out_nd = d_out_num_distinct; A.out_tk = d_out_total_kmers; A.out_nh = d_out_num_hits; A.out_np = d_out_num_probes;
+    A.span_keys = nullptr;
+    A.span_meta = want_hits ? st->span_meta.as<int32_t>() : nullptr;
+    A.span_taxon = want_hits ? st->span_taxon.as<int32_t>() : nullptr;
+    A.span_count = want_hits ? st->span_count.as<int32_t>() : nullptr;
+    A.status = st->d_status;
+    launch_fused(want_hits ? MODE_HITS : MODE_CLASSIFY, A, st->s);
+    HIPCHK(hipEventRecord(st->ev[1], st->s));
+    HIPCHK(hipEventRecord(st->ev[2], st->s));
+  } else {
+    launch_scan(ix->sp, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, st->span_keys.as<uint64_t>(),
+                st->span_meta.as<int32_t>(), st->span_count.as<int32_t>(), st->s);
+    HIPCHK(hipEventRecord(st->ev[1], st->s));
+    launch_probe(ix->view(), d_offsets, d_mate_offsets, R, st->span_keys.as<uint64_t>(), st->span_meta.as<int32_t>(),
+                 st->span_count.as<int32_t>(), st->span_taxon.as<int32_t>(), st->s);
+    HIPCHK(hipEventRecord(st->ev[2], st->s));
+    // the key slots are dead after the probe: the per-read taxon->count map reuses them
+    launch_classify(ix->d_parents, ix->T, d_offsets, d_mate_offsets, R, st->span_meta.as<int32_t>(),
+                    st->span_taxon.as<int32_t>(), st->span_count.as<int32_t>(), st->span_keys.as<uint64_t>(),
+                    min_hit_groups, st->d_thresholds, C, d_out_taxon, d_out_classified, d_out_num_distinct,
+                    d_out_total_kmers, d_out_num_hits, d_out_num_probes, st->s);
+  }
+  HIPCHK(hipEventRecord(st->ev[3], st->s));
+  HIPCHK(hipMemcpyAsync(st->h_status, st->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st->s));
+  HIPCHK(hipGetLastError());
+  st->timed = true;
+  return SLK_OK;
+}
+
 int32_t slk_classify_batch_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
                                   const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
                                   uint64_t total_bases, uint64_t total_mate_bases, int32_t min_hit_groups,
@@ -406,27 +486,9 @@ int32_t slk_classify_batch_device(slk_index *ix, slk_stream *st, const uint8_t *
     return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
   rc = set_device(ix);
   if (rc) return rc;
-  bool paired = d_mate_bases != nullptr;
-  rc = ensure_scratch(st, span_slots(total_bases, total_mate_bases, R, paired), R);
-  if (rc) return rc;
-  memcpy(st->h_thresholds, thresholds, C * sizeof(double));
-  HIPCHK(hipMemcpyAsync(st->d_thresholds, st->h_thresholds, C * sizeof(double), hipMemcpyHostToDevice, st->s));
-  HIPCHK(hipEventRecord(st->ev[0], st->s));
-  launch_scan(ix->sp, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, st->span_keys.as<uint64_t>(),
-              st->span_meta.as<int32_t>(), st->span_count.as<int32_t>(), st->s);
-  HIPCHK(hipEventRecord(st->ev[1], st->s));
-  launch_probe(ix->view(), d_offsets, d_mate_offsets, R, st->span_keys.as<uint64_t>(), st->span_meta.as<int32_t>(),
-               st->span_count.as<int32_t>(), st->span_taxon.as<int32_t>(), st->s);
-  HIPCHK(hipEventRecord(st->ev[2], st->s));
-  // the key slots are dead after the probe: the per-read taxon->count map reuses them
-  launch_classify(ix->d_parents, ix->T, d_offsets, d_mate_offsets, R, st->span_meta.as<int32_t>(),
-                  st->span_taxon.as<int32_t>(), st->span_count.as<int32_t>(), st->span_keys.as<uint64_t>(),
-                  min_hit_groups, st->d_thresholds, C, d_out_taxon, d_out_classified, d_out_num_distinct,
-                  d_out_total_kmers, d_out_num_hits, d_out_num_probes, st->s);
-  HIPCHK(hipEventRecord(st->ev[3], st->s));
-  HIPCHK(hipGetLastError());
-  st->timed = true;
-  return SLK_OK;
+  return run_classify(ix, st, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, total_bases, total_mate_bases,
+                      min_hit_groups, thresholds, C, d_out_taxon, d_out_classified, d_out_num_distinct,
+                      d_out_total_kmers, d_out_num_hits, d_out_num_probes, false);
 }
 
 int32_t slk_stream_last_stage_ms(slk_stream *st, float out_ms[3]) {
@@ -434,7 +496,9 @@ int32_t slk_stream_last_stage_ms(slk_stream *st, float out_ms[3]) {
   if (!st->timed) return fail(SLK_E_STATE, "no classify call has been issued on this stream");
   HIPCHK(hipSetDevice(st->ix->device));
   HIPCHK(hipEventSynchronize(st->ev[3]));
-  for (int i = 0; i < 3; i++) HIPCHK(hipEventElapsedTime(&out_ms[i], st->ev[i], st->ev[i + 1]));
+  HIPCHK(hipEventElapsedTime(&out_ms[0], st->ev[0], st->ev[1]));
+  HIPCHK(hipEventElapsedTime(&out_ms[1], st->ev[1], st->ev[2]));
+  HIPCHK(hipEventElapsedTime(&out_ms[2], st->ev[2], st->ev[3]));
   return SLK_OK;
 }
 
@@ -498,8 +562,17 @@ int32_t slk_spans_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, con
   if (rc) return rc;
   const uint64_t *d_off = st->offsets.as<uint64_t>();
   const uint64_t *d_moff = paired ? st->mate_offsets.as<uint64_t>() : nullptr;
-  launch_scan(ix->sp, st->bases.as<uint8_t>(), d_off, paired ? st->mate_bases.as<uint8_t>() : nullptr, d_moff, R,
-              st->span_keys.as<uint64_t>(), st->span_meta.as<int32_t>(), st->span_count.as<int32_t>(), st->s);
+  if (use_fused(ix)) {
+    FusedArgs A{};
+    A.P = ix->sp; A.bases = st->bases.as<uint8_t>(); A.offsets = d_off;
+    A.mate_bases = paired ? st->mate_bases.as<uint8_t>() : nullptr; A.mate_offsets = d_moff; A.R = R;
+    A.span_keys = st->span_keys.as<uint64_t>(); A.span_meta = st->span_meta.as<int32_t>();
+    A.span_count = st->span_count.as<int32_t>(); A.status = st->d_status;
+    launch_fused(MODE_SPANS, A, st->s);
+  } else {
+    launch_scan(ix->sp, st->bases.as<uint8_t>(), d_off, paired ? st->mate_bases.as<uint8_t>() : nullptr, d_moff, R,
+                st->span_keys.as<uint64_t>(), st->span_meta.as<int32_t>(), st->span_count.as<int32_t>(), st->s);
+  }
   HIPCHK(hipGetLastError());
   rc = counts_to_offsets(st, st->span_count.as<int32_t>(), R, out_span_offsets, spans_capacity);
   if (rc) return rc;
@@ -542,10 +615,10 @@ int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, 
   HIPCHK(st->out_nh.ensure(R * 4));
   const uint64_t *d_off = st->offsets.as<uint64_t>();
   const uint64_t *d_moff = paired ? st->mate_offsets.as<uint64_t>() : nullptr;
-  rc = slk_classify_batch_device(ix, st, st->bases.as<uint8_t>(), d_off,
-                                 paired ? st->mate_bases.as<uint8_t>() : nullptr, d_moff, R, total, mate_total,
-                                 min_hit_groups, thresholds, C, st->out_taxon.as<int32_t>(), st->out_cls.as<uint8_t>(),
-                                 st->out_nd.as<int32_t>(), st->out_tk.as<int32_t>(), st->out_nh.as<int32_t>(), nullptr);
+  rc = run_classify(ix, st, st->bases.as<uint8_t>(), d_off, paired ? st->mate_bases.as<uint8_t>() : nullptr, d_moff, R,
+                    total, mate_total, min_hit_groups, thresholds, C, st->out_taxon.as<int32_t>(),
+                    st->out_cls.as<uint8_t>(), st->out_nd.as<int32_t>(), st->out_tk.as<int32_t>(),
+                    st->out_nh.as<int32_t>(), nullptr, out_hit_offsets != nullptr);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(out_taxon, st->out_taxon.p, (size_t)C * R * 4, hipMemcpyDeviceToHost, st->s));
   HIPCHK(hipMemcpyAsync(out_classified, st->out_cls.p, (size_t)C * R, hipMemcpyDeviceToHost, st->s));
@@ -564,7 +637,7 @@ int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, 
     }
   }
   HIPCHK(hipStreamSynchronize(st->s));
-  return SLK_OK;
+  return check_status(st);
 }
 
 }  // extern "C"

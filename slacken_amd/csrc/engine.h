@@ -62,6 +62,33 @@ struct TableBuild {
   unsigned long long *n_inserted, *n_duplicate, *n_overflow;
 };
 
+// arguments of the fused wave-per-read kernels (fused.hip)
+struct FusedArgs {
+  ScanParams P;
+  TableView T;
+  const int32_t *parents;
+  int32_t ntax;
+  const uint8_t *bases;
+  const uint64_t *offsets;
+  const uint8_t *mate_bases;
+  const uint64_t *mate_offsets;
+  uint64_t R;
+  int32_t min_hit_groups;
+  const double *thresholds;
+  int32_t C;
+  int32_t *out_taxon;
+  uint8_t *out_classified;
+  int32_t *out_nd, *out_tk, *out_nh, *out_np;
+  uint64_t *span_keys;   // MODE_SPANS output (sparse per-read regions, see span_region)
+  int32_t *span_meta;    // MODE_SPANS / MODE_HITS output
+  int32_t *span_taxon;   // MODE_HITS output
+  int32_t *span_count;   // MODE_SPANS / MODE_HITS output
+  int32_t *status;       // device error bits: 1 = taxon map overflow
+};
+
+enum { MODE_SPANS = 0, MODE_CLASSIFY = 1, MODE_HITS = 2 };
+void launch_fused(int mode, const FusedArgs &A, hipStream_t s);
+
 // launchers (kernels.hip)
 void launch_table_insert(const TableBuild &t, const int64_t *keys, const int32_t *taxa, uint64_t n, hipStream_t s);
 void launch_table_lookup(const TableView &t, const int64_t *keys, uint64_t n, int32_t *out, hipStream_t s);
