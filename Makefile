@@ -1,7 +1,8 @@
 # Builds the gfx950 engine (libslacken_amd.so) in-tree, and the CPU oracle used by the tests.
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
-HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+WPS ?= 0
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -DSLK_WPS=$(WPS)
 CSRC := slacken_amd/csrc
 LIB := slacken_amd/lib/libslacken_amd.so
 

@@ -2,20 +2,24 @@
 // HBM intermediates (spans, hits and the per-read taxon map live in registers / LDS).  gfx950, wave64.  Integer/byte
 // work bounded by random 64-byte HBM probes: no MFMA.
 //
-//   scan   2-bit packing of 256 bases per step (coalesced dword loads, SWAR code/pack), per-lane m-mer extraction
-//          from the packed LDS ring (funnel shift), reverse complement by bit reversal, canonical/XOR/space mask,
-//          width-w window minimum by log-step lane shuffles, run-length merge of equal minima by ballot + bit scans.
+//   scan   2-bit packing of 256 bases per step (coalesced dword loads, SWAR code/pack) into TWO LDS rings, the bases and
+//          their reverse complement (mirrored), so that every lane extracts its forward and reverse m-mer with one
+//          funnel shift each; canonical/XOR/space mask; width-w window minimum by DPP lane shifts; run-length merge of
+//          equal minima by ballot + bit scans.
 //          Reference: KeyValueIndex.getSpans (S/slacken/KeyValueIndex.scala:163-173) = Supermers.splitFragment/spans
 //          (S/slacken/Supermers.scala:49-125) over MinSplitter.splitEncode (S/kmers/minimizer/MinSplitter.scala:98-172),
 //          ShiftScanner.allMatches (ShiftScanner.scala:90-159), RandomXOR/SpacedSeed (MinimizerPriorities.scala:144-321).
-//   probe  8 lanes read one 64-byte bucket (8 x 8 B, one HBM line per probe), 8 probes per wave instruction, all of a
-//          chunk's loads in flight before the first compare.  Reference: the left join + spanToHit
+//   probe  8 lanes read one 64-byte bucket (8 x 8 B, one HBM line per probe), 8 probes per wave instruction, four
+//          instructions' loads in flight before the first compare.  Reference: the left join + spanToHit
 //          (S/slacken/Classifier.scala:84-88, KeyValueIndex.scala:176-185).
-//   LCA    hits folded into a 128-slot LDS hash map (taxon -> k-mer count); resolveTree with one lane per distinct
-//          taxon.  Reference: TaxonCounts.toMap/totalKmers (S/slacken/TaxonCounts.scala:70-87),
+//   LCA    a fragment whose hits name ONE taxon (the common case) is resolved without touching the tree; otherwise the
+//          hits are folded into a 128-slot LDS hash map (taxon -> k-mer count) and resolveTree runs with one lane per
+//          distinct taxon.  Reference: TaxonCounts.toMap/totalKmers (S/slacken/TaxonCounts.scala:70-87),
 //          LowestCommonAncestor.apply/resolveTree (S/slacken/LowestCommonAncestor.scala:49-146), Classifier.classify
 //          (Classifier.scala:439-454).
-// Fragments containing a non-ACGTU character take a sequential single-lane scan (same state machine as kernels.hip).
+// Control flow per fragment: a producer state machine (START -> FAST rounds | SLOW sequential scan -> NEXT mate) fills the
+// LDS span buffer; ONE flush site probes and folds whatever is buffered; repeat until the fragment is exhausted.
+// Mates containing a non-ACGTU character take the sequential single-lane scan (same state machine as kernels.hip).
 #include "engine.h"
 
 namespace slk {
@@ -25,17 +29,24 @@ constexpr int SPAN_CAP = 128;  // buffered spans per wave before a flush
 constexpr int MAP_CAP = 128;   // taxon map slots per wave (power of two)
 constexpr int32_t MAP_EMPTY = -1;  // AMBIGUOUS_SPAN is never inserted, so -1 is free
 
+struct SeqState {  // the sequential scanner's registers, parked in LDS while the wave flushes
+  uint64_t fwd, rc, minv, cur_val, last_key;
+  uint32_t i, run_len, nvalid;
+  int32_t run_class, head, minage, cur_run, total, first, have_last;
+};
+
 struct __attribute__((aligned(16))) WaveLds {
-  uint64_t packed[16];           // 2-bit bases, MSB first, ring of 512 bases (two 256-base blocks)
+  uint32_t fwd_ring[32];         // 2-bit bases, MSB first inside each dword, ring of 512 bases (two 256-base blocks)
+  uint32_t rc_ring[32];          // complement of base p at ring position 511 - p
   uint64_t span_key[SPAN_CAP];
   int32_t span_meta[SPAN_CAP];
-  uint64_t stash[128];           // probe: (bucket, tag) per span of the chunk; resolveTree: dense (taxon,count) list
+  uint64_t stash[128];           // probe: (bucket byte offset, tag) per span of the chunk; resolveTree: dense (taxon,count)
   int32_t result[64];
   int32_t map_key[MAP_CAP];
   int32_t map_cnt[MAP_CAP];
   uint64_t seq_ring[64];         // window ring of the sequential (slow-path) scanner, w <= 64
+  SeqState seq;
 };
-
 
 // ---- wave helpers ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wave_sync() {  // order this wave's LDS traffic (lanes of one wave exchange data via LDS)
@@ -45,6 +56,21 @@ __device__ __forceinline__ void wave_sync() {  // order this wave's LDS traffic 
 }
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
   uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
+  return ((uint64_t)hi << 32) | lo;
+}
+// lane i <- lane i+1 / lane i-1 (DPP wave shifts; the vacated end lane reads 0)
+__device__ __forceinline__ uint64_t from_next(uint64_t v) {
+  uint32_t lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x130, 0xF, 0xF, false);
+  uint32_t hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x130, 0xF, 0xF, false);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t from_prev(uint64_t v) {
+  uint32_t lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x138, 0xF, 0xF, false);
+  uint32_t hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, false);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {  // src wave-uniform; result wave-uniform
+  uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src);
   return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ uint64_t bcast64(uint64_t v) {  // lane 0 -> all, result is wave-uniform
@@ -62,68 +88,57 @@ __device__ __forceinline__ int wave_max(int v) {
   return v;
 }
 __device__ __forceinline__ uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
-
-struct Ctx {
-  WaveLds *L;
-  int lane;
-  int nbuf;        // spans buffered in L->span_*           (wave-uniform)
-  int n_out;       // spans already flushed for this read   (wave-uniform)
-  bool first;      // Supermers.spans :72                    (wave-uniform)
-  bool have_last;  // lastMinimizer != Array()               (wave-uniform)
-  uint64_t last_key;
-  uint64_t base;   // span_region of this read
-  int32_t part_total, part_nd, part_np;  // per-lane partial sums over this read's hits
-};
-
-// ---- staging: 256 characters -> 2-bit codes in the packed ring -------------------------------------------------------
-// Characters 4*lane .. 4*lane+3 of block `blk`; only aligned dwords holding at least one wanted byte are touched.
-__device__ __forceinline__ uint32_t load4(const uint8_t *seq, uint32_t n, uint32_t pos, uint32_t &nchars) {
-  nchars = pos < n ? min(4u, n - pos) : 0u;
-  if (nchars == 0) return 0;
-  uintptr_t a = (uintptr_t)(seq + pos);
-  const uint32_t *al = (const uint32_t *)(a & ~(uintptr_t)3);
-  uint32_t mis = (uint32_t)(a & 3);
-  uint32_t d0 = al[0], d1 = 0;
-  if (mis != 0 && nchars > 4 - mis) d1 = al[1];
-  uint32_t v = mis ? __builtin_amdgcn_alignbyte(d1, d0, mis) : d0;
-  if (nchars < 4) v &= (1u << (nchars * 8)) - 1;
-  return v;
+__device__ __forceinline__ int lanes_below(uint64_t mask) {  // popcount(mask & lanes lower than this one)
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
+// ---- staging: 256 characters -> 2-bit codes in the two rings ----------------------------------------------------------
 // returns true in lanes that saw a character outside ACGTUacgtu (BitRepresentation.isValid, BitRepresentation.scala:140-143)
 __device__ __forceinline__ bool stage_block(WaveLds *L, const uint8_t *seq, uint32_t n, uint32_t blk, int lane) {
-  uint32_t nchars;
-  uint32_t v = load4(seq, n, blk * 256 + lane * 4, nchars);
-  bool bad = false;
-  const uint32_t VMASK = 1u | (1u << 2) | (1u << 6) | (1u << 0x13) | (1u << 0x14);  // A C G T U minus 'A'
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    uint32_t x = (((v >> (8 * j)) & 0xDF) - 0x41);
-    bool ok = x < 32 && ((VMASK >> x) & 1);
-    bad |= (j < (int)nchars) && !ok;
+  uint32_t pos = blk * 256 + lane * 4;
+  uint32_t nchars = pos < n ? min(4u, n - pos) : 0u;
+  uint32_t v = 0x41414141u;  // missing characters read as 'A' (never used by a window, never "bad")
+  if (nchars == 4) {
+    __builtin_memcpy(&v, seq + pos, 4);  // unaligned dword load
+  } else if (nchars > 0) {               // the fragment's last 1-3 characters: byte loads, nothing past the end is touched
+    uint32_t t = 0;
+    for (uint32_t j = 0; j < nchars; j++) t |= (uint32_t)seq[pos + j] << (8 * j);
+    v = (v & ~((1u << (8 * nchars)) - 1)) | t;
   }
+  // valid <=> (c & 0xC0) == 0x40 and (c & 0x1F) in {1,3,7,20,21}  (A C G T U, either case)
+  const uint32_t VM = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20) | (1u << 21);
+  uint32_t okbits = (VM >> (v & 31)) & (VM >> ((v >> 8) & 31)) & (VM >> ((v >> 16) & 31)) & (VM >> ((v >> 24) & 31)) & 1u;
+  bool bad = ((v & 0xC0C0C0C0u) != 0x40404040u) || okbits == 0;
   // (c >> 1) & 3 maps A,C,T/U,G (either case) to 0,1,2,3; x ^ (x >> 1) turns that into A=0 C=1 G=2 T=3
   uint32_t t = (v >> 1) & 0x03030303u;
   t ^= (t >> 1) & 0x01010101u;
   uint32_t pack = (t * 0x40100401u) >> 24;  // code0<<6 | code1<<4 | code2<<2 | code3
   uint32_t g = (blk * 64 + lane) & 127;     // group of 4 bases within the 512-base ring
-  ((uint8_t *)L->packed)[(g & ~7u) | (7u - (g & 7u))] = (uint8_t)pack;  // MSB-first inside each 64-bit word
+  ((uint8_t *)L->fwd_ring)[(g & ~3u) | (3u - (g & 3u))] = (uint8_t)pack;  // MSB-first inside each dword
+  // reverse complement of the group: complement, reverse the four 2-bit codes
+  uint32_t x = __brev(~pack) >> 24;                         // bit-reversed byte
+  x = ((x >> 1) & 0x55u) | ((x & 0x55u) << 1);              // swap the bits of each pair back
+  uint32_t gr = 127 - g;
+  ((uint8_t *)L->rc_ring)[(gr & ~3u) | (3u - (gr & 3u))] = (uint8_t)x;
   return bad;
+}
+
+// 64 bits of a ring starting at base position p (mod 512), left-aligned
+__device__ __forceinline__ uint64_t ring_bits(const uint32_t *ring, uint32_t p) {
+  uint32_t i = (p >> 4) & 31, s = (p & 15) * 2;
+  uint32_t w0 = ring[i], w1 = ring[(i + 1) & 31], w2 = ring[(i + 2) & 31];
+  uint32_t hi = (uint32_t)(((((uint64_t)w0 << 32) | w1) << s) >> 32);
+  uint32_t lo = (uint32_t)(((((uint64_t)w1 << 32) | w2) << s) >> 32);
+  return ((uint64_t)hi << 32) | lo;
 }
 
 // left-aligned key of the m-mer starting at base q (NTBitArray layout; SpacedSeed(RandomXOR) priority)
 __device__ __forceinline__ uint64_t key_at(const WaveLds *L, const ScanParams &P, uint32_t q) {
-  uint32_t wq = (q >> 5) & 15, o = (q & 31) * 2;
-  uint64_t a = L->packed[wq], b = L->packed[(wq + 1) & 15];
-  uint64_t fwd = o ? ((a << o) | (b >> (64 - o))) : a;
-  fwd &= P.keep;
+  uint64_t fwd = ring_bits(L->fwd_ring, q) & P.keep;
   uint64_t canon = fwd;
   if (P.canonical) {
-    // reverse complement: complement, reverse all 64 bits, swap the two bits of every pair back, drop the padding
-    uint64_t x = __brevll(~fwd);
-    x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
-    uint64_t rc = x << P.sh;
-    canon = umin64(fwd, rc);  // NTBitArray.writeCanonical :258-266
+    uint64_t rc = ring_bits(L->rc_ring, 512u - ((q + P.m) & 511u)) & P.keep;
+    canon = umin64(fwd, rc);  // NTBitArray.writeCanonical :258-266 == unsigned minimum of the two orientations
   }
   return (canon ^ P.xmask) & P.smask;
 }
@@ -159,60 +174,63 @@ __device__ __forceinline__ int32_t map_get(const WaveLds *L, int32_t taxon) {
 }
 
 // Look up the (<= 64) buffered spans [s0, s0+cnt) and return this lane's taxon (lane l <-> span s0+l).
-__device__ __forceinline__ int32_t probe_chunk(WaveLds *L, const TableView &T, int s0, int cnt, int lane) {
+__device__ __forceinline__ int32_t probe_chunk(WaveLds *L, const TableView &T, int s0, int cnt, int lane, int32_t meta) {
   const uint64_t NO_TAG = ~0ULL;  // a real tag has at most 64 - taxon_bits significant bits
-  uint64_t key = 0;
-  int32_t meta = 0;
-  if (lane < cnt) { key = L->span_key[s0 + lane]; meta = L->span_meta[s0 + lane]; }
+  uint64_t key = (lane < cnt) ? L->span_key[s0 + lane] : 0;
   int32_t flag = meta_flag(meta);
   bool seq = (lane < cnt) && flag == 1;
   uint64_t h = fmix64(key);
-  uint64_t bucket = h >> T.shift;
-  uint64_t tag = seq ? ((h & T.rem_mask) << T.disp_bits) : NO_TAG;
-  L->stash[2 * lane] = bucket;
-  L->stash[2 * lane + 1] = tag;
+  ulonglong2 st;
+  st.x = (h >> T.shift) << 6;                                      // byte offset of the home bucket
+  st.y = seq ? ((h & T.rem_mask) << T.disp_bits) : NO_TAG;         // tag at displacement 0
+  ((ulonglong2 *)L->stash)[lane] = st;
   L->result[lane] = 0;
   wave_sync();
   const int g = lane >> 3, c = lane & 7;
   const uint64_t tmask = (1ULL << T.taxon_bits) - 1;
-  // displacement 0: all eight steps' loads in flight before the first compare
-  uint64_t cell[8];
+  const char *cellbase = (const char *)T.cells + c * 8;
+  // displacement 0: four steps' loads (32 HBM lines per wave) in flight before the first compare, twice
+  uint32_t more = 0;  // bit s: my group's span s*8+g overflowed its home bucket and is still unresolved
 #pragma unroll
-  for (int s = 0; s < 8; s++) {
-    int idx = s * 8 + g;
-    uint64_t bkt = L->stash[2 * idx], want = L->stash[2 * idx + 1];
-    cell[s] = 0;
-    if (want != NO_TAG) cell[s] = T.cells[((bkt & T.bucket_mask) << 3) + c];
-  }
-  uint32_t more = 0;  // bit s set: group's span s*8+g must look at the next bucket
+  for (int h4 = 0; h4 < 8; h4 += 4) {
+    uint64_t cell[4];
 #pragma unroll
-  for (int s = 0; s < 8; s++) {
-    uint64_t want = L->stash[2 * (s * 8 + g) + 1];
-    bool act = want != NO_TAG;
-    bool match = act && cell[s] != 0 && (cell[s] >> T.taxon_bits) == want;
-    bool empty = cell[s] == 0;
-    uint64_t mm = __ballot(match), me = __ballot(empty);
-    uint32_t gm = (uint32_t)(mm >> (g * 8)) & 0xFF, ge = (uint32_t)(me >> (g * 8)) & 0xFF;
-    if (match) L->result[s * 8 + g] = (int32_t)(cell[s] & tmask);
-    if (act && gm == 0 && ge == 0) more |= 1u << s;  // bucket full, key not in it: overflowed to a later bucket
-  }
-  // rare: follow bucket-level linear probing (cells are never freed, so the first non-full bucket ends the search)
-  for (int d = 1; d <= T.max_disp && __ballot(more != 0) != 0; d++) {
+    for (int s = 0; s < 4; s++) {
+      ulonglong2 e = ((const ulonglong2 *)L->stash)[(h4 + s) * 8 + g];
+      cell[s] = 0;
+      if (e.y != NO_TAG) cell[s] = *(const uint64_t *)(cellbase + e.x);
+    }
 #pragma unroll
-    for (int s = 0; s < 8; s++) {
-      bool act = (more >> s) & 1;
-      uint64_t cl = 0, want = 0;
-      if (act) {
-        uint64_t bkt = L->stash[2 * (s * 8 + g)];
-        want = L->stash[2 * (s * 8 + g) + 1] + (uint64_t)d;
-        cl = T.cells[(((bkt + d) & T.bucket_mask) << 3) + c];
+    for (int s = 0; s < 4; s++) {
+      uint64_t want = L->stash[2 * ((h4 + s) * 8 + g) + 1];
+      bool act = want != NO_TAG;
+      bool empty = cell[s] == 0;
+      bool match = !empty && (cell[s] >> T.taxon_bits) == want;
+      if (match) L->result[(h4 + s) * 8 + g] = (int32_t)(cell[s] & tmask);
+      // a group is resolved once one of its lanes matched or saw an empty cell (cells are never freed)
+      uint64_t B = __ballot(match || empty || !act);
+      if (((B - 0x0101010101010101ULL) & ~B & 0x8080808080808080ULL) != 0) {  // some group's byte is zero (rare)
+        if (((B >> (g * 8)) & 0xFF) == 0) more |= 1u << (h4 + s);
       }
-      bool match = act && cl != 0 && (cl >> T.taxon_bits) == want;
-      bool empty = cl == 0;
-      uint64_t mm = __ballot(match), me = __ballot(empty);
-      uint32_t gm = (uint32_t)(mm >> (g * 8)) & 0xFF, ge = (uint32_t)(me >> (g * 8)) & 0xFF;
-      if (match) L->result[s * 8 + g] = (int32_t)(cl & tmask);
-      if (act && (gm != 0 || ge != 0)) more &= ~(1u << s);
+    }
+  }
+  if (__ballot(more != 0) != 0) {  // rare: bucket-level linear probing
+    for (int d = 1; d <= T.max_disp && __ballot(more != 0) != 0; d++) {
+      for (int s = 0; s < 8; s++) {
+        bool act = (more >> s) & 1;
+        uint64_t cl = 0, want = 0;
+        if (act) {
+          ulonglong2 e = ((const ulonglong2 *)L->stash)[s * 8 + g];
+          want = e.y + (uint64_t)d;
+          uint64_t off = (e.x + ((uint64_t)d << 6)) & ((T.bucket_mask << 6) | 63);
+          cl = *(const uint64_t *)(cellbase + off);
+        }
+        bool empty = cl == 0;
+        bool match = act && !empty && (cl >> T.taxon_bits) == want;
+        if (match) L->result[s * 8 + g] = (int32_t)(cl & tmask);
+        uint64_t B = __ballot(match || empty);
+        if (act && ((B >> (g * 8)) & 0xFF) != 0) more &= ~(1u << s);
+      }
     }
   }
   wave_sync();
@@ -222,106 +240,6 @@ __device__ __forceinline__ int32_t probe_chunk(WaveLds *L, const TableView &T, i
   return taxon;
 }
 
-template <int MODE>
-__device__ __forceinline__ void flush(Ctx &X, const FusedArgs &A) {
-  WaveLds *L = X.L;
-  const int lane = X.lane;
-  wave_sync();
-  for (int s0 = 0; s0 < X.nbuf; s0 += 64) {
-    int cnt = min(64, X.nbuf - s0);
-    if (MODE == MODE_SPANS) {
-      if (lane < cnt) {
-        A.span_keys[X.base + X.n_out + lane] = L->span_key[s0 + lane];
-        A.span_meta[X.base + X.n_out + lane] = L->span_meta[s0 + lane];
-      }
-    } else {
-      int32_t taxon = probe_chunk(L, A.T, s0, cnt, lane);
-      if (lane < cnt) {
-        int32_t meta = L->span_meta[s0 + lane];
-        int32_t count = meta_kmers(meta);
-        if (taxon != -2) X.part_total += count;                  // TaxonCounts.totalKmers :84-87
-        if (meta_distinct(meta) && taxon != 0) X.part_nd++;       // Classifier.scala:94
-        if (taxon != -1 && taxon != -2) {                         // TaxonCounts.toMap :70-81
-          X.part_np++;
-          map_insert(L, taxon, count, A.status);
-        }
-        if (MODE == MODE_HITS) {
-          A.span_meta[X.base + X.n_out + lane] = meta;
-          A.span_taxon[X.base + X.n_out + lane] = taxon;
-        }
-      }
-    }
-    X.n_out += cnt;
-  }
-  X.nbuf = 0;
-  wave_sync();
-}
-
-// ---- scan, fast path: every character of the mate is a nucleotide ----------------------------------------------------
-template <int MODE>
-__device__ void scan_mate_fast(Ctx &X, const FusedArgs &A, const uint8_t *seq, uint32_t n, uint32_t staged) {
-  const ScanParams &P = A.P;
-  WaveLds *L = X.L;
-  const int lane = X.lane;
-  const int w = P.w;
-  const uint32_t nwin = n - P.k + 1;           // caller guarantees n >= k
-  const uint32_t STEP = 64 - (w - 1);          // windows per round
-  uint32_t blk = staged / 256;
-  uint64_t carry_val = 0;
-  int carry_run = 0;
-  bool seg_first = true;                       // no span of this segment emitted yet
-  for (uint32_t i0 = 0; i0 < nwin; i0 += STEP) {
-    uint32_t need = min(n, i0 + 64 + P.m - 1);
-    while (staged < need) {
-      stage_block(L, seq, n, blk, lane);
-      blk++;
-      staged += 256;
-    }
-    if (X.nbuf > SPAN_CAP - 66) flush<MODE>(X, A);
-    wave_sync();
-    uint32_t q = i0 + lane;
-    uint64_t key = (q + P.m <= n) ? key_at(L, P, q) : ~0ULL;
-    // minimum over lanes [l, l+w): doubling, then one overlapping step (PosRankWindow's observable result)
-    uint64_t cur = key;
-    int covered = 1;
-    for (; covered * 2 <= w; covered *= 2) cur = umin64(cur, shfl64(cur, lane + covered));
-    uint64_t res = (covered < w) ? umin64(cur, shfl64(cur, lane + (w - covered))) : cur;
-    int nw = (int)min(STEP, nwin - i0);
-    bool valid = lane < nw;
-    uint64_t prev = shfl64(res, lane - 1);
-    bool is_start = valid && (lane == 0 ? (carry_run == 0 || res != carry_val) : (res != prev));
-    uint64_t S = __ballot(is_start);
-    if (S == 0) { carry_run += nw; continue; }  // MinSplitter.splitRead :154-158: equal value => same super-mer
-    int firstl = __builtin_ctzll(S), lastl = 63 - __builtin_clzll(S);
-    bool special = X.first || !X.have_last;     // distinct test of the segment's first span (Supermers.spans :84-86)
-    int nclose = 0;
-    if (carry_run > 0) {
-      if (lane == 0) put_span(L, X.nbuf, carry_val, carry_run + firstl, 1, seg_first ? (special || carry_val != X.last_key) : true);
-      nclose = 1;
-      seg_first = false;
-    }
-    int rank = __popcll(S & ((1ULL << lane) - 1));
-    if (is_start && lane != lastl) {
-      uint64_t rest = S >> (lane + 1);
-      int d = __builtin_ctzll(rest) + 1;
-      bool dist = (seg_first && lane == firstl) ? (special || res != X.last_key) : true;
-      put_span(L, X.nbuf + nclose + rank, res, d, 1, dist);
-    }
-    int emitted = nclose + __popcll(S) - 1;
-    if (emitted > 0) { seg_first = false; X.first = false; }
-    X.nbuf += emitted;
-    carry_val = shfl64(res, lastl);
-    carry_run = nw - lastl;
-  }
-  // the segment's last super-mer
-  if (lane == 0) put_span(L, X.nbuf, carry_val, carry_run, 1, seg_first ? (X.first || !X.have_last || carry_val != X.last_key) : true);
-  X.nbuf += 1;
-  X.first = false;
-  X.have_last = true;
-  X.last_key = carry_val;
-}
-
-// ---- scan, slow path: one lane walks the mate character by character (mates with ambiguous characters) ------------------
 __device__ __forceinline__ int char_code2(uint8_t c) {  // 0..3 nucleotide, 5 anything else (whitespace is not expected here)
   uint32_t x = ((uint32_t)(c & 0xDF)) - 0x41;
   switch (x) {
@@ -334,93 +252,63 @@ __device__ __forceinline__ int char_code2(uint8_t c) {  // 0..3 nucleotide, 5 an
   }
 }
 
-template <int MODE>
-__device__ void scan_mate_slow(Ctx &X, const FusedArgs &A, const uint8_t *seq, uint32_t n) {
-  const ScanParams &P = A.P;
-  WaveLds *L = X.L;
+// One lane walks a mate character by character until it ends or the span buffer is nearly full; state lives in L->seq.
+// Returns the new buffer fill, with bit 16 set once the mate is exhausted.
+__device__ __forceinline__ int seq_scan(WaveLds *L, ScanParams P, const uint8_t *seq, uint32_t n, int nbuf) {
+  SeqState S = L->seq;
   const int k = P.k, m = P.m, w = P.w;
-  // sequential state (meaningful in lane 0 only)
-  uint32_t i = 0, run_len = 0, nvalid = 0;
-  int run_class = 0, head = 0, minage = 0;
-  uint64_t fwd = 0, rc = 0, minv = 0, cur_val = 0;
-  int32_t cur_run = 0;
-  int nbuf = X.nbuf;
-  bool first = X.first, have_last = X.have_last;
-  uint64_t last_key = X.last_key;
   auto emit = [&](uint64_t key, int32_t kmers, int32_t flag) {
     bool seqlike = flag == 1;
-    bool distinct = seqlike && (first || !(have_last && key == last_key));
-    if (seqlike) { last_key = key; have_last = true; }
-    first = false;
+    bool distinct = seqlike && (S.first || !(S.have_last && key == S.last_key));  // Supermers.spans :84-90
+    if (seqlike) { S.last_key = key; S.have_last = 1; }
+    S.first = 0;
+    S.total += kmers;
     put_span(L, nbuf, seqlike ? key : 0, kmers, flag, distinct);
     nbuf++;
   };
-  bool done = false;
-  while (!done) {
-    if (X.lane == 0) {
-      while (i <= n && nbuf < SPAN_CAP - 2) {
-        int t = 5, cls = -1;
-        if (i < n) { t = char_code2(seq[i]); cls = (t < 4) ? 1 : 0; }
-        if (run_len > 0 && cls != run_class) {
-          if (run_class == 1 && nvalid >= (uint32_t)k) emit(cur_val, cur_run, 1);
-          else if (run_len >= (uint32_t)k) emit(0, (int32_t)run_len - (k - 1), 2);  // Supermers.scala:116-119
-          run_len = 0;
-        }
-        if (i == n) { i++; break; }
-        if (run_len == 0) { run_class = cls; nvalid = 0; fwd = 0; rc = 0; head = w - 1; minage = 0; minv = ~0ULL; cur_run = 0; }
-        run_len++;
-        if (t < 4) {
-          nvalid++;
-          fwd = (fwd << 2) | ((uint64_t)t << P.sh);
-          rc = ((rc >> 2) | ((uint64_t)(3 - t) << 62)) & P.keep;
-          if (nvalid >= (uint32_t)m) {
-            uint64_t canon = (P.canonical && rc < fwd) ? rc : fwd;
-            uint64_t key = (canon ^ P.xmask) & P.smask;
-            head = (head + 1 == w) ? 0 : head + 1;
-            L->seq_ring[head] = key;
-            if (key <= minv) { minv = key; minage = 0; }
-            else if (++minage >= w) {
-              int slot = (head + 1 == w) ? 0 : head + 1;
-              minv = ~0ULL;
-              for (int a = w - 1; a >= 0; a--) {
-                uint64_t v = L->seq_ring[slot];
-                if (v <= minv) { minv = v; minage = a; }
-                slot = (slot + 1 == w) ? 0 : slot + 1;
-              }
-            }
-            if (nvalid >= (uint32_t)k) {
-              if (cur_run == 0) { cur_val = minv; cur_run = 1; }
-              else if (minv == cur_val) cur_run++;
-              else { emit(cur_val, cur_run, 1); cur_val = minv; cur_run = 1; }
-            }
+  while (S.i <= n && nbuf < SPAN_CAP - 2) {
+    int t = 5, cls = -1;
+    if (S.i < n) { t = char_code2(seq[S.i]); cls = (t < 4) ? 1 : 0; }
+    if (S.run_len > 0 && cls != S.run_class) {
+      if (S.run_class == 1 && S.nvalid >= (uint32_t)k) emit(S.cur_val, S.cur_run, 1);
+      else if (S.run_len >= (uint32_t)k) emit(0, (int32_t)S.run_len - (k - 1), 2);  // Supermers.scala:116-119
+      S.run_len = 0;
+    }
+    if (S.i == n) { S.i++; break; }
+    if (S.run_len == 0) {
+      S.run_class = cls; S.nvalid = 0; S.fwd = 0; S.rc = 0; S.head = w - 1; S.minage = 0; S.minv = ~0ULL; S.cur_run = 0;
+    }
+    S.run_len++;
+    if (t < 4) {
+      S.nvalid++;
+      S.fwd = (S.fwd << 2) | ((uint64_t)t << P.sh);
+      S.rc = ((S.rc >> 2) | ((uint64_t)(3 - t) << 62)) & P.keep;
+      if (S.nvalid >= (uint32_t)m) {
+        uint64_t canon = (P.canonical && S.rc < S.fwd) ? S.rc : S.fwd;
+        uint64_t key = (canon ^ P.xmask) & P.smask;
+        S.head = (S.head + 1 == w) ? 0 : S.head + 1;
+        L->seq_ring[S.head] = key;
+        if (key <= S.minv) { S.minv = key; S.minage = 0; }
+        else if (++S.minage >= w) {
+          int slot = (S.head + 1 == w) ? 0 : S.head + 1;
+          S.minv = ~0ULL;
+          for (int a = w - 1; a >= 0; a--) {
+            uint64_t v = L->seq_ring[slot];
+            if (v <= S.minv) { S.minv = v; S.minage = a; }
+            slot = (slot + 1 == w) ? 0 : slot + 1;
           }
         }
-        i++;
+        if (S.nvalid >= (uint32_t)k) {
+          if (S.cur_run == 0) { S.cur_val = S.minv; S.cur_run = 1; }
+          else if (S.minv == S.cur_val) S.cur_run++;
+          else { emit(S.cur_val, S.cur_run, 1); S.cur_val = S.minv; S.cur_run = 1; }
+        }
       }
     }
-    X.nbuf = __builtin_amdgcn_readfirstlane(nbuf);
-    done = __builtin_amdgcn_readfirstlane((int)(i > n)) != 0;
-    if (!done) flush<MODE>(X, A);
-    nbuf = X.nbuf;
+    S.i++;
   }
-  X.first = __builtin_amdgcn_readfirstlane((int)first) != 0;
-  X.have_last = __builtin_amdgcn_readfirstlane((int)have_last) != 0;
-  X.last_key = bcast64(last_key);
-}
-
-template <int MODE>
-__device__ void scan_mate(Ctx &X, const FusedArgs &A, const uint8_t *seq, uint32_t n) {
-  // pre-scan: any character outside ACGTUacgtu? (stages block 0 as a side effect)
-  bool bad = false;
-  uint32_t nblk = (n + 255) / 256;
-  for (uint32_t b = nblk; b-- > 0;) bad |= stage_block(X.L, seq, n, b, X.lane);  // block 0 last: it stays staged
-  bool any_bad = __ballot(bad) != 0;
-  if (any_bad) {
-    scan_mate_slow<MODE>(X, A, seq, n);
-  } else if (n >= (uint32_t)A.P.k) {
-    // blocks were staged in descending order, so the ring's two halves end up holding blocks 0 and 1
-    scan_mate_fast<MODE>(X, A, seq, n, min(nblk, 2u) * 256);
-  }  // an all-valid mate shorter than k yields nothing (Supermers.scala:116)
+  L->seq = S;
+  return nbuf | ((S.i > n) ? 0x10000 : 0);
 }
 
 // LowestCommonAncestor.apply :49-78 (wave-uniform arguments and control flow)
@@ -432,102 +320,292 @@ __device__ int32_t lca_uniform(const int32_t *parents, int32_t ntax, int32_t a, 
   return 1;
 }
 
+// resolveTree over the LDS map (the general case: at least two distinct non-NONE taxa)
+__device__ __forceinline__ void resolve_map(WaveLds *L, const FusedArgs &A, uint64_t r, int lane, int32_t total, int32_t nd) {
+  int2 *dense = (int2 *)L->stash;
+  int D = 0;
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    int slot = lane + 64 * half;
+    int32_t kk = L->map_key[slot];
+    bool occ = kk != MAP_EMPTY;
+    uint64_t mask = __ballot(occ);
+    if (occ) dense[D + lanes_below(mask)] = make_int2(kk, L->map_cnt[slot]);
+    D += __popcll(mask);
+  }
+  wave_sync();
+  // step 1 (:101-123): LCA of the taxa with the maximal root-path score
+  int32_t maxTaxon = 0, best = 0;
+  for (int b0 = 0; b0 < D; b0 += 64) {
+    int i = b0 + lane;
+    bool act = i < D;
+    int32_t t = act ? dense[i].x : 0;
+    int32_t score = 0;
+    for (int32_t node = t; node != 0; node = ((uint32_t)node < (uint32_t)A.ntax) ? A.parents[node] : 0)
+      score += map_get(L, node);
+    int32_t mx = wave_max(act ? score : -1);
+    if (mx > best) { best = mx; maxTaxon = 0; }
+    if (mx == best && best > 0) {
+      uint64_t tie = __ballot(act && score == best && t != 0);
+      while (tie) {
+        int bl = __builtin_ctzll(tie);
+        tie &= tie - 1;
+        maxTaxon = lca_uniform(A.parents, A.ntax, maxTaxon, __builtin_amdgcn_readlane(t, bl));
+      }
+    }
+  }
+  for (int32_t c = 0; c < A.C; c++) {
+    double required = ceil(__dmul_rn(A.thresholds[c], (double)total));  // Math.ceil(confidence * totalKmers) :94
+    int32_t mt = maxTaxon;
+    int32_t ms = map_get(L, mt);  // :125
+    while (mt != 0 && (double)ms < required) {  // :126-144
+      int32_t sum = 0;
+      for (int b0 = 0; b0 < D; b0 += 64) {
+        int i = b0 + lane;
+        if (i < D) {
+          int2 e = dense[i];
+          for (int32_t x = e.x; x != 0; x = ((uint32_t)x < (uint32_t)A.ntax) ? A.parents[x] : 0)
+            if (x == mt) { sum += e.y; break; }  // Taxonomy.hasAncestor :236-244
+        }
+      }
+      ms = wave_sum(sum);
+      if ((double)ms >= required) break;
+      mt = ((uint32_t)mt < (uint32_t)A.ntax) ? A.parents[mt] : 0;
+    }
+    bool classified = (mt != 0) && (nd >= A.min_hit_groups);  // Classifier.scala:445
+    if (lane == 0) {
+      A.out_taxon[(uint64_t)c * A.R + r] = classified ? mt : 0;
+      A.out_classified[(uint64_t)c * A.R + r] = classified ? 1 : 0;
+    }
+  }
+}
+
+enum { PH_START = 0, PH_FAST = 1, PH_SLOW = 2, PH_NEXT = 3 };
+
+// SLK_WPS: waves per SIMD the register allocator must leave room for (k blocks of 256 threads per CU <=> k waves/SIMD)
+#ifndef SLK_WPS
+#define SLK_WPS 0
+#endif
+#if SLK_WPS > 0
+#define FUSED_BOUNDS __launch_bounds__(FW * 64, SLK_WPS)
+#else
+#define FUSED_BOUNDS __launch_bounds__(FW * 64)
+#endif
+
 template <int MODE>
-__global__ void __launch_bounds__(FW * 64) fused_kernel(FusedArgs A) {
+__global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
   __shared__ WaveLds lds[FW];
   const int lane = threadIdx.x & 63;
-  const int wib = threadIdx.x >> 6;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps per-read state in SGPRs
   WaveLds *L = &lds[wib];
+  const ScanParams &P = A.P;
+  const int w = P.w;
+  const uint32_t STEP = 64 - (w - 1);  // k-mer windows resolved per round
   const uint64_t nwaves = (uint64_t)gridDim.x * FW;
   for (uint64_t r = (uint64_t)blockIdx.x * FW + wib; r < A.R; r += nwaves) {
-    Ctx X;
-    X.L = L; X.lane = lane; X.nbuf = 0; X.n_out = 0;
-    X.first = true; X.have_last = false; X.last_key = 0;
-    X.base = span_region(A.offsets, A.mate_offsets, r);
-    X.part_total = 0; X.part_nd = 0; X.part_np = 0;
+    // ---- per-fragment state (wave-uniform unless noted) ----
+    int nbuf = 0, n_out = 0;
+    bool first = true, have_last = false;   // Supermers.spans :72-73
+    uint64_t last_key = 0;
+    const uint64_t base = span_region(A.offsets, A.mate_offsets, r);
+    int32_t total = 0, nd = 0, np = 0, t0 = 0;
+    bool map_mode = false;
+    int32_t acc_t0 = 0, acc_none = 0;       // per-lane partial sums while !map_mode
     if (MODE != MODE_SPANS) {
       L->map_key[lane] = MAP_EMPTY; L->map_key[lane + 64] = MAP_EMPTY;
       L->map_cnt[lane] = 0; L->map_cnt[lane + 64] = 0;
     }
-    uint64_t o0 = A.offsets[r];
-    scan_mate<MODE>(X, A, A.bases + o0, (uint32_t)(A.offsets[r + 1] - o0));
-    if (A.mate_bases) {
-      if (X.nbuf > SPAN_CAP - 2) flush<MODE>(X, A);
-      if (lane == 0) put_span(L, X.nbuf, 0, -(A.P.k - 1), 3, false);  // MATE_PAIR_BORDER (Supermers.scala:53-57)
-      X.nbuf += 1;
-      X.first = false;
-      uint64_t m0 = A.mate_offsets[r];
-      scan_mate<MODE>(X, A, A.mate_bases + m0, (uint32_t)(A.mate_offsets[r + 1] - m0));
+    int mate = 0, phase = PH_START;
+    bool done = false;
+    const uint8_t *seq = nullptr;
+    uint32_t n = 0;
+    // fast-path state
+    uint32_t i0 = 0, nwin = 0, staged = 0, blk = 0;
+    uint64_t carry_val = 0;
+    int carry_run = 0;
+    bool seg_first = true;
+
+    while (true) {
+      // ================= producer: fill the span buffer =================
+      while (!done && nbuf <= SPAN_CAP - 66) {
+        if (phase == PH_START) {
+          if (mate == 0) { uint64_t o = A.offsets[r]; seq = A.bases + o; n = (uint32_t)(A.offsets[r + 1] - o); }
+          else { uint64_t o = A.mate_offsets[r]; seq = A.mate_bases + o; n = (uint32_t)(A.mate_offsets[r + 1] - o); }
+          // pre-scan for characters outside ACGTUacgtu; blocks are staged in descending order, so the ring's two halves
+          // end up holding blocks 0 and 1
+          bool bad = false;
+          uint32_t nblk = (n + 255) / 256;
+          for (uint32_t b = nblk; b-- > 0;) bad |= stage_block(L, seq, n, b, lane);
+          if (__ballot(bad) != 0) {
+            if (lane == 0) {
+              SeqState S{};
+              S.first = first; S.have_last = have_last; S.last_key = last_key;
+              L->seq = S;
+            }
+            wave_sync();
+            phase = PH_SLOW;
+          } else if (n >= (uint32_t)P.k) {
+            nwin = n - P.k + 1;
+            total += (int32_t)nwin;  // the super-mers of a run partition its k-mer windows
+            i0 = 0; staged = min(nblk, 2u) * 256; blk = staged / 256;
+            carry_val = 0; carry_run = 0; seg_first = true;
+            phase = PH_FAST;
+          } else {
+            phase = PH_NEXT;  // an all-valid mate shorter than k yields nothing (Supermers.scala:116)
+          }
+        } else if (phase == PH_FAST) {
+          if (i0 >= nwin) {  // the segment's last super-mer
+            if (lane == 0)
+              put_span(L, nbuf, carry_val, carry_run, 1, seg_first ? (first || !have_last || carry_val != last_key) : true);
+            nbuf += 1;
+            first = false; have_last = true; last_key = carry_val;
+            phase = PH_NEXT;
+            continue;
+          }
+          uint32_t need = min(n, i0 + 64 + P.m - 1);
+          while (staged < need) { stage_block(L, seq, n, blk, lane); blk++; staged += 256; }
+          wave_sync();
+          uint32_t q = i0 + lane;
+          uint64_t key = (q + P.m <= n) ? key_at(L, P, q) : ~0ULL;
+          // minimum over lanes [l, l+w): doubling, then one overlapping step (PosRankWindow's observable result)
+          uint64_t cur = key;
+          int covered = 1;
+          if (w >= 2) { cur = umin64(cur, from_next(cur)); covered = 2; }
+          for (; covered * 2 <= w; covered *= 2) cur = umin64(cur, shfl64(cur, lane + covered));
+          uint64_t res = cur;
+          if (covered < w) {
+            int d = w - covered;
+            res = umin64(cur, d == 1 ? from_next(cur) : shfl64(cur, lane + d));
+          }
+          int nw = (int)min(STEP, nwin - i0);
+          i0 += STEP;
+          uint64_t prev = from_prev(res);
+          bool is_start = (lane < nw) && (lane == 0 ? (carry_run == 0 || res != carry_val) : (res != prev));
+          uint64_t S = __ballot(is_start);
+          if (S == 0) { carry_run += nw; continue; }  // MinSplitter.splitRead :154-158: equal value => same super-mer
+          int firstl = __builtin_ctzll(S), lastl = 63 - __builtin_clzll(S);
+          bool special = first || !have_last;         // distinct test of the segment's first span (Supermers.spans :84-86)
+          int nclose = 0;
+          if (carry_run > 0) {
+            if (lane == 0)
+              put_span(L, nbuf, carry_val, carry_run + firstl, 1, seg_first ? (special || carry_val != last_key) : true);
+            nclose = 1;
+            seg_first = false;
+          }
+          if (is_start && lane != lastl) {
+            int d = __builtin_ctzll(S >> (lane + 1)) + 1;
+            bool dist = (seg_first && lane == firstl) ? (special || res != last_key) : true;
+            put_span(L, nbuf + nclose + lanes_below(S), res, d, 1, dist);
+          }
+          int emitted = nclose + __popcll(S) - 1;
+          if (emitted > 0) { seg_first = false; first = false; }
+          nbuf += emitted;
+          carry_val = readlane64(res, lastl);
+          carry_run = nw - lastl;
+        } else if (phase == PH_SLOW) {
+          int nb = nbuf;
+          if (lane == 0) nb = seq_scan(L, P, seq, n, nbuf);
+          nb = __builtin_amdgcn_readfirstlane(nb);
+          nbuf = nb & 0xFFFF;
+          wave_sync();
+          if (nb & 0x10000) {
+            first = __builtin_amdgcn_readfirstlane(L->seq.first) != 0;
+            have_last = __builtin_amdgcn_readfirstlane(L->seq.have_last) != 0;
+            last_key = bcast64(L->seq.last_key);
+            total += __builtin_amdgcn_readfirstlane(L->seq.total);
+            phase = PH_NEXT;
+          } else {
+            break;  // buffer nearly full: flush, then resume
+          }
+        } else {  // PH_NEXT
+          if (mate == 0 && A.mate_bases) {
+            if (lane == 0) put_span(L, nbuf, 0, -(P.k - 1), 3, false);  // MATE_PAIR_BORDER (Supermers.scala:53-57)
+            nbuf += 1;
+            first = false;
+            mate = 1;
+            phase = PH_START;
+          } else {
+            done = true;
+          }
+        }
+      }
+
+      // ================= consumer: the one flush site =================
+      wave_sync();
+      for (int s0 = 0; s0 < nbuf; s0 += 64) {
+        int cnt = min(64, nbuf - s0);
+        bool in = lane < cnt;
+        if (MODE == MODE_SPANS) {
+          if (in) {
+            A.span_keys[base + n_out + lane] = L->span_key[s0 + lane];
+            A.span_meta[base + n_out + lane] = L->span_meta[s0 + lane];
+          }
+        } else {
+          int32_t meta = in ? L->span_meta[s0 + lane] : 0;
+          int32_t taxon = probe_chunk(L, A.T, s0, cnt, lane, meta);
+          int32_t count = meta_kmers(meta);
+          bool real = in && taxon >= 0;                                           // TaxonCounts.toMap :70-81 keeps these
+          nd += __popcll(__ballot(in && meta_distinct(meta) && taxon != 0));      // Classifier.scala:94
+          np += __popcll(__ballot(real));
+          if (!map_mode) {
+            uint64_t nz = __ballot(real && taxon != 0);
+            if (nz != 0) {
+              if (t0 == 0) t0 = __builtin_amdgcn_readlane(taxon, __builtin_ctzll(nz));
+              if (__ballot(real && taxon != 0 && taxon != t0) != 0) {
+                // a second taxon: move the single-taxon summary into the LDS map and continue there
+                int32_t c0 = wave_sum(acc_t0), cn = wave_sum(acc_none);
+                if (lane == 0 && c0 != 0) map_insert(L, t0, c0, A.status);
+                if (lane == 1 && cn != 0) map_insert(L, 0, cn, A.status);
+                map_mode = true;
+              }
+            }
+          }
+          if (map_mode) {
+            if (real) map_insert(L, taxon, count, A.status);
+          } else if (real) {
+            if (taxon != 0) acc_t0 += count;
+            else acc_none += count;
+          }
+          if (MODE == MODE_HITS && in) {
+            A.span_meta[base + n_out + lane] = meta;
+            A.span_taxon[base + n_out + lane] = taxon;
+          }
+        }
+        n_out += cnt;
+      }
+      nbuf = 0;
+      wave_sync();
+      if (done) break;
     }
-    flush<MODE>(X, A);
+
     if (MODE != MODE_CLASSIFY) {
-      if (lane == 0) A.span_count[r] = X.n_out;
+      if (lane == 0) A.span_count[r] = n_out;
     }
     if (MODE == MODE_SPANS) continue;
 
     // ---- per-read classification -------------------------------------------------------------------------------------
-    int32_t total = wave_sum(X.part_total), nd = wave_sum(X.part_nd), np = wave_sum(X.part_np);
-    // dense list of the map's entries
-    int2 *dense = (int2 *)L->stash;
-    int D = 0;
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-      int slot = lane + 64 * half;
-      int32_t kk = L->map_key[slot];
-      bool occ = kk != MAP_EMPTY;
-      uint64_t mask = __ballot(occ);
-      if (occ) dense[D + __popcll(mask & ((1ULL << lane) - 1))] = make_int2(kk, L->map_cnt[slot]);
-      D += __popcll(mask);
-    }
-    wave_sync();
-    // resolveTree step 1 (:101-123): LCA of the taxa with the maximal root-path score
-    int32_t maxTaxon = 0, best = 0;
-    for (int b0 = 0; b0 < D; b0 += 64) {
-      int i = b0 + lane;
-      bool act = i < D;
-      int32_t t = act ? dense[i].x : 0;
-      int32_t score = 0;
-      for (int32_t node = t; node != 0; node = ((uint32_t)node < (uint32_t)A.ntax) ? A.parents[node] : 0)
-        score += map_get(L, node);
-      int32_t mx = wave_max(act ? score : -1);
-      if (mx > best) { best = mx; maxTaxon = 0; }
-      if (mx == best && best > 0) {
-        uint64_t tie = __ballot(act && score == best && t != 0);
-        while (tie) {
-          int bl = __builtin_ctzll(tie);
-          tie &= tie - 1;
-          maxTaxon = lca_uniform(A.parents, A.ntax, maxTaxon, __shfl(t, bl));
+    if (map_mode) {
+      resolve_map(L, A, r, lane, total, nd);
+    } else {
+      // Every non-NONE hit names t0 (or there is none): resolveTree's first loop yields t0; lifting it changes nothing
+      // because NONE is in no clade, so the result is t0 iff its own k-mer count reaches the required score (:125-146).
+      bool need_count = false;
+      for (int32_t c = 0; c < A.C; c++) need_count |= A.thresholds[c] > 0.0;
+      int32_t c0 = (need_count && t0 != 0) ? wave_sum(acc_t0) : 0;
+      for (int32_t c = 0; c < A.C; c++) {
+        double required = ceil(__dmul_rn(A.thresholds[c], (double)total));
+        int32_t mt = (t0 != 0 && !((double)c0 < required)) ? t0 : 0;
+        bool classified = (mt != 0) && (nd >= A.min_hit_groups);
+        if (lane == 0) {
+          A.out_taxon[(uint64_t)c * A.R + r] = classified ? mt : 0;
+          A.out_classified[(uint64_t)c * A.R + r] = classified ? 1 : 0;
         }
-      }
-    }
-    for (int32_t c = 0; c < A.C; c++) {
-      double required = ceil(__dmul_rn(A.thresholds[c], (double)total));  // Math.ceil(confidence * totalKmers) :94
-      int32_t mt = maxTaxon;
-      int32_t ms = map_get(L, mt);  // :125
-      while (mt != 0 && (double)ms < required) {  // :126-144
-        int32_t sum = 0;
-        for (int b0 = 0; b0 < D; b0 += 64) {
-          int i = b0 + lane;
-          if (i < D) {
-            int2 e = dense[i];
-            for (int32_t x = e.x; x != 0; x = ((uint32_t)x < (uint32_t)A.ntax) ? A.parents[x] : 0)
-              if (x == mt) { sum += e.y; break; }  // Taxonomy.hasAncestor :236-244
-          }
-        }
-        ms = wave_sum(sum);
-        if ((double)ms >= required) break;
-        mt = ((uint32_t)mt < (uint32_t)A.ntax) ? A.parents[mt] : 0;
-      }
-      bool classified = (mt != 0) && (nd >= A.min_hit_groups);  // Classifier.scala:445
-      if (lane == 0) {
-        A.out_taxon[(uint64_t)c * A.R + r] = classified ? mt : 0;
-        A.out_classified[(uint64_t)c * A.R + r] = classified ? 1 : 0;
       }
     }
     if (lane == 0) {
       if (A.out_nd) A.out_nd[r] = nd;
       if (A.out_tk) A.out_tk[r] = total;
-      if (A.out_nh) A.out_nh[r] = X.n_out;
+      if (A.out_nh) A.out_nh[r] = n_out;
       if (A.out_np) A.out_np[r] = np;
     }
     wave_sync();
