@@ -8,9 +8,9 @@ LIB := slacken_amd/lib/libslacken_amd.so
 
 all: $(LIB) oracle
 
-$(LIB): $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/capi.hip $(CSRC)/engine.h include/slacken_amd.h
+$(LIB): $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/capi.hip $(CSRC)/engine.h include/slacken_amd.h
 	@mkdir -p slacken_amd/lib
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/capi.hip
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/capi.hip
 
 oracle:
 	$(MAKE) -C oracle

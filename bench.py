@@ -102,7 +102,8 @@ def make_reads_device(torch, genome_cat, genome_len, n_genomes, n_reads, seed, d
     for a, b in zip(b"ACGTN", b"TGCAN"):
         comp[a] = b
     acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
-    out = torch.empty((n_reads, READ_LEN), dtype=torch.uint8, device=device)
+    flat = torch.full((n_reads * READ_LEN + 64,), ord("A"), dtype=torch.uint8, device=device)  # 16+ readable pad bytes
+    out = flat[:n_reads * READ_LEN].view(n_reads, READ_LEN)
     ar = torch.arange(READ_LEN, device=device)
     CH = 1 << 20
     for s in range(0, n_reads, CH):
@@ -128,7 +129,7 @@ def make_reads_device(torch, genome_cat, genome_len, n_genomes, n_reads, seed, d
         r = torch.where(run_n[:, None] & in_run, torch.full_like(r, ord("N")), r)
         out[s:s + n] = r
     offsets = torch.arange(0, (n_reads + 1) * READ_LEN, READ_LEN, dtype=torch.int64, device=device)
-    return out.reshape(-1), offsets
+    return flat, offsets
 
 
 def main():

@@ -85,7 +85,7 @@ struct slk_stream {
   hipStream_t s = nullptr;
   DevBuf span_keys, span_meta, span_taxon, span_count;  // per-batch scratch (sparse per-read regions)
   DevBuf bases, offsets, mate_bases, mate_offsets;      // staging for the host-pointer entry points
-  DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items;
+  DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items, defer;
   double *d_thresholds = nullptr;
   double *h_thresholds = nullptr;  // pinned
   int32_t *d_status = nullptr;     // device error bits of the fused kernels
@@ -370,7 +370,7 @@ void slk_stream_destroy(slk_stream *st) {
   (void)hipStreamSynchronize(st->s);
   DevBuf *bufs[] = {&st->span_keys, &st->span_meta, &st->span_taxon, &st->span_count, &st->bases, &st->offsets,
                     &st->mate_bases, &st->mate_offsets, &st->out_taxon, &st->out_cls, &st->out_nd, &st->out_tk,
-                    &st->out_nh, &st->out_offsets, &st->out_items};
+                    &st->out_nh, &st->out_offsets, &st->out_items, &st->defer};
   for (DevBuf *b : bufs) b->release();
   if (st->d_thresholds) (void)hipFree(st->d_thresholds);
   if (st->h_thresholds) (void)hipHostFree(st->h_thresholds);
@@ -407,6 +407,11 @@ static int32_t check_ready(const slk_index *ix, const slk_stream *st, bool need_
 static bool use_fused(const slk_index *ix) {
   static const bool force_v1 = getenv("SLK_FORCE_V1") != nullptr && getenv("SLK_FORCE_V1")[0] == '1';
   return !force_v1 && ix->sp.w <= 32;
+}
+
+static bool force_wave() {  // SLK_FORCE_WAVE=1: A/B switch, classify with the wave-per-read kernel only
+  static const bool v = getenv("SLK_FORCE_WAVE") != nullptr && getenv("SLK_FORCE_WAVE")[0] == '1';
+  return v;
 }
 
 static int32_t check_status(slk_stream *st) {  // call after the stream has been synchronised
@@ -448,6 +453,14 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
     A.span_taxon = want_hits ? st->span_taxon.as<int32_t>() : nullptr;
     A.span_count = want_hits ? st->span_count.as<int32_t>() : nullptr;
     A.status = st->d_status;
+    A.only_flagged = nullptr;
+    if (!want_hits && ix->sp.w <= 16 && !force_wave()) {
+      // hot path: one lane per fragment; long fragments and map overflows are deferred to the wave-per-read kernel
+      HIPCHK(st->defer.ensure((R + 64) * sizeof(int32_t)));
+      HIPCHK(hipMemsetAsync(st->defer.p, 0, (R + 64) * sizeof(int32_t), st->s));
+      launch_lane(A, st->defer.as<int32_t>(), 1024, st->s);
+      A.only_flagged = st->defer.as<int32_t>();
+    }
     launch_fused(want_hits ? MODE_HITS : MODE_CLASSIFY, A, st->s);
     HIPCHK(hipEventRecord(st->ev[1], st->s));
     HIPCHK(hipEventRecord(st->ev[2], st->s));

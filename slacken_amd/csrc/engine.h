@@ -84,10 +84,13 @@ struct FusedArgs {
   int32_t *span_taxon;   // MODE_HITS output
   int32_t *span_count;   // MODE_SPANS / MODE_HITS output
   int32_t *status;       // device error bits: 1 = taxon map overflow
+  const int32_t *only_flagged;  // if set, the fused kernel processes only fragments r with only_flagged[r] != 0
 };
 
 enum { MODE_SPANS = 0, MODE_CLASSIFY = 1, MODE_HITS = 2 };
 void launch_fused(int mode, const FusedArgs &A, hipStream_t s);
+// lane-per-fragment classify kernel (lane.hip); fragments it cannot take are flagged in defer[] for launch_fused
+void launch_lane(const FusedArgs &A, int32_t *defer, uint32_t max_len, hipStream_t s);
 
 // launchers (kernels.hip)
 void launch_table_insert(const TableBuild &t, const int64_t *keys, const int32_t *taxa, uint64_t n, hipStream_t s);

@@ -402,7 +402,18 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
   const int w = P.w;
   const uint32_t STEP = 64 - (w - 1);  // k-mer windows resolved per round
   const uint64_t nwaves = (uint64_t)gridDim.x * FW;
-  for (uint64_t r = (uint64_t)blockIdx.x * FW + wib; r < A.R; r += nwaves) {
+  // Work list: every fragment, or (only_flagged) the fragments the lane kernel deferred -- found 64 at a time by ballot.
+  const uint64_t nunits = A.only_flagged ? (A.R + 63) / 64 : A.R;
+  for (uint64_t unit = (uint64_t)blockIdx.x * FW + wib; unit < nunits; unit += nwaves) {
+   uint64_t pending = 1;
+   if (A.only_flagged) {
+     uint64_t rr = unit * 64 + lane;
+     pending = __ballot(rr < A.R && A.only_flagged[rr] != 0);
+   }
+   while (pending) {
+    uint64_t r = unit;
+    if (A.only_flagged) r = unit * 64 + __builtin_ctzll(pending);
+    pending &= pending - 1;
     // ---- per-fragment state (wave-uniform unless noted) ----
     int nbuf = 0, n_out = 0;
     bool first = true, have_last = false;   // Supermers.spans :72-73
@@ -581,7 +592,7 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
     if (MODE != MODE_CLASSIFY) {
       if (lane == 0) A.span_count[r] = n_out;
     }
-    if (MODE == MODE_SPANS) continue;
+    if (MODE == MODE_SPANS) { wave_sync(); continue; }
 
     // ---- per-read classification -------------------------------------------------------------------------------------
     if (map_mode) {
@@ -609,6 +620,7 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
       if (A.out_np) A.out_np[r] = np;
     }
     wave_sync();
+   }
   }
 }
 

@@ -1,0 +1,421 @@
+// lane.hip -- the hot-path kernel for short fragments: ONE LANE PER FRAGMENT (64 fragments per wavefront, in lockstep),
+// scan -> probe -> per-read LCA in one launch with no HBM intermediates.  gfx950, wave64; integer/byte work, no MFMA.
+//
+// Why this shape: the per-read control flow of the classify path (ambiguity runs, run-length merging, distinct tracking,
+// the taxon map) is cheap per lane but expensive per wave; with one lane per read it costs nothing in scalar instructions
+// and every vector instruction does 64 reads' worth of work.  What a lane cannot do efficiently alone is the table probe
+// (a whole 64-byte bucket per lane costs 4x the address-unit work), so minimizers are pushed into a wave-shared LDS queue
+// and probed cooperatively: 8 lanes read one bucket (8 x 8 B = one HBM line), 8 probes per wave instruction.
+//
+//   scan    each lane streams its read 16 bytes at a time (prefetched), rolls the forward and reverse-complement m-mer,
+//           takes the canonical / XOR / spaced-seed key, a width-w sliding minimum (registers for w = 5, a van-Herk
+//           prefix/suffix ring in LDS otherwise) and merges equal consecutive minima into super-mer spans.
+//           Reference: KeyValueIndex.getSpans (S/slacken/KeyValueIndex.scala:163-173) = Supermers.splitByAmbiguity /
+//           splitFragment / spans (S/slacken/Supermers.scala:49-125,150-189), MinSplitter.splitRead
+//           (S/kmers/minimizer/MinSplitter.scala:133-172), PosRankWindow (PosRankWindow.scala:33-97), ShiftScanner.allMatches
+//           (ShiftScanner.scala:90-159), RandomXOR/SpacedSeed (MinimizerPriorities.scala:144-321).
+//   probe   the left join + spanToHit (S/slacken/Classifier.scala:84-88, KeyValueIndex.scala:176-185).
+//   LCA     hits are folded (LDS atomics) into an 8-slot taxon->count map per read; NONE hits are never needed by
+//           resolveTree and are only counted; one distinct taxon is resolved without touching the tree.
+//           Reference: TaxonCounts.toMap/totalKmers (S/slacken/TaxonCounts.scala:70-87), LowestCommonAncestor
+//           (S/slacken/LowestCommonAncestor.scala:49-146), Classifier.classify (S/slacken/Classifier.scala:439-454).
+// Fragments longer than LANE_MAX_LEN, and fragments whose 8-slot map overflows, are flagged in `defer` and re-done by the
+// wave-per-read kernel of fused.hip in the same stream.
+#include "engine.h"
+
+namespace slk {
+
+constexpr int LW = 4;             // waves per block
+constexpr int QCAP = 128;         // probe queue entries per wave (64 buffered + at most 64 pushed per step)
+constexpr int OMAP = 8;           // taxon map slots per fragment
+constexpr int32_t OMAP_EMPTY = -1;
+
+struct __attribute__((aligned(16))) LaneLds {
+  uint64_t q_key[QCAP];
+  uint32_t q_meta[QCAP];          // owner lane (6 bits) | distinct << 6 | kmers << 7
+  uint64_t stash[128];            // (bucket byte offset, tag) per queue entry of the batch
+  int32_t result[64];
+  int32_t omap_key[OMAP * 64];    // [slot][owner lane]
+  int32_t omap_cnt[OMAP * 64];
+  int32_t o_nd[64];               // hits with distinct && taxon != NONE (Classifier.scala:94)
+  int32_t o_ovf[64];              // map overflow flag
+};
+
+__device__ __forceinline__ void lane_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ uint64_t lmin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+
+// Probe the first `cnt` (<= 64) queue entries and fold the hits into their owners' maps.
+__device__ __forceinline__ void probe_batch(LaneLds *L, const TableView &T, int cnt, int lane) {
+  const uint64_t NO_TAG = ~0ULL;
+  bool in = lane < cnt;
+  uint64_t key = in ? L->q_key[lane] : 0;
+  uint32_t meta = in ? L->q_meta[lane] : 0;
+  uint64_t h = fmix64(key);
+  ulonglong2 st;
+  st.x = (h >> T.shift) << 6;
+  st.y = in ? ((h & T.rem_mask) << T.disp_bits) : NO_TAG;
+  ((ulonglong2 *)L->stash)[lane] = st;
+  L->result[lane] = 0;
+  lane_wave_sync();
+  const int g = lane >> 3, c = lane & 7;
+  const uint64_t tmask = (1ULL << T.taxon_bits) - 1;
+  const char *cellbase = (const char *)T.cells + c * 8;
+  uint32_t more = 0;
+#pragma unroll
+  for (int h4 = 0; h4 < 8; h4 += 4) {
+    uint64_t cell[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      ulonglong2 e = ((const ulonglong2 *)L->stash)[(h4 + s) * 8 + g];
+      cell[s] = 0;
+      if (e.y != NO_TAG) cell[s] = *(const uint64_t *)(cellbase + e.x);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      uint64_t want = L->stash[2 * ((h4 + s) * 8 + g) + 1];
+      bool act = want != NO_TAG;
+      bool empty = cell[s] == 0;
+      bool match = !empty && (cell[s] >> T.taxon_bits) == want;
+      if (match) L->result[(h4 + s) * 8 + g] = (int32_t)(cell[s] & tmask);
+      uint64_t B = __ballot(match || empty || !act);  // a group is resolved by a match or by an empty cell
+      if (((B - 0x0101010101010101ULL) & ~B & 0x8080808080808080ULL) != 0) {
+        if (((B >> (g * 8)) & 0xFF) == 0) more |= 1u << (h4 + s);
+      }
+    }
+  }
+  if (__ballot(more != 0) != 0) {  // rare: the key overflowed its home bucket
+    for (int d = 1; d <= T.max_disp && __ballot(more != 0) != 0; d++) {
+      for (int s = 0; s < 8; s++) {
+        bool act = (more >> s) & 1;
+        uint64_t cl = 0, want = 0;
+        if (act) {
+          ulonglong2 e = ((const ulonglong2 *)L->stash)[s * 8 + g];
+          want = e.y + (uint64_t)d;
+          uint64_t off = (e.x + ((uint64_t)d << 6)) & ((T.bucket_mask << 6) | 63);
+          cl = *(const uint64_t *)(cellbase + off);
+        }
+        bool empty = cl == 0;
+        bool match = act && !empty && (cl >> T.taxon_bits) == want;
+        if (match) L->result[s * 8 + g] = (int32_t)(cl & tmask);
+        uint64_t B = __ballot(match || empty);
+        if (act && ((B >> (g * 8)) & 0xFF) != 0) more &= ~(1u << s);
+      }
+    }
+  }
+  lane_wave_sync();
+  // deliver: entry lane -> owner's map (NONE hits carry no information for resolveTree)
+  int32_t taxon = L->result[lane];
+  if (in && taxon != 0) {
+    int owner = meta & 63;
+    int32_t kmers = (int32_t)(meta >> 7);
+    if (meta & 64) atomicAdd(&L->o_nd[owner], 1);
+    uint32_t slot = ((uint32_t)taxon * 0x9E3779B1u) >> 29;
+    int p = 0;
+    for (; p < OMAP; p++) {
+      int32_t old = atomicCAS(&L->omap_key[slot * 64 + owner], OMAP_EMPTY, taxon);
+      if (old == OMAP_EMPTY || old == taxon) { atomicAdd(&L->omap_cnt[slot * 64 + owner], kmers); break; }
+      slot = (slot + 1) & (OMAP - 1);
+    }
+    if (p == OMAP) L->o_ovf[owner] = 1;
+  }
+  lane_wave_sync();
+}
+
+struct OwnerMap {  // this lane's column of the LDS maps
+  const LaneLds *L;
+  int lane;
+  __device__ __forceinline__ int32_t key(int s) const { return L->omap_key[s * 64 + lane]; }
+  __device__ __forceinline__ int32_t cnt(int s) const { return L->omap_cnt[s * 64 + lane]; }
+  __device__ __forceinline__ int32_t get(int32_t t) const {
+    for (int s = 0; s < OMAP; s++) if (key(s) == t) return cnt(s);
+    return 0;
+  }
+};
+
+__device__ __forceinline__ int32_t lane_parent(const int32_t *parents, int32_t ntax, int32_t t) {
+  return ((uint32_t)t < (uint32_t)ntax) ? parents[t] : 0;
+}
+// LowestCommonAncestor.apply :49-78 without the path buffer
+__device__ int32_t lane_lca(const int32_t *parents, int32_t ntax, int32_t a, int32_t b) {
+  if (a == 0 || b == 0) return b == 0 ? a : b;
+  for (int32_t y = b; y != 0; y = lane_parent(parents, ntax, y))
+    for (int32_t x = a; x != 0; x = lane_parent(parents, ntax, x))
+      if (x == y) return y;
+  return 1;
+}
+
+// BitRepresentation.charToTwobit (BitRepresentation.scala:127-135) for one character: 0..3, or 5 for anything else
+__device__ __forceinline__ int lane_code(uint32_t c) {
+  const uint32_t VM = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20) | (1u << 21);  // A C G T U, either case
+  bool ok = ((c & 0xC0) == 0x40) && ((VM >> (c & 31)) & 1);
+  uint32_t t = (c >> 1) & 3;  // A,C,T/U,G -> 0,1,2,3
+  t ^= t >> 1;                // -> A=0 C=1 G=2 T=3
+  return ok ? (int)t : 5;
+}
+
+template <bool W5>
+__global__ void __launch_bounds__(LW * 64) lane_kernel(FusedArgs A, int32_t *defer, uint32_t max_len) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const ScanParams P = A.P;
+  const int k = P.k, m = P.m, w = P.w;
+  // per-wave LDS: fixed part, then (generic w only) the key ring and the suffix-minimum ring, [w][64] each
+  const size_t per_wave = sizeof(LaneLds) + (W5 ? 0 : (size_t)2 * w * 64 * sizeof(uint64_t));
+  LaneLds *L = (LaneLds *)(lds_raw + (size_t)wib * per_wave);
+  uint64_t *ring = (uint64_t *)((unsigned char *)L + sizeof(LaneLds));
+  uint64_t *suf = ring + (size_t)w * 64;
+  const bool paired = A.mate_bases != nullptr;
+  const uint64_t ntiles = (A.R + 63) / 64;
+  const uint64_t nwaves = (uint64_t)gridDim.x * LW;
+
+  for (uint64_t tile = (uint64_t)blockIdx.x * LW + wib; tile < ntiles; tile += nwaves) {
+    const uint64_t r = tile * 64 + lane;
+    const bool have = r < A.R;
+    // ---- fragment descriptor ----
+    const uint8_t *seq = A.bases;
+    uint32_t n = 0, n2 = 0;
+    const uint8_t *seq2 = nullptr;
+    if (have) {
+      uint64_t o = A.offsets[r];
+      seq = A.bases + o;
+      n = (uint32_t)(A.offsets[r + 1] - o);
+      if (paired) {
+        uint64_t o2 = A.mate_offsets[r];
+        seq2 = A.mate_bases + o2;
+        n2 = (uint32_t)(A.mate_offsets[r + 1] - o2);
+      }
+    }
+    bool too_long = have && ((uint64_t)n + n2 > max_len);
+    bool fin = !have || too_long;
+    // ---- per-lane LDS state ----
+#pragma unroll
+    for (int s = 0; s < OMAP; s++) { L->omap_key[s * 64 + lane] = OMAP_EMPTY; L->omap_cnt[s * 64 + lane] = 0; }
+    L->o_nd[lane] = 0;
+    L->o_ovf[lane] = 0;
+    // ---- scan state ----
+    uint32_t pos = 0;
+    int mate = 0;
+    uint32_t cur = 0, b1 = 0, b2 = 0, b3 = 0;  // 16 buffered characters
+    uint4 nxt = make_uint4(0, 0, 0, 0);         // the next 16, prefetched
+    if (!fin && n > 0) {
+      uint4 v;
+      __builtin_memcpy(&v, seq, 16);
+      cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
+      if (n > 16) __builtin_memcpy(&nxt, seq + 16, 16);
+    }
+    int run_class = 0;
+    uint32_t run_len = 0, nvalid = 0;
+    uint64_t fwd = 0, rc = 0;
+    uint64_t k1 = ~0ULL, p1 = ~0ULL, p2 = ~0ULL, m41 = ~0ULL;  // W5: previous key, pair minima, previous 4-minimum
+    uint64_t pre = ~0ULL;                                      // generic: prefix minimum of the current block
+    uint64_t cur_val = 0;
+    int32_t cur_run = 0;
+    bool first = true, have_last = false;
+    uint64_t last_key = 0;
+    int32_t total = 0, np = 0, nhits = 0;
+    int qn = 0;       // queue fill (wave-uniform)
+    int tphase = 0;   // generic window: step mod w (wave-uniform)
+
+    while (__ballot(!fin) != 0) {
+      bool emit = false;
+      uint64_t ekey = 0;
+      int32_t ekmers = 0;
+      if (!W5 && tphase == 0) pre = ~0ULL;  // a new w-block starts: empty prefix
+      if (!fin) {
+        const bool is_end = pos >= n;
+        int t = 5, cls = -1;
+        if (!is_end) {
+          t = lane_code(cur & 0xFF);
+          cls = (t < 4) ? 1 : 0;
+        }
+        if (run_len > 0 && cls != run_class) {  // the current run ends (Supermers.splitByAmbiguity :150-178)
+          if (run_class == 1 && nvalid >= (uint32_t)k) {
+            emit = true; ekey = cur_val; ekmers = cur_run;  // last super-mer of a SEQUENCE_FLAG run
+          } else if (run_len >= (uint32_t)k) {
+            // AMBIGUOUS_FLAG run of length >= k: one span, kmers = length - (k-1), never looked up (Supermers.scala:116-119)
+            total += (int32_t)run_len - (k - 1);
+            nhits++;
+            first = false;
+          }
+          run_len = 0;
+        }
+        if (is_end) {
+          if (mate == 0 && paired) {  // MATE_PAIR_BORDER pseudo-span (Supermers.scala:53-57): no k-mers, no lookup
+            nhits++;
+            first = false;
+            mate = 1;
+            seq = seq2; n = n2; pos = 0;
+            if (n > 0) {
+              uint4 v;
+              __builtin_memcpy(&v, seq, 16);
+              cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
+              if (n > 16) __builtin_memcpy(&nxt, seq + 16, 16);
+            }
+          } else {
+            fin = true;
+          }
+        } else {
+          if (run_len == 0) {  // a new run starts
+            run_class = cls; nvalid = 0; fwd = 0; rc = 0; cur_run = 0;
+            if (W5) { k1 = ~0ULL; p1 = ~0ULL; p2 = ~0ULL; m41 = ~0ULL; }
+            else { pre = ~0ULL; for (int j = 0; j < w; j++) { ring[j * 64 + lane] = ~0ULL; suf[j * 64 + lane] = ~0ULL; } }
+          }
+          run_len++;
+          if (t < 4) {
+            nvalid++;
+            fwd = (fwd << 2) | ((uint64_t)t << P.sh);                              // NTBitArray.shiftLongArrayKmerLeft :140-150
+            rc = ((rc >> 2) | ((uint64_t)(3 - t) << 62)) & P.keep;
+            if (nvalid >= (uint32_t)m) {
+              uint64_t canon = (P.canonical && rc < fwd) ? rc : fwd;               // NTBitArray.writeCanonical :258-266
+              uint64_t key = (canon ^ P.xmask) & P.smask;                          // RandomXOR, then SpacedSeed
+              uint64_t minv;
+              if (W5) {
+                uint64_t p = lmin64(key, k1);
+                uint64_t m4 = lmin64(p, p2);
+                minv = lmin64(key, m41);  // min of the last five keys
+                k1 = key; p2 = p1; p1 = p; m41 = m4;
+              } else {
+                // van Herk: window = suffix of the previous w-block  U  prefix of the current one (blocks on the step counter)
+                ring[tphase * 64 + lane] = key;
+                pre = lmin64(pre, key);
+                minv = (tphase == w - 1) ? pre : lmin64(pre, suf[(tphase + 1) * 64 + lane]);
+              }
+              if (nvalid >= (uint32_t)k) {  // one k-mer window is complete: its minimizer VALUE is minv
+                if (cur_run == 0) { cur_val = minv; cur_run = 1; }
+                else if (minv == cur_val) cur_run++;                               // MinSplitter.splitRead :154-158
+                else { emit = true; ekey = cur_val; ekmers = cur_run; cur_val = minv; cur_run = 1; }
+              }
+            } else if (!W5) {
+              ring[tphase * 64 + lane] = ~0ULL;
+            }
+          } else if (!W5) {
+            ring[tphase * 64 + lane] = ~0ULL;
+          }
+          // advance the character stream
+          pos++;
+          if ((pos & 3) == 0) { cur = b1; b1 = b2; b2 = b3; }
+          else cur >>= 8;
+          if ((pos & 15) == 0) {
+            cur = nxt.x; b1 = nxt.y; b2 = nxt.z; b3 = nxt.w;
+            if (pos + 16 < n) __builtin_memcpy(&nxt, seq + pos + 16, 16);
+          }
+        }
+      }
+      if (!W5) {  // end of a w-block: rebuild the suffix minima of the block just completed (wave-uniform control flow)
+        if (tphase == w - 1) {
+          uint64_t s = ~0ULL;
+          for (int j = w - 1; j >= 0; j--) { s = lmin64(s, ring[j * 64 + lane]); suf[j * 64 + lane] = s; }
+          tphase = 0;
+        } else {
+          tphase++;
+        }
+      }
+      // ---- queue the emitted sequence spans ----
+      bool distinct = false;
+      if (emit) {
+        distinct = first || !(have_last && ekey == last_key);  // Supermers.spans :84-90
+        last_key = ekey; have_last = true; first = false;
+        total += ekmers; np++; nhits++;
+      }
+      uint64_t E = __ballot(emit);
+      if (E != 0) {
+        if (emit) {
+          int slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(E >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)E, 0));
+          L->q_key[slot] = ekey;
+          L->q_meta[slot] = (uint32_t)lane | (distinct ? 64u : 0u) | ((uint32_t)ekmers << 7);
+        }
+        qn += __popcll(E);
+        if (qn >= 64) {
+          lane_wave_sync();
+          probe_batch(L, A.T, 64, lane);
+          int rest = qn - 64;  // < 64
+          uint64_t kk = 0; uint32_t mm = 0;
+          if (lane < rest) { kk = L->q_key[64 + lane]; mm = L->q_meta[64 + lane]; }
+          lane_wave_sync();
+          if (lane < rest) { L->q_key[lane] = kk; L->q_meta[lane] = mm; }
+          qn = rest;
+        }
+      }
+    }
+    if (qn > 0) {
+      lane_wave_sync();
+      probe_batch(L, A.T, qn, lane);
+      qn = 0;
+    }
+    lane_wave_sync();
+
+    // ---- per-read classification (one lane per read) ------------------------------------------------------------------
+    if (have) {
+      if (too_long || L->o_ovf[lane]) {
+        defer[r] = 1;  // re-done by the wave-per-read kernel
+      } else {
+        OwnerMap M{L, lane};
+        const int32_t nd = L->o_nd[lane];
+        int D = 0;
+        int32_t t0 = 0, c0 = 0;
+        for (int s = 0; s < OMAP; s++) {
+          int32_t kk = M.key(s);
+          if (kk != OMAP_EMPTY) { D++; t0 = kk; c0 = M.cnt(s); }
+        }
+        int32_t maxTaxon = t0;  // D <= 1: the single taxon (or NONE)
+        if (D >= 2) {           // resolveTree step 1 (:101-123): LCA of the taxa with the maximal root-path score
+          maxTaxon = 0;
+          int32_t best = 0;
+          for (int s = 0; s < OMAP; s++) {
+            int32_t taxon = M.key(s);
+            if (taxon == OMAP_EMPTY) continue;
+            int32_t score = 0;
+            for (int32_t node = taxon; node != 0; node = lane_parent(A.parents, A.ntax, node)) score += M.get(node);
+            if (score > best) { maxTaxon = taxon; best = score; }
+            else if (score == best) maxTaxon = lane_lca(A.parents, A.ntax, maxTaxon, taxon);
+          }
+        }
+        for (int32_t c = 0; c < A.C; c++) {
+          double required = ceil(__dmul_rn(A.thresholds[c], (double)total));  // Math.ceil(confidence * totalKmers) :94
+          int32_t mt = maxTaxon;
+          int32_t ms = (D >= 2) ? M.get(mt) : c0;                             // :125
+          while (mt != 0 && (double)ms < required) {                          // :126-144
+            if (D < 2) { mt = 0; break; }  // one taxon: its clade sum never grows (NONE is in no clade)
+            ms = 0;
+            for (int s = 0; s < OMAP; s++) {
+              int32_t taxon = M.key(s);
+              if (taxon == OMAP_EMPTY) continue;
+              for (int32_t x = taxon; x != 0; x = lane_parent(A.parents, A.ntax, x))
+                if (x == mt) { ms += M.cnt(s); break; }                       // Taxonomy.hasAncestor :236-244
+            }
+            if ((double)ms >= required) break;
+            mt = lane_parent(A.parents, A.ntax, mt);
+          }
+          bool classified = (mt != 0) && (nd >= A.min_hit_groups);            // Classifier.scala:445
+          A.out_taxon[(uint64_t)c * A.R + r] = classified ? mt : 0;
+          A.out_classified[(uint64_t)c * A.R + r] = classified ? 1 : 0;
+        }
+        if (A.out_nd) A.out_nd[r] = nd;
+        if (A.out_tk) A.out_tk[r] = total;
+        if (A.out_nh) A.out_nh[r] = nhits;
+        if (A.out_np) A.out_np[r] = np;
+      }
+    }
+    lane_wave_sync();
+  }
+}
+
+void launch_lane(const FusedArgs &A, int32_t *defer, uint32_t max_len, hipStream_t s) {
+  if (A.R == 0) return;
+  const bool w5 = A.P.w == 5;
+  size_t per_wave = sizeof(LaneLds) + (w5 ? 0 : (size_t)2 * A.P.w * 64 * sizeof(uint64_t));
+  size_t lds = per_wave * LW;
+  uint64_t tiles = (A.R + 63) / 64;
+  uint64_t blocks = (tiles + LW - 1) / LW;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  dim3 g((unsigned)blocks), b(LW * 64);
+  if (w5) hipLaunchKernelGGL(lane_kernel<true>, g, b, lds, s, A, defer, max_len);
+  else hipLaunchKernelGGL(lane_kernel<false>, g, b, lds, s, A, defer, max_len);
+}
+
+}  // namespace slk
