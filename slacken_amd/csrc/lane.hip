@@ -23,6 +23,8 @@
 // wave-per-read kernel of fused.hip in the same stream.
 #include "engine.h"
 
+#include <cstdlib>
+
 namespace slk {
 
 constexpr int LW = 4;             // waves per block
@@ -33,8 +35,7 @@ constexpr int32_t OMAP_EMPTY = -1;
 struct __attribute__((aligned(16))) LaneLds {
   uint64_t q_key[QCAP];
   uint32_t q_meta[QCAP];          // owner lane (6 bits) | distinct << 6 | kmers << 7
-  uint64_t stash[128];            // (bucket byte offset, tag) per queue entry of the batch
-  int32_t result[64];
+  uint64_t stash[128];            // (home bucket, meta, tag) 16 bytes per queue entry of the batch
   int32_t omap_key[OMAP * 64];    // [slot][owner lane]
   int32_t omap_cnt[OMAP * 64];
   int32_t o_nd[64];               // hits with distinct && taxon != NONE (Classifier.scala:94)
@@ -48,79 +49,85 @@ __device__ __forceinline__ void lane_wave_sync() {
 }
 __device__ __forceinline__ uint64_t lmin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
 
-// Probe the first `cnt` (<= 64) queue entries and fold the hits into their owners' maps.
-__device__ __forceinline__ void probe_batch(LaneLds *L, const TableView &T, int cnt, int lane) {
+// Fold one hit into its owner's 8-slot map (LDS atomics; several lanes may deliver to one owner at once).
+__device__ __forceinline__ void deliver(LaneLds *L, uint32_t meta, int32_t taxon) {
+  int owner = meta & 63;
+  int32_t kmers = (int32_t)(meta >> 7);
+  if (meta & 64) atomicAdd(&L->o_nd[owner], 1);  // distinct && taxon != NONE (Classifier.scala:94)
+  uint32_t slot = ((uint32_t)taxon * 0x9E3779B1u) >> 29;
+  int p = 0;
+  for (; p < OMAP; p++) {
+    int32_t old = atomicCAS(&L->omap_key[slot * 64 + owner], OMAP_EMPTY, taxon);
+    if (old == OMAP_EMPTY || old == taxon) { atomicAdd(&L->omap_cnt[slot * 64 + owner], kmers); break; }
+    slot = (slot + 1) & (OMAP - 1);
+  }
+  if (p == OMAP) L->o_ovf[owner] = 1;
+}
+
+// Probe the first `cnt` (<= 64) queue entries and fold the hits into their owners' maps.  FOUR lanes read one 64-byte
+// bucket (4 x 16 B = one HBM line), sixteen probes per wave instruction, four instructions per batch, all in flight
+// before the first compare.  The lane that finds the key delivers the hit itself (NONE hits carry no information for
+// resolveTree and are dropped).
+__device__ __forceinline__ void probe_batch(LaneLds *L, const TableView &T, int cnt, int lane, int dbg) {
   const uint64_t NO_TAG = ~0ULL;
   bool in = lane < cnt;
   uint64_t key = in ? L->q_key[lane] : 0;
   uint32_t meta = in ? L->q_meta[lane] : 0;
   uint64_t h = fmix64(key);
-  ulonglong2 st;
-  st.x = (h >> T.shift) << 6;
-  st.y = in ? ((h & T.rem_mask) << T.disp_bits) : NO_TAG;
-  ((ulonglong2 *)L->stash)[lane] = st;
-  L->result[lane] = 0;
+  uint4 st;
+  st.x = (uint32_t)(h >> T.shift);                                  // home bucket (< 2^32)
+  st.y = meta;
+  uint64_t tag = in ? ((h & T.rem_mask) << T.disp_bits) : NO_TAG;   // tag at displacement 0
+  st.z = (uint32_t)tag; st.w = (uint32_t)(tag >> 32);
+  ((uint4 *)L->stash)[lane] = st;
   lane_wave_sync();
-  const int g = lane >> 3, c = lane & 7;
+  const int g = lane >> 2, c = lane & 3;                            // 16 groups of 4 lanes
   const uint64_t tmask = (1ULL << T.taxon_bits) - 1;
-  const char *cellbase = (const char *)T.cells + c * 8;
+  const char *cellbase = (const char *)T.cells + c * 16;
+  ulonglong2 cell[4];
+  uint4 e[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    e[s] = ((const uint4 *)L->stash)[s * 16 + g];
+    cell[s] = *(const ulonglong2 *)(cellbase + ((uint64_t)e[s].x << 6));  // inactive entries read bucket 0: harmless
+  }
   uint32_t more = 0;
 #pragma unroll
-  for (int h4 = 0; h4 < 8; h4 += 4) {
-    uint64_t cell[4];
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-      ulonglong2 e = ((const ulonglong2 *)L->stash)[(h4 + s) * 8 + g];
-      cell[s] = 0;
-      if (e.y != NO_TAG) cell[s] = *(const uint64_t *)(cellbase + e.x);
+  for (int s = 0; s < 4; s++) {
+    uint64_t want = ((uint64_t)e[s].w << 32) | e[s].z;
+    bool act = want != NO_TAG;
+    bool e0 = cell[s].x == 0, e1 = cell[s].y == 0;
+    bool m0 = act && !e0 && (cell[s].x >> T.taxon_bits) == want;
+    bool m1 = act && !e1 && (cell[s].y >> T.taxon_bits) == want;
+    if ((m0 || m1) && !(dbg & 2)) {
+      int32_t taxon = (int32_t)((m0 ? cell[s].x : cell[s].y) & tmask);
+      deliver(L, e[s].y, taxon);
     }
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-      uint64_t want = L->stash[2 * ((h4 + s) * 8 + g) + 1];
-      bool act = want != NO_TAG;
-      bool empty = cell[s] == 0;
-      bool match = !empty && (cell[s] >> T.taxon_bits) == want;
-      if (match) L->result[(h4 + s) * 8 + g] = (int32_t)(cell[s] & tmask);
-      uint64_t B = __ballot(match || empty || !act);  // a group is resolved by a match or by an empty cell
-      if (((B - 0x0101010101010101ULL) & ~B & 0x8080808080808080ULL) != 0) {
-        if (((B >> (g * 8)) & 0xFF) == 0) more |= 1u << (h4 + s);
-      }
+    uint64_t B = __ballot(m0 || m1 || e0 || e1 || !act);  // a group is resolved by a match or by an empty cell
+    // any group of four lanes with no bit set?  (nibble == 0 test)
+    uint64_t nz = (B | (B >> 1) | (B >> 2) | (B >> 3)) & 0x1111111111111111ULL;
+    if (nz != 0x1111111111111111ULL) {
+      if (((B >> (g * 4)) & 0xF) == 0) more |= 1u << s;
     }
   }
   if (__ballot(more != 0) != 0) {  // rare: the key overflowed its home bucket
     for (int d = 1; d <= T.max_disp && __ballot(more != 0) != 0; d++) {
-      for (int s = 0; s < 8; s++) {
+      for (int s = 0; s < 4; s++) {
         bool act = (more >> s) & 1;
-        uint64_t cl = 0, want = 0;
+        ulonglong2 cl = make_ulonglong2(0, 0);
+        uint64_t want = 0;
         if (act) {
-          ulonglong2 e = ((const ulonglong2 *)L->stash)[s * 8 + g];
-          want = e.y + (uint64_t)d;
-          uint64_t off = (e.x + ((uint64_t)d << 6)) & ((T.bucket_mask << 6) | 63);
-          cl = *(const uint64_t *)(cellbase + off);
+          want = (((uint64_t)e[s].w << 32) | e[s].z) + (uint64_t)d;
+          cl = *(const ulonglong2 *)(cellbase + ((((uint64_t)e[s].x + d) & T.bucket_mask) << 6));
         }
-        bool empty = cl == 0;
-        bool match = act && !empty && (cl >> T.taxon_bits) == want;
-        if (match) L->result[s * 8 + g] = (int32_t)(cl & tmask);
-        uint64_t B = __ballot(match || empty);
-        if (act && ((B >> (g * 8)) & 0xFF) != 0) more &= ~(1u << s);
+        bool e0 = cl.x == 0, e1 = cl.y == 0;
+        bool m0 = act && !e0 && (cl.x >> T.taxon_bits) == want;
+        bool m1 = act && !e1 && (cl.y >> T.taxon_bits) == want;
+        if (m0 || m1) deliver(L, e[s].y, (int32_t)((m0 ? cl.x : cl.y) & tmask));
+        uint64_t B = __ballot(m0 || m1 || e0 || e1);
+        if (act && ((B >> (g * 4)) & 0xF) != 0) more &= ~(1u << s);
       }
     }
-  }
-  lane_wave_sync();
-  // deliver: entry lane -> owner's map (NONE hits carry no information for resolveTree)
-  int32_t taxon = L->result[lane];
-  if (in && taxon != 0) {
-    int owner = meta & 63;
-    int32_t kmers = (int32_t)(meta >> 7);
-    if (meta & 64) atomicAdd(&L->o_nd[owner], 1);
-    uint32_t slot = ((uint32_t)taxon * 0x9E3779B1u) >> 29;
-    int p = 0;
-    for (; p < OMAP; p++) {
-      int32_t old = atomicCAS(&L->omap_key[slot * 64 + owner], OMAP_EMPTY, taxon);
-      if (old == OMAP_EMPTY || old == taxon) { atomicAdd(&L->omap_cnt[slot * 64 + owner], kmers); break; }
-      slot = (slot + 1) & (OMAP - 1);
-    }
-    if (p == OMAP) L->o_ovf[owner] = 1;
   }
   lane_wave_sync();
 }
@@ -158,7 +165,7 @@ __device__ __forceinline__ int lane_code(uint32_t c) {
 }
 
 template <bool W5>
-__global__ void __launch_bounds__(LW * 64) lane_kernel(FusedArgs A, int32_t *defer, uint32_t max_len) {
+__global__ void __launch_bounds__(LW * 64) lane_kernel(FusedArgs A, int32_t *defer, uint32_t max_len, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -221,30 +228,84 @@ __global__ void __launch_bounds__(LW * 64) lane_kernel(FusedArgs A, int32_t *def
     int qn = 0;       // queue fill (wave-uniform)
     int tphase = 0;   // generic window: step mod w (wave-uniform)
 
+    const uint32_t VM = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20) | (1u << 21);  // A C G T U, either case
     while (__ballot(!fin) != 0) {
-      bool emit = false;
-      uint64_t ekey = 0;
-      int32_t ekmers = 0;
+      // One event per lane per step: a character, or the end of a mate.  Straight-line predicated code: the per-read
+      // control flow (Supermers.splitByAmbiguity :150-178, MinSplitter.splitRead :133-172) is data, not branches.
       if (!W5 && tphase == 0) pre = ~0ULL;  // a new w-block starts: empty prefix
-      if (!fin) {
-        const bool is_end = pos >= n;
-        int t = 5, cls = -1;
-        if (!is_end) {
-          t = lane_code(cur & 0xFF);
-          cls = (t < 4) ? 1 : 0;
+      const bool act = !fin;
+      const bool is_end = pos >= n;
+      const uint32_t c = cur & 0xFF;
+      const bool okc = ((c & 0xC0) == 0x40) && ((VM >> (c & 31)) & 1);  // BitRepresentation.isValid :140-143
+      uint32_t t = (c >> 1) & 3;  // A,C,T/U,G -> 0,1,2,3
+      t ^= t >> 1;                // -> A=0 C=1 G=2 T=3 (BitRepresentation.scala:35-39)
+      const int cls = is_end ? -1 : (okc ? 1 : 0);
+      // -- does the current run end here?
+      const bool run_end = act && run_len > 0 && cls != run_class;
+      const bool seqrun = run_class == 1 && nvalid >= (uint32_t)k;
+      const bool seq_close = run_end && seqrun;                              // last super-mer of a SEQUENCE_FLAG run
+      const bool amb_close = run_end && !seqrun && run_len >= (uint32_t)k;   // AMBIGUOUS_FLAG run >= k: one span, no lookup
+      total += amb_close ? (int32_t)run_len - (k - 1) : 0;                   // Supermers.scala:116-119
+      nhits += amb_close ? 1 : 0;
+      first = first && !amb_close;
+      const uint64_t ekey = cur_val;   // what a super-mer closing in this step carries
+      const int32_t ekmers = cur_run;
+      run_len = run_end ? 0u : run_len;
+      // -- consume the character
+      const bool proc = act && !is_end;
+      const bool new_run = proc && run_len == 0;
+      run_class = new_run ? cls : run_class;
+      nvalid = new_run ? 0u : nvalid;
+      cur_run = (new_run || seq_close) ? 0 : cur_run;
+      // (the window state needs no reset: a window is only used once w keys of the new run have been seen)
+      run_len += proc ? 1u : 0u;
+      const bool nt = proc && okc;
+      nvalid += nt ? 1u : 0u;
+      // Rolled unconditionally: whatever a non-nucleotide step shifts in has left the m-mer again before the next key is
+      // taken (a key needs m valid characters in a row, and both words hold exactly m bases).
+      fwd = (fwd << 2) | ((uint64_t)t << P.sh);                               // NTBitArray.shiftLongArrayKmerLeft :140-150
+      rc = ((rc >> 2) | ((uint64_t)(3 - t) << 62)) & P.keep;
+      const bool havekey = nt && nvalid >= (uint32_t)m;
+      const uint64_t canon = (P.canonical && rc < fwd) ? rc : fwd;             // NTBitArray.writeCanonical :258-266
+      const uint64_t key = (canon ^ P.xmask) & P.smask;                        // RandomXOR, then SpacedSeed
+      uint64_t minv;
+      if (W5) {
+        const uint64_t p = lmin64(key, k1);
+        const uint64_t m4 = lmin64(p, p2);
+        minv = lmin64(key, m41);  // minimum of the last five keys
+        // pushed unconditionally: a window is only used once the last five pushes were keys of the current run
+        k1 = key; p2 = p1; p1 = p; m41 = m4;
+      } else {
+        // van Herk: window = suffix of the previous w-block  U  prefix of the current one (blocks on the step counter)
+        const uint64_t kk = havekey ? key : ~0ULL;
+        ring[tphase * 64 + lane] = kk;
+        pre = lmin64(pre, kk);
+        minv = (tphase == w - 1) ? pre : lmin64(pre, suf[(tphase + 1) * 64 + lane]);
+      }
+      const bool havewin = havekey && nvalid >= (uint32_t)k;  // a k-mer window is complete: its minimizer VALUE is minv
+      const bool start = havewin && cur_run == 0;
+      const bool same = havewin && cur_run != 0 && minv == cur_val;            // MinSplitter.splitRead :154-158
+      const bool change = havewin && cur_run != 0 && minv != cur_val;
+      const bool emit = seq_close || change;
+      cur_val = (start || change) ? minv : cur_val;
+      cur_run = (start || change) ? 1 : (same ? cur_run + 1 : cur_run);
+      // -- advance the character stream
+      pos += proc ? 1u : 0u;
+      const bool nextdw = proc && (pos & 3) == 0;
+      cur = nextdw ? b1 : (proc ? (cur >> 8) : cur);
+      b1 = nextdw ? b2 : b1;
+      b2 = nextdw ? b3 : b2;
+      const bool refill = proc && (pos & 15) == 0;
+      if (__ballot(refill) != 0) {
+        if (refill) {
+          cur = nxt.x; b1 = nxt.y; b2 = nxt.z; b3 = nxt.w;
+          if (pos + 16 < n) __builtin_memcpy(&nxt, seq + pos + 16, 16);
         }
-        if (run_len > 0 && cls != run_class) {  // the current run ends (Supermers.splitByAmbiguity :150-178)
-          if (run_class == 1 && nvalid >= (uint32_t)k) {
-            emit = true; ekey = cur_val; ekmers = cur_run;  // last super-mer of a SEQUENCE_FLAG run
-          } else if (run_len >= (uint32_t)k) {
-            // AMBIGUOUS_FLAG run of length >= k: one span, kmers = length - (k-1), never looked up (Supermers.scala:116-119)
-            total += (int32_t)run_len - (k - 1);
-            nhits++;
-            first = false;
-          }
-          run_len = 0;
-        }
-        if (is_end) {
+      }
+      // -- end of a mate (rare; wave-uniform for equal-length reads)
+      const bool at_end = act && is_end;
+      if (__ballot(at_end) != 0) {
+        if (at_end) {
           if (mate == 0 && paired) {  // MATE_PAIR_BORDER pseudo-span (Supermers.scala:53-57): no k-mers, no lookup
             nhits++;
             first = false;
@@ -259,69 +320,25 @@ __global__ void __launch_bounds__(LW * 64) lane_kernel(FusedArgs A, int32_t *def
           } else {
             fin = true;
           }
-        } else {
-          if (run_len == 0) {  // a new run starts
-            run_class = cls; nvalid = 0; fwd = 0; rc = 0; cur_run = 0;
-            if (W5) { k1 = ~0ULL; p1 = ~0ULL; p2 = ~0ULL; m41 = ~0ULL; }
-            else { pre = ~0ULL; for (int j = 0; j < w; j++) { ring[j * 64 + lane] = ~0ULL; suf[j * 64 + lane] = ~0ULL; } }
-          }
-          run_len++;
-          if (t < 4) {
-            nvalid++;
-            fwd = (fwd << 2) | ((uint64_t)t << P.sh);                              // NTBitArray.shiftLongArrayKmerLeft :140-150
-            rc = ((rc >> 2) | ((uint64_t)(3 - t) << 62)) & P.keep;
-            if (nvalid >= (uint32_t)m) {
-              uint64_t canon = (P.canonical && rc < fwd) ? rc : fwd;               // NTBitArray.writeCanonical :258-266
-              uint64_t key = (canon ^ P.xmask) & P.smask;                          // RandomXOR, then SpacedSeed
-              uint64_t minv;
-              if (W5) {
-                uint64_t p = lmin64(key, k1);
-                uint64_t m4 = lmin64(p, p2);
-                minv = lmin64(key, m41);  // min of the last five keys
-                k1 = key; p2 = p1; p1 = p; m41 = m4;
-              } else {
-                // van Herk: window = suffix of the previous w-block  U  prefix of the current one (blocks on the step counter)
-                ring[tphase * 64 + lane] = key;
-                pre = lmin64(pre, key);
-                minv = (tphase == w - 1) ? pre : lmin64(pre, suf[(tphase + 1) * 64 + lane]);
-              }
-              if (nvalid >= (uint32_t)k) {  // one k-mer window is complete: its minimizer VALUE is minv
-                if (cur_run == 0) { cur_val = minv; cur_run = 1; }
-                else if (minv == cur_val) cur_run++;                               // MinSplitter.splitRead :154-158
-                else { emit = true; ekey = cur_val; ekmers = cur_run; cur_val = minv; cur_run = 1; }
-              }
-            } else if (!W5) {
-              ring[tphase * 64 + lane] = ~0ULL;
-            }
-          } else if (!W5) {
-            ring[tphase * 64 + lane] = ~0ULL;
-          }
-          // advance the character stream
-          pos++;
-          if ((pos & 3) == 0) { cur = b1; b1 = b2; b2 = b3; }
-          else cur >>= 8;
-          if ((pos & 15) == 0) {
-            cur = nxt.x; b1 = nxt.y; b2 = nxt.z; b3 = nxt.w;
-            if (pos + 16 < n) __builtin_memcpy(&nxt, seq + pos + 16, 16);
-          }
         }
       }
       if (!W5) {  // end of a w-block: rebuild the suffix minima of the block just completed (wave-uniform control flow)
         if (tphase == w - 1) {
-          uint64_t s = ~0ULL;
-          for (int j = w - 1; j >= 0; j--) { s = lmin64(s, ring[j * 64 + lane]); suf[j * 64 + lane] = s; }
+          uint64_t sm = ~0ULL;
+          for (int j = w - 1; j >= 0; j--) { sm = lmin64(sm, ring[j * 64 + lane]); suf[j * 64 + lane] = sm; }
           tphase = 0;
         } else {
           tphase++;
         }
       }
       // ---- queue the emitted sequence spans ----
-      bool distinct = false;
-      if (emit) {
-        distinct = first || !(have_last && ekey == last_key);  // Supermers.spans :84-90
-        last_key = ekey; have_last = true; first = false;
-        total += ekmers; np++; nhits++;
-      }
+      const bool distinct = emit && (first || !(have_last && ekey == last_key));  // Supermers.spans :84-90
+      last_key = emit ? ekey : last_key;
+      have_last = have_last || emit;
+      first = first && !emit;
+      total += emit ? ekmers : 0;
+      np += emit ? 1 : 0;
+      nhits += emit ? 1 : 0;
       uint64_t E = __ballot(emit);
       if (E != 0) {
         if (emit) {
@@ -332,7 +349,7 @@ __global__ void __launch_bounds__(LW * 64) lane_kernel(FusedArgs A, int32_t *def
         qn += __popcll(E);
         if (qn >= 64) {
           lane_wave_sync();
-          probe_batch(L, A.T, 64, lane);
+          if (!(dbg & 1)) probe_batch(L, A.T, 64, lane, dbg);
           int rest = qn - 64;  // < 64
           uint64_t kk = 0; uint32_t mm = 0;
           if (lane < rest) { kk = L->q_key[64 + lane]; mm = L->q_meta[64 + lane]; }
@@ -344,7 +361,7 @@ __global__ void __launch_bounds__(LW * 64) lane_kernel(FusedArgs A, int32_t *def
     }
     if (qn > 0) {
       lane_wave_sync();
-      probe_batch(L, A.T, qn, lane);
+      if (!(dbg & 1)) probe_batch(L, A.T, qn, lane, dbg);
       qn = 0;
     }
     lane_wave_sync();
@@ -414,8 +431,9 @@ void launch_lane(const FusedArgs &A, int32_t *defer, uint32_t max_len, hipStream
   uint64_t blocks = (tiles + LW - 1) / LW;
   if (blocks > 256 * 8) blocks = 256 * 8;
   dim3 g((unsigned)blocks), b(LW * 64);
-  if (w5) hipLaunchKernelGGL(lane_kernel<true>, g, b, lds, s, A, defer, max_len);
-  else hipLaunchKernelGGL(lane_kernel<false>, g, b, lds, s, A, defer, max_len);
+  static const int dbg = getenv("SLK_DEBUG_ABLATE") ? atoi(getenv("SLK_DEBUG_ABLATE")) : 0;  // timing experiments only: 1 = no probes, 2 = no map updates
+  if (w5) hipLaunchKernelGGL(lane_kernel<true>, g, b, lds, s, A, defer, max_len, dbg);
+  else hipLaunchKernelGGL(lane_kernel<false>, g, b, lds, s, A, defer, max_len, dbg);
 }
 
 }  // namespace slk
