@@ -142,13 +142,11 @@ def main():
     ap.add_argument("--genomes", type=int, default=2048)
     ap.add_argument("--genome-len", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=400000, help="reads timed by the CPU restatement")
     args = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from slacken_amd import dist as sdist
+    rank, world, local_rank = sdist.env_rank_world()
     if world != args.gpus:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}")
     if not torch.cuda.is_available():
@@ -236,10 +234,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     # per-stage device time: re-read the events of the LAST timed step (every step launches the same three kernels)
     stage_ms = np.array(st.last_stage_ms())
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sdist.max_over_ranks(elapsed, dist, device)
     ms_per_step = elapsed / args.steps * 1e3
     reads_per_s = world * n_reads / (elapsed / args.steps)
 
@@ -252,6 +247,13 @@ def main():
     dom_name = "slk::fused_kernel<MODE_CLASSIFY> (scan+probe+LCA, one launch per step)" if fused else "slk::probe_kernel"
     achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9
     path_achieved = bytes_per_launch / (float(stage_ms.sum()) * 1e-3) / 1e9
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tpath):  # FETCH_SIZE + WRITE_SIZE of the dominant kernel, rocprofv3 --pmc passes of this same command
+        tj = json.load(open(tpath))
+        if tj.get("reads_per_launch") == n_reads and tj.get("records") == int(args.records):
+            traffic = tj["hbm_bytes_per_launch"]
 
     out = {
         "metric": "classify_throughput_150bp_standard224scale",
@@ -279,7 +281,7 @@ def main():
             "path_frac_all_kernels": round(path_achieved / HBM_PEAK_GBPS, 4),
         },
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": round(dom_ms, 3)},
     }
 
@@ -292,25 +294,33 @@ def main():
 
 
 def cpu_baseline(args, gkeys, gtax, parents, d_bases, n_reads, rng):
-    """The CPU restatement (oracle/, OpenMP over reads) on a bounded sample of the same reads, against the genome
-    records plus random padding up to 2^24 records (hits come from the genome records; the padding keeps the
-    hash table far larger than the CPU caches, as the full library would)."""
+    """The CPU restatement (oracle/, OpenMP over reads) on a bounded sample of the same reads (sized for roughly 12 s),
+    against the genome records plus random padding up to 2^24 records (hits come from the genome records; the padding
+    keeps the hash table far larger than the CPU caches, as the full library would)."""
+    ncpu = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(ncpu))
     from oracle import oracle
-    S = min(args.cpu_sample, n_reads)
     p = oracle.params(k=K, m=M, spaces=SPACES)
     pad = max(0, (1 << 24) - len(gkeys))
     pkeys = (rng.integers(0, 2**63, pad, dtype=np.uint64) * np.uint64(2)) & np.uint64(p.space[0])
     ptax = np.full(pad, 1, np.int32)
     oix = oracle.Index(1, np.concatenate([gkeys, pkeys.view(np.int64)]), np.concatenate([gtax, ptax]))
+    probe_n = min(n_reads, 200000)
+    bases = d_bases[:probe_n * READ_LEN].cpu().numpy()
+    offsets = np.arange(0, (probe_n + 1) * READ_LEN, READ_LEN, dtype=np.uint64)
+    t = time.perf_counter()
+    res = oracle.classify_batch(p, oix, parents, bases, offsets)  # also warms the table
+    rate = probe_n / (time.perf_counter() - t)
+    S = int(min(n_reads, max(probe_n, rate * 12.0)))
     bases = d_bases[:S * READ_LEN].cpu().numpy()
     offsets = np.arange(0, (S + 1) * READ_LEN, READ_LEN, dtype=np.uint64)
-    oracle.classify_batch(p, oix, parents, bases[:1000 * READ_LEN], offsets[:1001])  # warm
     t = time.perf_counter()
     res = oracle.classify_batch(p, oix, parents, bases, offsets)
     dt = time.perf_counter() - t
     return {"value": round(S / dt / 1e6, 4), "unit": "M reads/s", "cores": int(res["threads"]), "kind": "port",
-            "sample": f"first {S} of the step's reads, CPU restatement (oracle/, OpenMP) vs {len(gkeys)} genome records "
-                      f"+ random padding to 2^24 records in a DRAM hash table; {dt:.1f} s"}
+            "sample": f"first {S} of the step's reads, CPU restatement (oracle/, OpenMP, {res['threads']} threads on "
+                      f"{ncpu} usable CPUs) vs {len(gkeys)} genome records + random padding to 2^24 records in a DRAM "
+                      f"hash table; {dt:.1f} s; the reference's own Spark path cannot run here (no JVM)"}
 
 
 if __name__ == "__main__":

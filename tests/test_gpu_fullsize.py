@@ -1,0 +1,127 @@
+"""Size-independent properties of the classify path at sizes the CPU oracle cannot reach (default: 2^30-record table,
+2M x 150 bp reads; SLK_FULLSIZE=1: BASELINE.json's 1e10 records / 1e7 reads).  Integer work => exact equality everywhere.
+  * determinism and batch-split invariance
+  * reverse-complement invariance (canonical minimizers: MinSplitterProps.scala:101-114 lifted to the whole path)
+  * the two independently written kernels (lane-per-read hot path, wave-per-read path) agree read for read
+  * a poly-A read is one super-mer of L-k+1 k-mers; per-taxon read counts add up to the classified reads"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big():
+    import torch
+    import bench
+    import slacken_amd
+    full = os.environ.get("SLK_FULLSIZE") == "1"
+    n_records, n_reads = (int(1e10), int(1e7)) if full else (1 << 30, 2_000_000)
+    dev = torch.device("cuda", 0)
+    parents, taxa, leaves = bench.build_taxonomy()
+    rng = np.random.default_rng(224)
+    G, GL = 256, 16384
+    genome_taxa = rng.choice(leaves, size=G, replace=False)
+    genomes = [np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, GL)] for _ in range(G)]
+    gkeys, gtax = bench.genome_records(slacken_amd, genomes, genome_taxa, parents, 0)
+    ix = slacken_amd.Index(expected_records=n_records, max_taxon=bench.TAX_EXTENT - 1)
+    ix.append(gkeys, gtax)
+    smask = ((2**62 - 1) & ~0x0CCCCCCC) << 2
+    smask -= 1 << 64
+    d_taxa = torch.from_numpy(taxa).to(dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    for s in range(0, n_records - len(gkeys), 1 << 27):
+        n = min(1 << 27, n_records - len(gkeys) - s)
+        keys = ((torch.randint(0, 2**32, (n,), generator=gen, device=dev, dtype=torch.int64) << 32) |
+                torch.randint(0, 2**32, (n,), generator=gen, device=dev, dtype=torch.int64)) & smask
+        tx = d_taxa[torch.randint(0, len(taxa), (n,), generator=gen, device=dev)]
+        torch.cuda.synchronize()
+        ix.append_device(keys.data_ptr(), tx.data_ptr(), n)
+        del keys, tx
+    ix.set_taxonomy(parents)
+    ix.finalize()
+    bases, offsets = bench.make_reads_device(torch, torch.from_numpy(np.concatenate(genomes)).to(dev), GL, G, n_reads, 150, dev)
+    return dict(torch=torch, ix=ix, st=ix.stream(), bases=bases, offsets=offsets, R=n_reads, dev=dev,
+                ntax=bench.TAX_EXTENT)
+
+
+def run(big, bases, offsets, R, thresholds=(0.0, 0.1)):
+    torch = big["torch"]
+    C = len(thresholds)
+    out = dict(taxon=torch.zeros(C * R, dtype=torch.int32, device=big["dev"]),
+               cls=torch.zeros(C * R, dtype=torch.uint8, device=big["dev"]),
+               nd=torch.zeros(R, dtype=torch.int32, device=big["dev"]),
+               tk=torch.zeros(R, dtype=torch.int32, device=big["dev"]),
+               nh=torch.zeros(R, dtype=torch.int32, device=big["dev"]),
+               np_=torch.zeros(R, dtype=torch.int32, device=big["dev"]))
+    big["st"].classify_batch_device(bases.data_ptr(), offsets.data_ptr(), R, R * 150, out["taxon"].data_ptr(),
+                                    out["cls"].data_ptr(), out["nd"].data_ptr(), out["tk"].data_ptr(),
+                                    out["nh"].data_ptr(), out["np_"].data_ptr(), thresholds=thresholds)
+    big["st"].synchronize()
+    return out
+
+
+def same(a, b, keys=("taxon", "cls", "nd", "tk", "nh", "np_")):
+    return all(bool((a[k] == b[k]).all()) for k in keys)
+
+
+def test_deterministic_and_split_invariant(big):
+    torch = big["torch"]
+    R = big["R"]
+    a = run(big, big["bases"], big["offsets"], R)
+    b = run(big, big["bases"], big["offsets"], R)
+    assert same(a, b)
+    # four sub-batches give the same per-read answers as one batch
+    q = R // 4
+    for j in range(4):
+        sub_b = big["bases"][j * q * 150:]
+        sub_o = big["offsets"][:q + 1].clone()
+        part = run(big, sub_b, sub_o, q, thresholds=(0.0,))
+        assert bool((part["taxon"] == a["taxon"][j * q:(j + 1) * q]).all())
+        assert bool((part["nd"] == a["nd"][j * q:(j + 1) * q]).all())
+    # accounting: k-mers of an all-valid 150 bp read = 116; probes <= spans; classified <=> taxon != 0
+    valid = a["nh"] > 0
+    assert int(a["tk"][valid].max()) <= 116 and int(a["tk"].min()) >= 0
+    assert bool((a["np_"] <= a["nh"]).all())
+    assert bool(((a["taxon"][:R] != 0) == (a["cls"][:R] != 0)).all())
+    counts = torch.bincount(a["taxon"][:R].long(), minlength=big["ntax"])
+    assert int(counts[1:].sum()) == int(a["cls"][:R].sum())
+
+
+def test_reverse_complement_invariance(big):
+    torch = big["torch"]
+    R = min(big["R"], 1_000_000)
+    b = big["bases"][:R * 150].view(R, 150)
+    comp = torch.arange(256, dtype=torch.uint8, device=big["dev"])
+    for x, y in zip(b"ACGT", b"TGCA"):
+        comp[x] = y
+    rc = torch.cat([comp[b.long()].flip(1).reshape(-1), torch.full((64,), 65, dtype=torch.uint8, device=big["dev"])])
+    fwd = run(big, big["bases"], big["offsets"][:R + 1], R)
+    rev = run(big, rc, big["offsets"][:R + 1], R)
+    assert same(fwd, rev, keys=("taxon", "cls", "nd", "tk", "nh", "np_"))
+
+
+def test_lane_and_wave_kernels_agree(big):
+    # host-pointer entry with hit lists runs the wave-per-read kernel; compare with the device-pointer hot path
+    R = 200_000
+    host_b = big["bases"][:R * 150].cpu().numpy()
+    host_o = np.arange(0, (R + 1) * 150, 150, dtype=np.uint64)
+    wave = big["st"].classify_batch(host_b, host_o, thresholds=(0.0, 0.1), with_hits=True)
+    lane = run(big, big["bases"], big["offsets"][:R + 1], R)
+    assert np.array_equal(wave["taxon"].reshape(-1), lane["taxon"].cpu().numpy())
+    assert np.array_equal(wave["classified"].reshape(-1), lane["cls"].cpu().numpy())
+    assert np.array_equal(wave["num_distinct"], lane["nd"].cpu().numpy())
+    assert np.array_equal(wave["total_kmers"], lane["tk"].cpu().numpy())
+    assert np.array_equal(wave["num_hits"], lane["nh"].cpu().numpy())
+
+
+def test_poly_a_known_answer(big):
+    torch = big["torch"]
+    R = 4096
+    bases = torch.full((R * 150 + 64,), ord("A"), dtype=torch.uint8, device=big["dev"])
+    out = run(big, bases, big["offsets"][:R + 1], R)
+    assert bool((out["nh"] == 1).all()) and bool((out["tk"] == 116).all()) and bool((out["np_"] == 1).all())
+    assert bool((out["taxon"] == out["taxon"][0]).all())
