@@ -244,7 +244,8 @@ def main():
     bytes_per_launch = total_bases + 64 * probes + 8 * n_reads
     fused = float(stage_ms[1]) < 0.05 and float(stage_ms[2]) < 0.05  # one fused launch: [fused, 0, ~0]
     dom_ms = float(stage_ms[0]) if fused else float(stage_ms[1])
-    dom_name = "slk::fused_kernel<MODE_CLASSIFY> (scan+probe+LCA, one launch per step)" if fused else "slk::probe_kernel"
+    dom_name = ("slk::lane_kernel<true> (scan+probe+LCA fused, lane per read; followed by the near-empty deferral "
+                "launch of slk::fused_kernel<1>)") if fused else "slk::probe_kernel"
     achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9
     path_achieved = bytes_per_launch / (float(stage_ms.sum()) * 1e-3) / 1e9
 
@@ -314,11 +315,15 @@ def cpu_baseline(args, gkeys, gtax, parents, d_bases, n_reads, rng):
     S = int(min(n_reads, max(probe_n, rate * 12.0)))
     bases = d_bases[:S * READ_LEN].cpu().numpy()
     offsets = np.arange(0, (S + 1) * READ_LEN, READ_LEN, dtype=np.uint64)
-    t = time.perf_counter()
-    res = oracle.classify_batch(p, oix, parents, bases, offsets)
-    dt = time.perf_counter() - t
+    passes, dt = 0, 0.0
+    while dt < 10.0 and passes < 8:  # about 10-30 s of wall time on the host cores
+        t = time.perf_counter()
+        res = oracle.classify_batch(p, oix, parents, bases, offsets)
+        dt += time.perf_counter() - t
+        passes += 1
+    S *= passes
     return {"value": round(S / dt / 1e6, 4), "unit": "M reads/s", "cores": int(res["threads"]), "kind": "port",
-            "sample": f"first {S} of the step's reads, CPU restatement (oracle/, OpenMP, {res['threads']} threads on "
+            "sample": f"{passes} pass(es) over the first {S // passes} of the step's reads, CPU restatement (oracle/, OpenMP, {res['threads']} threads on "
                       f"{ncpu} usable CPUs) vs {len(gkeys)} genome records + random padding to 2^24 records in a DRAM "
                       f"hash table; {dt:.1f} s; the reference's own Spark path cannot run here (no JVM)"}
 
