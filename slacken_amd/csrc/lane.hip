@@ -35,7 +35,7 @@ constexpr int32_t OMAP_EMPTY = -1;
 struct __attribute__((aligned(16))) LaneLds {
   uint64_t q_key[QCAP];
   uint32_t q_meta[QCAP];          // owner lane (6 bits) | distinct << 6 | kmers << 7
-  uint64_t stash[128];            // (home bucket, meta, tag) 16 bytes per queue entry of the batch
+  uint64_t stash[128];            // (home bucket, taxon found, tag) 16 bytes per queue entry of the batch
   int32_t omap_key[OMAP * 64];    // [slot][owner lane]
   int32_t omap_cnt[OMAP * 64];
   int32_t o_nd[64];               // hits with distinct && taxon != NONE (Classifier.scala:94)
@@ -49,85 +49,87 @@ __device__ __forceinline__ void lane_wave_sync() {
 }
 __device__ __forceinline__ uint64_t lmin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
 
-// Fold one hit into its owner's 8-slot map (LDS atomics; several lanes may deliver to one owner at once).
-__device__ __forceinline__ void deliver(LaneLds *L, uint32_t meta, int32_t taxon) {
-  int owner = meta & 63;
-  int32_t kmers = (int32_t)(meta >> 7);
-  if (meta & 64) atomicAdd(&L->o_nd[owner], 1);  // distinct && taxon != NONE (Classifier.scala:94)
-  uint32_t slot = ((uint32_t)taxon * 0x9E3779B1u) >> 29;
-  int p = 0;
-  for (; p < OMAP; p++) {
-    int32_t old = atomicCAS(&L->omap_key[slot * 64 + owner], OMAP_EMPTY, taxon);
-    if (old == OMAP_EMPTY || old == taxon) { atomicAdd(&L->omap_cnt[slot * 64 + owner], kmers); break; }
-    slot = (slot + 1) & (OMAP - 1);
-  }
-  if (p == OMAP) L->o_ovf[owner] = 1;
-}
-
-// Probe the first `cnt` (<= 64) queue entries and fold the hits into their owners' maps.  FOUR lanes read one 64-byte
-// bucket (4 x 16 B = one HBM line), sixteen probes per wave instruction, four instructions per batch, all in flight
-// before the first compare.  The lane that finds the key delivers the hit itself (NONE hits carry no information for
-// resolveTree and are dropped).
-__device__ __forceinline__ void probe_batch(LaneLds *L, const TableView &T, int cnt, int lane, int dbg) {
+// Probe `cnt` (<= 64) entries of the ring queue starting at `qhead` and fold the hits into their owners' maps.
+//   1. lane i hashes entry i and parks (home bucket, tag) in LDS;
+//   2. FOUR lanes read one 64-byte bucket (4 x 16 B = one HBM line), sixteen probes per wave instruction, four
+//      instructions in flight before the first compare; the lane that finds the key writes the taxon to result[entry];
+//   3. lane i folds entry i's hit into its owner's 8-slot map: ONE round of LDS atomics per batch (NONE hits carry no
+//      information for resolveTree and are dropped).
+__device__ __forceinline__ void probe_batch(LaneLds *L, const TableView &T, int qhead, int cnt, int lane, int dbg) {
   const uint64_t NO_TAG = ~0ULL;
-  bool in = lane < cnt;
-  uint64_t key = in ? L->q_key[lane] : 0;
-  uint32_t meta = in ? L->q_meta[lane] : 0;
-  uint64_t h = fmix64(key);
+  const bool in = lane < cnt;
+  const int qi = (qhead + lane) & (QCAP - 1);
+  const uint64_t key = L->q_key[qi];
+  const uint32_t meta = L->q_meta[qi];
+  const uint64_t h = fmix64(key);
   uint4 st;
-  st.x = (uint32_t)(h >> T.shift);                                  // home bucket (< 2^32)
-  st.y = meta;
-  uint64_t tag = in ? ((h & T.rem_mask) << T.disp_bits) : NO_TAG;   // tag at displacement 0
+  st.x = (uint32_t)(h >> T.shift);                                        // home bucket (< 2^32)
+  st.y = 0;                                                               // taxon found (filled in by step 2)
+  const uint64_t tag = in ? ((h & T.rem_mask) << T.disp_bits) : NO_TAG;   // tag at displacement 0
   st.z = (uint32_t)tag; st.w = (uint32_t)(tag >> 32);
   ((uint4 *)L->stash)[lane] = st;
   lane_wave_sync();
-  const int g = lane >> 2, c = lane & 3;                            // 16 groups of 4 lanes
+  const int g = lane >> 2, c = lane & 3;                                  // 16 groups of 4 lanes
   const uint64_t tmask = (1ULL << T.taxon_bits) - 1;
   const char *cellbase = (const char *)T.cells + c * 16;
   ulonglong2 cell[4];
-  uint4 e[4];
 #pragma unroll
   for (int s = 0; s < 4; s++) {
-    e[s] = ((const uint4 *)L->stash)[s * 16 + g];
-    cell[s] = *(const ulonglong2 *)(cellbase + ((uint64_t)e[s].x << 6));  // inactive entries read bucket 0: harmless
+    uint32_t bkt = ((const uint4 *)L->stash)[s * 16 + g].x;
+    if (dbg & 4) bkt &= 1023u;                                            // (timing experiment 4: every probe hits the L2)
+    cell[s] = *(const ulonglong2 *)(cellbase + ((uint64_t)bkt << 6));     // inactive entries read some bucket: harmless
   }
   uint32_t more = 0;
 #pragma unroll
   for (int s = 0; s < 4; s++) {
-    uint64_t want = ((uint64_t)e[s].w << 32) | e[s].z;
-    bool act = want != NO_TAG;
-    bool e0 = cell[s].x == 0, e1 = cell[s].y == 0;
-    bool m0 = act && !e0 && (cell[s].x >> T.taxon_bits) == want;
-    bool m1 = act && !e1 && (cell[s].y >> T.taxon_bits) == want;
-    if ((m0 || m1) && !(dbg & 2)) {
-      int32_t taxon = (int32_t)((m0 ? cell[s].x : cell[s].y) & tmask);
-      deliver(L, e[s].y, taxon);
-    }
-    uint64_t B = __ballot(m0 || m1 || e0 || e1 || !act);  // a group is resolved by a match or by an empty cell
-    // any group of four lanes with no bit set?  (nibble == 0 test)
-    uint64_t nz = (B | (B >> 1) | (B >> 2) | (B >> 3)) & 0x1111111111111111ULL;
-    if (nz != 0x1111111111111111ULL) {
+    const uint2 tg = *(const uint2 *)&((const uint4 *)L->stash)[s * 16 + g].z;
+    const uint64_t want = ((uint64_t)tg.y << 32) | tg.x;
+    const bool act = want != NO_TAG;
+    const bool e0 = cell[s].x == 0, e1 = cell[s].y == 0;
+    const bool m0 = act && !e0 && (cell[s].x >> T.taxon_bits) == want;
+    const bool m1 = act && !e1 && (cell[s].y >> T.taxon_bits) == want;
+    if (m0 || m1) ((uint4 *)L->stash)[s * 16 + g].y = (uint32_t)((m0 ? cell[s].x : cell[s].y) & tmask);
+    const uint64_t B = __ballot(m0 || m1 || e0 || e1 || !act);  // a group is resolved by a match or by an empty cell
+    const uint64_t nz = (B | (B >> 1) | (B >> 2) | (B >> 3)) & 0x1111111111111111ULL;
+    if (nz != 0x1111111111111111ULL) {                          // some group of four lanes has no bit set (3 % of probes)
       if (((B >> (g * 4)) & 0xF) == 0) more |= 1u << s;
     }
   }
-  if (__ballot(more != 0) != 0) {  // rare: the key overflowed its home bucket
+  if (__ballot(more != 0) != 0) {  // the key overflowed its home bucket: bucket-level linear probing
     for (int d = 1; d <= T.max_disp && __ballot(more != 0) != 0; d++) {
       for (int s = 0; s < 4; s++) {
-        bool act = (more >> s) & 1;
+        const bool act = (more >> s) & 1;
         ulonglong2 cl = make_ulonglong2(0, 0);
         uint64_t want = 0;
         if (act) {
-          want = (((uint64_t)e[s].w << 32) | e[s].z) + (uint64_t)d;
-          cl = *(const ulonglong2 *)(cellbase + ((((uint64_t)e[s].x + d) & T.bucket_mask) << 6));
+          const uint4 e = ((const uint4 *)L->stash)[s * 16 + g];
+          want = (((uint64_t)e.w << 32) | e.z) + (uint64_t)d;
+          cl = *(const ulonglong2 *)(cellbase + ((((uint64_t)e.x + d) & T.bucket_mask) << 6));
         }
-        bool e0 = cl.x == 0, e1 = cl.y == 0;
-        bool m0 = act && !e0 && (cl.x >> T.taxon_bits) == want;
-        bool m1 = act && !e1 && (cl.y >> T.taxon_bits) == want;
-        if (m0 || m1) deliver(L, e[s].y, (int32_t)((m0 ? cl.x : cl.y) & tmask));
-        uint64_t B = __ballot(m0 || m1 || e0 || e1);
+        const bool e0 = cl.x == 0, e1 = cl.y == 0;
+        const bool m0 = act && !e0 && (cl.x >> T.taxon_bits) == want;
+        const bool m1 = act && !e1 && (cl.y >> T.taxon_bits) == want;
+        if (m0 || m1) ((uint4 *)L->stash)[s * 16 + g].y = (uint32_t)((m0 ? cl.x : cl.y) & tmask);
+        const uint64_t B = __ballot(m0 || m1 || e0 || e1);
         if (act && ((B >> (g * 4)) & 0xF) != 0) more &= ~(1u << s);
       }
     }
+  }
+  lane_wave_sync();
+  // step 3: one lane per entry
+  const int32_t taxon = (int32_t)((const uint4 *)L->stash)[lane].y;
+  if (in && taxon != 0 && !(dbg & 2)) {
+    const int owner = meta & 63;
+    const int32_t kmers = (int32_t)(meta >> 7);
+    if (meta & 64) atomicAdd(&L->o_nd[owner], 1);  // distinct && taxon != NONE (Classifier.scala:94)
+    uint32_t slot = ((uint32_t)taxon * 0x9E3779B1u) >> 29;
+    int p = 0;
+    for (; p < OMAP; p++) {
+      int32_t old = atomicCAS(&L->omap_key[slot * 64 + owner], OMAP_EMPTY, taxon);
+      if (old == OMAP_EMPTY || old == taxon) { atomicAdd(&L->omap_cnt[slot * 64 + owner], kmers); break; }
+      slot = (slot + 1) & (OMAP - 1);
+    }
+    if (p == OMAP) L->o_ovf[owner] = 1;
   }
   lane_wave_sync();
 }
@@ -164,8 +166,17 @@ __device__ __forceinline__ int lane_code(uint32_t c) {
   return ok ? (int)t : 5;
 }
 
+#ifndef SLK_LANE_WPS
+#define SLK_LANE_WPS 0
+#endif
+#if SLK_LANE_WPS > 0
+#define LANE_BOUNDS __launch_bounds__(LW * 64, SLK_LANE_WPS)
+#else
+#define LANE_BOUNDS __launch_bounds__(LW * 64)
+#endif
+
 template <bool W5>
-__global__ void __launch_bounds__(LW * 64) lane_kernel(FusedArgs A, int32_t *defer, uint32_t max_len, int dbg) {
+__global__ void LANE_BOUNDS lane_kernel(FusedArgs A, int32_t *defer, uint32_t max_len, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -208,12 +219,10 @@ __global__ void __launch_bounds__(LW * 64) lane_kernel(FusedArgs A, int32_t *def
     uint32_t pos = 0;
     int mate = 0;
     uint32_t cur = 0, b1 = 0, b2 = 0, b3 = 0;  // 16 buffered characters
-    uint4 nxt = make_uint4(0, 0, 0, 0);         // the next 16, prefetched
     if (!fin && n > 0) {
       uint4 v;
       __builtin_memcpy(&v, seq, 16);
       cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
-      if (n > 16) __builtin_memcpy(&nxt, seq + 16, 16);
     }
     int run_class = 0;
     uint32_t run_len = 0, nvalid = 0;
@@ -226,6 +235,7 @@ __global__ void __launch_bounds__(LW * 64) lane_kernel(FusedArgs A, int32_t *def
     uint64_t last_key = 0;
     int32_t total = 0, np = 0, nhits = 0;
     int qn = 0;       // queue fill (wave-uniform)
+    int qhead = 0;    // ring position of the oldest queued entry (wave-uniform)
     int tphase = 0;   // generic window: step mod w (wave-uniform)
 
     const uint32_t VM = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20) | (1u << 21);  // A C G T U, either case
@@ -298,8 +308,11 @@ __global__ void __launch_bounds__(LW * 64) lane_kernel(FusedArgs A, int32_t *def
       const bool refill = proc && (pos & 15) == 0;
       if (__ballot(refill) != 0) {
         if (refill) {
-          cur = nxt.x; b1 = nxt.y; b2 = nxt.z; b3 = nxt.w;
-          if (pos + 16 < n) __builtin_memcpy(&nxt, seq + pos + 16, 16);
+          if (pos < n) {  // (no register prefetch: other waves cover this L2-resident read; saves four VGPRs)
+            uint4 v;
+            __builtin_memcpy(&v, seq + pos, 16);
+            cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
+          }
         }
       }
       // -- end of a mate (rare; wave-uniform for equal-length reads)
@@ -315,8 +328,7 @@ __global__ void __launch_bounds__(LW * 64) lane_kernel(FusedArgs A, int32_t *def
               uint4 v;
               __builtin_memcpy(&v, seq, 16);
               cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
-              if (n > 16) __builtin_memcpy(&nxt, seq + 16, 16);
-            }
+                    }
           } else {
             fin = true;
           }
@@ -342,26 +354,22 @@ __global__ void __launch_bounds__(LW * 64) lane_kernel(FusedArgs A, int32_t *def
       uint64_t E = __ballot(emit);
       if (E != 0) {
         if (emit) {
-          int slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(E >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)E, 0));
+          int slot = (qhead + qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(E >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)E, 0))) & (QCAP - 1);
           L->q_key[slot] = ekey;
           L->q_meta[slot] = (uint32_t)lane | (distinct ? 64u : 0u) | ((uint32_t)ekmers << 7);
         }
         qn += __popcll(E);
         if (qn >= 64) {
           lane_wave_sync();
-          if (!(dbg & 1)) probe_batch(L, A.T, 64, lane, dbg);
-          int rest = qn - 64;  // < 64
-          uint64_t kk = 0; uint32_t mm = 0;
-          if (lane < rest) { kk = L->q_key[64 + lane]; mm = L->q_meta[64 + lane]; }
-          lane_wave_sync();
-          if (lane < rest) { L->q_key[lane] = kk; L->q_meta[lane] = mm; }
-          qn = rest;
+          if (!(dbg & 1)) probe_batch(L, A.T, qhead, 64, lane, dbg);
+          qhead = (qhead + 64) & (QCAP - 1);
+          qn -= 64;
         }
       }
     }
     if (qn > 0) {
       lane_wave_sync();
-      if (!(dbg & 1)) probe_batch(L, A.T, qn, lane, dbg);
+      if (!(dbg & 1)) probe_batch(L, A.T, qhead, qn, lane, dbg);
       qn = 0;
     }
     lane_wave_sync();
