@@ -458,7 +458,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
       // hot path: one lane per fragment; long fragments and map overflows are deferred to the wave-per-read kernel
       HIPCHK(st->defer.ensure((R + 64) * sizeof(int32_t)));
       HIPCHK(hipMemsetAsync(st->defer.p, 0, (R + 64) * sizeof(int32_t), st->s));
-      launch_lane(A, st->defer.as<int32_t>(), 1024, st->s);
+      launch_lane(A, st->defer.as<int32_t>(), 1000, st->s);  // queue entries carry 10-bit k-mer counts
       A.only_flagged = st->defer.as<int32_t>();
     }
     launch_fused(want_hits ? MODE_HITS : MODE_CLASSIFY, A, st->s);

@@ -34,7 +34,7 @@ constexpr int32_t OMAP_EMPTY = -1;
 
 struct __attribute__((aligned(16))) LaneLds {
   uint64_t q_key[QCAP];
-  uint32_t q_meta[QCAP];          // owner lane (6 bits) | distinct << 6 | kmers << 7
+  uint32_t q_meta[QCAP];          // owner lane (6 bits) | distinct << 6 | kmers << 7 (10 bits) | displacement << 17 (6 bits)
   uint64_t stash[128];            // (home bucket, taxon found, tag) 16 bytes per queue entry of the batch
   int32_t omap_key[OMAP * 64];    // [slot][owner lane]
   int32_t omap_cnt[OMAP * 64];
@@ -55,7 +55,7 @@ __device__ __forceinline__ uint64_t lmin64(uint64_t a, uint64_t b) { return a < 
 //      instructions in flight before the first compare; the lane that finds the key writes the taxon to result[entry];
 //   3. lane i folds entry i's hit into its owner's 8-slot map: ONE round of LDS atomics per batch (NONE hits carry no
 //      information for resolveTree and are dropped).
-__device__ __forceinline__ void probe_batch(LaneLds *L, const TableView &T, int qhead, int cnt, int lane, int dbg) {
+__device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int qhead, int qn, int cnt, int lane, int dbg) {
   const uint64_t NO_TAG = ~0ULL;
   const bool in = lane < cnt;
   const int qi = (qhead + lane) & (QCAP - 1);
@@ -63,9 +63,10 @@ __device__ __forceinline__ void probe_batch(LaneLds *L, const TableView &T, int 
   const uint32_t meta = L->q_meta[qi];
   const uint64_t h = fmix64(key);
   uint4 st;
-  st.x = (uint32_t)(h >> T.shift);                                        // home bucket (< 2^32)
+  const uint32_t disp = (meta >> 17) & 63;                                // > 0 for an entry re-queued after a full bucket
+  st.x = (uint32_t)(((h >> T.shift) + disp) & T.bucket_mask);             // bucket to read (< 2^32)
   st.y = 0;                                                               // taxon found (filled in by step 2)
-  const uint64_t tag = in ? ((h & T.rem_mask) << T.disp_bits) : NO_TAG;   // tag at displacement 0
+  const uint64_t tag = in ? (((h & T.rem_mask) << T.disp_bits) + disp) : NO_TAG;  // the tag's low bits are the displacement
   st.z = (uint32_t)tag; st.w = (uint32_t)(tag >> 32);
   ((uint4 *)L->stash)[lane] = st;
   lane_wave_sync();
@@ -79,7 +80,7 @@ __device__ __forceinline__ void probe_batch(LaneLds *L, const TableView &T, int 
     if (dbg & 4) bkt &= 1023u;                                            // (timing experiment 4: every probe hits the L2)
     cell[s] = *(const ulonglong2 *)(cellbase + ((uint64_t)bkt << 6));     // inactive entries read some bucket: harmless
   }
-  uint32_t more = 0;
+  int requeued = 0;
 #pragma unroll
   for (int s = 0; s < 4; s++) {
     const uint2 tg = *(const uint2 *)&((const uint4 *)L->stash)[s * 16 + g].z;
@@ -91,28 +92,22 @@ __device__ __forceinline__ void probe_batch(LaneLds *L, const TableView &T, int 
     if (m0 || m1) ((uint4 *)L->stash)[s * 16 + g].y = (uint32_t)((m0 ? cell[s].x : cell[s].y) & tmask);
     const uint64_t B = __ballot(m0 || m1 || e0 || e1 || !act);  // a group is resolved by a match or by an empty cell
     const uint64_t nz = (B | (B >> 1) | (B >> 2) | (B >> 3)) & 0x1111111111111111ULL;
-    if (nz != 0x1111111111111111ULL) {                          // some group of four lanes has no bit set (3 % of probes)
-      if (((B >> (g * 4)) & 0xF) == 0) more |= 1u << s;
-    }
-  }
-  if (__ballot(more != 0) != 0) {  // the key overflowed its home bucket: bucket-level linear probing
-    for (int d = 1; d <= T.max_disp && __ballot(more != 0) != 0; d++) {
-      for (int s = 0; s < 4; s++) {
-        const bool act = (more >> s) & 1;
-        ulonglong2 cl = make_ulonglong2(0, 0);
-        uint64_t want = 0;
-        if (act) {
-          const uint4 e = ((const uint4 *)L->stash)[s * 16 + g];
-          want = (((uint64_t)e.w << 32) | e.z) + (uint64_t)d;
-          cl = *(const ulonglong2 *)(cellbase + ((((uint64_t)e.x + d) & T.bucket_mask) << 6));
-        }
-        const bool e0 = cl.x == 0, e1 = cl.y == 0;
-        const bool m0 = act && !e0 && (cl.x >> T.taxon_bits) == want;
-        const bool m1 = act && !e1 && (cl.y >> T.taxon_bits) == want;
-        if (m0 || m1) ((uint4 *)L->stash)[s * 16 + g].y = (uint32_t)((m0 ? cl.x : cl.y) & tmask);
-        const uint64_t B = __ballot(m0 || m1 || e0 || e1);
-        if (act && ((B >> (g * 4)) & 0xF) != 0) more &= ~(1u << s);
+    if (nz != 0x1111111111111111ULL) {
+      // Some bucket was full without holding its key (3 % of the probes): bucket-level linear probing continues in the
+      // next bucket.  Rather than following it here with a dependent load, the entry goes back to the tail of the
+      // queue with its displacement raised, and takes an ordinary slot of a later batch.
+      const int qj = (qhead + s * 16 + g) & (QCAP - 1);
+      const uint32_t m_old = L->q_meta[qj];
+      const bool again = c == 0 && ((B >> (g * 4)) & 0xF) == 0 && (int)((m_old >> 17) & 63) < T.max_disp;
+      const uint64_t k_old = L->q_key[qj];
+      const uint64_t R = __ballot(again);
+      lane_wave_sync();  // every key is in registers before a tail slot (which may wrap onto this batch) is written
+      if (again) {
+        const int slot = (qhead + qn + requeued + __builtin_amdgcn_mbcnt_hi((uint32_t)(R >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)R, 0))) & (QCAP - 1);
+        L->q_key[slot] = k_old;
+        L->q_meta[slot] = m_old + (1u << 17);
       }
+      requeued += __popcll(R);
     }
   }
   lane_wave_sync();
@@ -120,7 +115,7 @@ __device__ __forceinline__ void probe_batch(LaneLds *L, const TableView &T, int 
   const int32_t taxon = (int32_t)((const uint4 *)L->stash)[lane].y;
   if (in && taxon != 0 && !(dbg & 2)) {
     const int owner = meta & 63;
-    const int32_t kmers = (int32_t)(meta >> 7);
+    const int32_t kmers = (int32_t)((meta >> 7) & 0x3FF);
     if (meta & 64) atomicAdd(&L->o_nd[owner], 1);  // distinct && taxon != NONE (Classifier.scala:94)
     uint32_t slot = ((uint32_t)taxon * 0x9E3779B1u) >> 29;
     int p = 0;
@@ -132,6 +127,7 @@ __device__ __forceinline__ void probe_batch(LaneLds *L, const TableView &T, int 
     if (p == OMAP) L->o_ovf[owner] = 1;
   }
   lane_wave_sync();
+  return requeued;
 }
 
 struct OwnerMap {  // this lane's column of the LDS maps
@@ -361,16 +357,20 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, int32_t *defer, uint32_t ma
         qn += __popcll(E);
         if (qn >= 64) {
           lane_wave_sync();
-          if (!(dbg & 1)) probe_batch(L, A.T, qhead, 64, lane, dbg);
+          int back = 0;
+          if (!(dbg & 1)) back = probe_batch(L, A.T, qhead, qn, 64, lane, dbg);
           qhead = (qhead + 64) & (QCAP - 1);
-          qn -= 64;
+          qn += back - 64;
         }
       }
     }
-    if (qn > 0) {
+    while (qn > 0) {  // drain, including entries re-queued by the batches themselves
       lane_wave_sync();
-      if (!(dbg & 1)) probe_batch(L, A.T, qhead, qn, lane, dbg);
-      qn = 0;
+      const int cnt = min(qn, 64);
+      int back = 0;
+      if (!(dbg & 1)) back = probe_batch(L, A.T, qhead, qn, cnt, lane, dbg);
+      qhead = (qhead + cnt) & (QCAP - 1);
+      qn += back - cnt;
     }
     lane_wave_sync();
 
