@@ -189,3 +189,63 @@ def test_api_errors(world):
     with pytest.raises(slacken_amd.SlackenError) as e:
         st.classify_batch(bases, offsets, hits_capacity=3)
     assert e.value.code == -5
+
+
+@pytest.mark.parametrize("ps", [dict(k=31, m=31, spaces=0), dict(k=21, m=12, spaces=5), dict(k=45, m=32, spaces=16),
+                                dict(k=35, m=31, spaces=7, canonical=False), dict(k=40, m=25, spaces=3)],
+                         ids=lambda ps: f"k{ps['k']}m{ps['m']}s{ps['spaces']}")
+def test_classify_parity_other_splitters(orc, ps):
+    """Window widths other than 5 run the van-Herk variant of the lane kernel (w <= 16); non-canonical and full-width
+    keys exercise the key arithmetic.  Hot path and hit-list path against the oracle."""
+    import slacken_amd
+    ps = full(ps)
+    p = orc.params(**ps)
+    rng = np.random.default_rng(ps["k"] * 7 + ps["m"])
+    parents = taxgen.taxonomy(8 * 16, rng)
+    lib = synth.Library(orc, p, parents, n_genomes=6, genome_len=6000, pad_records=3000)
+    ix = slacken_amd.Index(expected_records=len(lib.keys), max_taxon=len(parents) - 1, **ps)
+    ix.append(lib.keys, lib.taxa)
+    ix.set_taxonomy(parents)
+    ix.finalize()
+    world = dict(p=p, st=ix.stream(), oix=orc.Index(1, lib.keys, lib.taxa), parents=parents)
+    reads = synth.make_reads(lib, 1500, rng, vary_length=True, n_single=0.1, n_run=0.05)
+    check_classify(orc, world, reads, thresholds=(0.0, 0.2))
+    check_classify(orc, world, reads[:600], reads[600:1200], thresholds=(0.0,))
+
+
+def test_many_taxa_per_read_take_the_deferred_path(orc):
+    """More than 8 distinct taxa in one fragment overflow the lane kernel's per-read map: the fragment is re-done by the
+    wave-per-read kernel (128-slot map).  More than 128 is reported as an error, never silently wrong."""
+    import slacken_amd
+    p = orc.params()
+    rng = np.random.default_rng(99)
+    parents = taxgen.taxonomy(8 * 64, rng)
+    taxa = np.array(taxgen.defined_taxa(parents))
+    reads = [synth.random_dna(150, rng) for _ in range(300)] + [synth.random_dna(400, rng) for _ in range(20)]
+    keys, tx = [], []
+    for r in reads:  # every minimizer of every read is a record with its own random taxon
+        kk = orc.minimizer_keys(p, r.tobytes())
+        keys.append(kk)
+        tx.append(rng.choice(taxa, size=len(kk)))
+    keys, idx = np.unique(np.concatenate(keys), return_index=True)
+    tx = np.concatenate(tx)[idx].astype(np.int32)
+    ix = slacken_amd.Index(expected_records=len(keys), max_taxon=len(parents) - 1)
+    ix.append(keys, tx)
+    ix.set_taxonomy(parents)
+    ix.finalize()
+    world = dict(p=p, st=ix.stream(), oix=orc.Index(1, keys, tx), parents=parents)
+    got = check_classify(orc, world, reads, thresholds=(0.0, 0.3))
+    assert (got["num_distinct"][:300] > 8).all()
+    # > 128 distinct taxa in one fragment: loud failure
+    big = [synth.random_dna(3000, rng)]
+    kk = np.unique(orc.minimizer_keys(p, big[0].tobytes()))
+    many = rng.choice(taxa, size=len(kk), replace=len(kk) > len(taxa)).astype(np.int32)
+    ix2 = slacken_amd.Index(expected_records=len(kk), max_taxon=len(parents) - 1)
+    ix2.append(kk, many)
+    ix2.set_taxonomy(parents)
+    ix2.finalize()
+    if len(np.unique(many)) > 128:
+        bases, offsets = synth.pack(big)
+        with pytest.raises(slacken_amd.SlackenError) as e:
+            ix2.stream().classify_batch(bases, offsets, with_hits=False)
+        assert e.value.code == -5
