@@ -168,6 +168,32 @@ int32_t slk_classify_batch_device(slk_index *ix, slk_stream *st, const uint8_t *
                                   int32_t *d_out_total_kmers, int32_t *d_out_num_hits,
                                   int32_t *d_out_num_probes);
 
+/* ---- staged device entry points: the same three steps as separate calls, for the TABLE-SHARDED mode (the record
+ * table exceeds one GPU's HBM: each rank holds the records whose hash falls to it, minimizers are exchanged with an
+ * all-to-all between slk_scan_device and slk_classify_hits_device; SURVEY.md 8e, BASELINE.json configs[3]) and for an
+ * index build from sequences.  All pointers are device pointers; asynchronous on st.
+ *   span slot of fragment r, span j:  offsets[r] (+ mate_offsets[r] + r when paired) + j   (at most L-k+1 [+1+L2-k+1]
+ *   spans per fragment, so slots never overlap); d_span_* must hold total_bases (+ total_mate_bases + R) + 1 entries. */
+/* getSpans (KeyValueIndex.scala:163-173): d_span_keys (left-aligned minimizers, 0 for flagged spans),
+ * d_span_meta (kmers << 4 | flag << 1 | distinct), d_span_count[R]. */
+int32_t slk_scan_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
+                        const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
+                        uint64_t *d_span_keys, int32_t *d_span_meta, int32_t *d_span_count);
+/* the join (Classifier.scala:84): taxon or NONE for n minimizers against THIS index's records */
+int32_t slk_lookup_device(slk_index *ix, slk_stream *st, const int64_t *d_keys, uint64_t n, int32_t *d_out_taxa);
+/* Which rank owns a minimizer in table-sharded mode: fmix64(key) mod n_shards (host helper; the device side of the
+ * Python host uses the same bijective mixer) */
+uint32_t slk_shard_of(int64_t key, uint32_t n_shards);
+/* classifyHits (Classifier.scala:124-147, 439-454) over span slots whose taxa have been filled in (d_span_taxon: record
+ * taxon / NONE for SEQUENCE spans; AMBIGUOUS and MATE_PAIR_BORDER spans are recognised from d_span_meta).  d_scratch:
+ * as many 8-byte entries as span slots. */
+int32_t slk_classify_hits_device(slk_index *ix, slk_stream *st, const uint64_t *d_offsets,
+                                 const uint64_t *d_mate_offsets, uint64_t R, const int32_t *d_span_meta,
+                                 const int32_t *d_span_taxon, const int32_t *d_span_count, uint64_t *d_scratch,
+                                 int32_t min_hit_groups, const double *thresholds, int32_t C, int32_t *d_out_taxon,
+                                 uint8_t *d_out_classified, int32_t *d_out_num_distinct, int32_t *d_out_total_kmers,
+                                 int32_t *d_out_num_hits);
+
 /* Per-stage device timing of the last slk_classify_batch_device call on st, in milliseconds (HIP events on the
  * stream the kernels ran on): [0]=scan, [1]=probe, [2]=classify.  Synchronises st. */
 int32_t slk_stream_last_stage_ms(slk_stream *st, float out_ms[3]);

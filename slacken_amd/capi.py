@@ -43,7 +43,8 @@ EXPORTS = ["slk_device_count", "slk_last_error", "slk_version", "slk_index_creat
            "slk_index_append_device", "slk_index_set_taxonomy", "slk_index_finalize", "slk_index_get_info",
            "slk_index_lookup", "slk_index_destroy", "slk_stream_create", "slk_stream_synchronize",
            "slk_stream_hip_stream", "slk_stream_destroy", "slk_spans_batch", "slk_classify_batch",
-           "slk_classify_batch_device", "slk_stream_last_stage_ms"]
+           "slk_classify_batch_device", "slk_stream_last_stage_ms", "slk_scan_device", "slk_lookup_device",
+           "slk_shard_of", "slk_classify_hits_device"]
 
 
 def lib_path():
@@ -88,6 +89,12 @@ def lib():
     L.slk_classify_batch_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_uint64, C.c_uint64,
                                             C.c_int32, C.POINTER(C.c_double), C.c_int32, i32p, u8p, i32p, i32p, i32p, i32p]
     L.slk_stream_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.slk_scan_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, u64p, i32p, i32p]
+    L.slk_lookup_device.argtypes = [vp, vp, i64p, C.c_uint64, i32p]
+    L.slk_shard_of.argtypes = [C.c_int64, C.c_uint32]
+    L.slk_shard_of.restype = C.c_uint32
+    L.slk_classify_hits_device.argtypes = [vp, vp, u64p, u64p, C.c_uint64, i32p, i32p, i32p, u64p, C.c_int32,
+                                           C.POINTER(C.c_double), C.c_int32, i32p, u8p, i32p, i32p, i32p]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is C.c_int:  # default: int32 status
@@ -239,6 +246,24 @@ class Stream:
                                                d_mate_offsets, R, total_bases, total_mate_bases, min_hit_groups, thr,
                                                Cn, d_out_taxon, d_out_classified, d_out_num_distinct,
                                                d_out_total_kmers, d_out_num_hits, d_out_num_probes))
+
+    def scan_device(self, d_bases, d_offsets, R, d_span_keys, d_span_meta, d_span_count, d_mate_bases=None,
+                    d_mate_offsets=None):
+        _check(lib().slk_scan_device(self.index.h, self.h, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R,
+                                     d_span_keys, d_span_meta, d_span_count))
+
+    def lookup_device(self, d_keys, n, d_out_taxa):
+        _check(lib().slk_lookup_device(self.index.h, self.h, d_keys, n, d_out_taxa))
+
+    def classify_hits_device(self, d_offsets, R, d_span_meta, d_span_taxon, d_span_count, d_scratch, d_out_taxon,
+                             d_out_classified, d_out_num_distinct=None, d_out_total_kmers=None, d_out_num_hits=None,
+                             d_mate_offsets=None, min_hit_groups=2, thresholds=(0.0,)):
+        Cn = len(thresholds)
+        thr = (C.c_double * Cn)(*thresholds)
+        _check(lib().slk_classify_hits_device(self.index.h, self.h, d_offsets, d_mate_offsets, R, d_span_meta,
+                                              d_span_taxon, d_span_count, d_scratch, min_hit_groups, thr, Cn,
+                                              d_out_taxon, d_out_classified, d_out_num_distinct, d_out_total_kmers,
+                                              d_out_num_hits))
 
     def last_stage_ms(self):
         out = (C.c_float * 3)()

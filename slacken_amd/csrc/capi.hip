@@ -159,7 +159,7 @@ int32_t slk_index_create(const slk_params *p, const slk_table_config *cfg, int32
   float lf = cfg->load_factor > 0 ? cfg->load_factor : 0.70f;
   if (lf > 0.95f) lf = 0.95f;
   uint64_t cells_needed = (uint64_t)((double)std::max<uint64_t>(cfg->expected_records, 1) / lf) + 8;
-  int bb = std::max(tb + 3, ceil_log2_u64((cells_needed + 7) / 8));
+  int bb = std::max(tb + 4, ceil_log2_u64((cells_needed + 7) / 8));  // >= 4 displacement bits: 15 buckets of linear probing
   if (bb > 40) { delete ix; return fail(SLK_E_CAPACITY, "table of 2^%d buckets is too large", bb); }
   ix->bucket_bits = bb;
   ix->taxon_bits = tb;
@@ -502,6 +502,65 @@ int32_t slk_classify_batch_device(slk_index *ix, slk_stream *st, const uint8_t *
   return run_classify(ix, st, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, total_bases, total_mate_bases,
                       min_hit_groups, thresholds, C, d_out_taxon, d_out_classified, d_out_num_distinct,
                       d_out_total_kmers, d_out_num_hits, d_out_num_probes, false);
+}
+
+int32_t slk_scan_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
+                        const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
+                        uint64_t *d_span_keys, int32_t *d_span_meta, int32_t *d_span_count) {
+  int32_t rc = check_ready(ix, st, false);
+  if (rc) return rc;
+  if (R && (!d_bases || !d_offsets || !d_span_keys || !d_span_meta || !d_span_count)) return fail(SLK_E_INVALID, "null argument");
+  if ((d_mate_bases == nullptr) != (d_mate_offsets == nullptr))
+    return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
+  rc = set_device(ix);
+  if (rc) return rc;
+  if (use_fused(ix)) {
+    FusedArgs A{};
+    A.P = ix->sp; A.bases = d_bases; A.offsets = d_offsets; A.mate_bases = d_mate_bases; A.mate_offsets = d_mate_offsets;
+    A.R = R; A.span_keys = d_span_keys; A.span_meta = d_span_meta; A.span_count = d_span_count; A.status = st->d_status;
+    launch_fused(MODE_SPANS, A, st->s);
+  } else {
+    launch_scan(ix->sp, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, d_span_keys, d_span_meta, d_span_count, st->s);
+  }
+  HIPCHK(hipGetLastError());
+  return SLK_OK;
+}
+
+int32_t slk_lookup_device(slk_index *ix, slk_stream *st, const int64_t *d_keys, uint64_t n, int32_t *d_out_taxa) {
+  int32_t rc = check_ready(ix, st, false);
+  if (rc) return rc;
+  if (n && (!d_keys || !d_out_taxa)) return fail(SLK_E_INVALID, "null argument");
+  rc = set_device(ix);
+  if (rc) return rc;
+  launch_table_lookup(ix->view(), d_keys, n, d_out_taxa, st->s);
+  HIPCHK(hipGetLastError());
+  return SLK_OK;
+}
+
+uint32_t slk_shard_of(int64_t key, uint32_t n_shards) {
+  return n_shards ? (uint32_t)(fmix64((uint64_t)key) % n_shards) : 0;
+}
+
+int32_t slk_classify_hits_device(slk_index *ix, slk_stream *st, const uint64_t *d_offsets,
+                                 const uint64_t *d_mate_offsets, uint64_t R, const int32_t *d_span_meta,
+                                 const int32_t *d_span_taxon, const int32_t *d_span_count, uint64_t *d_scratch,
+                                 int32_t min_hit_groups, const double *thresholds, int32_t C, int32_t *d_out_taxon,
+                                 uint8_t *d_out_classified, int32_t *d_out_num_distinct, int32_t *d_out_total_kmers,
+                                 int32_t *d_out_num_hits) {
+  int32_t rc = check_ready(ix, st, true);
+  if (rc) return rc;
+  if (C < 1 || C > MAX_THRESHOLDS || !thresholds) return fail(SLK_E_INVALID, "need 1..%d thresholds", MAX_THRESHOLDS);
+  if (R && (!d_offsets || !d_span_meta || !d_span_taxon || !d_span_count || !d_scratch || !d_out_taxon || !d_out_classified))
+    return fail(SLK_E_INVALID, "null argument");
+  rc = set_device(ix);
+  if (rc) return rc;
+  memcpy(st->h_thresholds, thresholds, C * sizeof(double));
+  HIPCHK(hipMemcpyAsync(st->d_thresholds, st->h_thresholds, C * sizeof(double), hipMemcpyHostToDevice, st->s));
+  launch_classify(ix->d_parents, ix->T, d_offsets, d_mate_offsets, R, d_span_meta, d_span_taxon, d_span_count, d_scratch,
+                  min_hit_groups, st->d_thresholds, C, d_out_taxon, d_out_classified, d_out_num_distinct,
+                  d_out_total_kmers, d_out_num_hits, nullptr, st->s);
+  HIPCHK(hipGetLastError());
+  return SLK_OK;
 }
 
 int32_t slk_stream_last_stage_ms(slk_stream *st, float out_ms[3]) {

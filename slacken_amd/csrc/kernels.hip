@@ -289,6 +289,8 @@ __global__ void __launch_bounds__(256) classify_kernel(Tax tx, const uint64_t *_
   for (int32_t j = 0; j < n; j++) {
     int32_t meta = span_meta[base + j];
     int32_t taxon = span_taxon[base + j];
+    if (meta_flag(meta) == 2) taxon = -1;       // spanToHit: the flag wins over any record (KeyValueIndex.scala:176-185)
+    else if (meta_flag(meta) == 3) taxon = -2;
     int32_t count = meta_kmers(meta);
     if (taxon != -2) total += count;                         // TaxonCounts.totalKmers :84-87
     if (meta_distinct(meta) && taxon != 0) nd++;              // Classifier.scala:94 (distinct is false for flagged spans)

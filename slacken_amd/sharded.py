@@ -1,0 +1,117 @@
+"""Table-sharded classify (BASELINE.json configs[3]): the record table is too large for one GPU's HBM, so
+rank g holds the records with fmix64(key) mod G == g.  Per batch every rank scans ITS reads, sends each minimizer to
+its owner (all-to-all of 8-byte keys over RCCL/xGMI), owners look them up in their shard, the taxa return by the inverse
+all-to-all (4 bytes each), and every rank finishes its own reads' LCA locally.  This replaces the reference's shuffle +
+join (S/slacken/Classifier.scala:84) for the one case where data must move; with a table that fits, use the replicated
+mode (no collective at all).
+
+Host plumbing only: torch for device buffers and the collectives, the engine's staged entry points
+(slk_scan_device / slk_lookup_device / slk_classify_hits_device) for all compute."""
+import numpy as np
+
+_C1 = 0xff51afd7ed558ccd - (1 << 64)
+_C2 = 0xc4ceb9fe1a85ec53 - (1 << 64)
+
+
+def fmix64_torch(x):
+    """The engine's bijective 64-bit mixer (engine.h fmix64) on an int64 tensor (two's-complement wrap-around)."""
+    m31 = (1 << 31) - 1
+    x = x ^ ((x >> 33) & m31)
+    x = x * _C1
+    x = x ^ ((x >> 33) & m31)
+    x = x * _C2
+    x = x ^ ((x >> 33) & m31)
+    return x
+
+
+def shard_of_torch(keys, world):
+    """fmix64(key) mod world as unsigned arithmetic, int64 tensor in -> int64 tensor out (== slk_shard_of)."""
+    h = fmix64_torch(keys)
+    if world & (world - 1) == 0:
+        return h & (world - 1)
+    half = (h >> 1) & ((1 << 63) - 1)          # floor(h_unsigned / 2)
+    return ((half % world) * 2 + (h & 1)) % world
+
+
+def shard_of_numpy(keys, world):
+    k = np.asarray(keys).astype(np.int64).view(np.uint64)
+    x = k.copy()
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint64(33)
+        x *= np.uint64(0xff51afd7ed558ccd)
+        x ^= x >> np.uint64(33)
+        x *= np.uint64(0xc4ceb9fe1a85ec53)
+        x ^= x >> np.uint64(33)
+    return (x % np.uint64(world)).astype(np.int64)
+
+
+class ShardedClassifier:
+    """index: this rank's slacken_amd.Index holding ONLY the records with shard_of(key) == rank (plus the taxonomy)."""
+
+    def __init__(self, index, rank=0, world=1, dist=None, device=None, exchange_on_cpu=False):
+        import torch
+        self.torch, self.ix, self.st = torch, index, index.stream()
+        self.rank, self.world, self.dist = rank, world, dist
+        self.device = device if device is not None else torch.device("cuda", 0)
+        self.on_cpu = exchange_on_cpu  # gloo has no device all-to-all: stage the exchange through host memory (tests)
+
+    def _all_to_all(self, send, send_counts):
+        """send: tensor sorted by destination rank; returns (received tensor, recv_counts list)."""
+        torch = self.torch
+        if self.world == 1 or self.dist is None:
+            return send, list(send_counts)
+        dev = "cpu" if self.on_cpu else self.device
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+        rcnt = torch.empty(self.world, dtype=torch.int64, device=dev)
+        self.dist.all_to_all_single(rcnt, sc)
+        recv_counts = [int(v) for v in rcnt.tolist()]
+        src = send.to(dev)
+        out = torch.empty(sum(recv_counts), dtype=send.dtype, device=dev)
+        self.dist.all_to_all_single(out, src, output_split_sizes=recv_counts, input_split_sizes=list(send_counts))
+        return out.to(self.device), recv_counts
+
+    def classify(self, d_bases, d_offsets, R, total_bases, thresholds=(0.0,), min_hit_groups=2):
+        """d_bases uint8 [total_bases + >=16 pad], d_offsets int64 [R+1] (device tensors). Single-end fragments."""
+        torch, dev = self.torch, self.device
+        slots = total_bases + 1
+        keys = torch.empty(slots, dtype=torch.int64, device=dev)
+        meta = torch.empty(slots, dtype=torch.int32, device=dev)
+        count = torch.zeros(max(R, 1), dtype=torch.int32, device=dev)
+        taxon = torch.zeros(slots, dtype=torch.int32, device=dev)
+        self.st.scan_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, keys.data_ptr(), meta.data_ptr(), count.data_ptr())
+        self.st.synchronize()
+        cnt = count[:R].long()
+        total = int(cnt.sum().item())
+        starts = torch.cumsum(cnt, 0) - cnt
+        slot = torch.repeat_interleave(d_offsets[:R], cnt) + (torch.arange(total, device=dev) -
+                                                              torch.repeat_interleave(starts, cnt))
+        seq = ((meta[slot] >> 1) & 7) == 1
+        seq_slot = slot[seq]
+        k = keys[seq_slot]
+        owner = shard_of_torch(k, self.world)
+        order = torch.argsort(owner, stable=True)
+        send_counts = torch.bincount(owner, minlength=self.world).tolist()
+        recv_keys, recv_counts = self._all_to_all(k[order].contiguous(), send_counts)
+        found = torch.zeros(max(recv_keys.numel(), 1), dtype=torch.int32, device=dev)
+        if recv_keys.numel():
+            recv_keys = recv_keys.contiguous()
+            self.st.lookup_device(recv_keys.data_ptr(), recv_keys.numel(), found.data_ptr())
+            self.st.synchronize()
+        back, _ = self._all_to_all(found[:recv_keys.numel()].contiguous(), recv_counts)
+        taxa_seq = torch.empty_like(back)
+        taxa_seq[order] = back
+        taxon[seq_slot] = taxa_seq
+        C = len(thresholds)
+        out = dict(taxon=torch.zeros(C * max(R, 1), dtype=torch.int32, device=dev),
+                   classified=torch.zeros(C * max(R, 1), dtype=torch.uint8, device=dev),
+                   num_distinct=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
+                   total_kmers=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
+                   num_hits=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
+                   exchanged_keys=int(k.numel()))
+        scratch = keys  # the key slots are dead after the exchange
+        self.st.classify_hits_device(d_offsets.data_ptr(), R, meta.data_ptr(), taxon.data_ptr(), count.data_ptr(),
+                                     scratch.data_ptr(), out["taxon"].data_ptr(), out["classified"].data_ptr(),
+                                     out["num_distinct"].data_ptr(), out["total_kmers"].data_ptr(),
+                                     out["num_hits"].data_ptr(), min_hit_groups=min_hit_groups, thresholds=thresholds)
+        self.st.synchronize()
+        return out

@@ -1,0 +1,83 @@
+"""Table-sharded mode (configs[3]): ownership function on CPU; on the GPU box two gloo ranks share the card, each holds
+half of the records, classifies half of the reads through the key/taxon all-to-all, and the union must equal the oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import slacken_amd
+from slacken_amd import sharded
+
+
+def test_shard_function_agrees_everywhere():
+    L = slacken_amd.lib()
+    rng = np.random.default_rng(3)
+    keys = rng.integers(-2**63, 2**63 - 1, 5000, dtype=np.int64)
+    for world in (1, 2, 3, 7, 8):
+        want = np.array([L.slk_shard_of(int(k), world) for k in keys])
+        assert np.array_equal(sharded.shard_of_numpy(keys, world), want)
+        assert np.array_equal(sharded.shard_of_torch(torch.from_numpy(keys), world).numpy(), want)
+        assert len(np.unique(want)) == world or world == 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank(rank, world, port, payload, outdir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    keys, taxa, parents, bases, offsets = payload
+    mine = sharded.shard_of_numpy(keys, world) == rank
+    ix = slacken_amd.Index(expected_records=max(int(mine.sum()), 16), max_taxon=len(parents) - 1)
+    ix.append(keys[mine], taxa[mine])
+    ix.set_taxonomy(parents)
+    ix.finalize()
+    R = len(offsets) - 1
+    lo, hi = (rank * R) // world, ((rank + 1) * R) // world
+    dev = torch.device("cuda", 0)
+    b0, b1 = int(offsets[lo]), int(offsets[hi])
+    d_bases = torch.cat([torch.from_numpy(bases[b0:b1]), torch.full((64,), 65, dtype=torch.uint8)]).to(dev)
+    d_off = torch.from_numpy((offsets[lo:hi + 1] - offsets[lo]).astype(np.int64)).to(dev)
+    sc = sharded.ShardedClassifier(ix, rank, world, dist, dev, exchange_on_cpu=True)
+    out = sc.classify(d_bases, d_off, hi - lo, b1 - b0, thresholds=(0.0, 0.2))
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), lo=lo, hi=hi, **{k: v.cpu().numpy() for k, v in out.items()
+                                                                     if hasattr(v, "cpu")})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_half_table_each(orc, tmp_path):
+    import torch.multiprocessing as mp
+    import synth
+    import taxgen
+    rng = np.random.default_rng(41)
+    parents = taxgen.taxonomy(8 * 32, rng)
+    p = orc.params()
+    lib = synth.Library(orc, p, parents, n_genomes=8, genome_len=10000, pad_records=20000)
+    reads = synth.make_reads(lib, 3000, rng, n_single=0.1, n_run=0.05, vary_length=True)
+    bases, offsets = synth.pack(reads)
+    want = orc.classify_batch(p, orc.Index(1, lib.keys, lib.taxa), parents, bases, offsets, thresholds=(0.0, 0.2))
+    mp.spawn(_rank, args=(2, _free_port(), (lib.keys, lib.taxa, parents, bases, offsets), str(tmp_path)), nprocs=2, join=True)
+    R = len(reads)
+    got = {k: np.zeros((2, R), np.int64) if k in ("taxon", "classified") else np.zeros(R, np.int64)
+           for k in ("taxon", "classified", "num_distinct", "total_kmers", "num_hits")}
+    for rank in range(2):
+        z = np.load(os.path.join(str(tmp_path), f"r{rank}.npz"))
+        lo, hi = int(z["lo"]), int(z["hi"])
+        n = hi - lo
+        for c in range(2):
+            got["taxon"][c, lo:hi] = z["taxon"][c * n:(c + 1) * n]
+            got["classified"][c, lo:hi] = z["classified"][c * n:(c + 1) * n]
+        for k in ("num_distinct", "total_kmers", "num_hits"):
+            got[k][lo:hi] = z[k][:n]
+    for k in got:
+        assert np.array_equal(got[k], want[k]), k
