@@ -7,11 +7,17 @@ HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-functi
 CSRC := slacken_amd/csrc
 LIB := slacken_amd/lib/libslacken_amd.so
 
-all: $(LIB) oracle
+CLI := slacken_amd/bin/slacken-amd
+
+all: $(LIB) $(CLI) oracle
 
 $(LIB): $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/capi.hip $(CSRC)/engine.h include/slacken_amd.h
 	@mkdir -p slacken_amd/lib
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/capi.hip
+
+$(CLI): slacken_amd/host/slacken_cli.cpp slacken_amd/host/taxonomy.hpp include/slacken_amd.h $(LIB)
+	@mkdir -p slacken_amd/bin
+	g++ -O2 -std=c++17 -Wall -o $@ slacken_amd/host/slacken_cli.cpp -Lslacken_amd/lib -lslacken_amd -lz -Wl,-rpath,'$$ORIGIN/../lib'
 
 oracle:
 	$(MAKE) -C oracle

@@ -1,0 +1,99 @@
+"""Independent Python restatement of the reference's host-side pieces around the hot path, used to check the C++ host layer
+(slacken_amd/host): KrakenReport (S/slacken/KrakenReport.scala:26-116), Taxonomy.fromNodesAndNames (S/slacken/Taxonomy.scala:
+81-109), FASTA/FASTQ text parsing (S/kmers/input/FileInputs.scala:155-221).  No reference output exists for these in the
+repository (its only test is a property spec, KrakenReportProps.scala:33-52, restated in test_host_cli.py): parity unpinned."""
+import re
+from decimal import Decimal, ROUND_HALF_UP
+
+RANKS = ["unclassified", "root", "superkingdom", "kingdom", "phylum", "class", "order", "family", "genus", "species"]
+CODES = ["U", "R", "D", "K", "P", "C", "O", "F", "G", "S"]
+
+
+class Taxonomy:
+    def __init__(self, nodes, names, merged=()):
+        n = max([t + 1 for t, _, _ in nodes] + [a + 1 for a, _ in merged] + [2])
+        self.parents = [0] * n
+        self.ranks = [None] * n
+        self.names = [None] * n
+        for t, nm in names:
+            self.names[t] = nm
+        self.names[0] = "unclassified"
+        for t, p, r in nodes:
+            self.parents[t] = p
+            self.ranks[t] = RANKS.index(r) if r in RANKS else None
+        self.parents[1] = 0
+        self.ranks[0], self.ranks[1] = 0, 1
+        self.children = [[] for _ in range(n)]
+        for t in range(n):
+            if self.parents[t] != 0 or t == 1:
+                self.children[self.parents[t]].insert(0, t)
+
+
+def fmt_6_2f(x):
+    # java.util.Formatter rounds the shortest round-trip digits (repr) HALF_UP, not the exact binary value
+    s = str(Decimal(repr(float(x))).quantize(Decimal("0.01"), rounding=ROUND_HALF_UP))
+    return s.rjust(6)
+
+
+def kraken_report(tax, counts):
+    own, clade, total = {}, {}, 0
+    for t, c in counts:
+        own[t] = own.get(t, 0) + c
+        total += c
+        p = t
+        while p != 0:
+            clade[p] = clade.get(p, 0) + c
+            p = tax.parents[p]
+        if t == 0:
+            clade[0] = c
+    out = ["#Perc\tAggregate\tIn taxon\tRank\tTaxon\tName"]
+
+    def line(t, rank, rd, depth):
+        return "\t".join([fmt_6_2f(100.0 * clade.get(t, 0) / total), str(clade.get(t, 0)), str(own.get(t, 0)),
+                          CODES[rank] + (str(rd) if rd else ""), str(t), "  " * depth + (tax.names[t] or "")])
+
+    def dfs(t, rank, rd, depth):
+        if tax.ranks[t] is not None:
+            rank, rd = tax.ranks[t], 0
+        else:
+            rd += 1
+        out.append(line(t, rank, rd, depth))
+        kids = sorted(((c, clade.get(c, 0)) for c in tax.children[t]), key=lambda x: -x[1])   # stable
+        for c, n in kids:
+            if n > 0:
+                dfs(c, rank, rd, depth + 1)
+
+    if own.get(0, 0):
+        out.append(line(0, 0, 0, 0))
+    dfs(1, 1, 0, 0)
+    return out, own, clade
+
+
+def _jsplit(s, pattern):
+    """java.lang.String.split: trailing empty strings removed"""
+    parts = re.split(pattern, s)
+    while parts and parts[-1] == "":
+        parts.pop()
+    return parts if parts else ([] if s else [""])
+
+
+def parse_fasta(text):
+    out = []
+    for rec in text.split(">"):
+        spl = _jsplit(rec, "[\n\r]+")
+        if len(spl) >= 2:
+            out.append((_jsplit(spl[0], " ")[0] if _jsplit(spl[0], " ") else "", "".join(spl[1:])))
+    return out
+
+
+def parse_fastq(text):
+    lines = text.split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    lines = [l[:-1] if l.endswith("\r") else l for l in lines]
+    out = []
+    for i in range(len(lines)):
+        w = lines[i:i + 4]
+        if len(w) >= 3 and w[0][:1] == "@" and w[2][:1] == "+":
+            out.append((w[0].split(" ")[0][1:], w[1]))
+    return out

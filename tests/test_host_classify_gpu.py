@@ -1,0 +1,130 @@
+"""End to end through the C++ host (`slacken-amd classify`): a library in Slacken's on-disk layout (<loc>/ *.parquet,
+<loc>.properties, <loc>_taxonomy/*.dmp; KeyValueIndex.scala:125-139, IndexParams.scala:92-101), FASTA / FASTQ(.gz) inputs,
+per-read output files and Kraken reports in the reference's directory layout (Classifier.scala:184-227,415-420).  Expected
+lines are the golden vectors (tests/golden, produced by the CPU oracle); the report is checked against hostmodel.py."""
+import glob
+import gzip
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import hostmodel
+from test_host_cli import CLI, ROOT, write_taxonomy
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def make_library(tmp_path):
+    import parquet_to_slkrec as conv
+    g = json.load(open(os.path.join(GOLD, "golden_classify.json")))
+    lib = np.load(os.path.join(GOLD, "library.npz"))
+    loc = str(tmp_path / "golden_lib")
+    conv.write_parquet_dir(loc, lib["keys"], lib["taxa"], buckets=7)
+    mask = int(np.uint64(0xe37e28c4271b5a2d).astype(np.int64))
+    with open(loc + ".properties", "w") as f:
+        f.write(f"#Properties for Slacken\n#Sun Oct 04 09:00:00 UTC 2026\nk={g['k']}\nm={g['m']}\nbuckets=7\nversion=1\n"
+                f"splitter=randomXOR\nminimizerSpaces={g['spaces']}\nXORmask={mask}\ncanonical=true\n")
+    tax = write_taxonomy(loc + "_taxonomy", lib["parents"], np.random.default_rng(3))
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "parquet_to_slkrec.py"), loc])
+    reads = [line.rstrip("\n").split("\t") for line in open(os.path.join(GOLD, "reads.tsv"))]
+    return g, loc, tax, reads
+
+
+def read_out(d, sample="all"):
+    files = sorted(glob.glob(os.path.join(d, f"sample={sample}", "part-*.txt.gz")))
+    assert files, d
+    return [l for fn in files for l in gzip.open(fn, "rt").read().split("\n") if l]
+
+
+def classify(*args):
+    r = subprocess.run([CLI, "classify", *map(str, args)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return r
+
+
+@pytest.mark.gpu
+def test_cli_single_reads_golden(tmp_path):
+    g, loc, tax, reads = make_library(tmp_path)
+    fa = tmp_path / "reads.fasta"
+    with open(fa, "w") as f:        # multi-line FASTA, descriptions after the id
+        for t, s in reads[:300]:
+            f.write(f">{t} length={len(s)}\n{s[:60]}\n{s[60:]}\n")
+    fq = tmp_path / "reads.fq.gz"
+    with gzip.open(fq, "wt") as f:
+        for t, s in reads[300:]:
+            f.write(f"@{t} x\n{s}\n+\n{'I' * len(s)}\n")
+    out = tmp_path / "out" / "gold"
+    classify("-i", loc, "-o", out, "-c", "0.0", "0.15", "0.5", str(fa), str(fq))
+    by_title = {r["title"]: r for r in g["reads"]}
+    for thr, suffix in ((0.0, "0.00"), (0.15, "0.15"), (0.5, "0.50")):   # max decimals of the list = 2
+        lines = read_out(f"{out}_c{suffix}")
+        want = [r for r in g["reads"] if r["hits"]]
+        assert [l.split("\t")[1] for l in lines] == [r["title"] for r in want]
+        for l, r in zip(lines, want):
+            cu, title, taxon, lens, detail = l.split("\t")
+            assert (int(taxon), cu) == (r[f"c{thr}"][0], "C" if r[f"c{thr}"][1] else "U")
+            assert [lens, detail] == r["line"].split("\t")[3:]
+            if thr == 0.0:
+                assert l == r["line"]
+        counts = {}
+        for r in want:
+            counts[r[f"c{thr}"][0]] = counts.get(r[f"c{thr}"][0], 0) + 1
+        rep = open(f"{out}_c{suffix}/all_kreport.txt").read().rstrip("\n").split("\n")
+        assert rep == hostmodel.kraken_report(tax, sorted(counts.items()))[0]
+
+
+@pytest.mark.gpu
+def test_cli_paired_samples_and_flags(tmp_path):
+    g, loc, tax, reads = make_library(tmp_path)
+    f1, f2 = tmp_path / "s_1.fq", tmp_path / "s_2.fq"
+    with open(f1, "w") as a, open(f2, "w") as b:
+        order = list(range(0, 300, 2))
+        for i in order:
+            a.write(f"@{reads[i][0]}/1\n{reads[i][1]}\n+\n{'I' * len(reads[i][1])}\n")
+        for i in reversed(order):    # the mate file in another order: pairing is by id, not by position
+            b.write(f"@{reads[i][0]}/2\n{reads[i + 1][1]}\n+\n{'I' * len(reads[i + 1][1])}\n")
+    out = tmp_path / "paired"
+    classify("-i", loc, "-o", out, "-p", f1, f2)
+    lines = read_out(f"{out}_c0.0")
+    assert lines == [p["line"] for p in g["pairs"] if p["line"]]
+    # --nounclassified drops U rows from both the lines and the report; --nodetailed writes reports only
+    out2 = tmp_path / "paired2"
+    classify("-i", loc, "-o", out2, "-p", "--nounclassified", f1, f2)
+    kept = read_out(f"{out2}_c0.0")
+    assert kept == [l for l in lines if l.startswith("C")] and 0 < len(kept) < len(lines)
+    rep2 = open(f"{out2}_c0.0/all_kreport.txt").read()
+    assert "unclassified" not in rep2
+    out3 = tmp_path / "paired3"
+    classify("-i", loc, "-o", out3, "-p", "--nodetailed", f1, f2)
+    assert not glob.glob(f"{out3}_c0.0/sample=*")
+    assert open(f"{out3}_c0.0/all_kreport.txt").read() == open(f"{out}_c0.0/all_kreport.txt").read()
+    # --sample-regex: group 1 of the first match is the sample id (Classifier.scala:138-142); unmatched -> "other"
+    out4 = tmp_path / "multi"
+    classify("-i", loc, "-o", out4, "--sample-regex", r"sra\.(\d)", "-p", f1, f2)
+    samples = sorted(os.path.basename(d)[len("sample="):] for d in glob.glob(f"{out4}_c0.0/sample=*"))
+    assert len(samples) > 1 and all(len(s) == 1 and s.isdigit() for s in samples)
+    merged = sorted(l for s in samples for l in read_out(f"{out4}_c0.0", s))
+    assert merged == sorted(lines)
+    for s in samples:
+        assert all(l.split("\t")[1].split("sra.")[1][0] == s for l in read_out(f"{out4}_c0.0", s))
+        assert os.path.exists(f"{out4}_c0.0/{s}_kreport.txt")
+
+
+def test_parquet_roundtrip(tmp_path):
+    import parquet_to_slkrec as conv
+    rng = np.random.default_rng(1)
+    keys = rng.integers(-2**62, 2**62, 1000).astype(np.int64)
+    taxa = rng.integers(1, 1000, 1000).astype(np.int32)
+    loc = str(tmp_path / "lib")
+    conv.write_parquet_dir(loc, keys, taxa, buckets=5)
+    k2, t2 = conv.read_parquet_dir(loc)
+    assert sorted(zip(k2.tolist(), t2.tolist())) == sorted(zip(keys.tolist(), taxa.tolist()))
+    conv.write_slkrec(loc + ".slkrec", k2, t2)
+    raw = open(loc + ".slkrec", "rb").read()
+    assert raw[:8] == b"SLKREC1\0" and len(raw) == 24 + 12 * 1000
+    assert np.array_equal(np.frombuffer(raw, np.int64, 1000, 24), k2)
