@@ -11,9 +11,9 @@ CLI := slacken_amd/bin/slacken-amd
 
 all: $(LIB) $(CLI) oracle
 
-$(LIB): $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/capi.hip $(CSRC)/engine.h include/slacken_amd.h
+$(LIB): $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/build.hip $(CSRC)/capi.hip $(CSRC)/engine.h include/slacken_amd.h
 	@mkdir -p slacken_amd/lib
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/capi.hip
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/build.hip $(CSRC)/capi.hip
 
 $(CLI): slacken_amd/host/slacken_cli.cpp slacken_amd/host/taxonomy.hpp include/slacken_amd.h $(LIB)
 	@mkdir -p slacken_amd/bin

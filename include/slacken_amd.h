@@ -116,7 +116,23 @@ int32_t slk_index_append_device(slk_index *ix, const int64_t *d_keys, const int3
 /* parents[t] = parent taxon, parents[ROOT] = NONE, unused ids = NONE: Taxonomy.parents (S/slacken/Taxonomy.scala:81-109,159);
  * replaces the bcTaxonomy broadcast (KeyValueIndex.scala:44-47). */
 int32_t slk_index_set_taxonomy(slk_index *ix, const int32_t *parents, int32_t T);
+/* Library construction from taxon-labelled sequences (BASELINE config 5, the dynamic 2-step library): every super-mer's
+ * minimizer of every sequence, labelled with the sequence's taxon, merged per minimizer by LCA -- SplitterMinimizers.find
+ * (S/slacken/Minimizers.scala:43-76) + groupBy(id).agg(TaxonLCA) (KeyValueIndex.makeRecords, KeyValueIndex.scala:85-93;
+ * LowestCommonAncestor.scala:152-170).  Sequences are split around anything that is not ACGTU (either case), as
+ * InputReader.removeInvalid does for library input (S/kmers/input/InputReader.scala:60-72); they must be free of
+ * whitespace.  Sequence i is bases[offsets[i] .. offsets[i+1]) with taxon taxa[i]; sequences with taxon NONE are
+ * skipped (the reference filters on Taxonomy.isDefined, KeyValueIndex.scala:118-120 -- the caller applies that filter).
+ * Needs the taxonomy (slk_index_set_taxonomy) and an unfinalized index whose slk_table_config.expected_records bounds
+ * the number of distinct minimizers.  May be called any number of times, also mixed with slk_index_append of records
+ * whose keys do not occur in the sequences; the result does not depend on the order or batching of the calls. */
+int32_t slk_index_add_sequences(slk_index *ix, const uint8_t *bases, const uint64_t *offsets, const int32_t *taxa,
+                                uint64_t n_sequences);
 int32_t slk_index_finalize(slk_index *ix);
+/* The table's records as (key, taxon) arrays -- what KeyValueIndex.writeRecords would persist (KeyValueIndex.scala:125-139).
+ * The order is unspecified (a set).  *n_records receives the number of records; if it exceeds capacity only the first
+ * `capacity` were written and SLK_E_CAPACITY is returned.  keys/taxa may be NULL with capacity 0 to query the count. */
+int32_t slk_index_export(const slk_index *ix, int64_t *keys, int32_t *taxa, uint64_t capacity, uint64_t *n_records);
 int32_t slk_index_get_info(const slk_index *ix, slk_index_info *out);
 /* Point lookups (host arrays), for tests and tooling: taxon or NONE per key -- the left join + spanToHit's
  * otherwise(NONE) (KeyValueIndex.scala:176-185). */

@@ -77,6 +77,11 @@ def lib():
         L.orc_spans.argtypes = [C.POINTER(Params), C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(Span), C.c_int]
         L.orc_minimizer_keys.argtypes = [C.POINTER(Params), C.c_char_p, C.c_long, i64p, C.c_long]
         L.orc_minimizer_keys.restype = C.c_long
+        L.orc_library_minimizers.argtypes = [C.POINTER(Params), C.c_char_p, C.c_long, i64p, C.c_long]
+        L.orc_library_minimizers.restype = C.c_long
+        L.orc_build_records.argtypes = [C.POINTER(Params), i32p, C.c_int32, C.c_char_p, u64p, i32p, C.c_long, i64p, i32p,
+                                        C.c_long]
+        L.orc_build_records.restype = C.c_long
         L.orc_index_create.argtypes = [C.c_int, i64p, i32p, C.c_size_t]
         L.orc_index_create.restype = C.c_void_p
         L.orc_index_destroy.argtypes = [C.c_void_p]
@@ -187,6 +192,33 @@ def minimizer_keys(p, seq):
     if n < 0:
         raise ValueError(f"orc_minimizer_keys failed: {n}")
     return out[:n]
+
+
+def library_minimizers(p, seq):
+    """SplitterMinimizers.find for one library sequence (after removeInvalid): int64 minimizers, one per super-mer."""
+    seq = _b(seq)
+    out = np.zeros(max(1, len(seq)), np.int64)
+    n = lib().orc_library_minimizers(C.byref(p), seq, len(seq), _p(out, C.c_int64), len(out))
+    if n < 0:
+        raise ValueError(f"orc_library_minimizers failed: {n}")
+    return out[:n]
+
+
+def build_records(p, parents, bases, offsets, taxa):
+    """KeyValueIndex.makeRecords: (keys sorted ascending, LCA taxa) of taxon-labelled sequences (same argument meaning as
+    slk_index_add_sequences)."""
+    parents = np.ascontiguousarray(parents, np.int32)
+    bases = np.ascontiguousarray(bases, np.uint8)
+    offsets = np.ascontiguousarray(offsets, np.uint64)
+    taxa = np.ascontiguousarray(taxa, np.int32)
+    cap = int(offsets[-1]) + 1
+    keys = np.zeros(cap, np.int64)
+    tx = np.zeros(cap, np.int32)
+    n = lib().orc_build_records(C.byref(p), _p(parents, C.c_int32), len(parents), bases.tobytes(), _p(offsets, C.c_uint64),
+                                _p(taxa, C.c_int32), len(taxa), _p(keys, C.c_int64), _p(tx, C.c_int32), cap)
+    if n < 0:
+        raise ValueError(f"orc_build_records failed: {n}")
+    return keys[:n].copy(), tx[:n].copy()
 
 
 class Index:

@@ -415,6 +415,78 @@ long orc_minimizer_keys(const orc_params *p, const char *seq, long n, int64_t *o
   return cnt;
 }
 
+/* ---- library construction (BASELINE config 5): KeyValueIndex.makeRecords, S/slacken/KeyValueIndex.scala:85-93 ---- */
+
+/* One (taxon, sequence) row of SplitterMinimizers.find (S/slacken/Minimizers.scala:43-56) after InputReader.removeInvalid
+ * (S/kmers/input/InputReader.scala:60-72): every match of the regex [ACTGUactgu][ACTGUactgu\n\r]* is one fragment, and
+ * superkmerPositions (MinSplitter.scala:114-117,180-216; same window walk as splitRead) yields one minimizer per super-mer. */
+long orc_library_minimizers(const orc_params *p, const char *seq, long n, int64_t *out_keys, long cap) {
+  if (p->W != 1) return -2;
+  long cnt = 0, pos = 0;
+  scratch_t s = {0};
+  orc_supermer *sm = NULL;
+  long sm_cap = 0;
+  while (pos < n) {
+    if (orc_char_to_twobit((unsigned char)seq[pos]) >= 4) { pos++; continue; } /* a match starts at a nucleotide */
+    long end = pos + 1;
+    while (end < n && orc_char_to_twobit((unsigned char)seq[end]) < 5) end++;   /* nucleotides and \n \r */
+    long len = end - pos;
+    if (len + 2 > sm_cap) { free(sm); sm_cap = len + 2; sm = (orc_supermer *)malloc(sizeof(orc_supermer) * (size_t)sm_cap); }
+    int ns = split_encode_scratch(p, seq + pos, (int)len, &s, sm, (int)sm_cap);
+    if (ns < 0) { cnt = ns; break; }
+    for (int i = 0; i < ns; i++) {
+      if (cnt >= cap) { cnt = -5; break; }
+      out_keys[cnt++] = (int64_t)sm[i].key[0];
+    }
+    if (cnt < 0) break;
+    pos = end;
+  }
+  free(sm);
+  scratch_free(&s);
+  return cnt;
+}
+
+typedef struct { int64_t key; int32_t taxon; long order; } build_pair;
+static int build_pair_cmp(const void *a, const void *b) {
+  const build_pair *x = (const build_pair *)a, *y = (const build_pair *)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->order < y->order ? -1 : (x->order > y->order);
+}
+
+/* minimizersTaxa.groupBy(id).agg(TaxonLCA) (KeyValueIndex.scala:85-93; TaxonLCA: zero = NONE, reduce = lca,
+ * LowestCommonAncestor.scala:152-170).  Output sorted by key (signed).  Returns the number of records, -5 if cap is short. */
+long orc_build_records(const orc_params *p, const int32_t *parents, int32_t T, const char *bases, const uint64_t *offsets,
+                       const int32_t *taxa, long S, int64_t *out_keys, int32_t *out_taxa, long cap) {
+  long total = 0, np = 0;
+  for (long i = 0; i < S; i++) total += (long)(offsets[i + 1] - offsets[i]);
+  build_pair *pairs = (build_pair *)malloc(sizeof(build_pair) * (size_t)(total + 1));
+  int64_t *tmp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(total + 1));
+  long rc = 0;
+  for (long i = 0; i < S && rc >= 0; i++) {
+    long len = (long)(offsets[i + 1] - offsets[i]);
+    long n = orc_library_minimizers(p, bases + offsets[i], len, tmp, len + 1);
+    if (n < 0) { rc = n; break; }
+    for (long j = 0; j < n; j++) { pairs[np].key = tmp[j]; pairs[np].taxon = taxa[i]; pairs[np].order = np; np++; }
+  }
+  long cnt = 0;
+  if (rc >= 0) {
+    qsort(pairs, (size_t)np, sizeof(build_pair), build_pair_cmp);
+    for (long i = 0; i < np;) {
+      int32_t acc = ORC_NONE; /* zero */
+      long j = i;
+      for (; j < np && pairs[j].key == pairs[i].key; j++) acc = orc_lca(parents, T, acc, pairs[j].taxon);
+      if (cnt >= cap) { cnt = -5; break; }
+      out_keys[cnt] = pairs[i].key;
+      out_taxa[cnt] = acc;
+      cnt++;
+      i = j;
+    }
+  } else cnt = rc;
+  free(pairs);
+  free(tmp);
+  return cnt;
+}
+
 /* ---- index: the records side of `taggedSpans.join(index.records, idColumnNames, "left")`, Classifier.scala:84 ---- */
 struct orc_index {
   int W;

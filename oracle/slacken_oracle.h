@@ -102,6 +102,10 @@ int orc_spans(const orc_params *p, const char *seq1, int n1, const char *seq2, i
 /* All SEQUENCE_FLAG span keys (word 0 only, W must be 1) of one sequence, in order: the (id1) side of
  * SplitterMinimizers.find (S/slacken/Minimizers.scala:43-76) used by the index build. Returns the count or <0. */
 long orc_minimizer_keys(const orc_params *p, const char *seq, long n, int64_t *out_keys, long cap);
+/* library construction (KeyValueIndex.makeRecords :85-93): minimizers of one library sequence; LCA-merged records of many */
+long orc_library_minimizers(const orc_params *p, const char *seq, long n, int64_t *out_keys, long cap);
+long orc_build_records(const orc_params *p, const int32_t *parents, int32_t T, const char *bases, const uint64_t *offsets,
+                       const int32_t *taxa, long S, int64_t *out_keys, int32_t *out_taxa, long cap);
 
 /* index ("records" table): keys are W words per record, left-aligned as in the Parquet id columns */
 orc_index *orc_index_create(int W, const int64_t *keys, const int32_t *taxa, size_t n);

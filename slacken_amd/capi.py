@@ -41,7 +41,7 @@ HIT_DTYPE = np.dtype([("taxon", "<i4"), ("count", "<i4")])
 # every symbol include/slacken_amd.h declares
 EXPORTS = ["slk_device_count", "slk_last_error", "slk_version", "slk_index_create", "slk_index_append",
            "slk_index_append_device", "slk_index_set_taxonomy", "slk_index_finalize", "slk_index_get_info",
-           "slk_index_lookup", "slk_index_destroy", "slk_stream_create", "slk_stream_synchronize",
+           "slk_index_lookup", "slk_index_add_sequences", "slk_index_export", "slk_index_destroy", "slk_stream_create", "slk_stream_synchronize",
            "slk_stream_hip_stream", "slk_stream_destroy", "slk_spans_batch", "slk_classify_batch",
            "slk_classify_batch_device", "slk_stream_last_stage_ms", "slk_scan_device", "slk_lookup_device",
            "slk_shard_of", "slk_classify_hits_device"]
@@ -75,6 +75,8 @@ def lib():
     L.slk_index_finalize.argtypes = [vp]
     L.slk_index_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
     L.slk_index_lookup.argtypes = [vp, i64p, C.c_uint64, i32p]
+    L.slk_index_add_sequences.argtypes = [vp, u8p, u64p, i32p, C.c_uint64]
+    L.slk_index_export.argtypes = [vp, i64p, i32p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.slk_index_destroy.argtypes = [vp]
     L.slk_index_destroy.restype = None
     L.slk_stream_create.argtypes = [vp, C.POINTER(vp)]
@@ -149,6 +151,22 @@ class Index:
     def set_taxonomy(self, parents):
         parents = _np(parents, np.int32)
         _check(lib().slk_index_set_taxonomy(self.h, _ptr(parents), parents.size))
+
+    def add_sequences(self, bases, offsets, taxa):
+        """Library construction (KeyValueIndex.makeRecords): minimizers of taxon-labelled sequences, LCA-merged."""
+        bases, offsets, taxa = _np(bases, np.uint8), _np(offsets, np.uint64), _np(taxa, np.int32)
+        assert offsets.size == taxa.size + 1
+        _check(lib().slk_index_add_sequences(self.h, _ptr(bases), _ptr(offsets), _ptr(taxa), taxa.size))
+
+    def export(self):
+        """(keys, taxa) of every record in the table, sorted by key."""
+        n = C.c_uint64(0)
+        _check(lib().slk_index_export(self.h, None, None, 0, C.byref(n)))
+        keys, taxa = np.zeros(n.value, np.int64), np.zeros(n.value, np.int32)
+        if n.value:
+            _check(lib().slk_index_export(self.h, _ptr(keys), _ptr(taxa), n.value, C.byref(n)))
+        order = np.argsort(keys, kind="stable")
+        return keys[order], taxa[order]
 
     def finalize(self):
         _check(lib().slk_index_finalize(self.h))

@@ -277,6 +277,91 @@ int32_t slk_index_set_taxonomy(slk_index *ix, const int32_t *parents, int32_t T)
   return SLK_OK;
 }
 
+int32_t slk_index_add_sequences(slk_index *ix, const uint8_t *bases, const uint64_t *offsets, const int32_t *taxa,
+                                uint64_t S) {
+  if (!ix || (S && (!bases || !offsets || !taxa))) return fail(SLK_E_INVALID, "null argument");
+  if (ix->finalized) return fail(SLK_E_STATE, "index is finalized");
+  if (!ix->d_parents) return fail(SLK_E_STATE, "slk_index_add_sequences needs the taxonomy (LCA merging): call slk_index_set_taxonomy first");
+  if (ix->sp.w > BUILD_MAX_W) return fail(SLK_E_UNSUPPORTED, "library construction supports windows of up to %d m-mers (k - m + 1 = %d)", BUILD_MAX_W, ix->sp.w);
+  int32_t rc = set_device(ix);
+  if (rc) return rc;
+  const int32_t max_t = (1 << ix->taxon_bits) - 1;
+  const uint32_t k = (uint32_t)ix->sp.k, CW = BUILD_CHUNK_WINDOWS;
+  for (uint64_t i = 0; i < S; i++) {
+    if (offsets[i + 1] < offsets[i]) return fail(SLK_E_INVALID, "offsets must be non-decreasing (sequence %llu)", (unsigned long long)i);
+    if (taxa[i] < 0 || taxa[i] > max_t)
+      return fail(SLK_E_INVALID, "sequence %llu: taxon %d outside [0, %d] (slk_table_config.max_taxon)", (unsigned long long)i, taxa[i], max_t);
+  }
+  // groups of whole sequences of about 1 GiB; each is cut into chunks of CW windows overlapping by k-1 bases
+  const uint64_t GROUP = 1ULL << 30;
+  DevBuf d_bases, d_start, d_len, d_tax;
+  std::vector<uint64_t> cstart;
+  std::vector<uint32_t> clen;
+  std::vector<int32_t> ctax;
+  uint64_t i = 0;
+  while (i < S) {
+    uint64_t j = i, g0 = offsets[i];
+    while (j < S && (j == i || offsets[j + 1] - g0 <= GROUP)) j++;
+    uint64_t gbytes = offsets[j] - g0;
+    cstart.clear(); clen.clear(); ctax.clear();
+    for (uint64_t q = i; q < j; q++) {
+      uint64_t len = offsets[q + 1] - offsets[q];
+      if (taxa[q] == 0 || len < k) continue;
+      uint64_t windows = len - k + 1;
+      for (uint64_t w0 = 0; w0 < windows; w0 += CW) {
+        uint64_t nw = std::min<uint64_t>(CW, windows - w0);
+        cstart.push_back(offsets[q] - g0 + w0);
+        clen.push_back((uint32_t)(nw + k - 1));
+        ctax.push_back(taxa[q]);
+      }
+    }
+    if (!cstart.empty()) {
+      uint64_t nc = cstart.size();
+      HIPCHK(d_bases.ensure(gbytes + 16));
+      HIPCHK(d_start.ensure(nc * 8));
+      HIPCHK(d_len.ensure(nc * 4));
+      HIPCHK(d_tax.ensure(nc * 4));
+      HIPCHK(hipMemcpyAsync(d_bases.p, bases + g0, gbytes, hipMemcpyHostToDevice, ix->build_stream));
+      HIPCHK(hipMemsetAsync((uint8_t *)d_bases.p + gbytes, 0, 16, ix->build_stream));
+      HIPCHK(hipMemcpyAsync(d_start.p, cstart.data(), nc * 8, hipMemcpyHostToDevice, ix->build_stream));
+      HIPCHK(hipMemcpyAsync(d_len.p, clen.data(), nc * 4, hipMemcpyHostToDevice, ix->build_stream));
+      HIPCHK(hipMemcpyAsync(d_tax.p, ctax.data(), nc * 4, hipMemcpyHostToDevice, ix->build_stream));
+      launch_build(ix->sp, build_view(ix), ix->d_parents, ix->T, d_bases.as<uint8_t>(), d_start.as<uint64_t>(),
+                   d_len.as<uint32_t>(), d_tax.as<int32_t>(), nc, ix->build_stream);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(ix->build_stream));
+    }
+    i = j;
+  }
+  d_bases.release(); d_start.release(); d_len.release(); d_tax.release();
+  return read_build_counters(ix);
+}
+
+int32_t slk_index_export(const slk_index *ix, int64_t *keys, int32_t *taxa, uint64_t capacity, uint64_t *n_records) {
+  if (!ix || !n_records || (capacity && (!keys || !taxa))) return fail(SLK_E_INVALID, "null argument");
+  (void)hipSetDevice(ix->device);
+  DevBuf dk, dt, dc;
+  HIPCHK(dk.ensure(std::max<uint64_t>(capacity, 1) * 8));
+  HIPCHK(dt.ensure(std::max<uint64_t>(capacity, 1) * 4));
+  HIPCHK(dc.ensure(8));
+  HIPCHK(hipMemset(dc.p, 0, 8));
+  TableView v = ix->view();
+  launch_export(v, ix->nbuckets, dk.as<int64_t>(), dt.as<int32_t>(), capacity, dc.as<unsigned long long>(), ix->build_stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ix->build_stream));
+  unsigned long long n = 0;
+  HIPCHK(hipMemcpy(&n, dc.p, 8, hipMemcpyDeviceToHost));
+  *n_records = n;
+  uint64_t got = std::min<uint64_t>(n, capacity);
+  if (got) {
+    HIPCHK(hipMemcpy(keys, dk.p, got * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(taxa, dt.p, got * 4, hipMemcpyDeviceToHost));
+  }
+  dk.release(); dt.release(); dc.release();
+  if (n > capacity && capacity) return fail(SLK_E_CAPACITY, "%llu records, capacity %llu", n, (unsigned long long)capacity);
+  return SLK_OK;
+}
+
 int32_t slk_index_finalize(slk_index *ix) {
   if (!ix) return fail(SLK_E_INVALID, "null argument");
   int32_t rc = set_device(ix);

@@ -94,6 +94,14 @@ void launch_lane(const FusedArgs &A, int32_t *defer, uint32_t max_len, hipStream
 
 // launchers (kernels.hip)
 void launch_table_insert(const TableBuild &t, const int64_t *keys, const int32_t *taxa, uint64_t n, hipStream_t s);
+// build.hip: minimizers of taxon-labelled sequence chunks merged by LCA straight into the table; table -> records
+constexpr uint32_t BUILD_CHUNK_WINDOWS = 512;
+constexpr int BUILD_MAX_W = 28;
+void launch_build(const ScanParams &P, const TableBuild &T, const int32_t *parents, int32_t ntax, const uint8_t *bases,
+                  const uint64_t *chunk_start, const uint32_t *chunk_len, const int32_t *chunk_taxon, uint64_t nchunks,
+                  hipStream_t s);
+void launch_export(const TableView &T, uint64_t nbuckets, int64_t *keys, int32_t *taxa, uint64_t capacity,
+                   unsigned long long *counter, hipStream_t s);
 void launch_table_lookup(const TableView &t, const int64_t *keys, uint64_t n, int32_t *out, hipStream_t s);
 void launch_scan(const ScanParams &P, const uint8_t *bases, const uint64_t *offsets, const uint8_t *mate_bases,
                  const uint64_t *mate_offsets, uint64_t R, uint64_t *span_keys, int32_t *span_meta, int32_t *span_count,

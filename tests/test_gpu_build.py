@@ -1,0 +1,134 @@
+"""Device library construction (slk_index_add_sequences, build.hip) against the oracle's restatement of
+KeyValueIndex.makeRecords, bit for bit on the exported records, and classification with the built index."""
+import numpy as np
+import pytest
+
+import synth
+import taxgen
+from test_oracle_build import messy_genome
+
+pytestmark = pytest.mark.gpu
+
+
+def pack(seqs):
+    bases = np.frombuffer("".join(seqs).encode(), np.uint8)
+    offsets = np.zeros(len(seqs) + 1, np.uint64)
+    np.cumsum([len(s) for s in seqs], out=offsets[1:])
+    return bases, offsets
+
+
+def genomes(rng, parents, n, lo, hi, shared=400):
+    taxa = np.array(taxgen.defined_taxa(parents))
+    base = messy_genome(rng, 4000)
+    seqs, tx = [], []
+    for _ in range(n):
+        g = list(messy_genome(rng, int(rng.integers(lo, hi))))
+        a = int(rng.integers(0, 3000))
+        cut = min(shared, len(g))
+        g[:cut] = base[a:a + cut]
+        seqs.append("".join(g))
+        tx.append(int(taxa[rng.integers(1, len(taxa))]))
+    return seqs, tx
+
+
+@pytest.mark.parametrize("k,m,spaces", [(35, 31, 7), (31, 12, 0), (35, 31, 0), (40, 32, 4)])
+def test_build_matches_oracle(orc, k, m, spaces):
+    import slacken_amd
+    rng = np.random.default_rng(k * 100 + m)
+    parents = taxgen.taxonomy(8 * 16, rng)
+    p = orc.params(k=k, m=m, spaces=spaces)
+    seqs, tx = genomes(rng, parents, 40, 10, 6000)
+    seqs += ["", "ACGT", "N" * 100, synth.random_dna(k, rng).tobytes().decode(), synth.random_dna(k - 1, rng).tobytes().decode()]
+    tx += [5, 5, 5, 5, 5]
+    seqs.append(synth.random_dna(3000, rng).tobytes().decode())     # taxon NONE: skipped
+    tx.append(0)
+    bases, offsets = pack(seqs)
+    keep = [i for i, t in enumerate(tx) if t != 0]
+    wb, wo = pack([seqs[i] for i in keep])
+    want_k, want_t = orc.build_records(p, parents, wb, wo, [tx[i] for i in keep])
+
+    def build(parts):
+        ix = slacken_amd.Index(k=k, m=m, spaces=spaces, expected_records=int(offsets[-1]) // 2 + 1000, max_taxon=len(parents) - 1)
+        ix.set_taxonomy(parents)
+        for idx in parts:
+            b, o = pack([seqs[i] for i in idx])
+            ix.add_sequences(b, o, [tx[i] for i in idx])
+        return ix
+
+    ix = build([list(range(len(seqs)))])
+    got_k, got_t = ix.export()
+    assert np.array_equal(got_k, want_k) and np.array_equal(got_t, want_t)
+    assert ix.info().records == len(want_k)
+    # any batching / order of the calls gives the same records
+    perm = rng.permutation(len(seqs)).tolist()
+    ix2 = build([perm[:7], perm[7:30], perm[30:]])
+    k2, t2 = ix2.export()
+    assert np.array_equal(k2, want_k) and np.array_equal(t2, want_t)
+    ix.finalize()
+    assert np.array_equal(ix.lookup(want_k), want_t)
+
+
+def test_long_sequences_many_chunks(orc):
+    import slacken_amd
+    rng = np.random.default_rng(77)
+    parents = taxgen.taxonomy(8 * 8, rng)
+    p = orc.params()
+    seqs = [synth.random_dna(300_000, rng).tobytes().decode(), messy_genome(rng, 150_000)]
+    seqs.append(seqs[0][100_000:180_000])      # a second taxon shares 80 kbp with the first
+    tx = [10, 20, 30]
+    bases, offsets = pack(seqs)
+    want_k, want_t = orc.build_records(p, parents, bases, offsets, tx)
+    ix = slacken_amd.Index(expected_records=len(want_k) * 2, max_taxon=len(parents) - 1)
+    ix.set_taxonomy(parents)
+    ix.add_sequences(bases, offsets, tx)
+    got_k, got_t = ix.export()
+    assert np.array_equal(got_k, want_k) and np.array_equal(got_t, want_t)
+    lca = orc.lca(parents, 10, 30)
+    assert (got_t == lca).sum() > 10_000
+
+
+def test_built_index_classifies_like_oracle(orc):
+    """two-step shape: records built on the device stay in HBM and are classified against directly"""
+    import slacken_amd
+    rng = np.random.default_rng(5)
+    parents = taxgen.taxonomy(8 * 32, rng)
+    p = orc.params()
+    lib = synth.Library(orc, p, parents, n_genomes=8, genome_len=20000)
+    seqs = [g.tobytes().decode() for g in lib.genomes]
+    bases, offsets = pack(seqs)
+    ix = slacken_amd.Index(expected_records=len(lib.keys) * 2, max_taxon=len(parents) - 1)
+    ix.set_taxonomy(parents)
+    ix.add_sequences(bases, offsets, lib.genome_taxa)
+    got_k, got_t = ix.export()
+    order = np.argsort(lib.keys)
+    assert np.array_equal(got_k, lib.keys[order]) and np.array_equal(got_t, lib.taxa[order])
+    ix.finalize()
+    reads = synth.make_reads(lib, 3000, rng)
+    rb, ro = synth.pack(reads)
+    want = orc.classify_batch(p, orc.Index(1, lib.keys, lib.taxa), parents, rb, ro, thresholds=(0.0, 0.15))
+    got = ix.stream().classify_batch(rb, ro, thresholds=(0.0, 0.15), with_hits=False)
+    for key in ("taxon", "classified", "num_distinct", "total_kmers"):
+        assert np.array_equal(got[key], want[key])
+
+
+def test_append_then_add_sequences_and_errors(orc):
+    import slacken_amd
+    rng = np.random.default_rng(6)
+    parents = taxgen.taxonomy(8 * 8, rng)
+    p = orc.params()
+    g = synth.random_dna(4000, rng).tobytes().decode()
+    bases, offsets = pack([g])
+    ix = slacken_amd.Index(expected_records=5000, max_taxon=len(parents) - 1)
+    with pytest.raises(slacken_amd.SlackenError):          # needs the taxonomy
+        ix.add_sequences(bases, offsets, [3])
+    ix.set_taxonomy(parents)
+    with pytest.raises(slacken_amd.SlackenError):          # taxon out of range
+        ix.add_sequences(bases, offsets, [len(parents) + 100000])
+    ix.append([12345 << 16], [7])
+    ix.add_sequences(bases, offsets, [3])
+    k1, t1 = ix.export()
+    wk, wt = orc.build_records(p, parents, bases, offsets, [3])
+    assert sorted(k1.tolist()) == sorted(wk.tolist() + [12345 << 16])
+    ix.finalize()
+    with pytest.raises(slacken_amd.SlackenError):
+        ix.add_sequences(bases, offsets, [3])
