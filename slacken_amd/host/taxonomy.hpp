@@ -118,6 +118,29 @@ struct Taxonomy {
     return fromNodesAndNames(nodes, names, merged);
   }
 
+  // Taxonomy.depth :217-224: the depth of the nearest ranked ancestor-or-self; NONE = -1
+  int depth(Taxon t) const {
+    while (t > 0 && t < size()) {
+      if (ranks[t] != NO_RANK) return ranks[t] - 1;
+      t = parents[t];
+    }
+    return -1;
+  }
+
+  // Taxonomy.taxaWithDescendants :304-311 as a membership vector
+  std::vector<uint8_t> withDescendants(const std::vector<Taxon> &taxa) const {
+    std::vector<uint8_t> in(parents.size(), 0);
+    std::vector<Taxon> stack(taxa.begin(), taxa.end());
+    while (!stack.empty()) {
+      Taxon t = stack.back();
+      stack.pop_back();
+      if (t < 0 || t >= size() || in[t]) continue;
+      in[t] = 1;
+      for (Taxon c : children()[t]) stack.push_back(c);
+    }
+    return in;
+  }
+
   // Taxonomy.children :186-195: built by PREPENDING while iterating taxids upward => each list is in descending id order
   const std::vector<std::vector<Taxon>> &children() const {
     if (children_.empty()) {

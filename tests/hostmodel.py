@@ -97,3 +97,34 @@ def parse_fastq(text):
         if len(w) >= 3 and w[0][:1] == "@" and w[2][:1] == "+":
             out.append((w[0].split(" ")[0][1:], w[1]))
     return out
+
+
+# ---- Dynamic (two-step) library: S/slacken/Dynamic.scala:174-185,213-243,362-374; Taxonomy.scala:217-224,304-311 ----
+def depth(tax, t):
+    while t != 0:
+        if tax.ranks[t] is not None:
+            return tax.ranks[t] - 1
+        t = tax.parents[t]
+    return -1
+
+
+def count_filter(tax, counts, rank_depth, threshold):
+    """CountFilter.taxa: keys of the aggregator at depth >= rank whose clade total reaches the threshold (ascending)."""
+    clade = {}
+    for t, c in counts:
+        p = t
+        while p != 0:
+            clade[p] = clade.get(p, 0) + c
+            p = tax.parents[p]
+    return sorted(t for t, _ in counts if depth(tax, t) >= rank_depth and clade.get(t, 0) >= threshold)
+
+
+def with_descendants(tax, taxa):
+    out, stack = set(), list(taxa)
+    while stack:
+        t = stack.pop()
+        if t in out:
+            continue
+        out.add(t)
+        stack.extend(tax.children[t])
+    return out

@@ -1,0 +1,171 @@
+"""`slacken-amd classify2` (two-step classification with a dynamic library, BASELINE config 5) end to end against a Python
+restatement of Dynamic.scala driven by the CPU oracle: detected taxon set, the records of the dynamic library (through the
+classifications they produce) and the per-read output.  Library layout as the reference expects it: <lib>/library/**/*.fna
+and <lib>/seqid2taxid.map (Slacken.scala:116-121)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import hostmodel
+import synth
+import taxgen
+from test_host_cli import CLI, ROOT
+from test_host_classify_gpu import read_out
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+pytestmark = pytest.mark.gpu
+
+
+def write_ranked_taxonomy(d, parents):
+    """level L of taxgen's generator gets the L-th standard rank (superkingdom .. species); a few nodes are 'no rank'"""
+    os.makedirs(d, exist_ok=True)
+    ls = (len(parents) - 2) // taxgen.N_RANKS
+    nodes, names = [(1, 1, "no rank")], [(1, "root")]
+    for t in range(2, len(parents)):
+        level = (t - 2) // ls + 1
+        rank = hostmodel.RANKS[level + 1] if t % 7 else "no rank"
+        nodes.append((t, int(parents[t]), rank))
+        names.append((t, f"Taxon {t}"))
+    with open(os.path.join(d, "nodes.dmp"), "w") as f:
+        for t, p, r in nodes:
+            f.write(f"{t}\t|\t{p}\t|\t{r}\t|\n")
+    with open(os.path.join(d, "names.dmp"), "w") as f:
+        for t, nm in names:
+            f.write(f"{t}\t|\t{nm}\t|\t\t|\tscientific name\t|\n")
+    return hostmodel.Taxonomy(nodes, names)
+
+
+def setup(tmp_path, orc, seed=9):
+    import parquet_to_slkrec as conv
+    rng = np.random.default_rng(seed)
+    p = orc.params()
+    parents = taxgen.taxonomy(8 * 12, rng)
+    ls = (len(parents) - 2) // taxgen.N_RANKS
+    species = list(range(7 * ls + 2, 8 * ls + 2))
+    genus = list(range(6 * ls + 2, 7 * ls + 2))
+    g_taxa = [species[i] for i in (0, 1, 2, 3, 5, 8)] + [genus[1], genus[2]]
+    genomes = [synth.random_dna(30000, rng) for _ in g_taxa]
+    for g in range(1, len(genomes)):          # shared stretches => LCA records
+        genomes[g][1000:2500] = genomes[g - 1][1000:2500]
+    # each genome is three sequences with their own ids; sequences carry Ns and line breaks in the files
+    seq_ids, seqs, seq_taxa = [], [], []
+    for gi, (g, t) in enumerate(zip(genomes, g_taxa)):
+        for part, (a, b) in enumerate(((0, 12000), (12000, 12020), (12020, 30000))):
+            s = g[a:b].tobytes().decode()
+            if part == 2:
+                s = s[:500] + "N" * 30 + s[530:3000] + "R" + s[3001:]
+            seq_ids.append(f"NC_{gi:03d}.{part}")
+            seqs.append(s)
+            seq_taxa.append(t)
+    lib = tmp_path / "k2lib"
+    for sub, idx in (("bacteria", range(0, 12)), ("archaea/deep", range(12, len(seqs)))):
+        os.makedirs(lib / "library" / sub, exist_ok=True)
+        with open(lib / "library" / sub / "library.fna", "w") as f:
+            for i in idx:
+                f.write(f">{seq_ids[i]} some organism\n")
+                f.write("\n".join(seqs[i][j:j + 80] for j in range(0, len(seqs[i]), 80)) + "\n")
+    (lib / "library" / "ignored.txt").write_text(">NC_000.0\nACGT\n")
+    with open(lib / "seqid2taxid.map", "w") as f:
+        for sid, t in zip(seq_ids, seq_taxa):
+            f.write(f"{sid}\t{t}\n")
+        f.write("NC_missing.1\t5\n")
+    # base index = all genomes, in Slacken's on-disk layout
+    bases = np.frombuffer("".join(seqs).encode(), np.uint8)
+    offsets = np.zeros(len(seqs) + 1, np.uint64)
+    np.cumsum([len(s) for s in seqs], out=offsets[1:])
+    bk, bt = orc.build_records(p, parents, bases, offsets, seq_taxa)
+    loc = str(tmp_path / "base")
+    conv.write_parquet_dir(loc, bk, bt, buckets=3)
+    conv.write_slkrec(loc + ".slkrec", bk, bt)
+    with open(loc + ".properties", "w") as f:
+        f.write("k=35\nm=31\nbuckets=3\nversion=1\nsplitter=randomXOR\nminimizerSpaces=7\ncanonical=true\n")
+    tax = write_ranked_taxonomy(loc + "_taxonomy", parents)
+    # sample: many reads from genomes 0, 1 and 6 (a genus-level label), a handful from genome 4, plus noise
+    class L:
+        pass
+    reads = []
+    for gi, n in ((0, 400), (1, 300), (6, 300), (4, 12)):
+        L.genomes = [genomes[gi]]
+        reads += synth.make_reads(L, n, rng, frac_random=0.0, short=0.0)
+    L.genomes = []
+    reads += synth.make_reads(L, 100, rng)
+    reads = [(f"read{i}", r.tobytes().decode()) for i, r in enumerate(reads)]
+    fq = tmp_path / "sample.fq"
+    with open(fq, "w") as f:
+        for t, s in reads:
+            f.write(f"@{t}\n{s}\n+\n{'I' * len(s)}\n")
+    return dict(p=p, parents=parents, tax=tax, lib=str(lib), loc=loc, fq=str(fq), reads=reads, seqs=seqs, seq_taxa=seq_taxa,
+                seq_ids=seq_ids, base=(bk, bt))
+
+
+def restate(orc, S, criterion, threshold, init_conf=0.15, rank_depth=8, thresholds=(0.0,)):
+    p, parents, tax = S["p"], S["parents"], S["tax"]
+    base = orc.Index(1, *S["base"])
+    counts = {}
+    if criterion == "reads":
+        for _, s in S["reads"]:
+            res, hits = orc.classify_read(p, base, parents, s, None, 2, init_conf)
+            if hits and res["classified"]:
+                counts[res["taxon"]] = counts.get(res["taxon"], 0) + 1
+    else:
+        seen = set()
+        for _, s in S["reads"]:
+            res, hits = orc.classify_read(p, base, parents, s, None, 2, 0.0)
+            keys = [sp["key"][0] for sp in orc.spans(p, s)]
+            assert len(keys) == len(hits)
+            for (t, _), key in zip(hits, keys):
+                if t in (-1, -2) or hostmodel.depth(tax, t) < rank_depth:
+                    continue
+                if criterion == "distinct":
+                    if (t, key) in seen:
+                        continue
+                    seen.add((t, key))
+                counts[t] = counts.get(t, 0) + 1
+    keep = hostmodel.count_filter(tax, sorted(counts.items()), rank_depth, threshold)
+    full = hostmodel.with_descendants(tax, keep)
+    sel = [i for i, t in enumerate(S["seq_taxa"]) if t in full]
+    b = np.frombuffer("".join(S["seqs"][i] for i in sel).encode(), np.uint8)
+    o = np.zeros(len(sel) + 1, np.uint64)
+    np.cumsum([len(S["seqs"][i]) for i in sel], out=o[1:])
+    dk, dt = orc.build_records(p, parents, b, o, [S["seq_taxa"][i] for i in sel])
+    dyn = orc.Index(1, dk, dt)
+    lines = {thr: [] for thr in thresholds}
+    for title, s in S["reads"]:
+        for thr in thresholds:
+            res, hits = orc.classify_read(p, dyn, parents, s, None, 2, thr)
+            if hits:
+                lines[thr].append(orc.output_line(res["classified"], title, res["taxon"], hits, 35))
+    return keep, lines, len(dk)
+
+
+def run2(*args):
+    r = subprocess.run([CLI, "classify2", *map(str, args)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return r.stderr
+
+
+def test_classify2_default_criterion(tmp_path, orc):
+    S = setup(tmp_path, orc)
+    out = tmp_path / "o" / "dyn"
+    os.makedirs(tmp_path / "o")
+    err = run2("-i", S["loc"], "-o", out, "--library", S["lib"], "-R", 50, "-c", "0.0", "0.1", S["fq"])
+    keep, lines, nrec = restate(orc, S, "reads", 50, thresholds=(0.0, 0.1))
+    assert [int(l) for l in open(f"{out}_taxonSet.txt").read().split()] == keep and len(keep) >= 2
+    assert f"dynamic index: {nrec} records" in err
+    assert read_out(f"{out}_c0.0") == lines[0.0]
+    assert read_out(f"{out}_c0.1") == lines[0.1]
+    # the genome with only 12 reads is not in the set: its reads are no longer classified to its species
+    assert any(l.startswith("C") for l in lines[0.0]) and os.path.exists(f"{out}_c0.0/all_kreport.txt")
+
+
+@pytest.mark.parametrize("flag,criterion,threshold", [("-C", "total", 400), ("-D", "distinct", 300)])
+def test_classify2_minimizer_criteria(tmp_path, orc, flag, criterion, threshold):
+    S = setup(tmp_path, orc, seed=10)
+    out = tmp_path / "dyn"
+    run2("-i", S["loc"], "-o", out, "--library", S["lib"], flag, threshold, "--rank", "genus", S["fq"])
+    keep, lines, _ = restate(orc, S, criterion, threshold, rank_depth=7)
+    assert [int(l) for l in open(f"{out}_taxonSet.txt").read().split()] == keep and keep
+    assert read_out(f"{out}_c0.0") == lines[0.0]
