@@ -3,7 +3,8 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 WPS ?= 0
 LWPS ?= 0
-HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -DSLK_WPS=$(WPS) -DSLK_LANE_WPS=$(LWPS)
+LLW ?= 4
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -DSLK_WPS=$(WPS) -DSLK_LANE_WPS=$(LWPS) -DSLK_LANE_LW=$(LLW)
 CSRC := slacken_amd/csrc
 LIB := slacken_amd/lib/libslacken_amd.so
 

@@ -48,7 +48,8 @@ EXPORTS = ["slk_device_count", "slk_last_error", "slk_version", "slk_index_creat
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libslacken_amd.so")
+    # SLACKEN_AMD_LIB: another build of the same library (A/B experiments with different compile-time settings)
+    return os.environ.get("SLACKEN_AMD_LIB") or os.path.join(_HERE, "lib", "libslacken_amd.so")
 
 
 _lib = None

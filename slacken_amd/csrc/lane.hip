@@ -27,19 +27,21 @@
 
 namespace slk {
 
-constexpr int LW = 4;             // waves per block
+#ifndef SLK_LANE_LW
+#define SLK_LANE_LW 4
+#endif
+constexpr int LW = SLK_LANE_LW;   // waves per block
 constexpr int QCAP = 128;         // probe queue entries per wave (64 buffered + at most 64 pushed per step)
 constexpr int OMAP = 8;           // taxon map slots per fragment
-constexpr int32_t OMAP_EMPTY = -1;
+constexpr int OMAP_CNT_BITS = 10; // a fragment the lane kernel takes has <= LANE_MAX_LEN (1000) k-mers; taxon ids need <= 22 bits
+constexpr uint32_t OMAP_CNT_MASK = (1u << OMAP_CNT_BITS) - 1;
 
 struct __attribute__((aligned(16))) LaneLds {
   uint64_t q_key[QCAP];
   uint32_t q_meta[QCAP];          // owner lane (6 bits) | distinct << 6 | kmers << 7 (10 bits) | displacement << 17 (6 bits)
   uint64_t stash[128];            // (home bucket, taxon found, tag) 16 bytes per queue entry of the batch
-  int32_t omap_key[OMAP * 64];    // [slot][owner lane]
-  int32_t omap_cnt[OMAP * 64];
-  int32_t o_nd[64];               // hits with distinct && taxon != NONE (Classifier.scala:94)
-  int32_t o_ovf[64];              // map overflow flag
+  uint32_t omap[OMAP * 64];       // [slot][owner lane]: taxon << 10 | k-mer count; 0 = empty (NONE hits are not stored)
+  uint32_t o_flags[64];           // low bits: hits with distinct && taxon != NONE (Classifier.scala:94); bit 31: map overflow
 };
 
 __device__ __forceinline__ void lane_wave_sync() {
@@ -116,15 +118,17 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int q
   if (in && taxon != 0 && !(dbg & 2)) {
     const int owner = meta & 63;
     const int32_t kmers = (int32_t)((meta >> 7) & 0x3FF);
-    if (meta & 64) atomicAdd(&L->o_nd[owner], 1);  // distinct && taxon != NONE (Classifier.scala:94)
+    if (meta & 64) atomicAdd(&L->o_flags[owner], 1u);  // distinct && taxon != NONE (Classifier.scala:94)
     uint32_t slot = ((uint32_t)taxon * 0x9E3779B1u) >> 29;
+    const uint32_t fresh = ((uint32_t)taxon << OMAP_CNT_BITS) | (uint32_t)kmers;
     int p = 0;
     for (; p < OMAP; p++) {
-      int32_t old = atomicCAS(&L->omap_key[slot * 64 + owner], OMAP_EMPTY, taxon);
-      if (old == OMAP_EMPTY || old == taxon) { atomicAdd(&L->omap_cnt[slot * 64 + owner], kmers); break; }
+      uint32_t old = atomicCAS(&L->omap[slot * 64 + owner], 0u, fresh);
+      if (old == 0u) break;
+      if ((old >> OMAP_CNT_BITS) == (uint32_t)taxon) { atomicAdd(&L->omap[slot * 64 + owner], (uint32_t)kmers); break; }
       slot = (slot + 1) & (OMAP - 1);
     }
-    if (p == OMAP) L->o_ovf[owner] = 1;
+    if (p == OMAP) atomicOr(&L->o_flags[owner], 0x80000000u);
   }
   lane_wave_sync();
   return requeued;
@@ -133,8 +137,8 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int q
 struct OwnerMap {  // this lane's column of the LDS maps
   const LaneLds *L;
   int lane;
-  __device__ __forceinline__ int32_t key(int s) const { return L->omap_key[s * 64 + lane]; }
-  __device__ __forceinline__ int32_t cnt(int s) const { return L->omap_cnt[s * 64 + lane]; }
+  __device__ __forceinline__ int32_t key(int s) const { return (int32_t)(L->omap[s * 64 + lane] >> OMAP_CNT_BITS); }  // 0 = empty
+  __device__ __forceinline__ int32_t cnt(int s) const { return (int32_t)(L->omap[s * 64 + lane] & OMAP_CNT_MASK); }
   __device__ __forceinline__ int32_t get(int32_t t) const {
     for (int s = 0; s < OMAP; s++) if (key(s) == t) return cnt(s);
     return 0;
@@ -208,9 +212,8 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, int32_t *defer, uint32_t ma
     bool fin = !have || too_long;
     // ---- per-lane LDS state ----
 #pragma unroll
-    for (int s = 0; s < OMAP; s++) { L->omap_key[s * 64 + lane] = OMAP_EMPTY; L->omap_cnt[s * 64 + lane] = 0; }
-    L->o_nd[lane] = 0;
-    L->o_ovf[lane] = 0;
+    for (int s = 0; s < OMAP; s++) L->omap[s * 64 + lane] = 0;
+    L->o_flags[lane] = 0;
     // ---- scan state ----
     uint32_t pos = 0;
     int mate = 0;
@@ -376,16 +379,17 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, int32_t *defer, uint32_t ma
 
     // ---- per-read classification (one lane per read) ------------------------------------------------------------------
     if (have) {
-      if (too_long || L->o_ovf[lane]) {
+      const uint32_t oflags = L->o_flags[lane];
+      if (too_long || (oflags & 0x80000000u)) {
         defer[r] = 1;  // re-done by the wave-per-read kernel
       } else {
         OwnerMap M{L, lane};
-        const int32_t nd = L->o_nd[lane];
+        const int32_t nd = (int32_t)oflags;
         int D = 0;
         int32_t t0 = 0, c0 = 0;
         for (int s = 0; s < OMAP; s++) {
           int32_t kk = M.key(s);
-          if (kk != OMAP_EMPTY) { D++; t0 = kk; c0 = M.cnt(s); }
+          if (kk != 0) { D++; t0 = kk; c0 = M.cnt(s); }
         }
         int32_t maxTaxon = t0;  // D <= 1: the single taxon (or NONE)
         if (D >= 2) {           // resolveTree step 1 (:101-123): LCA of the taxa with the maximal root-path score
@@ -393,7 +397,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, int32_t *defer, uint32_t ma
           int32_t best = 0;
           for (int s = 0; s < OMAP; s++) {
             int32_t taxon = M.key(s);
-            if (taxon == OMAP_EMPTY) continue;
+            if (taxon == 0) continue;
             int32_t score = 0;
             for (int32_t node = taxon; node != 0; node = lane_parent(A.parents, A.ntax, node)) score += M.get(node);
             if (score > best) { maxTaxon = taxon; best = score; }
@@ -409,7 +413,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, int32_t *defer, uint32_t ma
             ms = 0;
             for (int s = 0; s < OMAP; s++) {
               int32_t taxon = M.key(s);
-              if (taxon == OMAP_EMPTY) continue;
+              if (taxon == 0) continue;
               for (int32_t x = taxon; x != 0; x = lane_parent(A.parents, A.ntax, x))
                 if (x == mt) { ms += M.cnt(s); break; }                       // Taxonomy.hasAncestor :236-244
             }
@@ -437,7 +441,8 @@ void launch_lane(const FusedArgs &A, int32_t *defer, uint32_t max_len, hipStream
   size_t lds = per_wave * LW;
   uint64_t tiles = (A.R + 63) / 64;
   uint64_t blocks = (tiles + LW - 1) / LW;
-  if (blocks > 256 * 8) blocks = 256 * 8;
+  static const int bpc = getenv("SLK_LANE_BLOCKS_PER_CU") ? atoi(getenv("SLK_LANE_BLOCKS_PER_CU")) : 0;  // (tuning experiment)
+  if (bpc > 0 && blocks > (uint64_t)256 * bpc) blocks = (uint64_t)256 * bpc;
   dim3 g((unsigned)blocks), b(LW * 64);
   static const int dbg = getenv("SLK_DEBUG_ABLATE") ? atoi(getenv("SLK_DEBUG_ABLATE")) : 0;  // timing experiments only: 1 = no probes, 2 = no map updates
   if (w5) hipLaunchKernelGGL(lane_kernel<true>, g, b, lds, s, A, defer, max_len, dbg);
