@@ -18,7 +18,7 @@ $(LIB): $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/build.hip
 
 $(CLI): slacken_amd/host/slacken_cli.cpp slacken_amd/host/taxonomy.hpp include/slacken_amd.h $(LIB)
 	@mkdir -p slacken_amd/bin
-	g++ -O2 -std=c++17 -Wall -o $@ slacken_amd/host/slacken_cli.cpp -Lslacken_amd/lib -lslacken_amd -lz -Wl,-rpath,'$$ORIGIN/../lib'
+	g++ -O2 -std=c++17 -Wall -o $@ slacken_amd/host/slacken_cli.cpp -Lslacken_amd/lib -lslacken_amd -lz -ldl -Wl,-rpath,'$$ORIGIN/../lib'
 
 oracle:
 	$(MAKE) -C oracle

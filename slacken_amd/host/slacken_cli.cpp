@@ -10,6 +10,7 @@
 //   per-read output  S/slacken/Classifier.scala:41-44,124-147,184-227, S/slacken/TaxonCounts.scala:94-121
 //   report           S/slacken/KrakenReport.scala (taxonomy.hpp)
 // Host-only subcommands (`report`, `parse`, `props`) exist so that this layer can be tested without a GPU.
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <cstring>
@@ -86,7 +87,28 @@ static Records read_records(const std::string &location) {
 
 // ---- sequence input ----
 struct Fragment { std::string header, nucleotides; };
+static bool ends_with(const std::string &s, const char *suf);
+// bzip2 through the system's libbz2 (no development header in this image: the three stable high-level entry points are
+// declared here and resolved at run time)
+static std::string slurp_bz2(const std::string &path) {
+  void *h = dlopen("libbz2.so.1", RTLD_NOW);
+  if (!h) h = dlopen("libbz2.so.1.0", RTLD_NOW);
+  if (!h) die("bzip2 input needs libbz2.so.1: " + path);
+  auto bzopen = (void *(*)(const char *, const char *))dlsym(h, "BZ2_bzopen");
+  auto bzread = (int (*)(void *, void *, int))dlsym(h, "BZ2_bzread");
+  auto bzclose = (void (*)(void *))dlsym(h, "BZ2_bzclose");
+  if (!bzopen || !bzread || !bzclose) die("libbz2 lacks BZ2_bzopen/BZ2_bzread/BZ2_bzclose");
+  void *b = bzopen(path.c_str(), "rb");
+  if (!b) die("cannot open " + path);
+  std::string out;
+  std::vector<char> buf(1 << 20);
+  int n;
+  while ((n = bzread(b, buf.data(), (int)buf.size())) > 0) out.append(buf.data(), n);
+  bzclose(b);
+  return out;
+}
 static std::string slurp(const std::string &path) {  // gzread also reads plain files
+  if (ends_with(path, ".bz2")) return slurp_bz2(path);
   gzFile g = gzopen(path.c_str(), "rb");
   if (!g) die("cannot open " + path);
   std::string out;
@@ -128,15 +150,13 @@ static std::vector<Fragment> read_fasta(const std::string &path) {
 // FastqTextInput (:188-221): every 4-line window whose 1st line starts with '@' and 3rd with '+'
 static std::vector<Fragment> read_fastq(const std::string &path) {
   std::string all = slurp(path);
-  std::vector<std::string> lines;
+  std::vector<std::string> lines;  // Spark's text reader: lines end with \n, \r\n or \r
   size_t i = 0;
   while (i < all.size()) {
-    size_t j = all.find('\n', i);
+    size_t j = all.find_first_of("\n\r", i);
     if (j == std::string::npos) j = all.size();
-    size_t e = j;
-    if (e > i && all[e - 1] == '\r') e--;
-    lines.emplace_back(all, i, e - i);
-    i = j + 1;
+    lines.emplace_back(all, i, j - i);
+    i = (j + 1 < all.size() && all[j] == '\r' && all[j + 1] == '\n') ? j + 2 : j + 1;
   }
   std::vector<Fragment> out;
   for (size_t l = 0; l + 2 < lines.size(); l++) {  // the window may be cut short at the end of the file; it needs 3 lines
@@ -153,8 +173,8 @@ static std::string lower(std::string s) { for (auto &c : s) c = (char)tolower(c)
 static bool ends_with(const std::string &s, const char *suf) { size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; }
 static std::vector<Fragment> read_file(const std::string &file) {  // FileInputs.forFile :64-85
   std::string lo = lower(file);
-  if (ends_with(lo, "fq") || ends_with(lo, "fastq") || ends_with(lo, ".fq.gz") || ends_with(lo, ".fastq.gz")) return read_fastq(file);
-  if (ends_with(lo, ".bz2")) die("bzip2 input is not supported: " + file);
+  if (ends_with(lo, "fq") || ends_with(lo, "fastq") || ends_with(lo, ".fq.gz") || ends_with(lo, ".fastq.gz") ||
+      ends_with(lo, ".fq.bz2") || ends_with(lo, ".fastq.bz2")) return read_fastq(file);
   return read_fasta(file);  // (.fai-indexed long-sequence reading is a library-build input, not a classify input)
 }
 static std::string remove_suffix(const std::string &h, const char *suf) { return ends_with(h, suf) ? h.substr(0, h.size() - strlen(suf)) : h; }

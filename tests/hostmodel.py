@@ -87,10 +87,9 @@ def parse_fasta(text):
 
 
 def parse_fastq(text):
-    lines = text.split("\n")
+    lines = re.split("\r\n|\n|\r", text)      # Spark's text reader: \n, \r\n and \r all end a line
     if lines and lines[-1] == "":
         lines.pop()
-    lines = [l[:-1] if l.endswith("\r") else l for l in lines]
     out = []
     for i in range(len(lines)):
         w = lines[i:i + 4]

@@ -132,3 +132,43 @@ def test_append_then_add_sequences_and_errors(orc):
     ix.finalize()
     with pytest.raises(slacken_amd.SlackenError):
         ix.add_sequences(bases, offsets, [3])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_genomes_classify_to_ancestor_or_self(orc, seed):
+    """The reference's end-to-end property (T/slacken/ClassifierTest.scala:75-124): ~100 random genomes (1-10 kb) on leaf
+    taxa, library built from them (here: on the device), 1000 simulated 200 bp reads, minHitGroups = 1, confidence 0; random
+    k, m, spaces: every CLASSIFIED read's taxon is the true taxon or one of its ancestors.  (m is limited to the engine's
+    32; the device results are additionally compared with the oracle.)"""
+    import slacken_amd
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.integers(15, 33))
+    k = int(rng.integers(m, m + 28))
+    spaces = int(rng.integers(0, m // 2 + 1))
+    parents = taxgen.taxonomy(100 * 8, rng)
+    taxa = np.array(taxgen.defined_taxa(parents))
+    leaves = np.setdiff1d(taxa, parents[taxa])
+    leaves = leaves[leaves != 1]
+    gs = [synth.random_dna(int(rng.integers(1000, 10000)), rng) for _ in leaves]
+    bases = np.concatenate(gs)
+    offsets = np.zeros(len(gs) + 1, np.uint64)
+    np.cumsum([len(g) for g in gs], out=offsets[1:])
+    ix = slacken_amd.Index(k=k, m=m, spaces=spaces, expected_records=int(offsets[-1]), max_taxon=len(parents) - 1)
+    ix.set_taxonomy(parents)
+    ix.add_sequences(bases, offsets, leaves.astype(np.int32))
+    rec_k, rec_t = ix.export()
+    ix.finalize()
+    reads, truth = [], []
+    for _ in range(1000):
+        g = int(rng.integers(0, len(gs)))
+        a = int(rng.integers(0, len(gs[g]) - 200))
+        reads.append(gs[g][a:a + 200])
+        truth.append(int(leaves[g]))
+    rb, ro = synth.pack(reads)
+    got = ix.stream().classify_batch(rb, ro, thresholds=(0.0,), min_hit_groups=1, with_hits=False)
+    assert got["classified"][0].sum() > 900
+    for r in np.nonzero(got["classified"][0])[0]:
+        assert int(got["taxon"][0][r]) in taxgen.path_to_root(parents, truth[r]), (k, m, spaces, r)
+    p = orc.params(k=k, m=m, spaces=spaces)
+    want = orc.classify_batch(p, orc.Index(1, rec_k, rec_t), parents, rb, ro, thresholds=(0.0,), min_hit_groups=1)
+    assert np.array_equal(got["taxon"], want["taxon"]) and np.array_equal(got["classified"], want["classified"])

@@ -181,3 +181,26 @@ def test_classify_without_gpu_fails_loudly(tmp_path):
     (tmp_path / "r.fa").write_text(">a\nACGT\n")
     r = subprocess.run([CLI, "classify", "-i", loc, "-o", str(tmp_path / "out"), str(tmp_path / "r.fa")], capture_output=True, text=True)
     assert r.returncode != 0 and "slk_index_create" in r.stderr
+
+
+@pytest.mark.parametrize("sep", ["\n", "\r\n", "\r"])
+@pytest.mark.parametrize("comp", ["", ".gz", ".bz2"])
+def test_input_round_trip_separators_and_compression(tmp_path, sep, comp):
+    """T/kmers/InputReaderProps.scala:93-148: FASTA / FASTQ records written with each of the three line separators and with
+    no / gzip / bzip2 compression read back as the same (id, nucleotides) fragments (mixed case, ambiguous codes kept)."""
+    import bz2
+    rng = np.random.default_rng(len(sep) * 10 + len(comp))
+    alphabet = list("ACGTacgtNRK")
+    recs = [("".join(rng.choice(list("abcXYZ019"), size=10)), "".join(rng.choice(alphabet, size=int(rng.integers(35, 200)))))
+            for _ in range(int(rng.integers(1, 10)))]
+    opener = {"": open, ".gz": gzip.open, ".bz2": bz2.open}[comp]
+    fa = tmp_path / f"x.fasta{comp}"
+    with opener(fa, "wb") as f:                                # the reference's generator: the sequence on one line
+        f.write("".join(f">{h}{sep}{s}{sep}" for h, s in recs).encode())
+    got = [tuple(l.split("\t")) for l in run("parse", fa).rstrip("\n").split("\n")]
+    assert got == recs
+    fq = tmp_path / f"x.fastq{comp}"
+    with opener(fq, "wb") as f:
+        f.write(sep.join(f"@{h}{sep}{s}{sep}+{sep}{'I' * len(s)}" for h, s in recs).encode())
+    got = [tuple(l.split("\t")) for l in run("parse", fq).rstrip("\n").split("\n")]
+    assert got == recs == hostmodel.parse_fastq(sep.join(f"@{h}{sep}{s}{sep}+{sep}{'I' * len(s)}" for h, s in recs))
