@@ -37,22 +37,6 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def py_lca(parents, a, b):
-    if a == 0 or b == 0:
-        return a if b == 0 else b
-    pa = set()
-    x = a
-    while x != 0:
-        pa.add(x)
-        x = int(parents[x])
-    y = b
-    while y != 0:
-        if y in pa:
-            return y
-        y = int(parents[y])
-    return 1
-
-
 def build_taxonomy(seed=2240):
     import taxgen
     rng = np.random.default_rng(seed)
@@ -66,32 +50,19 @@ def build_taxonomy(seed=2240):
 
 
 def genome_records(slacken_amd, genomes, genome_taxa, parents, device):
-    """(key, LCA taxon) records of the genomes: the engine's scan kernel finds the minimizers (spans_batch), duplicates
-    across genomes are merged by LCA (TaxonLCA, LowestCommonAncestor.scala:152-170)."""
-    tmp = slacken_amd.Index(k=K, m=M, spaces=SPACES, expected_records=16, max_taxon=7, device=device)
-    tmp.finalize()
-    st = tmp.stream()
+    """(key, LCA taxon) records of the genomes, built on the device by the config-5 builder (slk_index_add_sequences:
+    minimizers of every genome, duplicates across genomes merged by LCA -- KeyValueIndex.makeRecords, KeyValueIndex.scala:85-93)
+    and exported sorted by key."""
     lens = np.array([len(g) for g in genomes], np.uint64)
     offsets = np.zeros(len(genomes) + 1, np.uint64)
     np.cumsum(lens, out=offsets[1:])
-    off, sp = st.spans_batch(np.concatenate(genomes), offsets)
-    seq = sp["flag"] == 1
-    keys = sp["key"][seq]
-    owner = np.repeat(np.arange(len(genomes)), np.diff(off.astype(np.int64)))[seq]
-    tax = genome_taxa[owner].astype(np.int32)
-    st.close()
+    tmp = slacken_amd.Index(k=K, m=M, spaces=SPACES, expected_records=int(offsets[-1]) // 2 + 1024, max_taxon=TAX_EXTENT - 1,
+                            device=device)
+    tmp.set_taxonomy(parents)
+    tmp.add_sequences(np.concatenate(genomes), offsets, genome_taxa.astype(np.int32))
+    keys, tax = tmp.export()
     tmp.close()
-    order = np.argsort(keys, kind="stable")
-    keys, tax = keys[order], tax[order]
-    uniq, start = np.unique(keys, return_index=True)
-    out_tax = tax[start].copy()
-    ends = np.append(start[1:], len(keys))
-    for i in np.nonzero(ends - start > 1)[0]:
-        t = 0
-        for x in tax[start[i]:ends[i]]:
-            t = py_lca(parents, t, int(x))
-        out_tax[i] = t
-    return uniq.astype(np.int64), out_tax.astype(np.int32)
+    return keys, tax
 
 
 def make_reads_device(torch, genome_cat, genome_len, n_genomes, n_reads, seed, device):
