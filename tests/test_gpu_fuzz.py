@@ -1,0 +1,68 @@
+"""Randomised differential test of the engine against the oracle over the whole supported parameter space: splitter
+(k, m <= 32, spaced seed, XOR mask, canonical or not), taxonomy, library, read shapes (empty .. 2500 bases, so that both the
+lane-per-read kernel and the deferred wave-per-read path are taken; ragged pairs; ambiguous and lower-case characters),
+confidence thresholds and minHitGroups.  Every output of slk_classify_batch is compared bit for bit."""
+import numpy as np
+import pytest
+
+import synth
+import taxgen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_differential(orc, seed):
+    import slacken_amd
+    rng = np.random.default_rng(9000 + seed)
+    m = int(rng.integers(8, 33))
+    wmax = 32 if seed % 4 else 16
+    k = int(rng.integers(m, m + wmax))
+    spaces = int(rng.integers(0, m // 2 + 1)) if seed % 3 else 0
+    canonical = bool(seed % 5 != 0)
+    xor_mask = int(rng.integers(0, 2**63)) * 2 + int(rng.integers(0, 2)) if seed % 2 else 0xe37e28c4271b5a2d
+    p = orc.params(k=k, m=m, spaces=spaces, xor_mask=xor_mask, canonical=canonical)
+    parents = taxgen.taxonomy(8 * int(rng.integers(4, 64)), rng)
+    lib = synth.Library(orc, p, parents, n_genomes=int(rng.integers(2, 12)), genome_len=int(rng.integers(3000, 12000)),
+                        pad_records=int(rng.integers(0, 3000)), seed=seed)
+    ix = slacken_amd.Index(k=k, m=m, spaces=spaces, xor_mask=xor_mask, canonical=canonical,
+                           expected_records=len(lib.keys), max_taxon=len(parents) - 1)
+    ix.append(lib.keys, lib.taxa)
+    ix.set_taxonomy(parents)
+    ix.finalize()
+    st = ix.stream()
+    oix = orc.Index(1, lib.keys, lib.taxa)
+    n = 1500
+    length = int(rng.integers(60, 1300))
+    reads = synth.make_reads(lib, n, rng, length=length, vary_length=True, n_single=0.1, n_run=0.05, short=0.05,
+                             frac_random=0.15, sub_rate=float(rng.choice([0.0, 0.01, 0.05])))
+    mates = None
+    if seed % 2:
+        mates = synth.make_reads(lib, n, rng, length=int(rng.integers(40, 600)), vary_length=True, short=0.1)
+    thresholds = tuple(sorted(float(x) for x in rng.choice([0.0, 0.01, 0.05, 0.07, 0.15, 0.3, 0.5, 0.9, 1.0], size=3, replace=False)))
+    mhg = int(rng.integers(1, 4))
+    bases, offsets = synth.pack(reads)
+    mb = mo = None
+    if mates is not None:
+        mb, mo = synth.pack(mates)
+    want = orc.classify_batch(p, oix, parents, bases, offsets, mb, mo, min_hit_groups=mhg, thresholds=thresholds)
+    full = st.classify_batch(bases, offsets, mb, mo, min_hit_groups=mhg, thresholds=thresholds, with_hits=True)
+    fast = st.classify_batch(bases, offsets, mb, mo, min_hit_groups=mhg, thresholds=thresholds, with_hits=False)
+    ctx = dict(k=k, m=m, spaces=spaces, canonical=canonical, paired=mates is not None, mhg=mhg, thresholds=thresholds)
+    for name, got in (("hit-list path", full), ("hot path", fast)):
+        for key in ("taxon", "classified", "num_distinct", "total_kmers"):
+            assert np.array_equal(got[key], want[key]), (name, key, ctx)
+    assert np.array_equal(full["num_hits"], want["num_hits"]), ctx
+    ho = full["hit_offsets"].astype(np.int64)
+    for i in rng.choice(n, size=60, replace=False):
+        _, hits = orc.classify_read(p, oix, parents, reads[i].tobytes(), None if mates is None else mates[i].tobytes(),
+                                    mhg, thresholds[0])
+        g = full["hits"][ho[i]:ho[i + 1]]
+        assert [(int(t), int(c)) for t, c in zip(g["taxon"], g["count"])] == hits, (int(i), ctx)
+    # spans (kernel-1-only entry) on a subset
+    off, sp = st.spans_batch(bases[:int(offsets[200])], offsets[:201])
+    for i in range(0, 200, 7):
+        ws = orc.spans(p, reads[i].tobytes())
+        g = sp[int(off[i]):int(off[i + 1])]
+        assert [(int(x["key"]), int(x["kmers"]), int(x["flag"]), bool(x["distinct"])) for x in g] == \
+               [((s["key"][0] - (1 << 64)) if s["key"][0] >= (1 << 63) else s["key"][0], s["kmers"], s["flag"], s["distinct"]) for s in ws], (i, ctx)

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""End-to-end timing of `slacken-amd classify` (parse + H2D + kernels + D2H + formatting + gzip) on synthetic reads against a
+small synthetic library.  Run on the GPU box; prints one JSON object."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def main():
+    import slacken_amd
+    import taxgen
+    import parquet_to_slkrec as conv
+    from test_host_classify2_gpu import write_ranked_taxonomy
+    R = int(os.environ.get("R", 2_000_000))
+    rng = np.random.default_rng(3)
+    parents = taxgen.taxonomy(8 * 64, rng)
+    taxa = np.array(taxgen.defined_taxa(parents))
+    G, L = 64, 1 << 20
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    bases = acgt[rng.integers(0, 4, G * L, dtype=np.uint8)]
+    offsets = np.arange(G + 1, dtype=np.uint64) * np.uint64(L)
+    ix = slacken_amd.Index(expected_records=G * L // 2, max_taxon=len(parents) - 1)
+    ix.set_taxonomy(parents)
+    ix.add_sequences(bases, offsets, rng.choice(taxa[len(taxa) // 2:], G).astype(np.int32))
+    keys, tx = ix.export()
+    ix.close()
+    d = tempfile.mkdtemp(prefix="slkcli_")
+    loc = os.path.join(d, "lib")
+    conv.write_slkrec(loc + ".slkrec", keys, tx)
+    with open(loc + ".properties", "w") as f:
+        f.write("k=35\nm=31\nversion=1\nsplitter=randomXOR\nminimizerSpaces=7\n")
+    write_ranked_taxonomy(loc + "_taxonomy", parents)
+    starts = rng.integers(0, G * L - 150, R)
+    fq = os.path.join(d, "reads.fq")
+    with open(fq, "wb") as f:
+        CH = 100000
+        qual = b"I" * 150
+        for s in range(0, R, CH):
+            e = min(R, s + CH)
+            blk = bases[(starts[s:e, None] + np.arange(150)[None, :])]
+            f.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (s + i, blk[i].tobytes(), qual) for i in range(e - s)))
+    out = {}
+    for name, extra in (("detailed", []), ("reports_only", ["--nodetailed"])):
+        t0 = time.perf_counter()
+        r = subprocess.run([os.path.join(ROOT, "slacken_amd", "bin", "slacken-amd"), "classify", "-i", loc, "-o",
+                            os.path.join(d, "out_" + name), *extra, fq], capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        assert r.returncode == 0, r.stderr
+        out[name] = dict(reads=R, seconds=round(dt, 2), M_reads_per_s=round(R / dt / 1e6, 3))
+    out["fastq_MB"] = round(os.path.getsize(fq) / 1e6)
+    out["records"] = len(keys)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
