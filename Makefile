@@ -16,9 +16,9 @@ $(LIB): $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/build.hip
 	@mkdir -p slacken_amd/lib
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/build.hip $(CSRC)/capi.hip
 
-$(CLI): slacken_amd/host/slacken_cli.cpp slacken_amd/host/taxonomy.hpp include/slacken_amd.h $(LIB)
+$(CLI): slacken_amd/host/slacken_cli.cpp slacken_amd/host/taxonomy.hpp slacken_amd/host/seqio.hpp slacken_amd/host/output.hpp include/slacken_amd.h $(LIB)
 	@mkdir -p slacken_amd/bin
-	g++ -O2 -std=c++17 -Wall -o $@ slacken_amd/host/slacken_cli.cpp -Lslacken_amd/lib -lslacken_amd -lz -ldl -Wl,-rpath,'$$ORIGIN/../lib'
+	g++ -O2 -std=c++17 -Wall -o $@ slacken_amd/host/slacken_cli.cpp -Lslacken_amd/lib -lslacken_amd -lz -ldl -lpthread -Wl,-rpath,'$$ORIGIN/../lib'
 
 oracle:
 	$(MAKE) -C oracle

@@ -1,0 +1,253 @@
+// output.hpp -- per-read output lines, gzip part files and Kraken reports of the host layer (C++17, header only).
+// Mirrors (S/ = src/main/scala/com/jnpersson/ in the reference):
+//   ClassifiedRead.outputLine                         S/slacken/Classifier.scala:41-44
+//   TaxonCounts.lengthString / pairsInOrderString     S/slacken/TaxonCounts.scala:94-121
+//   Classifier.classifyHits (sample id)               S/slacken/Classifier.scala:124-147
+//   Classifier.writePerSampleOutput                   S/slacken/Classifier.scala:184-227, locations :415-420
+// Formatting and compression run on a small thread pool: a batch is cut into slices, each slice is formatted and deflated
+// into one gzip MEMBER per (threshold, sample), and the members are appended to the part file in read order (a
+// concatenation of gzip members is a gzip file).
+#pragma once
+#include <zlib.h>
+
+#include <filesystem>
+#include <functional>
+#include <future>
+#include <map>
+#include <queue>
+#include <regex>
+
+#include "../../include/slacken_amd.h"
+#include "seqio.hpp"
+#include "taxonomy.hpp"
+
+namespace slk_host {
+
+// Double.toString for the values a confidence list can hold (shortest repr that round-trips; at least one decimal)
+inline std::string java_double_to_string(double d) {
+  char b[64];
+  for (int prec = 1; prec <= 17; prec++) {
+    snprintf(b, sizeof b, "%.*g", prec, d);
+    if (strtod(b, nullptr) == d) break;
+  }
+  std::string s = b;
+  if (s.find('e') != std::string::npos) return s;  // (scientific notation: not reachable for sensible thresholds)
+  if (s.find('.') == std::string::npos) s += ".0";
+  return s;
+}
+
+inline void append_int(std::string &s, long v) {
+  char b[24];
+  int n = snprintf(b, sizeof b, "%ld", v);
+  s.append(b, (size_t)n);
+}
+// TaxonCounts.lengthString :114-121 over un-merged hits
+inline void append_length_string(std::string &s, const slk_hit *h, size_t n, int k) {
+  long a = 0, b = 0;
+  size_t border = n;
+  for (size_t i = 0; i < n; i++) if (h[i].taxon == SLK_TAXON_MATE_PAIR_BORDER) { border = i; break; }
+  for (size_t i = 0; i < border; i++) a += h[i].count;
+  append_int(s, a + (k - 1));
+  if (border == n) return;
+  for (size_t i = border + 1; i < n; i++) b += h[i].count;
+  s.push_back('|');
+  append_int(s, b + (k - 1));
+}
+// TaxonCounts.pairsInOrderString :94-110 (TaxonCounts.fromHits :31-48 merges adjacent equal taxa)
+inline void append_pairs_in_order(std::string &s, const slk_hit *h, size_t n) {
+  size_t i = 0;
+  while (i < n) {
+    size_t j = i;
+    long c = 0;
+    while (j < n && h[j].taxon == h[i].taxon) { c += h[j].count; j++; }
+    if (h[i].taxon == SLK_TAXON_MATE_PAIR_BORDER) s.append("|:|");
+    else if (h[i].taxon == SLK_TAXON_AMBIGUOUS) { s.append("A:"); append_int(s, c); }
+    else { append_int(s, h[i].taxon); s.push_back(':'); append_int(s, c); }
+    if (j < n) s.push_back(' ');
+    i = j;
+  }
+}
+
+inline std::string gzip_member(const std::string &text) {
+  z_stream zs;
+  memset(&zs, 0, sizeof zs);
+  if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
+  std::string out;
+  out.resize(deflateBound(&zs, (uLong)text.size()) + 32);
+  zs.next_in = (Bytef *)text.data();
+  zs.avail_in = (uInt)text.size();
+  zs.next_out = (Bytef *)&out[0];
+  zs.avail_out = (uInt)out.size();
+  int rc = deflate(&zs, Z_FINISH);
+  if (rc != Z_STREAM_END) { deflateEnd(&zs); throw std::runtime_error("deflate failed"); }
+  out.resize(zs.total_out);
+  deflateEnd(&zs);
+  return out;
+}
+
+class ThreadPool {
+  std::vector<std::thread> th_;
+  std::queue<std::function<void()>> q_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  bool stop_ = false;
+
+ public:
+  explicit ThreadPool(size_t n) {
+    for (size_t i = 0; i < n; i++)
+      th_.emplace_back([this] {
+        for (;;) {
+          std::function<void()> f;
+          {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+            if (q_.empty()) return;
+            f = std::move(q_.front());
+            q_.pop();
+          }
+          f();
+        }
+      });
+  }
+  ~ThreadPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+  size_t size() const { return th_.size(); }
+  template <class F> auto submit(F f) -> std::future<decltype(f())> {
+    auto task = std::make_shared<std::packaged_task<decltype(f())()>>(std::move(f));
+    auto fut = task->get_future();
+    { std::lock_guard<std::mutex> lk(mu_); q_.push([task] { (*task)(); }); }
+    cv_.notify_one();
+    return fut;
+  }
+};
+
+// One classified batch: the fragments and what slk_classify_batch returned for them (threshold-major taxon / classified).
+struct ClassifiedBatch {
+  std::unique_ptr<FragmentBatch> frags;
+  int C = 0;
+  std::vector<int32_t> taxon;
+  std::vector<uint8_t> classified;
+  std::vector<uint64_t> hit_offs;
+  std::vector<slk_hit> hits;
+  std::vector<uint64_t> span_offs;  // only when spans were requested
+  std::vector<slk_span> spans;
+};
+
+struct OutputOptions {
+  std::string output, sample_regex;
+  std::vector<double> thresholds;
+  bool with_unclassified = true, detailed = true;
+  int k = 35;
+};
+
+class OutputSink {
+  using Key = std::pair<int, std::string>;  // (threshold index, sample id)
+  struct SliceOut {
+    std::map<Key, std::string> gz;
+    std::map<Key, std::map<Taxon, long>> counts;
+  };
+  const OutputOptions o_;
+  const Taxonomy &tax_;
+  std::vector<std::string> locations_;
+  std::regex re_;
+  ThreadPool pool_;
+  std::deque<std::future<SliceOut>> pending_;
+  std::map<Key, FILE *> files_;
+  std::map<Key, std::map<Taxon, long>> counts_;
+
+  std::string sample_of(std::string_view title) const {  // Classifier.scala:138-142
+    if (o_.sample_regex.empty()) return "all";
+    std::cmatch m;
+    if (std::regex_search(title.data(), title.data() + title.size(), m, re_) && m.size() > 1) return m[1].str();
+    return "other";
+  }
+
+  SliceOut do_slice(std::shared_ptr<const ClassifiedBatch> b, size_t i0, size_t i1) const {
+    SliceOut out;
+    std::map<Key, std::string> text;
+    const size_t n = b->frags->size();
+    for (size_t i = i0; i < i1; i++) {
+      const size_t h0 = b->hit_offs[i], h1 = b->hit_offs[i + 1];
+      if (h1 == h0) continue;  // no span => no row at all (grouping is over span rows, Classifier.scala:92)
+      std::string_view title = b->frags->title(i);
+      std::string sample = sample_of(title);
+      for (int c = 0; c < b->C; c++) {
+        const bool classified = b->classified[(size_t)c * n + i] != 0;
+        if (!classified && !o_.with_unclassified) continue;
+        const int32_t t = b->taxon[(size_t)c * n + i];
+        Key key(c, sample);
+        out.counts[key][t] += 1;
+        if (!o_.detailed) continue;
+        std::string &s = text[key];  // ClassifiedRead.outputLine, Classifier.scala:41-44
+        s.push_back(classified ? 'C' : 'U');
+        s.push_back('\t');
+        s.append(title);
+        s.push_back('\t');
+        append_int(s, t);
+        s.push_back('\t');
+        append_length_string(s, &b->hits[h0], h1 - h0, o_.k);
+        s.push_back('\t');
+        append_pairs_in_order(s, &b->hits[h0], h1 - h0);
+        s.push_back('\n');
+      }
+    }
+    for (auto &kv : text) out.gz[kv.first] = gzip_member(kv.second);
+    return out;
+  }
+
+  void commit(SliceOut so) {
+    for (auto &kv : so.gz) {
+      FILE *&f = files_[kv.first];
+      if (!f) {
+        std::string dir = locations_[kv.first.first] + "/sample=" + kv.first.second;  // Classifier.perReadOutputsLocation :415-416
+        std::filesystem::create_directories(dir);
+        f = fopen((dir + "/part-00000.txt.gz").c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot write under " + dir);
+      }
+      if (fwrite(kv.second.data(), 1, kv.second.size(), f) != kv.second.size()) throw std::runtime_error("write failed");
+    }
+    for (auto &kv : so.counts) {
+      auto &dst = counts_[kv.first];
+      for (auto &tc : kv.second) dst[tc.first] += tc.second;
+    }
+  }
+
+ public:
+  OutputSink(const OutputOptions &o, const Taxonomy &tax, size_t threads)
+      : o_(o), tax_(tax), pool_(std::max<size_t>(1, threads)) {
+    size_t max_dec = 0;  // thresholds' directory names (Classifier.scala:189-191)
+    for (double t : o_.thresholds) { std::string s = java_double_to_string(t); max_dec = std::max(max_dec, s.size() - s.find('.') - 1); }
+    for (double t : o_.thresholds) {
+      char b[64];
+      snprintf(b, sizeof b, "%.*f", (int)max_dec, t);
+      locations_.push_back(o_.output + "_c" + b);
+      std::filesystem::create_directories(locations_.back());
+    }
+    if (!o_.sample_regex.empty()) re_ = std::regex(o_.sample_regex);
+  }
+  ~OutputSink() { for (auto &kv : files_) if (kv.second) fclose(kv.second); }
+
+  void submit(std::shared_ptr<const ClassifiedBatch> b) {
+    const size_t n = b->frags->size(), SL = 32768;
+    for (size_t i0 = 0; i0 < n; i0 += SL) {
+      size_t i1 = std::min(n, i0 + SL);
+      pending_.push_back(pool_.submit([this, b, i0, i1] { return do_slice(b, i0, i1); }));
+    }
+    while (pending_.size() > 8 * pool_.size()) { commit(pending_.front().get()); pending_.pop_front(); }
+  }
+
+  void finish() {  // Classifier.reportOutputLocation :419-420 + KrakenReport
+    while (!pending_.empty()) { commit(pending_.front().get()); pending_.pop_front(); }
+    for (auto &kv : files_) if (kv.second) { fclose(kv.second); kv.second = nullptr; }
+    for (auto &kv : counts_) {
+      std::vector<std::pair<Taxon, long>> counts(kv.second.begin(), kv.second.end());
+      std::ofstream rep(locations_[kv.first.first] + "/" + kv.first.second + "_kreport.txt");
+      KrakenReport(tax_, counts).print(rep);
+    }
+  }
+};
+
+}  // namespace slk_host

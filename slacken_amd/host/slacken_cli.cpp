@@ -10,20 +10,30 @@
 //   per-read output  S/slacken/Classifier.scala:41-44,124-147,184-227, S/slacken/TaxonCounts.scala:94-121
 //   report           S/slacken/KrakenReport.scala (taxonomy.hpp)
 // Host-only subcommands (`report`, `parse`, `props`) exist so that this layer can be tested without a GPU.
-#include <dlfcn.h>
-#include <zlib.h>
-
+#include <chrono>
 #include <cstring>
 #include <filesystem>
 #include <iostream>
-#include <regex>
 #include <unordered_map>
 
 #include "../../include/slacken_amd.h"
+#include "output.hpp"
+#include "seqio.hpp"
 #include "taxonomy.hpp"
 
 using namespace slk_host;
 namespace fs = std::filesystem;
+
+// wall-clock per sub-task, as Dynamic.Timer prints it (Dynamic.scala:46-54)
+struct Timer {
+  std::string task;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit Timer(std::string t) : task(std::move(t)) {}
+  ~Timer() {
+    double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::cerr << "Finish task: " << task << " [" << s << " s]" << std::endl;
+  }
+};
 
 [[noreturn]] static void die(const std::string &msg) {
   std::cerr << "slacken-amd: " << msg << std::endl;
@@ -85,146 +95,6 @@ static Records read_records(const std::string &location) {
   return r;
 }
 
-// ---- sequence input ----
-struct Fragment { std::string header, nucleotides; };
-static bool ends_with(const std::string &s, const char *suf);
-// bzip2 through the system's libbz2 (no development header in this image: the three stable high-level entry points are
-// declared here and resolved at run time)
-static std::string slurp_bz2(const std::string &path) {
-  void *h = dlopen("libbz2.so.1", RTLD_NOW);
-  if (!h) h = dlopen("libbz2.so.1.0", RTLD_NOW);
-  if (!h) die("bzip2 input needs libbz2.so.1: " + path);
-  auto bzopen = (void *(*)(const char *, const char *))dlsym(h, "BZ2_bzopen");
-  auto bzread = (int (*)(void *, void *, int))dlsym(h, "BZ2_bzread");
-  auto bzclose = (void (*)(void *))dlsym(h, "BZ2_bzclose");
-  if (!bzopen || !bzread || !bzclose) die("libbz2 lacks BZ2_bzopen/BZ2_bzread/BZ2_bzclose");
-  void *b = bzopen(path.c_str(), "rb");
-  if (!b) die("cannot open " + path);
-  std::string out;
-  std::vector<char> buf(1 << 20);
-  int n;
-  while ((n = bzread(b, buf.data(), (int)buf.size())) > 0) out.append(buf.data(), n);
-  bzclose(b);
-  return out;
-}
-static std::string slurp(const std::string &path) {  // gzread also reads plain files
-  if (ends_with(path, ".bz2")) return slurp_bz2(path);
-  gzFile g = gzopen(path.c_str(), "rb");
-  if (!g) die("cannot open " + path);
-  std::string out;
-  std::vector<char> buf(1 << 20);
-  int n;
-  while ((n = gzread(g, buf.data(), (unsigned)buf.size())) > 0) out.append(buf.data(), n);
-  gzclose(g);
-  return out;
-}
-static std::string first_token(const std::string &s) { return s.substr(0, s.find(' ')); }  // headerLine.split(" ")(0)
-
-// FastaTextInput (FileInputs.scala:156-183): records separated by '>', lines by [\n\r]+, records with < 2 lines are skipped
-static std::vector<Fragment> read_fasta(const std::string &path) {
-  std::string all = slurp(path);
-  std::vector<Fragment> out;
-  size_t pos = 0;
-  while (pos <= all.size()) {
-    size_t end = all.find('>', pos);
-    if (end == std::string::npos) end = all.size();
-    std::vector<std::string> lines;
-    size_t i = pos;
-    while (i < end) {
-      size_t j = i;
-      while (j < end && all[j] != '\n' && all[j] != '\r') j++;
-      if (j > i || lines.empty()) lines.emplace_back(all, i, j - i);   // split keeps a leading empty string only
-      while (j < end && (all[j] == '\n' || all[j] == '\r')) j++;
-      i = j;
-    }
-    if (lines.size() >= 2) {
-      Fragment f;
-      f.header = first_token(lines[0]);
-      for (size_t l = 1; l < lines.size(); l++) f.nucleotides += lines[l];
-      out.push_back(std::move(f));
-    }
-    pos = end + 1;
-  }
-  return out;
-}
-// FastqTextInput (:188-221): every 4-line window whose 1st line starts with '@' and 3rd with '+'
-static std::vector<Fragment> read_fastq(const std::string &path) {
-  std::string all = slurp(path);
-  std::vector<std::string> lines;  // Spark's text reader: lines end with \n, \r\n or \r
-  size_t i = 0;
-  while (i < all.size()) {
-    size_t j = all.find_first_of("\n\r", i);
-    if (j == std::string::npos) j = all.size();
-    lines.emplace_back(all, i, j - i);
-    i = (j + 1 < all.size() && all[j] == '\r' && all[j + 1] == '\n') ? j + 2 : j + 1;
-  }
-  std::vector<Fragment> out;
-  for (size_t l = 0; l + 2 < lines.size(); l++) {  // the window may be cut short at the end of the file; it needs 3 lines
-    if (!lines[l].empty() && lines[l][0] == '@' && !lines[l + 2].empty() && lines[l + 2][0] == '+') {
-      Fragment f;
-      f.header = first_token(lines[l]).substr(1);
-      f.nucleotides = lines[l + 1];
-      out.push_back(std::move(f));
-    }
-  }
-  return out;
-}
-static std::string lower(std::string s) { for (auto &c : s) c = (char)tolower(c); return s; }
-static bool ends_with(const std::string &s, const char *suf) { size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; }
-static std::vector<Fragment> read_file(const std::string &file) {  // FileInputs.forFile :64-85
-  std::string lo = lower(file);
-  if (ends_with(lo, "fq") || ends_with(lo, "fastq") || ends_with(lo, ".fq.gz") || ends_with(lo, ".fastq.gz") ||
-      ends_with(lo, ".fq.bz2") || ends_with(lo, ".fastq.bz2")) return read_fastq(file);
-  return read_fasta(file);  // (.fai-indexed long-sequence reading is a library-build input, not a classify input)
-}
-static std::string remove_suffix(const std::string &h, const char *suf) { return ends_with(h, suf) ? h.substr(0, h.size() - strlen(suf)) : h; }
-
-// Double.toString for the values a confidence list can hold (shortest repr that round-trips; at least one decimal)
-static std::string java_double_to_string(double d) {
-  char b[64];
-  for (int prec = 1; prec <= 17; prec++) {
-    snprintf(b, sizeof b, "%.*g", prec, d);
-    if (strtod(b, nullptr) == d) break;
-  }
-  std::string s = b;
-  if (s.find('e') != std::string::npos) return s;  // (scientific notation: not reachable for sensible thresholds)
-  if (s.find('.') == std::string::npos) s += ".0";
-  return s;
-}
-
-// TaxonCounts.lengthString :114-121 and pairsInOrderString :94-110 over un-merged hits
-static std::string length_string(const slk_hit *h, size_t n, int k) {
-  long a = 0, b = 0;
-  size_t border = n;
-  for (size_t i = 0; i < n; i++) if (h[i].taxon == SLK_TAXON_MATE_PAIR_BORDER) { border = i; break; }
-  for (size_t i = 0; i < border; i++) a += h[i].count;
-  if (border == n) return std::to_string(a + (k - 1));
-  for (size_t i = border + 1; i < n; i++) b += h[i].count;
-  return std::to_string(a + (k - 1)) + "|" + std::to_string(b + (k - 1));
-}
-static std::string pairs_in_order(const slk_hit *h, size_t n) {
-  std::string s;
-  size_t i = 0;
-  while (i < n) {
-    size_t j = i;
-    long c = 0;
-    while (j < n && h[j].taxon == h[i].taxon) { c += h[j].count; j++; }  // TaxonCounts.fromHits merges adjacent equals
-    if (h[i].taxon == SLK_TAXON_MATE_PAIR_BORDER) s += "|:|";
-    else if (h[i].taxon == SLK_TAXON_AMBIGUOUS) s += "A:" + std::to_string(c);
-    else s += std::to_string(h[i].taxon) + ":" + std::to_string(c);
-    if (j < n) s += " ";
-    i = j;
-  }
-  return s;
-}
-
-struct GzWriter {
-  gzFile g = nullptr;
-  void open(const std::string &path) { g = gzopen(path.c_str(), "wb"); if (!g) die("cannot write " + path); }
-  void line(const std::string &s) { gzwrite(g, s.data(), (unsigned)s.size()); gzputc(g, '\n'); }
-  ~GzWriter() { if (g) gzclose(g); }
-};
-
 static int cmd_report(int argc, char **argv) {  // report <taxonomy dir> <counts.tsv: taxon \t count>
   if (argc < 2) die("usage: report TAXONOMY_DIR COUNTS_TSV");
   Taxonomy tax = Taxonomy::load(argv[0]);
@@ -237,14 +107,16 @@ static int cmd_report(int argc, char **argv) {  // report <taxonomy dir> <counts
 }
 static int cmd_parse(int argc, char **argv) {  // parse <file> [<file2>]: header \t nucleotides [\t nucleotides2]
   if (argc < 1) die("usage: parse FILE [MATE_FILE]");
-  auto a = read_file(argv[0]);
-  if (argc == 1) { for (auto &f : a) std::cout << f.header << '\t' << f.nucleotides << '\n'; return 0; }
-  auto b = read_file(argv[1]);
-  std::unordered_map<std::string, size_t> idx;
-  for (size_t i = 0; i < b.size(); i++) idx.emplace(remove_suffix(b[i].header, "/2"), i);
-  for (auto &f : a) {
-    auto it = idx.find(remove_suffix(f.header, "/1"));
-    if (it != idx.end()) std::cout << remove_suffix(f.header, "/1") << '\t' << f.nucleotides << '\t' << b[it->second].nucleotides << '\n';
+  std::vector<std::string> files(argv, argv + std::min(argc, 2));
+  FragmentSource src(files, argc >= 2);
+  for (;;) {
+    FragmentBatch b;
+    if (!src.fill(b, 4096, (size_t)64 << 20)) break;
+    for (size_t i = 0; i < b.size(); i++) {
+      std::cout << b.title(i) << '\t' << b.seq(i);
+      if (b.paired) std::cout << '\t' << b.mate(i);
+      std::cout << '\n';
+    }
   }
   return 0;
 }
@@ -327,129 +199,65 @@ struct DeviceIndex {
   }
 };
 
-struct Inputs { std::vector<Fragment> frags, mates; bool paired = false; };
-// paired: join by header after stripping /1 and /2 (InputReader.scala:105-131)
-static Inputs read_inputs(const std::vector<std::string> &files, bool paired) {
-  Inputs in;
-  in.paired = paired;
-  if (!paired) for (auto &f : files) { auto v = read_file(f); in.frags.insert(in.frags.end(), std::make_move_iterator(v.begin()), std::make_move_iterator(v.end())); }
-  else for (size_t i = 0; i < files.size(); i += 2) {
-    auto a = read_file(files[i]), b = read_file(files[i + 1]);
-    std::unordered_map<std::string, size_t> idx;
-    for (size_t j = 0; j < b.size(); j++) idx.emplace(remove_suffix(b[j].header, "/2"), j);
-    for (auto &f : a) {
-      std::string h = remove_suffix(f.header, "/1");
-      auto it = idx.find(h);
-      if (it == idx.end()) continue;
-      in.frags.push_back({h, f.nucleotides});
-      in.mates.push_back({h, b[it->second].nucleotides});
+// One pass of the hot path over all input fragments: batches are parsed ahead on a reader thread, classified here, and
+// handed to f (shared ownership: output formatting keeps them alive on its own threads).
+template <class F>
+static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &files, bool paired, int min_hits,
+                            const std::vector<double> &thresholds, bool want_spans, F f) {
+  BatchPrefetcher reader(files, paired);
+  const int C = (int)thresholds.size();
+  std::vector<int32_t> nd, tk;
+  size_t total = 0;
+  while (auto frags = reader.next()) {
+    auto b = std::make_shared<ClassifiedBatch>();
+    b->frags = std::move(frags);
+    b->C = C;
+    const FragmentBatch &fb = *b->frags;
+    const size_t n = fb.size();
+    total += n;
+    b->taxon.resize((size_t)C * n); b->classified.resize((size_t)C * n); nd.resize(n); tk.resize(n);
+    b->hit_offs.resize(n + 1);
+    const size_t cap = fb.bases.size() + fb.mate_bases.size() + n + 1;
+    b->hits.resize(cap);
+    const uint8_t *mb = fb.paired ? fb.mate_bases.data() : nullptr;
+    const uint64_t *mo = fb.paired ? fb.mate_offs.data() : nullptr;
+    SLK_CALL(slk_classify_batch(dev.ix, dev.st, fb.bases.data(), fb.offs.data(), mb, mo, n, min_hits, thresholds.data(), C,
+                                b->taxon.data(), b->classified.data(), nd.data(), tk.data(), b->hit_offs.data(), b->hits.data(), cap));
+    b->hits.resize(b->hit_offs[n]);
+    b->hits.shrink_to_fit();
+    if (want_spans) {
+      b->span_offs.resize(n + 1);
+      b->spans.resize(cap);
+      SLK_CALL(slk_spans_batch(dev.ix, dev.st, fb.bases.data(), fb.offs.data(), mb, mo, n, b->span_offs.data(), b->spans.data(), cap));
     }
+    f(std::shared_ptr<const ClassifiedBatch>(b));
   }
-  return in;
+  std::cerr << total << " fragments" << std::endl;
 }
 
-// One pass of the hot path over all fragments, in batches; f(i, taxon[C], classified[C], hits, n_hits, spans or null)
-// is called for every fragment that produced at least one span (the others yield no row, Classifier.scala:92).
-template <class F>
-static void classify_all(DeviceIndex &dev, const Inputs &in, int min_hits, const std::vector<double> &thresholds, bool want_spans, F f) {
-  const size_t R = in.frags.size(), BATCH = 1 << 20;
-  const int C = (int)thresholds.size();
-  std::vector<uint8_t> bases, mbases, cls;
-  std::vector<uint64_t> offs, moffs, hit_offs, span_offs;
-  std::vector<int32_t> taxon, nd, tk, t1(C);
-  std::vector<uint8_t> c1(C);
-  std::vector<slk_hit> hits;
-  std::vector<slk_span> spans;
-  for (size_t b0 = 0; b0 < R; b0 += BATCH) {
-    size_t n = std::min(BATCH, R - b0);
-    bases.clear(); mbases.clear();
-    offs.assign(1, 0); moffs.assign(1, 0);
-    for (size_t i = 0; i < n; i++) {
-      const std::string &s = in.frags[b0 + i].nucleotides;
-      bases.insert(bases.end(), s.begin(), s.end());
-      offs.push_back(bases.size());
-      if (in.paired) { const std::string &t = in.mates[b0 + i].nucleotides; mbases.insert(mbases.end(), t.begin(), t.end()); moffs.push_back(mbases.size()); }
-    }
-    taxon.resize((size_t)C * n); cls.resize((size_t)C * n); nd.resize(n); tk.resize(n);
-    hit_offs.resize(n + 1);
-    size_t cap = bases.size() + mbases.size() + n + 1;
-    hits.resize(cap);
-    const uint8_t *mb = in.paired ? mbases.data() : nullptr;
-    const uint64_t *mo = in.paired ? moffs.data() : nullptr;
-    SLK_CALL(slk_classify_batch(dev.ix, dev.st, bases.data(), offs.data(), mb, mo, n, min_hits, thresholds.data(), C, taxon.data(),
-                                cls.data(), nd.data(), tk.data(), hit_offs.data(), hits.data(), cap));
-    if (want_spans) {
-      span_offs.resize(n + 1);
-      spans.resize(cap);
-      SLK_CALL(slk_spans_batch(dev.ix, dev.st, bases.data(), offs.data(), mb, mo, n, span_offs.data(), spans.data(), cap));
-    }
-    for (size_t i = 0; i < n; i++) {
-      size_t h0 = hit_offs[i], h1 = hit_offs[i + 1];
-      if (h1 == h0) continue;
-      for (int c = 0; c < C; c++) { t1[c] = taxon[(size_t)c * n + i]; c1[c] = cls[(size_t)c * n + i]; }
-      f(b0 + i, t1.data(), c1.data(), &hits[h0], h1 - h0, want_spans ? &spans[span_offs[i]] : nullptr);
-    }
-  }
+static size_t host_threads() {
+  const char *e = getenv("SLK_HOST_THREADS");
+  long v = e ? atol(e) : 0;
+  if (v > 0) return (size_t)v;
+  unsigned hc = std::thread::hardware_concurrency();
+  return std::min<size_t>(32, std::max<unsigned>(2, hc) - 1);
 }
 
 // Classifier.classifyHitsAndWrite / writePerSampleOutput (Classifier.scala:156-227): per-read lines and Kraken reports
-static void classify_and_write(DeviceIndex &dev, const IndexParams &ip, const Taxonomy &tax, const Inputs &in, const ClassifyOpts &o) {
-  size_t max_dec = 0;  // thresholds' directory names (:189-191)
-  for (double t : o.thresholds) { std::string s = java_double_to_string(t); max_dec = std::max(max_dec, s.size() - s.find('.') - 1); }
-  std::regex re;
-  if (!o.sample_regex.empty()) re = std::regex(o.sample_regex);
-  const int C = (int)o.thresholds.size();
-  struct SampleOut { std::vector<GzWriter> writers; std::vector<std::map<Taxon, long>> counts; };
-  std::map<std::string, SampleOut> samples;
-  std::vector<std::string> locations(C);
-  for (int c = 0; c < C; c++) {
-    char b[64];
-    snprintf(b, sizeof b, "%.*f", (int)max_dec, o.thresholds[c]);
-    locations[c] = o.output + "_c" + b;
-    fs::create_directories(locations[c]);
-  }
-  auto sample_of = [&](const std::string &title) -> std::string {  // Classifier.scala:138-142
-    if (o.sample_regex.empty()) return "all";
-    std::smatch m;
-    if (std::regex_search(title, m, re) && m.size() > 1) return m[1].str();
-    return "other";
-  };
-  auto out_for = [&](const std::string &sample) -> SampleOut & {
-    auto it = samples.find(sample);
-    if (it != samples.end()) return it->second;
-    SampleOut &so = samples[sample];
-    so.writers.resize(C);
-    so.counts.resize(C);
-    if (o.detailed) for (int c = 0; c < C; c++) {
-      std::string dir = locations[c] + "/sample=" + sample;  // Classifier.perReadOutputsLocation :415-416
-      fs::create_directories(dir);
-      so.writers[c].open(dir + "/part-00000.txt.gz");
-    }
-    return so;
-  };
-  classify_all(dev, in, o.min_hits, o.thresholds, false,
-               [&](size_t i, const int32_t *taxon, const uint8_t *cls, const slk_hit *hits, size_t nh, const slk_span *) {
-    const std::string &title = in.frags[i].header;
-    SampleOut &so = out_for(sample_of(title));
-    for (int c = 0; c < C; c++) {
-      bool classified = cls[c] != 0;
-      if (!classified && !o.with_unclassified) continue;
-      so.counts[c][taxon[c]] += 1;
-      if (o.detailed)  // ClassifiedRead.outputLine, Classifier.scala:41-44
-        so.writers[c].line(std::string(classified ? "C" : "U") + "\t" + title + "\t" + std::to_string(taxon[c]) + "\t" +
-                           length_string(hits, nh, ip.k) + "\t" + pairs_in_order(hits, nh));
-    }
-  });
-  for (auto &kv : samples)
-    for (int c = 0; c < C; c++) {
-      std::vector<std::pair<Taxon, long>> counts(kv.second.counts[c].begin(), kv.second.counts[c].end());
-      std::ofstream rep(locations[c] + "/" + kv.first + "_kreport.txt");  // Classifier.reportOutputLocation :419-420
-      KrakenReport(tax, counts).print(rep);
-    }
+static void classify_and_write(DeviceIndex &dev, const IndexParams &ip, const Taxonomy &tax, const ClassifyOpts &o) {
+  OutputOptions oo;
+  oo.output = o.output; oo.sample_regex = o.sample_regex; oo.thresholds = o.thresholds;
+  oo.with_unclassified = o.with_unclassified; oo.detailed = o.detailed; oo.k = ip.k;
+  Timer t("Classify reads");
+  OutputSink sink(oo, tax, host_threads());
+  classify_stream(dev, o.files, o.paired, o.min_hits, o.thresholds, false,
+                  [&](std::shared_ptr<const ClassifiedBatch> b) { sink.submit(std::move(b)); });
+  sink.finish();
 }
 
 // KeyValueIndex.load (KeyValueIndex.scala:413-426): parameters, taxonomy and records into HBM
 static void load_index(const std::string &location, IndexParams &ip, Taxonomy &tax, DeviceIndex &dev) {
+  Timer t("Load index " + location);
   ip = read_index_params(location);
   tax = Taxonomy::load(location + "_taxonomy");
   Records rec = read_records(location);
@@ -467,9 +275,7 @@ static int cmd_classify(int argc, char **argv) {
   Taxonomy tax;
   DeviceIndex dev;
   load_index(o.index, ip, tax, dev);
-  Inputs in = read_inputs(o.files, o.paired);
-  std::cerr << in.frags.size() << " fragments" << std::endl;
-  classify_and_write(dev, ip, tax, in, o);
+  classify_and_write(dev, ip, tax, o);
   return 0;
 }
 
@@ -488,9 +294,7 @@ static int cmd_classify2(int argc, char **argv) {
   const int rank_depth = rank - 1;
   IndexParams ip;
   Taxonomy tax;
-  std::vector<std::pair<Taxon, long>> counts;
-  Inputs in = read_inputs(o.files, o.paired);  // getInputFragments(withAmbiguous = true), Dynamic.scala:323
-  std::cerr << in.frags.size() << " fragments" << std::endl;
+  std::vector<std::pair<Taxon, long>> counts;  // (inputs: getInputFragments(withAmbiguous = true), Dynamic.scala:323)
   int32_t max_taxon;
   {
     DeviceIndex base;
@@ -503,14 +307,14 @@ static int cmd_classify2(int argc, char **argv) {
     if (o.min_count >= 0 || o.min_distinct >= 0) {
       // MinimizerTotalCount / MinimizerDistinctCount: hits with a true taxon at depth >= rank (minimizersInSubjects :73-86)
       std::vector<std::pair<Taxon, int64_t>> pairs;
-      classify_all(base, in, o.min_hits, {0.0}, o.min_distinct >= 0,
-                   [&](size_t, const int32_t *, const uint8_t *, const slk_hit *hits, size_t nh, const slk_span *spans) {
-        for (size_t j = 0; j < nh; j++) {
-          Taxon t = hits[j].taxon;
-          if (t == SLK_TAXON_AMBIGUOUS || t == SLK_TAXON_MATE_PAIR_BORDER || tax.depth(t) < rank_depth) continue;
-          if (o.min_distinct >= 0) pairs.emplace_back(t, spans[j].key);
-          else m[t] += 1;
-        }
+      classify_stream(base, o.files, o.paired, o.min_hits, {0.0}, o.min_distinct >= 0, [&](std::shared_ptr<const ClassifiedBatch> b) {
+        for (size_t i = 0; i < b->frags->size(); i++)
+          for (size_t j = b->hit_offs[i]; j < b->hit_offs[i + 1]; j++) {
+            Taxon t = b->hits[j].taxon;
+            if (t == SLK_TAXON_AMBIGUOUS || t == SLK_TAXON_MATE_PAIR_BORDER || tax.depth(t) < rank_depth) continue;
+            if (o.min_distinct >= 0) pairs.emplace_back(t, b->spans[b->span_offs[i] + (j - b->hit_offs[i])].key);
+            else m[t] += 1;
+          }
       });
       if (o.min_distinct >= 0) {
         std::sort(pairs.begin(), pairs.end());
@@ -519,9 +323,9 @@ static int cmd_classify2(int argc, char **argv) {
       }
     } else {
       // ClassifiedReadCount(threshold, confidence): classified reads per taxon (classifiedReadsPerTaxon :133-141)
-      classify_all(base, in, o.min_hits, {o.init_confidence}, false,
-                   [&](size_t, const int32_t *taxon, const uint8_t *cls, const slk_hit *, size_t, const slk_span *) {
-        if (cls[0]) m[taxon[0]] += 1;
+      classify_stream(base, o.files, o.paired, o.min_hits, {o.init_confidence}, false, [&](std::shared_ptr<const ClassifiedBatch> b) {
+        for (size_t i = 0; i < b->frags->size(); i++)
+          if (b->hit_offs[i + 1] > b->hit_offs[i] && b->classified[i]) m[b->taxon[i]] += 1;
       });
     }
     counts.assign(m.begin(), m.end());
@@ -560,15 +364,18 @@ static int cmd_classify2(int argc, char **argv) {
   std::vector<uint64_t> offsets(1, 0);
   std::vector<int32_t> taxa;
   size_t n_titles = 0;
-  for (auto &file : fna)
-    for (auto &fr : read_fasta(file)) {
-      auto it = labels.find(fr.header);
+  for (auto &file : fna) {
+    RecordStream rs(file);
+    std::string_view h, sq;
+    while (rs.next(h, sq)) {
+      auto it = labels.find(std::string(h));
       if (it == labels.end()) continue;
-      bases.insert(bases.end(), fr.nucleotides.begin(), fr.nucleotides.end());
+      bases.insert(bases.end(), sq.begin(), sq.end());
       offsets.push_back(bases.size());
       taxa.push_back(it->second);
       n_titles++;
     }
+  }
   std::cerr << "Construct dynamic records from: " << n_titles << " sequences, " << bases.size() << " bases" << std::endl;
   // distinct minimizers <= super-mers: about 2/(w+1) per k-mer window on random sequence, at most one per window
   const int w = ip.k - ip.m + 1;
@@ -586,7 +393,7 @@ static int cmd_classify2(int argc, char **argv) {
   slk_index_info info;
   SLK_CALL(slk_index_get_info(dyn.ix, &info));
   std::cerr << "dynamic index: " << info.records << " records" << std::endl;
-  classify_and_write(dyn, ip, tax, in, o);
+  classify_and_write(dyn, ip, tax, o);
   return 0;
 }
 

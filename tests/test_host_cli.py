@@ -204,3 +204,32 @@ def test_input_round_trip_separators_and_compression(tmp_path, sep, comp):
         f.write(sep.join(f"@{h}{sep}{s}{sep}+{sep}{'I' * len(s)}" for h, s in recs).encode())
     got = [tuple(l.split("\t")) for l in run("parse", fq).rstrip("\n").split("\n")]
     assert got == recs == hostmodel.parse_fastq(sep.join(f"@{h}{sep}{s}{sep}+{sep}{'I' * len(s)}" for h, s in recs))
+
+
+@pytest.mark.parametrize("chunk", [1, 2, 3, 5, 17, 4096])
+def test_streaming_parser_is_chunk_border_proof(tmp_path, chunk):
+    """The reader works on fixed-size chunks; records, line ends (incl. \\r\\n) and the 3-line FASTQ look-ahead may straddle any
+    chunk border.  SLK_IO_CHUNK forces tiny chunks."""
+    env = dict(os.environ, SLK_IO_CHUNK=str(chunk))
+
+    def parse(*files):
+        out = subprocess.run([CLI, "parse", *map(str, files)], check=True, capture_output=True, text=True, env=env).stdout
+        return [tuple(l.split("\t")) for l in out.rstrip("\n").split("\n")] if out.strip() else []
+
+    fa = tmp_path / "a.fasta"
+    fa.write_text(FASTA)
+    assert parse(fa) == hostmodel.parse_fasta(FASTA)
+    for sep in ("\n", "\r\n", "\r"):
+        text = FASTQ.replace("\n", sep)
+        fq = tmp_path / "a.fastq"
+        fq.write_bytes(text.encode())
+        assert parse(fq) == hostmodel.parse_fastq(text)
+    # paired: the first records line up, then the mate file is in another order and lacks one mate
+    a, b = tmp_path / "x_1.fq", tmp_path / "x_2.fq"
+    ids = [f"p{i}" for i in range(12)]
+    a.write_text("".join(f"@{i}/1\n{'ACGT' * 3}{n}\n+\nIIII\n" for n, i in enumerate(ids)))
+    order = ids[:4] + ids[4:][::-1]
+    order.remove("p7")
+    b.write_text("".join(f"@{i}/2\n{'TTGA' * 2}{ids.index(i)}\n+\nIIII\n" for i in order))
+    got = parse(a, b)
+    assert got == [(i, f"{'ACGT' * 3}{n}", f"{'TTGA' * 2}{n}") for n, i in enumerate(ids) if i != "p7"]

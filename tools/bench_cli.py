@@ -56,6 +56,7 @@ def main():
                             os.path.join(d, "out_" + name), *extra, fq], capture_output=True, text=True)
         dt = time.perf_counter() - t0
         assert r.returncode == 0, r.stderr
+        out[name + "_log"] = [l for l in r.stderr.split("\n") if "task" in l or "fragments" in l]
         out[name] = dict(reads=R, seconds=round(dt, 2), M_reads_per_s=round(R / dt / 1e6, 3))
     out["fastq_MB"] = round(os.path.getsize(fq) / 1e6)
     out["records"] = len(keys)
