@@ -4,7 +4,8 @@ ARCH ?= gfx950
 WPS ?= 0
 LWPS ?= 0
 LLW ?= 4
-HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -DSLK_WPS=$(WPS) -DSLK_LANE_WPS=$(LWPS) -DSLK_LANE_LW=$(LLW)
+EXTRA ?=
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -DSLK_WPS=$(WPS) -DSLK_LANE_WPS=$(LWPS) -DSLK_LANE_LW=$(LLW) $(EXTRA)
 CSRC := slacken_amd/csrc
 LIB := slacken_amd/lib/libslacken_amd.so
 

@@ -23,6 +23,7 @@
 // wave-per-read kernel of fused.hip in the same stream.
 #include "engine.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace slk {
@@ -32,6 +33,10 @@ namespace slk {
 #endif
 constexpr int LW = SLK_LANE_LW;   // waves per block
 constexpr int QCAP = 128;         // probe queue entries per wave (64 buffered + at most 64 pushed per step)
+#ifndef SLK_SBLK
+#define SLK_SBLK 5
+#endif
+constexpr int SBLK = SLK_SBLK;           // read stream: 16-byte sub-blocks fetched per refill (48 bytes per lane)
 constexpr int OMAP = 8;           // taxon map slots per fragment
 constexpr int OMAP_CNT_BITS = 10; // a fragment the lane kernel takes has <= LANE_MAX_LEN (1000) k-mers; taxon ids need <= 22 bits
 constexpr uint32_t OMAP_CNT_MASK = (1u << OMAP_CNT_BITS) - 1;
@@ -40,9 +45,24 @@ struct __attribute__((aligned(16))) LaneLds {
   uint64_t q_key[QCAP];
   uint32_t q_meta[QCAP];          // owner lane (6 bits) | distinct << 6 | kmers << 7 (10 bits) | displacement << 17 (6 bits)
   uint64_t stash[128];            // (home bucket, taxon found, tag) 16 bytes per queue entry of the batch
+  uint4 sbuf[(SBLK - 1) * 64];    // read stream: the staged 16-byte sub-blocks 1.. of every lane, [sub-block - 1][lane]
   uint32_t omap[OMAP * 64];       // [slot][owner lane]: taxon << 10 | k-mer count; 0 = empty (NONE hits are not stored)
   uint32_t o_flags[64];           // low bits: hits with distinct && taxon != NONE (Classifier.scala:94); bit 31: map overflow
 };
+
+#ifndef SLK_PROBE_NT
+#define SLK_PROBE_NT 0
+#endif
+__device__ __forceinline__ ulonglong2 SLK_PROBE_LOAD(const ulonglong2 *p) {
+#if SLK_PROBE_NT
+  ulonglong2 v;
+  v.x = __builtin_nontemporal_load(&p->x);
+  v.y = __builtin_nontemporal_load(&p->y);
+  return v;
+#else
+  return *p;
+#endif
+}
 
 __device__ __forceinline__ void lane_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -80,7 +100,9 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int q
   for (int s = 0; s < 4; s++) {
     uint32_t bkt = ((const uint4 *)L->stash)[s * 16 + g].x;
     if (dbg & 4) bkt &= 1023u;                                            // (timing experiment 4: every probe hits the L2)
-    cell[s] = *(const ulonglong2 *)(cellbase + ((uint64_t)bkt << 6));     // inactive entries read some bucket: harmless
+    // non-temporal: a bucket is touched once; keeping it out of the L2's way leaves the read stream's lines resident
+    // between a lane's consecutive 16-byte loads (inactive entries read some bucket: harmless)
+    cell[s] = SLK_PROBE_LOAD((const ulonglong2 *)(cellbase + ((uint64_t)bkt << 6)));
   }
   int requeued = 0;
 #pragma unroll
@@ -166,6 +188,25 @@ __device__ __forceinline__ int lane_code(uint32_t c) {
   return ok ? (int)t : 5;
 }
 
+// Read stream.  A lane consumes its read 16 bytes at a time; fetching those 16 bytes alone every 16 steps asks the L2 for
+// every 64-byte line about four times, and with 20 waves x 64 lanes per CU the lines do not survive in the L2 between two
+// requests (PMC: ~1.0e8 of 5.2e8 fabric reads per launch were re-fetched read bytes).  So a refill fetches SBLK sub-blocks
+// back to back (the L1 merges requests to a line that is already on its way), keeps the first in registers and parks the
+// others in the lane's own LDS slots.  Measured per 10 M x 150 bp launch: 16 bytes per refill 9.28 ms, 48: 9.0, 64: 8.8,
+// 80: 8.5 (two refills per 150-base read), 96: 8.6, 112 and more: slower (the LDS they take costs resident waves).  Sub-blocks starting at or beyond the end of the read are not fetched, so nothing
+// beyond the 16 readable bytes after the last read is touched.
+__device__ __forceinline__ uint4 stream_refill(LaneLds *L, int lane, const uint8_t *seq, uint32_t p, uint32_t n) {
+  uint4 v[SBLK];
+#pragma unroll
+  for (int i = 0; i < SBLK; i++) {
+    v[i] = make_uint4(0, 0, 0, 0);
+    if (p + 16u * i < n) __builtin_memcpy(&v[i], seq + p + 16u * i, 16);
+  }
+#pragma unroll
+  for (int i = 1; i < SBLK; i++) L->sbuf[(i - 1) * 64 + lane] = v[i];
+  return v[0];
+}
+
 #ifndef SLK_LANE_WPS
 #define SLK_LANE_WPS 0
 #endif
@@ -202,6 +243,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, int32_t *defer, uint32_t ma
       uint64_t o = A.offsets[r];
       seq = A.bases + o;
       n = (uint32_t)(A.offsets[r + 1] - o);
+      if (dbg & 8) seq = A.bases + A.offsets[r & 1023];  // (timing experiment 8: the read stream comes from the L2)
       if (paired) {
         uint64_t o2 = A.mate_offsets[r];
         seq2 = A.mate_bases + o2;
@@ -218,9 +260,9 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, int32_t *defer, uint32_t ma
     uint32_t pos = 0;
     int mate = 0;
     uint32_t cur = 0, b1 = 0, b2 = 0, b3 = 0;  // 16 buffered characters
+    int sb = 1;  // next staged sub-block (SBLK: none left, fetch)
     if (!fin && n > 0) {
-      uint4 v;
-      __builtin_memcpy(&v, seq, 16);
+      uint4 v = stream_refill(L, lane, seq, 0, n);
       cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
     }
     int run_class = 0;
@@ -307,9 +349,10 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, int32_t *defer, uint32_t ma
       const bool refill = proc && (pos & 15) == 0;
       if (__ballot(refill) != 0) {
         if (refill) {
-          if (pos < n) {  // (no register prefetch: other waves cover this L2-resident read; saves four VGPRs)
+          if (pos < n) {
             uint4 v;
-            __builtin_memcpy(&v, seq + pos, 16);
+            if (sb < SBLK) { v = L->sbuf[(sb - 1) * 64 + lane]; sb++; }
+            else { v = stream_refill(L, lane, seq, pos, n); sb = 1; }
             cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
           }
         }
@@ -324,10 +367,10 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, int32_t *defer, uint32_t ma
             mate = 1;
             seq = seq2; n = n2; pos = 0;
             if (n > 0) {
-              uint4 v;
-              __builtin_memcpy(&v, seq, 16);
+              uint4 v = stream_refill(L, lane, seq, 0, n);
+              sb = 1;
               cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
-                    }
+            }
           } else {
             fin = true;
           }
@@ -438,13 +481,21 @@ void launch_lane(const FusedArgs &A, int32_t *defer, uint32_t max_len, hipStream
   if (A.R == 0) return;
   const bool w5 = A.P.w == 5;
   size_t per_wave = sizeof(LaneLds) + (w5 ? 0 : (size_t)2 * A.P.w * 64 * sizeof(uint64_t));
-  size_t lds = per_wave * LW;
+  static const int extra_lds = getenv("SLK_LANE_EXTRA_LDS") ? atoi(getenv("SLK_LANE_EXTRA_LDS")) : 0;  // (occupancy experiment)
+  size_t lds = per_wave * LW + (size_t)extra_lds;
   uint64_t tiles = (A.R + 63) / 64;
   uint64_t blocks = (tiles + LW - 1) / LW;
   static const int bpc = getenv("SLK_LANE_BLOCKS_PER_CU") ? atoi(getenv("SLK_LANE_BLOCKS_PER_CU")) : 0;  // (tuning experiment)
   if (bpc > 0 && blocks > (uint64_t)256 * bpc) blocks = (uint64_t)256 * bpc;
   dim3 g((unsigned)blocks), b(LW * 64);
   static const int dbg = getenv("SLK_DEBUG_ABLATE") ? atoi(getenv("SLK_DEBUG_ABLATE")) : 0;  // timing experiments only: 1 = no probes, 2 = no map updates
+  static bool occ_printed = false;
+  if (getenv("SLK_DEBUG_OCC") && !occ_printed) {  // (tuning aid)
+    occ_printed = true;
+    int nb = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, w5 ? (const void *)lane_kernel<true> : (const void *)lane_kernel<false>, LW * 64, lds);
+    fprintf(stderr, "[slk] lane kernel: %zu B LDS per block, %d blocks (%d waves) resident per CU\n", lds, nb, nb * LW);
+  }
   if (w5) hipLaunchKernelGGL(lane_kernel<true>, g, b, lds, s, A, defer, max_len, dbg);
   else hipLaunchKernelGGL(lane_kernel<false>, g, b, lds, s, A, defer, max_len, dbg);
 }
