@@ -78,22 +78,38 @@ static IndexParams read_index_params(const std::string &location) {  // IndexPar
 }
 
 // ---- records (<idx>.slkrec written by tools/parquet_to_slkrec.py) ----
-struct Records { std::vector<int64_t> keys; std::vector<int32_t> taxa; };
-static Records read_records(const std::string &location) {
-  std::string path = location + ".slkrec";
-  FILE *f = fopen(path.c_str(), "rb");
-  if (!f) die("cannot open " + path + " (convert the Parquet table once with tools/parquet_to_slkrec.py " + location + ")");
-  char magic[8];
-  uint64_t n; uint32_t idl, rsv;
-  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "SLKREC1", 8) != 0) die(path + ": bad magic");
-  if (fread(&n, 8, 1, f) != 1 || fread(&idl, 4, 1, f) != 1 || fread(&rsv, 4, 1, f) != 1) die(path + ": truncated header");
-  if (idl != 1) die(path + ": " + std::to_string(idl) + " id columns; this engine supports minimizers up to 32 nt (one column)");
-  Records r;
-  r.keys.resize(n); r.taxa.resize(n);
-  if (n && (fread(r.keys.data(), 8, n, f) != n || fread(r.taxa.data(), 4, n, f) != n)) die(path + ": truncated");
-  fclose(f);
-  return r;
-}
+// <idx>.slkrec: "SLKREC1\0", u64 n, u32 id columns (1), u32 largest taxon (0 = not recorded), int64 keys[n], int32 taxa[n].
+// Streamed into the device table in chunks: a standard library is ~120 GB of records, which must not need as much host memory.
+struct RecordFile {
+  FILE *f = nullptr;
+  std::string path;
+  uint64_t n = 0;
+  uint32_t max_taxon = 0;
+  explicit RecordFile(const std::string &location) : path(location + ".slkrec") {
+    f = fopen(path.c_str(), "rb");
+    if (!f) die("cannot open " + path + " (convert the Parquet table once with tools/parquet_to_slkrec.py " + location + ")");
+    char magic[8];
+    uint32_t idl;
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "SLKREC1", 8) != 0) die(path + ": bad magic");
+    if (fread(&n, 8, 1, f) != 1 || fread(&idl, 4, 1, f) != 1 || fread(&max_taxon, 4, 1, f) != 1) die(path + ": truncated header");
+    if (idl != 1) die(path + ": " + std::to_string(idl) + " id columns; this engine supports minimizers up to 32 nt (one column)");
+  }
+  ~RecordFile() { if (f) fclose(f); }
+  void read_at(uint64_t off, void *dst, size_t bytes) {
+    if (fseeko(f, (off_t)off, SEEK_SET) != 0 || fread(dst, 1, bytes, f) != bytes) die(path + ": truncated");
+  }
+  static constexpr uint64_t CHUNK = 1ull << 24;
+  template <class F> void for_each_chunk(bool with_keys, F fn) {  // fn(keys or null, taxa, count)
+    std::vector<int64_t> keys(with_keys ? std::min(n, CHUNK) : 0);
+    std::vector<int32_t> taxa(std::min(n, CHUNK));
+    for (uint64_t o = 0; o < n; o += CHUNK) {
+      uint64_t c = std::min(CHUNK, n - o);
+      if (with_keys) read_at(24 + o * 8, keys.data(), c * 8);
+      read_at(24 + n * 8 + o * 4, taxa.data(), c * 4);
+      fn(with_keys ? keys.data() : nullptr, taxa.data(), c);
+    }
+  }
+};
 
 static int cmd_report(int argc, char **argv) {  // report <taxonomy dir> <counts.tsv: taxon \t count>
   if (argc < 2) die("usage: report TAXONOMY_DIR COUNTS_TSV");
@@ -260,13 +276,14 @@ static void load_index(const std::string &location, IndexParams &ip, Taxonomy &t
   Timer t("Load index " + location);
   ip = read_index_params(location);
   tax = Taxonomy::load(location + "_taxonomy");
-  Records rec = read_records(location);
-  int32_t max_taxon = tax.size() - 1;
-  for (int32_t t : rec.taxa) max_taxon = std::max(max_taxon, t);
-  dev.create(ip, tax, rec.keys.size(), max_taxon);
-  SLK_CALL(slk_index_append(dev.ix, rec.keys.data(), rec.taxa.data(), rec.keys.size()));
+  RecordFile rec(location);
+  int32_t max_taxon = std::max<int32_t>(tax.size() - 1, (int32_t)rec.max_taxon);
+  if (rec.max_taxon == 0)  // an older file without the recorded maximum: one pass over the taxon column
+    rec.for_each_chunk(false, [&](const int64_t *, const int32_t *taxa, uint64_t c) { for (uint64_t i = 0; i < c; i++) max_taxon = std::max(max_taxon, taxa[i]); });
+  dev.create(ip, tax, rec.n, max_taxon);
+  rec.for_each_chunk(true, [&](const int64_t *keys, const int32_t *taxa, uint64_t c) { SLK_CALL(slk_index_append(dev.ix, keys, taxa, c)); });
   dev.finalize();
-  std::cerr << "index: " << rec.keys.size() << " records, k=" << ip.k << " m=" << ip.m << " spaces=" << ip.spaces << std::endl;
+  std::cerr << "index: " << rec.n << " records, k=" << ip.k << " m=" << ip.m << " spaces=" << ip.spaces << std::endl;
 }
 
 static int cmd_classify(int argc, char **argv) {

@@ -128,3 +128,6 @@ def test_parquet_roundtrip(tmp_path):
     raw = open(loc + ".slkrec", "rb").read()
     assert raw[:8] == b"SLKREC1\0" and len(raw) == 24 + 12 * 1000
     assert np.array_equal(np.frombuffer(raw, np.int64, 1000, 24), k2)
+    # the streaming converter (what the command line runs) writes the same file, whatever the batch size
+    assert conv.convert(loc, batch_rows=77) == 1000
+    assert open(loc + ".slkrec", "rb").read() == raw

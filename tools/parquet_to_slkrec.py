@@ -16,7 +16,7 @@ def write_slkrec(path, keys, taxa):
     keys = np.ascontiguousarray(keys, np.int64)
     taxa = np.ascontiguousarray(taxa, np.int32)
     with open(path, "wb") as f:
-        f.write(b"SLKREC1\0" + struct.pack("<QII", len(keys), 1, 0))
+        f.write(b"SLKREC1\0" + struct.pack("<QII", len(keys), 1, int(taxa.max()) if len(taxa) else 0))
         f.write(keys.tobytes())
         f.write(taxa.tobytes())
 
@@ -45,8 +45,37 @@ def write_parquet_dir(location, keys, taxa, buckets):
         pq.write_table(tab, os.path.join(location, f"part-00000-test_{b:05d}.c000.snappy.parquet"), compression="snappy")
 
 
+def convert(location, batch_rows=1 << 22):
+    """Streams <location>/*.parquet into <location>.slkrec one record batch at a time (a standard library is ~1e10 rows)."""
+    files = sorted(glob.glob(os.path.join(location, "*.parquet")))
+    if not files:
+        raise SystemExit(f"no *.parquet under {location}")
+    n = 0
+    for fn in files:
+        pf = pq.ParquetFile(fn)
+        if "id2" in pf.schema_arrow.names:
+            raise SystemExit("this engine supports minimizers up to 32 nt (one id column)")
+        n += pf.metadata.num_rows
+    pos, max_taxon = 0, 0
+    with open(location + ".slkrec", "wb") as f:
+        f.write(b"SLKREC1\0" + struct.pack("<QII", n, 1, 0))
+        for fn in files:
+            for batch in pq.ParquetFile(fn).iter_batches(batch_size=batch_rows, columns=["id1", "taxon"]):
+                k = np.ascontiguousarray(batch.column("id1").to_numpy(zero_copy_only=False), np.int64)
+                t = np.ascontiguousarray(batch.column("taxon").to_numpy(zero_copy_only=False), np.int32)
+                f.seek(24 + pos * 8)
+                f.write(k.tobytes())
+                f.seek(24 + n * 8 + pos * 4)
+                f.write(t.tobytes())
+                pos += len(k)
+                if len(t):
+                    max_taxon = max(max_taxon, int(t.max()))
+        assert pos == n
+        f.seek(20)
+        f.write(struct.pack("<I", max_taxon))
+    return n
+
+
 if __name__ == "__main__":
     loc = sys.argv[1]
-    keys, taxa = read_parquet_dir(loc)
-    write_slkrec(loc + ".slkrec", keys, taxa)
-    print(f"{len(keys)} records -> {loc}.slkrec")
+    print(f"{convert(loc)} records -> {loc}.slkrec")
