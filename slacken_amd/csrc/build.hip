@@ -44,7 +44,7 @@ __device__ int32_t tax_lca(const int32_t *parents, int32_t ntax, int32_t a, int3
 
 // Insert (key, taxon) or merge the taxon into the existing record.  Returns 1 if a new record was created, 0 if merged,
 // -1 if no cell could be found within the displacement limit.
-__device__ int insert_merge(const TableBuild &t, const int32_t *parents, int32_t ntax, uint64_t key, int32_t taxon) {
+__device__ int insert_merge(const TableBuild &t, const int32_t *parents, int32_t ntax, uint64_t key, int32_t taxon, int &max_d) {
   const uint64_t h = fmix64(key);
   const uint64_t home = h >> t.shift;
   const uint64_t rem_hi = (h & t.rem_mask) << t.disp_bits;
@@ -58,7 +58,7 @@ __device__ int insert_merge(const TableBuild &t, const int32_t *parents, int32_t
       if (cur == 0) {
         unsigned long long old = atomicCAS(&bucket[c], 0ULL, val);
         if (old == 0) {
-          if (d > 0) atomicMax(t.max_disp, d);
+          max_d = max(max_d, d);
           return 1;
         }
         cur = old;  // somebody else took this cell: it may be this very key
@@ -116,12 +116,12 @@ __global__ void __launch_bounds__(BW * 64) build_kernel(ScanParams P, TableBuild
   int head = w - 1, minage = 0;
   bool have_cur = false;
   uint32_t qhead = 0, qn = 0;             // wave-uniform
-  long long created = 0, failed = 0;      // per lane
+  int created = 0, failed = 0, max_d = 0;  // per lane
 
   auto flush = [&](uint32_t cnt) {        // insert cnt (<= 64) queued records, one per lane
     if (lane < cnt) {
       uint32_t e = (qhead + lane) & 127;
-      int r = insert_merge(T, parents, ntax, L.q_key[wib][e], L.q_tax[wib][e]);
+      int r = insert_merge(T, parents, ntax, L.q_key[wib][e], L.q_tax[wib][e], max_d);
       created += (r == 1);
       failed += (r < 0);
     }
@@ -184,12 +184,14 @@ __global__ void __launch_bounds__(BW * 64) build_kernel(ScanParams P, TableBuild
   if (qn) flush(qn);  // qn < 64 here
 
   for (int o = 32; o > 0; o >>= 1) {
-    created += __shfl_xor((int)created, o);
-    failed += __shfl_xor((int)failed, o);
+    created += __shfl_xor(created, o);
+    failed += __shfl_xor(failed, o);
+    max_d = max(max_d, __shfl_xor(max_d, o));
   }
   if (lane == 0) {
     if (created) atomicAdd(T.n_inserted, (unsigned long long)created);
     if (failed) atomicAdd(T.n_overflow, (unsigned long long)failed);
+    if (max_d) atomicMax(T.max_disp, max_d);
   }
 }
 
@@ -205,16 +207,26 @@ __host__ __device__ inline uint64_t fmix64_inverse(uint64_t x) {
 __global__ void __launch_bounds__(256) export_kernel(TableView T, uint64_t ncells, int64_t *__restrict__ keys,
                                                      int32_t *__restrict__ taxa, uint64_t capacity,
                                                      unsigned long long *__restrict__ counter) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t i;
   const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t tmask = (1ULL << T.taxon_bits) - 1, dmask = (1ULL << T.disp_bits) - 1;
-  for (; i < ncells; i += step) {
-    uint64_t cell = T.cells[i];
-    if (cell == 0) continue;
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < ncells; base += step) {  // wave-uniform trip count
+    i = base + threadIdx.x;
+    uint64_t cell = i < ncells ? T.cells[i] : 0;
+    const bool has = cell != 0;
+    const uint64_t mask = __ballot(has);
+    if (mask == 0) continue;
+    // one atomic per wave: the lanes' output slots are consecutive
+    unsigned long long first = 0;
+    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+    if (has && before == 0) first = atomicAdd(counter, (unsigned long long)__popcll(mask));
+    const int leader = __ffsll((long long)mask) - 1;
+    first = ((unsigned long long)(uint32_t)__shfl((int)(first >> 32), leader) << 32) | (uint32_t)__shfl((int)first, leader);
+    if (!has) continue;
     uint64_t tag = cell >> T.taxon_bits;
     uint64_t home = ((i >> 3) - (tag & dmask)) & T.bucket_mask;
     uint64_t h = (T.shift >= 64 ? 0 : (home << T.shift)) | (tag >> T.disp_bits);
-    unsigned long long slot = atomicAdd(counter, 1ULL);
+    unsigned long long slot = first + before;
     if (slot < capacity) {
       keys[slot] = (int64_t)fmix64_inverse(h);
       taxa[slot] = (int32_t)(cell & tmask);

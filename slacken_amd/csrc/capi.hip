@@ -26,11 +26,15 @@ static int32_t fail(int32_t code, const char *fmt, ...) {
   return code;
 }
 
+// A failed HIP call leaves its code behind as the thread's "last error"; it is read back (cleared) here so that it cannot
+// be mistaken for the result of a later kernel launch that is checked with hipGetLastError().
 #define HIPCHK(expr)                                                                                   \
   do {                                                                                                 \
     hipError_t e_ = (expr);                                                                            \
-    if (e_ != hipSuccess) return fail(SLK_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                                      __FILE__, __LINE__);                                             \
+    if (e_ != hipSuccess) {                                                                            \
+      (void)hipGetLastError();                                                                         \
+      return fail(SLK_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    }                                                                                                  \
   } while (0)
 
 #define MAX_THRESHOLDS 16
@@ -82,6 +86,7 @@ struct slk_index {
 
 struct slk_stream {
   slk_index *ix = nullptr;
+  int32_t device = 0;  // copy: the stream may be destroyed after its index
   hipStream_t s = nullptr;
   DevBuf span_keys, span_meta, span_taxon, span_count;  // per-batch scratch (sparse per-read regions)
   DevBuf bases, offsets, mate_bases, mate_offsets;      // staging for the host-pointer entry points
@@ -96,8 +101,12 @@ struct slk_stream {
 
 static int32_t check_status(slk_stream *st);
 
+// Every entry point that launches kernels starts here: select the index's device and drop whatever error code an earlier,
+// unrelated HIP call of this thread (this library's or the application's) left behind, so that the hipGetLastError()
+// after a launch reports that launch.
 static int32_t set_device(const slk_index *ix) {
   HIPCHK(hipSetDevice(ix->device));
+  (void)hipGetLastError();
   return SLK_OK;
 }
 
@@ -428,6 +437,7 @@ int32_t slk_stream_create(slk_index *ix, slk_stream **out) {
   if (rc) return rc;
   slk_stream *st = new slk_stream();
   st->ix = ix;
+  st->device = ix->device;
   HIPCHK(hipStreamCreate(&st->s));
   HIPCHK(hipMalloc((void **)&st->d_thresholds, MAX_THRESHOLDS * sizeof(double)));
   HIPCHK(hipHostMalloc((void **)&st->h_thresholds, MAX_THRESHOLDS * sizeof(double), hipHostMallocDefault));
@@ -442,7 +452,7 @@ int32_t slk_stream_create(slk_index *ix, slk_stream **out) {
 
 int32_t slk_stream_synchronize(slk_stream *st) {
   if (!st) return fail(SLK_E_INVALID, "null argument");
-  HIPCHK(hipSetDevice(st->ix->device));
+  { int32_t rc_ = set_device(st->ix); if (rc_) return rc_; }
   HIPCHK(hipStreamSynchronize(st->s));
   return check_status(st);
 }
@@ -451,7 +461,7 @@ void *slk_stream_hip_stream(slk_stream *st) { return st ? (void *)st->s : nullpt
 
 void slk_stream_destroy(slk_stream *st) {
   if (!st) return;
-  (void)hipSetDevice(st->ix->device);
+  (void)hipSetDevice(st->device);
   (void)hipStreamSynchronize(st->s);
   DevBuf *bufs[] = {&st->span_keys, &st->span_meta, &st->span_taxon, &st->span_count, &st->bases, &st->offsets,
                     &st->mate_bases, &st->mate_offsets, &st->out_taxon, &st->out_cls, &st->out_nd, &st->out_tk,
@@ -651,7 +661,7 @@ int32_t slk_classify_hits_device(slk_index *ix, slk_stream *st, const uint64_t *
 int32_t slk_stream_last_stage_ms(slk_stream *st, float out_ms[3]) {
   if (!st || !out_ms) return fail(SLK_E_INVALID, "null argument");
   if (!st->timed) return fail(SLK_E_STATE, "no classify call has been issued on this stream");
-  HIPCHK(hipSetDevice(st->ix->device));
+  { int32_t rc_ = set_device(st->ix); if (rc_) return rc_; }
   HIPCHK(hipEventSynchronize(st->ev[3]));
   HIPCHK(hipEventElapsedTime(&out_ms[0], st->ev[0], st->ev[1]));
   HIPCHK(hipEventElapsedTime(&out_ms[1], st->ev[1], st->ev[2]));

@@ -24,6 +24,8 @@ __global__ void __launch_bounds__(256) table_insert_kernel(TableBuild t, const i
                                                            const int32_t *__restrict__ taxa, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  // The counters are summed per lane and added once per wave at the end: 1e10 atomics on one address would bound the build.
+  int n_ins = 0, n_dup = 0, n_ovf = 0, max_d = 0;
   for (; i < n; i += stride) {
     int32_t taxon = taxa[i];
     if (taxon == 0) continue;  // a record with taxon NONE is indistinguishable from a miss
@@ -41,19 +43,31 @@ __global__ void __launch_bounds__(256) table_insert_kernel(TableBuild t, const i
           unsigned long long old = atomicCAS(&bucket[c], 0ULL, val);
           if (old == 0) {
             done = true;
-            atomicAdd(t.n_inserted, 1ULL);
-            if (d > 0) atomicMax(t.max_disp, d);
+            n_ins++;
+            max_d = max(max_d, d);
             break;
           }
           cur = old;
         }
         if ((cur >> t.taxon_bits) == tag) {  // same key already present: contract violation, keep the first
           done = true;
-          atomicAdd(t.n_duplicate, 1ULL);
+          n_dup++;
         }
       }
     }
-    if (!done) atomicAdd(t.n_overflow, 1ULL);
+    if (!done) n_ovf++;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    n_ins += __shfl_xor(n_ins, o);
+    n_dup += __shfl_xor(n_dup, o);
+    n_ovf += __shfl_xor(n_ovf, o);
+    max_d = max(max_d, __shfl_xor(max_d, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (n_ins) atomicAdd(t.n_inserted, (unsigned long long)n_ins);
+    if (n_dup) atomicAdd(t.n_duplicate, (unsigned long long)n_dup);
+    if (n_ovf) atomicAdd(t.n_overflow, (unsigned long long)n_ovf);
+    if (max_d) atomicMax(t.max_disp, max_d);
   }
 }
 
