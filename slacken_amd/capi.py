@@ -1,4 +1,6 @@
-"""ctypes binding of include/slacken_amd.h (one Python method per C entry point; no compute happens in Python)."""
+"""ctypes binding of include/slacken_amd.h (one Python method per C entry point; no compute happens in Python).
+In a process that also uses PyTorch-ROCm, `import torch` before the first slacken_amd call: torch bundles its own HIP runtime,
+and whichever runtime is loaded first is the one that can open the GPU."""
 import ctypes as C
 import os
 from dataclasses import dataclass, field

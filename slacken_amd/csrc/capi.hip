@@ -97,6 +97,15 @@ struct slk_stream {
   int32_t *h_status = nullptr;     // pinned copy, refreshed after every classify launch
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool timed = false;
+  struct LastCall {  // the arguments of the classify call in flight, for the unbounded re-run (check_status)
+    bool valid = false, want_hits = false;
+    const uint8_t *bases = nullptr, *mate_bases = nullptr;
+    const uint64_t *offsets = nullptr, *mate_offsets = nullptr;
+    uint64_t R = 0, total = 0, mate_total = 0;
+    int32_t min_hit_groups = 0, C = 0;
+    int32_t *out_taxon = nullptr, *out_nd = nullptr, *out_tk = nullptr, *out_nh = nullptr, *out_np = nullptr;
+    uint8_t *out_cls = nullptr;
+  } last;
 };
 
 static int32_t check_status(slk_stream *st);
@@ -509,11 +518,40 @@ static bool force_wave() {  // SLK_FORCE_WAVE=1: A/B switch, classify with the w
   return v;
 }
 
+static int32_t ensure_scratch(slk_stream *st, uint64_t slots, uint64_t R);
+static uint64_t span_slots(uint64_t total_bases, uint64_t total_mate_bases, uint64_t R, bool paired);
+
+// The fused kernels keep a fragment's taxon -> count map in LDS (8 slots per lane, 128 per wave).  A fragment that hits more
+// distinct taxa than that (long reads across conserved regions can) raises status bit 1; the batch is then classified again
+// by the staged kernels, whose per-fragment map lives in HBM scratch and is unbounded -- the same three kernels that serve
+// windows wider than 32 m-mers.  Slower (HBM intermediates), rare, and bit-identical for every other fragment.
+static int32_t run_unbounded(slk_stream *st) {
+  slk_index *ix = st->ix;
+  const slk_stream::LastCall &L = st->last;
+  const bool paired = L.mate_bases != nullptr;
+  int32_t rc = ensure_scratch(st, span_slots(L.total, L.mate_total, L.R, paired), L.R);
+  if (rc) return rc;
+  launch_scan(ix->sp, L.bases, L.offsets, L.mate_bases, L.mate_offsets, L.R, st->span_keys.as<uint64_t>(),
+              st->span_meta.as<int32_t>(), st->span_count.as<int32_t>(), st->s);
+  launch_probe(ix->view(), L.offsets, L.mate_offsets, L.R, st->span_keys.as<uint64_t>(), st->span_meta.as<int32_t>(),
+               st->span_count.as<int32_t>(), st->span_taxon.as<int32_t>(), st->s);
+  launch_classify(ix->d_parents, ix->T, L.offsets, L.mate_offsets, L.R, st->span_meta.as<int32_t>(),
+                  st->span_taxon.as<int32_t>(), st->span_count.as<int32_t>(), st->span_keys.as<uint64_t>(),
+                  L.min_hit_groups, st->d_thresholds, L.C, L.out_taxon, L.out_cls, L.out_nd, L.out_tk, L.out_nh, L.out_np, st->s);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st->s));
+  return SLK_OK;
+}
+
 static int32_t check_status(slk_stream *st) {  // call after the stream has been synchronised
   int32_t v = *st->h_status;
   if (v != 0) {
     *st->h_status = 0;
     HIPCHK(hipMemsetAsync(st->d_status, 0, sizeof(int32_t), st->s));
+    if (v == 1 && st->last.valid) {
+      st->last.valid = false;
+      return run_unbounded(st);
+    }
     if (v & 1) return fail(SLK_E_CAPACITY, "a fragment hit more than %d distinct taxa; the per-read taxon map overflowed", 128);
     return fail(SLK_E_HIP, "device status %d", v);
   }
@@ -536,6 +574,14 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
   memcpy(st->h_thresholds, thresholds, C * sizeof(double));
   HIPCHK(hipMemcpyAsync(st->d_thresholds, st->h_thresholds, C * sizeof(double), hipMemcpyHostToDevice, st->s));
   HIPCHK(hipEventRecord(st->ev[0], st->s));
+  {
+    slk_stream::LastCall &L = st->last;
+    L.valid = fused; L.want_hits = want_hits;
+    L.bases = d_bases; L.offsets = d_offsets; L.mate_bases = d_mate_bases; L.mate_offsets = d_mate_offsets;
+    L.R = R; L.total = total_bases; L.mate_total = total_mate_bases; L.min_hit_groups = min_hit_groups; L.C = C;
+    L.out_taxon = d_out_taxon; L.out_cls = d_out_classified; L.out_nd = d_out_num_distinct; L.out_tk = d_out_total_kmers;
+    L.out_nh = d_out_num_hits; L.out_np = d_out_num_probes;
+  }
   if (fused) {
     FusedArgs A{};
     A.P = ix->sp; A.T = ix->view(); A.parents = ix->d_parents; A.ntax = ix->T;
@@ -786,6 +832,9 @@ int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, 
                     total, mate_total, min_hit_groups, thresholds, C, st->out_taxon.as<int32_t>(),
                     st->out_cls.as<uint8_t>(), st->out_nd.as<int32_t>(), st->out_tk.as<int32_t>(),
                     st->out_nh.as<int32_t>(), nullptr, out_hit_offsets != nullptr);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(st->s));
+  rc = check_status(st);  // (re-runs the batch through the unbounded path if a taxon map overflowed)
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(out_taxon, st->out_taxon.p, (size_t)C * R * 4, hipMemcpyDeviceToHost, st->s));
   HIPCHK(hipMemcpyAsync(out_classified, st->out_cls.p, (size_t)C * R, hipMemcpyDeviceToHost, st->s));

@@ -215,7 +215,7 @@ def test_classify_parity_other_splitters(orc, ps):
 
 def test_many_taxa_per_read_take_the_deferred_path(orc):
     """More than 8 distinct taxa in one fragment overflow the lane kernel's per-read map: the fragment is re-done by the
-    wave-per-read kernel (128-slot map).  More than 128 is reported as an error, never silently wrong."""
+    wave-per-read kernel (128-slot map).  More than 128 sends the batch through the staged kernels (unbounded map)."""
     import slacken_amd
     p = orc.params()
     rng = np.random.default_rng(99)
@@ -236,16 +236,33 @@ def test_many_taxa_per_read_take_the_deferred_path(orc):
     world = dict(p=p, st=ix.stream(), oix=orc.Index(1, keys, tx), parents=parents)
     got = check_classify(orc, world, reads, thresholds=(0.0, 0.3))
     assert (got["num_distinct"][:300] > 8).all()
-    # > 128 distinct taxa in one fragment: loud failure
-    big = [synth.random_dna(3000, rng)]
-    kk = np.unique(orc.minimizer_keys(p, big[0].tobytes()))
+    # > 128 distinct taxa in one fragment overflow the wave kernel's map too: the batch is classified again by the staged
+    # kernels with an unbounded map (check_status -> run_unbounded), with and without hit lists, sync and async entry
+    big = [synth.random_dna(3000, rng), synth.random_dna(150, rng), synth.random_dna(6000, rng)] + reads[:50]
+    kk = np.unique(np.concatenate([orc.minimizer_keys(p, b.tobytes()) for b in big]))
     many = rng.choice(taxa, size=len(kk), replace=len(kk) > len(taxa)).astype(np.int32)
     ix2 = slacken_amd.Index(expected_records=len(kk), max_taxon=len(parents) - 1)
     ix2.append(kk, many)
     ix2.set_taxonomy(parents)
     ix2.finalize()
-    if len(np.unique(many)) > 128:
-        bases, offsets = synth.pack(big)
-        with pytest.raises(slacken_amd.SlackenError) as e:
-            ix2.stream().classify_batch(bases, offsets, with_hits=False)
-        assert e.value.code == -5
+    world2 = dict(p=p, st=ix2.stream(), oix=orc.Index(1, kk, many), parents=parents)
+    got = check_classify(orc, world2, big, thresholds=(0.0, 0.1, 0.5))
+    assert got["num_distinct"][0] > 128 and got["num_distinct"][2] > 128
+    check_classify(orc, world2, big[:25], big[25:50], thresholds=(0.0,))
+    # the same stream keeps working on ordinary batches afterwards
+    check_classify(orc, world2, reads[:100], thresholds=(0.0,))
+    import torch
+    bases, offsets = synth.pack(big)
+    d_b = torch.from_numpy(np.concatenate([bases, np.zeros(64, np.uint8)])).cuda()
+    d_o = torch.from_numpy(offsets.astype(np.int64)).cuda()
+    R = len(big)
+    outs = [torch.zeros(R, dtype=torch.int32, device="cuda") for _ in range(5)]
+    d_c = torch.zeros(R, dtype=torch.uint8, device="cuda")
+    st = world2["st"]
+    st.classify_batch_device(d_b.data_ptr(), d_o.data_ptr(), R, int(offsets[-1]), outs[0].data_ptr(), d_c.data_ptr(),
+                             outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), outs[4].data_ptr(),
+                             min_hit_groups=2, thresholds=(0.0,))
+    st.synchronize()
+    want = orc.classify_batch(p, world2["oix"], parents, bases, offsets, thresholds=(0.0,))
+    assert np.array_equal(outs[0].cpu().numpy(), want["taxon"][0]) and np.array_equal(d_c.cpu().numpy(), want["classified"][0])
+    assert np.array_equal(outs[1].cpu().numpy(), want["num_distinct"]) and np.array_equal(outs[3].cpu().numpy(), want["num_hits"])
