@@ -17,9 +17,22 @@ $(LIB): $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/build.hip
 	@mkdir -p slacken_amd/lib
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/build.hip $(CSRC)/capi.hip
 
-$(CLI): slacken_amd/host/slacken_cli.cpp slacken_amd/host/taxonomy.hpp slacken_amd/host/seqio.hpp slacken_amd/host/output.hpp include/slacken_amd.h $(LIB)
+# Parquet input of the CLI: the Arrow C++ libraries inside the pyarrow wheel, if there is one (no Arrow dev package here)
+PYARROW_DIR := $(shell python3 -c "import pyarrow, os; print(os.path.dirname(pyarrow.__file__))" 2>/dev/null)
+ifneq ($(wildcard $(PYARROW_DIR)/libparquet.so.*),)
+PQ_LIB := $(notdir $(firstword $(sort $(wildcard $(PYARROW_DIR)/libparquet.so.[0-9]*))))
+AR_LIB := $(notdir $(firstword $(sort $(wildcard $(PYARROW_DIR)/libarrow.so.[0-9]*))))
+PQ_CXXFLAGS := -DSLK_HAVE_PARQUET -I$(PYARROW_DIR)/include
+PQ_LDFLAGS := -L$(PYARROW_DIR) -l:$(PQ_LIB) -l:$(AR_LIB) -Wl,-rpath,$(PYARROW_DIR)
+endif
+
+slacken_amd/bin/parquet_source.o: slacken_amd/host/parquet_source.cpp slacken_amd/host/parquet_source.hpp
 	@mkdir -p slacken_amd/bin
-	g++ -O2 -std=c++17 -Wall -o $@ slacken_amd/host/slacken_cli.cpp -Lslacken_amd/lib -lslacken_amd -lz -ldl -lpthread -Wl,-rpath,'$$ORIGIN/../lib'
+	g++ -O2 -std=c++20 -Wall $(PQ_CXXFLAGS) -c -o $@ slacken_amd/host/parquet_source.cpp
+
+$(CLI): slacken_amd/bin/parquet_source.o slacken_amd/host/slacken_cli.cpp slacken_amd/host/taxonomy.hpp slacken_amd/host/seqio.hpp slacken_amd/host/output.hpp include/slacken_amd.h $(LIB)
+	@mkdir -p slacken_amd/bin
+	g++ -O2 -std=c++17 -Wall -o $@ slacken_amd/host/slacken_cli.cpp slacken_amd/bin/parquet_source.o $(PQ_LDFLAGS) -Lslacken_amd/lib -lslacken_amd -lz -ldl -lpthread -Wl,-rpath,'$$ORIGIN/../lib'
 
 oracle:
 	$(MAKE) -C oracle

@@ -1,0 +1,20 @@
+// parquet_source.hpp -- the library's record table read straight from Slacken's Parquet files (<idx>/*.parquet, columns
+// id1: int64, taxon: int32; KeyValueIndex.writeRecords / loadRecords, S/slacken/KeyValueIndex.scala:125-159).
+// Implemented in parquet_source.cpp against the Arrow C++ libraries that ship inside the pyarrow wheel (this image has no
+// Arrow development package); when those are absent at build time the functions report "unavailable" and the host falls
+// back to the flat <idx>.slkrec written by tools/parquet_to_slkrec.py.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <string>
+
+namespace slk_host {
+
+bool parquet_available();
+// Row count of all *.parquet files under dir (footers only) and the largest taxon according to the column statistics
+// (-1 if some file carries none).  Throws std::runtime_error on unreadable files or an unsupported schema.
+uint64_t parquet_count_rows(const std::string &dir, int64_t *max_taxon);
+// Streams the records in batches.
+void parquet_for_each_batch(const std::string &dir, const std::function<void(const int64_t *, const int32_t *, uint64_t)> &fn);
+
+}  // namespace slk_host

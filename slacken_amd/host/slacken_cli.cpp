@@ -4,8 +4,8 @@
 //                    --[no]detailed, -c, --sample-regex, files, @list)
 //   index params     S/kmers/IndexParams.scala:30-47, S/kmers/SplitterFormat.scala:42-64 (<idx>.properties)
 //   taxonomy         S/slacken/Taxonomy.scala:116-137 (<idx>_taxonomy/{nodes,names,merged}.dmp)
-//   records          the Parquet table (id1: int64, taxon: int32) converted once by tools/parquet_to_slkrec.py into
-//                    <idx>.slkrec (this image has no Arrow C++ development package; pyarrow does the conversion)
+//   records          the Parquet table (id1: int64, taxon: int32), read natively (parquet_source.cpp) or, converted once by tools/parquet_to_slkrec.py, from
+//                    the flat <idx>.slkrec
 //   inputs           S/kmers/input/FileInputs.scala:64-85,156-221, InputReader.scala:105-131 (FASTA, FASTQ, gz, pairing)
 //   per-read output  S/slacken/Classifier.scala:41-44,124-147,184-227, S/slacken/TaxonCounts.scala:94-121
 //   report           S/slacken/KrakenReport.scala (taxonomy.hpp)
@@ -18,6 +18,7 @@
 
 #include "../../include/slacken_amd.h"
 #include "output.hpp"
+#include "parquet_source.hpp"
 #include "seqio.hpp"
 #include "taxonomy.hpp"
 
@@ -87,7 +88,7 @@ struct RecordFile {
   uint32_t max_taxon = 0;
   explicit RecordFile(const std::string &location) : path(location + ".slkrec") {
     f = fopen(path.c_str(), "rb");
-    if (!f) die("cannot open " + path + " (convert the Parquet table once with tools/parquet_to_slkrec.py " + location + ")");
+    if (!f) die("cannot open " + path + " (this build reads Parquet " + (parquet_available() ? "natively, but " + location + "/ holds no *.parquet" : "only through tools/parquet_to_slkrec.py " + location) + ")");
     char magic[8];
     uint32_t idl;
     if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "SLKREC1", 8) != 0) die(path + ": bad magic");
@@ -136,6 +137,38 @@ static int cmd_parse(int argc, char **argv) {  // parse <file> [<file2>]: header
   }
   return 0;
 }
+// records <idx>: how many records the library holds and a checksum of them, from the Parquet files (native reader) and
+// from <idx>.slkrec when present -- lets the readers be tested without a GPU
+static int cmd_records(int argc, char **argv) {
+  if (argc < 1) die("usage: records INDEX_LOCATION");
+  std::string location = argv[0];
+  auto report = [](const char *src, uint64_t n, uint64_t kx, int64_t ts, int32_t mt) {
+    std::cout << src << " n=" << n << " key_xor=" << kx << " taxon_sum=" << ts << " max_taxon=" << mt << '\n';
+  };
+  if (parquet_available() && fs::is_directory(location)) {
+    uint64_t n = 0, kx = 0; int64_t ts = 0; int32_t mt = 0;
+    int64_t stat_max = -1;
+    uint64_t rows = parquet_count_rows(location, &stat_max);
+    parquet_for_each_batch(location, [&](const int64_t *k, const int32_t *t, uint64_t c) {
+      for (uint64_t i = 0; i < c; i++) { kx ^= (uint64_t)k[i] * 0x9E3779B97F4A7C15ull; ts += t[i]; mt = std::max(mt, t[i]); }
+      n += c;
+    });
+    if (rows != n) die("row count of the footers differs from the rows read");
+    if (stat_max >= 0 && stat_max != mt) die("column statistics disagree with the data");
+    report("parquet", n, kx, ts, mt);
+  }
+  if (fs::exists(location + ".slkrec")) {
+    RecordFile rec(location);
+    uint64_t n = 0, kx = 0; int64_t ts = 0; int32_t mt = 0;
+    rec.for_each_chunk(true, [&](const int64_t *k, const int32_t *t, uint64_t c) {
+      for (uint64_t i = 0; i < c; i++) { kx ^= (uint64_t)k[i] * 0x9E3779B97F4A7C15ull; ts += t[i]; mt = std::max(mt, t[i]); }
+      n += c;
+    });
+    report("slkrec", n, kx, ts, mt);
+  }
+  return 0;
+}
+
 static int cmd_props(int argc, char **argv) {
   if (argc < 1) die("usage: props INDEX_LOCATION");
   IndexParams ip = read_index_params(argv[0]);
@@ -276,14 +309,27 @@ static void load_index(const std::string &location, IndexParams &ip, Taxonomy &t
   Timer t("Load index " + location);
   ip = read_index_params(location);
   tax = Taxonomy::load(location + "_taxonomy");
-  RecordFile rec(location);
-  int32_t max_taxon = std::max<int32_t>(tax.size() - 1, (int32_t)rec.max_taxon);
-  if (rec.max_taxon == 0)  // an older file without the recorded maximum: one pass over the taxon column
-    rec.for_each_chunk(false, [&](const int64_t *, const int32_t *taxa, uint64_t c) { for (uint64_t i = 0; i < c; i++) max_taxon = std::max(max_taxon, taxa[i]); });
-  dev.create(ip, tax, rec.n, max_taxon);
-  rec.for_each_chunk(true, [&](const int64_t *keys, const int32_t *taxa, uint64_t c) { SLK_CALL(slk_index_append(dev.ix, keys, taxa, c)); });
+  // records: the flat <idx>.slkrec if it exists, else Slacken's Parquet table itself
+  uint64_t n_records = 0;
+  if (!fs::exists(location + ".slkrec") && parquet_available() && fs::is_directory(location)) {
+    int64_t mt = -1;
+    n_records = parquet_count_rows(location, &mt);
+    int32_t max_taxon = std::max<int32_t>(tax.size() - 1, (int32_t)std::max<int64_t>(mt, 0));
+    if (mt < 0)  // no column statistics: one pass over the taxon column
+      parquet_for_each_batch(location, [&](const int64_t *, const int32_t *taxa, uint64_t c) { for (uint64_t i = 0; i < c; i++) max_taxon = std::max(max_taxon, taxa[i]); });
+    dev.create(ip, tax, n_records, max_taxon);
+    parquet_for_each_batch(location, [&](const int64_t *keys, const int32_t *taxa, uint64_t c) { SLK_CALL(slk_index_append(dev.ix, keys, taxa, c)); });
+  } else {
+    RecordFile rec(location);
+    n_records = rec.n;
+    int32_t max_taxon = std::max<int32_t>(tax.size() - 1, (int32_t)rec.max_taxon);
+    if (rec.max_taxon == 0)  // an older file without the recorded maximum: one pass over the taxon column
+      rec.for_each_chunk(false, [&](const int64_t *, const int32_t *taxa, uint64_t c) { for (uint64_t i = 0; i < c; i++) max_taxon = std::max(max_taxon, taxa[i]); });
+    dev.create(ip, tax, rec.n, max_taxon);
+    rec.for_each_chunk(true, [&](const int64_t *keys, const int32_t *taxa, uint64_t c) { SLK_CALL(slk_index_append(dev.ix, keys, taxa, c)); });
+  }
   dev.finalize();
-  std::cerr << "index: " << rec.n << " records, k=" << ip.k << " m=" << ip.m << " spaces=" << ip.spaces << std::endl;
+  std::cerr << "index: " << n_records << " records, k=" << ip.k << " m=" << ip.m << " spaces=" << ip.spaces << std::endl;
 }
 
 static int cmd_classify(int argc, char **argv) {
@@ -417,7 +463,7 @@ static int cmd_classify2(int argc, char **argv) {
 int main(int argc, char **argv) {
   int i = 1;
   while (i < argc && std::string(argv[i]) == "--partitions") i += 2;  // global Spark option of the reference: accepted, unused
-  if (i >= argc) die("usage: slacken-amd [--partitions N] classify|classify2|report|parse|props ...");
+  if (i >= argc) die("usage: slacken-amd [--partitions N] classify|classify2|report|parse|props|records ...");
   std::string cmd = argv[i++];
   try {
     if (cmd == "classify") return cmd_classify(argc - i, argv + i);
@@ -425,6 +471,7 @@ int main(int argc, char **argv) {
     if (cmd == "report") return cmd_report(argc - i, argv + i);
     if (cmd == "parse") return cmd_parse(argc - i, argv + i);
     if (cmd == "props") return cmd_props(argc - i, argv + i);
+    if (cmd == "records") return cmd_records(argc - i, argv + i);
   } catch (const std::exception &e) {
     die(e.what());
   }

@@ -19,7 +19,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def make_library(tmp_path):
+def make_library(tmp_path, convert=True):
     import parquet_to_slkrec as conv
     g = json.load(open(os.path.join(GOLD, "golden_classify.json")))
     lib = np.load(os.path.join(GOLD, "library.npz"))
@@ -30,7 +30,8 @@ def make_library(tmp_path):
         f.write(f"#Properties for Slacken\n#Sun Oct 04 09:00:00 UTC 2026\nk={g['k']}\nm={g['m']}\nbuckets=7\nversion=1\n"
                 f"splitter=randomXOR\nminimizerSpaces={g['spaces']}\nXORmask={mask}\ncanonical=true\n")
     tax = write_taxonomy(loc + "_taxonomy", lib["parents"], np.random.default_rng(3))
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "parquet_to_slkrec.py"), loc])
+    if convert:   # (otherwise the CLI reads the Parquet files themselves)
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "parquet_to_slkrec.py"), loc])
     reads = [line.rstrip("\n").split("\t") for line in open(os.path.join(GOLD, "reads.tsv"))]
     return g, loc, tax, reads
 
@@ -48,8 +49,9 @@ def classify(*args):
 
 
 @pytest.mark.gpu
-def test_cli_single_reads_golden(tmp_path):
-    g, loc, tax, reads = make_library(tmp_path)
+@pytest.mark.parametrize("convert", [True, False], ids=["slkrec", "parquet"])
+def test_cli_single_reads_golden(tmp_path, convert):
+    g, loc, tax, reads = make_library(tmp_path, convert)
     fa = tmp_path / "reads.fasta"
     with open(fa, "w") as f:        # multi-line FASTA, descriptions after the id
         for t, s in reads[:300]:
@@ -113,6 +115,32 @@ def test_cli_paired_samples_and_flags(tmp_path):
     for s in samples:
         assert all(l.split("\t")[1].split("sra.")[1][0] == s for l in read_out(f"{out4}_c0.0", s))
         assert os.path.exists(f"{out4}_c0.0/{s}_kreport.txt")
+
+
+def test_native_parquet_reader_matches_converter(tmp_path):
+    """`slacken-amd records`: the C++ Parquet reader (Arrow C++ from the pyarrow wheel) and the flat file written by the
+    converter hold the same records; snappy-compressed bucket files as Spark writes them, several row groups."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    rng = np.random.default_rng(2)
+    n = 50_000
+    keys = rng.integers(-2**62, 2**62, n).astype(np.int64)
+    taxa = rng.integers(1, 3_000_000, n).astype(np.int32)
+    loc = str(tmp_path / "lib")
+    os.makedirs(loc)
+    for b in range(4):
+        sel = np.arange(n) % 4 == b
+        tab = pa.table({"id1": pa.array(keys[sel], pa.int64()), "taxon": pa.array(taxa[sel], pa.int32())})
+        pq.write_table(tab, os.path.join(loc, f"part-00000-x_{b:05d}.c000.snappy.parquet"), compression="snappy", row_group_size=3000)
+    open(os.path.join(loc, "_SUCCESS"), "w").close()
+    import parquet_to_slkrec as conv
+    conv.convert(loc)
+    out = subprocess.run([CLI, "records", loc], check=True, capture_output=True, text=True).stdout.strip().split("\n")
+    if len(out) == 1:
+        pytest.skip("CLI built without Parquet support")
+    assert out[0].split(" ", 1)[1] == out[1].split(" ", 1)[1]
+    assert f"n={n} " in out[0] and f"max_taxon={int(taxa.max())}" in out[0]
+    assert f"taxon_sum={int(taxa.astype(np.int64).sum())}" in out[0]
 
 
 def test_parquet_roundtrip(tmp_path):

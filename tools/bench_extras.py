@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
+    import torch  # noqa: F401  (before the engine's library: one HIP runtime per process)
     import slacken_amd
     import taxgen
     rng = np.random.default_rng(5)
@@ -54,6 +55,26 @@ def main():
     out["host_entry"] = dict(reads=R, seconds=round(dt, 4), M_reads_per_s=round(R / dt / 1e6, 1),
                              classified=float(res["classified"][0].mean()),
                              note="slk_classify_batch with pageable host buffers: H2D of 150 B/read + kernels + D2H, one call")
+    # ---- long reads (device entry): every fragment is longer than the lane kernel takes, so the wave-per-read kernel runs ----
+    import torch
+    for L_read, R in ((10_000, 100_000), (1000, 1_000_000), (1001, 1_000_000)):
+        starts = rng.integers(0, G * L - L_read, R)
+        d_all = torch.from_numpy(bases).cuda()
+        idx = torch.from_numpy(starts).cuda()[:, None] + torch.arange(L_read, device="cuda")[None, :]
+        d_b = torch.cat([d_all[idx.reshape(-1)], torch.zeros(64, dtype=torch.uint8, device="cuda")])
+        del idx
+        d_o = torch.arange(0, (R + 1) * L_read, L_read, dtype=torch.int64, device="cuda")
+        d_t = torch.zeros(R, dtype=torch.int32, device="cuda")
+        d_c = torch.zeros(R, dtype=torch.uint8, device="cuda")
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st.classify_batch_device(d_b.data_ptr(), d_o.data_ptr(), R, R * L_read, d_t.data_ptr(), d_c.data_ptr())
+            st.synchronize()
+            dt = time.perf_counter() - t0
+        out[f"reads_{L_read}bp"] = dict(reads=R, ms=round(dt * 1e3, 2), Gbp_per_s=round(R * L_read / dt / 1e9, 1),
+                                        classified=float(d_c.float().mean().item()))
+        del d_b, d_o, d_all
     print(json.dumps(out))
 
 
