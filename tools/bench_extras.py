@@ -75,6 +75,35 @@ def main():
         out[f"reads_{L_read}bp"] = dict(reads=R, ms=round(dt * 1e3, 2), Gbp_per_s=round(R * L_read / dt / 1e9, 1),
                                         classified=float(d_c.float().mean().item()))
         del d_b, d_o, d_all
+    # ---- paired 2 x 150 and other read lengths on the hot path (device entry) ----
+    d_all = torch.from_numpy(bases).cuda()
+
+    def make(R, L_read, seed):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(seed)
+        stt = torch.randint(0, G * L - L_read, (R,), generator=g, device="cuda")
+        idx = stt[:, None] + torch.arange(L_read, device="cuda")[None, :]
+        b = torch.cat([d_all[idx.reshape(-1)], torch.zeros(64, dtype=torch.uint8, device="cuda")])
+        o = torch.arange(0, (R + 1) * L_read, L_read, dtype=torch.int64, device="cuda")
+        return b, o
+
+    R = 4_000_000
+    d_t = torch.zeros(R, dtype=torch.int32, device="cuda")
+    d_c = torch.zeros(R, dtype=torch.uint8, device="cuda")
+    for name, L1, L2 in (("single_100", 100, 0), ("single_150", 150, 0), ("single_250", 250, 0), ("paired_2x150", 150, 150), ("paired_2x100", 100, 100)):
+        b1, o1 = make(R, L1, 1)
+        kw = {}
+        if L2:
+            b2, o2 = make(R, L2, 2)
+            kw = dict(d_mate_bases=b2.data_ptr(), d_mate_offsets=o2.data_ptr(), total_mate_bases=R * L2)
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st.classify_batch_device(b1.data_ptr(), o1.data_ptr(), R, R * L1, d_t.data_ptr(), d_c.data_ptr(), **kw)
+            st.synchronize()
+            dt = time.perf_counter() - t0
+        out[name] = dict(fragments=R, ms=round(dt * 1e3, 2), M_fragments_per_s=round(R / dt / 1e6, 1),
+                         Gbp_per_s=round(R * (L1 + L2) / dt / 1e9, 1))
     print(json.dumps(out))
 
 
