@@ -46,7 +46,8 @@ EXPORTS = ["slk_device_count", "slk_last_error", "slk_version", "slk_index_creat
            "slk_index_lookup", "slk_index_add_sequences", "slk_index_export", "slk_index_destroy", "slk_stream_create", "slk_stream_synchronize",
            "slk_stream_hip_stream", "slk_stream_destroy", "slk_spans_batch", "slk_classify_batch",
            "slk_classify_batch_device", "slk_stream_last_stage_ms", "slk_scan_device", "slk_lookup_device",
-           "slk_shard_of", "slk_classify_hits_device"]
+           "slk_shard_of", "slk_classify_hits_device", "slk_shard_emit_device", "slk_shard_scatter_device",
+           "slk_shard_apply_device"]
 
 
 def lib_path():
@@ -100,6 +101,11 @@ def lib():
     L.slk_shard_of.restype = C.c_uint32
     L.slk_classify_hits_device.argtypes = [vp, vp, u64p, u64p, C.c_uint64, i32p, i32p, i32p, u64p, C.c_int32,
                                            C.POINTER(C.c_double), C.c_int32, i32p, u8p, i32p, i32p, i32p]
+    L.slk_shard_emit_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_uint32, i64p, u64p, C.c_uint64, u64p,
+                                        i32p]
+    L.slk_shard_scatter_device.argtypes = [vp, vp, u64p, i32p, C.c_uint64, i32p]
+    L.slk_shard_apply_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, i32p, C.c_int32, C.POINTER(C.c_double),
+                                         C.c_int32, i32p, u8p, i32p, i32p, i32p, i32p]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is C.c_int:  # default: int32 status
@@ -275,6 +281,23 @@ class Stream:
 
     def lookup_device(self, d_keys, n, d_out_taxa):
         _check(lib().slk_lookup_device(self.index.h, self.h, d_keys, n, d_out_taxa))
+
+    def shard_emit_device(self, d_bases, d_offsets, R, n_shards, n_sublists, d_send_keys, d_send_slots, capacity_per_sublist,
+                          d_send_counts, d_defer, d_mate_bases=None, d_mate_offsets=None):
+        _check(lib().slk_shard_emit_device(self.index.h, self.h, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, n_shards,
+                                           n_sublists, d_send_keys, d_send_slots, capacity_per_sublist, d_send_counts, d_defer))
+
+    def shard_scatter_device(self, d_slots, d_taxa, n, d_taxa_by_slot):
+        _check(lib().slk_shard_scatter_device(self.index.h, self.h, d_slots, d_taxa, n, d_taxa_by_slot))
+
+    def shard_apply_device(self, d_bases, d_offsets, R, d_taxa_by_slot, d_out_taxon, d_out_classified, d_defer,
+                           d_out_num_distinct=None, d_out_total_kmers=None, d_out_num_hits=None, d_mate_bases=None,
+                           d_mate_offsets=None, min_hit_groups=2, thresholds=(0.0,)):
+        Cn = len(thresholds)
+        thr = (C.c_double * Cn)(*thresholds)
+        _check(lib().slk_shard_apply_device(self.index.h, self.h, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R,
+                                            d_taxa_by_slot, min_hit_groups, thr, Cn, d_out_taxon, d_out_classified,
+                                            d_out_num_distinct, d_out_total_kmers, d_out_num_hits, d_defer))
 
     def classify_hits_device(self, d_offsets, R, d_span_meta, d_span_taxon, d_span_count, d_scratch, d_out_taxon,
                              d_out_classified, d_out_num_distinct=None, d_out_total_kmers=None, d_out_num_hits=None,

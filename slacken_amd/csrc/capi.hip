@@ -552,6 +552,7 @@ static int32_t check_status(slk_stream *st) {  // call after the stream has been
       st->last.valid = false;
       return run_unbounded(st);
     }
+    if (v & 2) return fail(SLK_E_CAPACITY, "a send list of slk_shard_emit_device overflowed its capacity_per_sublist");
     if (v & 1) return fail(SLK_E_CAPACITY, "a fragment hit more than %d distinct taxa; the per-read taxon map overflowed", 128);
     return fail(SLK_E_HIP, "device status %d", v);
   }
@@ -673,13 +674,88 @@ int32_t slk_lookup_device(slk_index *ix, slk_stream *st, const int64_t *d_keys, 
   if (n && (!d_keys || !d_out_taxa)) return fail(SLK_E_INVALID, "null argument");
   rc = set_device(ix);
   if (rc) return rc;
-  launch_table_lookup(ix->view(), d_keys, n, d_out_taxa, st->s);
+  launch_lookup_coop(ix->view(), d_keys, n, d_out_taxa, st->s);
   HIPCHK(hipGetLastError());
   return SLK_OK;
 }
 
 uint32_t slk_shard_of(int64_t key, uint32_t n_shards) {
   return n_shards ? (uint32_t)(fmix64((uint64_t)key) % n_shards) : 0;
+}
+
+static bool lane_path_ok(const slk_index *ix) { return use_fused(ix) && ix->sp.w <= 16 && ix->taxon_bits <= 22; }
+
+int32_t slk_shard_emit_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
+                              const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
+                              uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys, uint64_t *d_send_slots,
+                              uint64_t capacity_per_sublist, uint64_t *d_send_counts, int32_t *d_defer) {
+  int32_t rc = check_ready(ix, st, false);
+  if (rc) return rc;
+  if (!lane_path_ok(ix)) return fail(SLK_E_UNSUPPORTED, "splitter outside the fused kernel's range: use the staged calls");
+  if (n_sublists < 1 || n_sublists > 4096 || (n_sublists & (n_sublists - 1))) return fail(SLK_E_INVALID, "n_sublists must be a power of two <= 4096");
+  if (n_shards < 1 || n_shards > 64 || !d_send_counts || !d_defer || (R && (!d_bases || !d_offsets || !d_send_keys || !d_send_slots)))
+    return fail(SLK_E_INVALID, "bad argument");
+  if ((d_mate_bases == nullptr) != (d_mate_offsets == nullptr))
+    return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
+  rc = set_device(ix);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(d_send_counts, 0, (size_t)n_shards * n_sublists * sizeof(uint64_t), st->s));
+  HIPCHK(hipMemsetAsync(d_defer, 0, (R ? R : 1) * sizeof(int32_t), st->s));
+  FusedArgs A{};
+  A.P = ix->sp; A.bases = d_bases; A.offsets = d_offsets; A.mate_bases = d_mate_bases; A.mate_offsets = d_mate_offsets; A.R = R;
+  A.status = st->d_status;
+  ShardIO S{};
+  S.n_shards = (int32_t)n_shards; S.n_sub = (int32_t)n_sublists; S.cap = capacity_per_sublist; S.send_keys = d_send_keys; S.send_slots = d_send_slots;
+  S.send_counts = (unsigned long long *)d_send_counts;
+  st->last.valid = false;
+  launch_lane_sharded(LANE_EMIT, A, S, d_defer, 1000, st->s);
+  HIPCHK(hipMemcpyAsync(st->h_status, st->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st->s));
+  HIPCHK(hipGetLastError());
+  return SLK_OK;
+}
+
+int32_t slk_shard_scatter_device(slk_index *ix, slk_stream *st, const uint64_t *d_slots, const int32_t *d_taxa, uint64_t n,
+                                 int32_t *d_taxa_by_slot) {
+  int32_t rc = check_ready(ix, st, false);
+  if (rc) return rc;
+  if (n && (!d_slots || !d_taxa || !d_taxa_by_slot)) return fail(SLK_E_INVALID, "null argument");
+  rc = set_device(ix);
+  if (rc) return rc;
+  launch_scatter_taxa(d_slots, d_taxa, n, d_taxa_by_slot, st->s);
+  HIPCHK(hipGetLastError());
+  return SLK_OK;
+}
+
+int32_t slk_shard_apply_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
+                               const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
+                               const int32_t *d_taxa_by_slot, int32_t min_hit_groups, const double *thresholds, int32_t C,
+                               int32_t *d_out_taxon, uint8_t *d_out_classified, int32_t *d_out_num_distinct,
+                               int32_t *d_out_total_kmers, int32_t *d_out_num_hits, int32_t *d_defer) {
+  int32_t rc = check_ready(ix, st, true);
+  if (rc) return rc;
+  if (!lane_path_ok(ix)) return fail(SLK_E_UNSUPPORTED, "splitter outside the fused kernel's range: use the staged calls");
+  if (C < 1 || C > MAX_THRESHOLDS || !thresholds) return fail(SLK_E_INVALID, "need 1..%d thresholds", MAX_THRESHOLDS);
+  if (!d_defer || (R && (!d_bases || !d_offsets || !d_taxa_by_slot || !d_out_taxon || !d_out_classified)))
+    return fail(SLK_E_INVALID, "null argument");
+  if ((d_mate_bases == nullptr) != (d_mate_offsets == nullptr))
+    return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
+  rc = set_device(ix);
+  if (rc) return rc;
+  memcpy(st->h_thresholds, thresholds, C * sizeof(double));
+  HIPCHK(hipMemcpyAsync(st->d_thresholds, st->h_thresholds, C * sizeof(double), hipMemcpyHostToDevice, st->s));
+  FusedArgs A{};
+  A.P = ix->sp; A.parents = ix->d_parents; A.ntax = ix->T;
+  A.bases = d_bases; A.offsets = d_offsets; A.mate_bases = d_mate_bases; A.mate_offsets = d_mate_offsets; A.R = R;
+  A.min_hit_groups = min_hit_groups; A.thresholds = st->d_thresholds; A.C = C;
+  A.out_taxon = d_out_taxon; A.out_classified = d_out_classified;
+  A.out_nd = d_out_num_distinct; A.out_tk = d_out_total_kmers; A.out_nh = d_out_num_hits;
+  A.status = st->d_status;
+  ShardIO S{};
+  S.taxa = d_taxa_by_slot;
+  st->last.valid = false;
+  launch_lane_sharded(LANE_APPLY, A, S, d_defer, 1000, st->s);
+  HIPCHK(hipGetLastError());
+  return SLK_OK;
 }
 
 int32_t slk_classify_hits_device(slk_index *ix, slk_stream *st, const uint64_t *d_offsets,

@@ -87,6 +87,26 @@ struct FusedArgs {
   const int32_t *only_flagged;  // if set, the fused kernel processes only fragments r with only_flagged[r] != 0
 };
 
+// Table-sharded classification (BASELINE configs[3]): the lane kernel runs twice per batch.  LANE_EMIT scans the
+// fragments and, instead of probing, appends every minimizer to the send list of the rank that owns it
+// (fmix64(key) mod n_shards) together with the slot its taxon must come back to; LANE_APPLY scans again and takes each
+// probe's taxon from those slots (filled from the owners' answers) instead of from the local table.
+struct ShardIO {
+  int32_t n_shards;
+  int32_t n_sub;                     // sub-lists per shard (power of two): waves append to sub-list (wave id mod n_sub), so that
+                                     // the cursor atomics spread over n_sub addresses per shard instead of serialising on one
+  uint64_t cap;                      // capacity of each sub-list
+  int64_t *send_keys;                // [n_shards][n_sub][cap]
+  uint64_t *send_slots;              // [n_shards][n_sub][cap]: span_region(r) + ordinal of the probe within fragment r
+  unsigned long long *send_counts;   // [n_shards][n_sub] cursors; a cursor beyond cap raises status bit 2
+  const int32_t *taxa;               // LANE_APPLY: taxon per slot
+};
+enum { LANE_LOCAL = 0, LANE_EMIT = 1, LANE_APPLY = 2 };
+void launch_lane_sharded(int mode, const FusedArgs &A, const ShardIO &S, int32_t *defer, uint32_t max_len, hipStream_t s);
+// cooperative point lookups (4 lanes x 16 B per bucket) and the scatter of returned taxa to their slots (shard.hip)
+void launch_lookup_coop(const TableView &t, const int64_t *keys, uint64_t n, int32_t *out, hipStream_t s);
+void launch_scatter_taxa(const uint64_t *slots, const int32_t *taxa, uint64_t n, int32_t *taxa_by_slot, hipStream_t s);
+
 enum { MODE_SPANS = 0, MODE_CLASSIFY = 1, MODE_HITS = 2 };
 void launch_fused(int mode, const FusedArgs &A, hipStream_t s);
 // lane-per-fragment classify kernel (lane.hip); fragments it cannot take are flagged in defer[] for launch_fused

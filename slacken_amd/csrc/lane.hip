@@ -71,6 +71,26 @@ __device__ __forceinline__ void lane_wave_sync() {
 }
 __device__ __forceinline__ uint64_t lmin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
 
+// Fold entry `meta`'s hit into its owner's 8-slot map: ONE round of LDS atomics per batch (NONE hits carry no information
+// for resolveTree and are dropped).
+__device__ __forceinline__ void fold_hit(LaneLds *L, bool in, uint32_t meta, int32_t taxon) {
+  if (in && taxon != 0) {
+    const int owner = meta & 63;
+    const int32_t kmers = (int32_t)((meta >> 7) & 0x3FF);
+    if (meta & 64) atomicAdd(&L->o_flags[owner], 1u);  // distinct && taxon != NONE (Classifier.scala:94)
+    uint32_t slot = ((uint32_t)taxon * 0x9E3779B1u) >> 29;
+    const uint32_t fresh = ((uint32_t)taxon << OMAP_CNT_BITS) | (uint32_t)kmers;
+    int p = 0;
+    for (; p < OMAP; p++) {
+      uint32_t old = atomicCAS(&L->omap[slot * 64 + owner], 0u, fresh);
+      if (old == 0u) break;
+      if ((old >> OMAP_CNT_BITS) == (uint32_t)taxon) { atomicAdd(&L->omap[slot * 64 + owner], (uint32_t)kmers); break; }
+      slot = (slot + 1) & (OMAP - 1);
+    }
+    if (p == OMAP) atomicOr(&L->o_flags[owner], 0x80000000u);
+  }
+}
+
 // Probe `cnt` (<= 64) entries of the ring queue starting at `qhead` and fold the hits into their owners' maps.
 //   1. lane i hashes entry i and parks (home bucket, tag) in LDS;
 //   2. FOUR lanes read one 64-byte bucket (4 x 16 B = one HBM line), sixteen probes per wave instruction, four
@@ -137,23 +157,58 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int q
   lane_wave_sync();
   // step 3: one lane per entry
   const int32_t taxon = (int32_t)((const uint4 *)L->stash)[lane].y;
-  if (in && taxon != 0 && !(dbg & 2)) {
-    const int owner = meta & 63;
-    const int32_t kmers = (int32_t)((meta >> 7) & 0x3FF);
-    if (meta & 64) atomicAdd(&L->o_flags[owner], 1u);  // distinct && taxon != NONE (Classifier.scala:94)
-    uint32_t slot = ((uint32_t)taxon * 0x9E3779B1u) >> 29;
-    const uint32_t fresh = ((uint32_t)taxon << OMAP_CNT_BITS) | (uint32_t)kmers;
-    int p = 0;
-    for (; p < OMAP; p++) {
-      uint32_t old = atomicCAS(&L->omap[slot * 64 + owner], 0u, fresh);
-      if (old == 0u) break;
-      if ((old >> OMAP_CNT_BITS) == (uint32_t)taxon) { atomicAdd(&L->omap[slot * 64 + owner], (uint32_t)kmers); break; }
-      slot = (slot + 1) & (OMAP - 1);
-    }
-    if (p == OMAP) atomicOr(&L->o_flags[owner], 0x80000000u);
-  }
+  if (!(dbg & 2)) fold_hit(L, in, meta, taxon);
   lane_wave_sync();
   return requeued;
+}
+
+// ---- table-sharded mode (engine.h: ShardIO) ------------------------------------------------------------------------------
+// The queue entries of these two modes carry the probe's ordinal within its fragment; with the fragment's span region (kept
+// per lane in the LDS words the local mode uses as probe stash) that names the slot through which the owner's answer returns.
+__device__ __forceinline__ uint64_t lane_readlane64(uint64_t v, int src) {
+  uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src);
+  return ((uint64_t)hi << 32) | lo;
+}
+// LANE_EMIT: append the batch's minimizers to their owners' send lists (one atomic per owner per batch)
+__device__ __forceinline__ void emit_batch(LaneLds *L, const ShardIO &S, int32_t *status, int qhead, int cnt, int lane, uint32_t sub) {
+  const bool in = lane < cnt;
+  const int qi = (qhead + lane) & (QCAP - 1);
+  const uint64_t key = L->q_key[qi];
+  const uint32_t meta = L->q_meta[qi];
+  const uint64_t slot = L->stash[meta & 63] + ((meta >> 7) & 0x3FF);
+  const uint64_t h = fmix64(key);
+  const uint32_t ns = (uint32_t)S.n_shards;
+  const uint32_t g = (ns & (ns - 1)) == 0 ? (uint32_t)(h & (ns - 1)) : (uint32_t)(h % ns);  // == slk_shard_of
+  for (uint32_t sh = 0; sh < ns; sh++) {
+    const bool mine = in && g == sh;
+    const uint64_t m = __ballot(mine);
+    if (m == 0) continue;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned long long base = 0;
+    const uint64_t list = (uint64_t)sh * (uint32_t)S.n_sub + sub;
+    if (lane == leader) base = atomicAdd(&S.send_counts[list], (unsigned long long)__popcll(m));
+    base = lane_readlane64(base, leader);
+    if (mine) {
+      const uint64_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+      if (pos < S.cap) {
+        S.send_keys[list * S.cap + pos] = (int64_t)key;
+        S.send_slots[list * S.cap + pos] = slot;
+      } else {
+        atomicOr(status, 2);
+      }
+    }
+  }
+  lane_wave_sync();
+}
+// LANE_APPLY: the batch's taxa come from the slots the owners' answers were scattered to
+__device__ __forceinline__ void apply_batch(LaneLds *L, const ShardIO &S, int qhead, int cnt, int lane) {
+  const bool in = lane < cnt;
+  const int qi = (qhead + lane) & (QCAP - 1);
+  const uint32_t meta = L->q_meta[qi];
+  const uint64_t slot = L->stash[meta & 63] + ((meta >> 17) & 0x3FF);
+  const int32_t taxon = in ? S.taxa[slot] : 0;
+  fold_hit(L, in, meta, taxon);
+  lane_wave_sync();
 }
 
 struct OwnerMap {  // this lane's column of the LDS maps
@@ -216,8 +271,8 @@ __device__ __forceinline__ uint4 stream_refill(LaneLds *L, int lane, const uint8
 #define LANE_BOUNDS __launch_bounds__(LW * 64)
 #endif
 
-template <bool W5>
-__global__ void LANE_BOUNDS lane_kernel(FusedArgs A, int32_t *defer, uint32_t max_len, int dbg) {
+template <bool W5, int MODE>
+__global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, uint32_t max_len, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -252,6 +307,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, int32_t *defer, uint32_t ma
     }
     bool too_long = have && ((uint64_t)n + n2 > max_len);
     bool fin = !have || too_long;
+    if (MODE != LANE_LOCAL) L->stash[lane] = have ? span_region(A.offsets, A.mate_offsets, r) : 0;  // (read after a wave sync)
     // ---- per-lane LDS state ----
 #pragma unroll
     for (int s = 0; s < OMAP; s++) L->omap[s * 64 + lane] = 0;
@@ -398,13 +454,17 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, int32_t *defer, uint32_t ma
         if (emit) {
           int slot = (qhead + qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(E >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)E, 0))) & (QCAP - 1);
           L->q_key[slot] = ekey;
-          L->q_meta[slot] = (uint32_t)lane | (distinct ? 64u : 0u) | ((uint32_t)ekmers << 7);
+          if (MODE == LANE_EMIT) L->q_meta[slot] = (uint32_t)lane | ((uint32_t)(np - 1) << 7);
+          else L->q_meta[slot] = (uint32_t)lane | (distinct ? 64u : 0u) | ((uint32_t)ekmers << 7) |
+                                 (MODE == LANE_APPLY ? (uint32_t)(np - 1) << 17 : 0u);
         }
         qn += __popcll(E);
         if (qn >= 64) {
           lane_wave_sync();
           int back = 0;
-          if (!(dbg & 1)) back = probe_batch(L, A.T, qhead, qn, 64, lane, dbg);
+          if (MODE == LANE_EMIT) emit_batch(L, S, A.status, qhead, 64, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1));
+          else if (MODE == LANE_APPLY) apply_batch(L, S, qhead, 64, lane);
+          else if (!(dbg & 1)) back = probe_batch(L, A.T, qhead, qn, 64, lane, dbg);
           qhead = (qhead + 64) & (QCAP - 1);
           qn += back - 64;
         }
@@ -414,7 +474,9 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, int32_t *defer, uint32_t ma
       lane_wave_sync();
       const int cnt = min(qn, 64);
       int back = 0;
-      if (!(dbg & 1)) back = probe_batch(L, A.T, qhead, qn, cnt, lane, dbg);
+      if (MODE == LANE_EMIT) emit_batch(L, S, A.status, qhead, cnt, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1));
+      else if (MODE == LANE_APPLY) apply_batch(L, S, qhead, cnt, lane);
+      else if (!(dbg & 1)) back = probe_batch(L, A.T, qhead, qn, cnt, lane, dbg);
       qhead = (qhead + cnt) & (QCAP - 1);
       qn += back - cnt;
     }
@@ -425,7 +487,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, int32_t *defer, uint32_t ma
       const uint32_t oflags = L->o_flags[lane];
       if (too_long || (oflags & 0x80000000u)) {
         defer[r] = 1;  // re-done by the wave-per-read kernel
-      } else {
+      } else if (MODE != LANE_EMIT) {
         OwnerMap M{L, lane};
         const int32_t nd = (int32_t)oflags;
         int D = 0;
@@ -477,7 +539,8 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, int32_t *defer, uint32_t ma
   }
 }
 
-void launch_lane(const FusedArgs &A, int32_t *defer, uint32_t max_len, hipStream_t s) {
+template <int MODE>
+static void launch_lane_mode(const FusedArgs &A, const ShardIO &S, int32_t *defer, uint32_t max_len, hipStream_t s) {
   if (A.R == 0) return;
   const bool w5 = A.P.w == 5;
   size_t per_wave = sizeof(LaneLds) + (w5 ? 0 : (size_t)2 * A.P.w * 64 * sizeof(uint64_t));
@@ -493,11 +556,19 @@ void launch_lane(const FusedArgs &A, int32_t *defer, uint32_t max_len, hipStream
   if (getenv("SLK_DEBUG_OCC") && !occ_printed) {  // (tuning aid)
     occ_printed = true;
     int nb = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, w5 ? (const void *)lane_kernel<true> : (const void *)lane_kernel<false>, LW * 64, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, w5 ? (const void *)lane_kernel<true, MODE> : (const void *)lane_kernel<false, MODE>, LW * 64, lds);
     fprintf(stderr, "[slk] lane kernel: %zu B LDS per block, %d blocks (%d waves) resident per CU\n", lds, nb, nb * LW);
   }
-  if (w5) hipLaunchKernelGGL(lane_kernel<true>, g, b, lds, s, A, defer, max_len, dbg);
-  else hipLaunchKernelGGL(lane_kernel<false>, g, b, lds, s, A, defer, max_len, dbg);
+  if (w5) hipLaunchKernelGGL((lane_kernel<true, MODE>), g, b, lds, s, A, S, defer, max_len, dbg);
+  else hipLaunchKernelGGL((lane_kernel<false, MODE>), g, b, lds, s, A, S, defer, max_len, dbg);
+}
+
+void launch_lane(const FusedArgs &A, int32_t *defer, uint32_t max_len, hipStream_t s) {
+  launch_lane_mode<LANE_LOCAL>(A, ShardIO{}, defer, max_len, s);
+}
+void launch_lane_sharded(int mode, const FusedArgs &A, const ShardIO &S, int32_t *defer, uint32_t max_len, hipStream_t s) {
+  if (mode == LANE_EMIT) launch_lane_mode<LANE_EMIT>(A, S, defer, max_len, s);
+  else launch_lane_mode<LANE_APPLY>(A, S, defer, max_len, s);
 }
 
 }  // namespace slk

@@ -5,8 +5,12 @@ all-to-all (4 bytes each), and every rank finishes its own reads' LCA locally.  
 join (S/slacken/Classifier.scala:84) for the one case where data must move; with a table that fits, use the replicated
 mode (no collective at all).
 
-Host plumbing only: torch for device buffers and the collectives, the engine's staged entry points
-(slk_scan_device / slk_lookup_device / slk_classify_hits_device) for all compute."""
+Host plumbing only: torch for device buffers and the collectives, the engine for all compute.  Two routes:
+  fast    slk_shard_emit_device -> all-to-all -> slk_lookup_device -> all-to-all -> slk_shard_scatter_device ->
+          slk_shard_apply_device: the fused lane-per-fragment kernel runs on both sides of the exchange, no span arrays;
+          takes fragments of up to 1000 bases with at most 8 distinct taxa;
+  staged  slk_scan_device / slk_lookup_device / slk_classify_hits_device with the exchange lists built by torch ops: takes
+          everything, and the fragments the fast route hands back (`defer`)."""
 import numpy as np
 
 _C1 = 0xff51afd7ed558ccd - (1 << 64)
@@ -70,8 +74,94 @@ class ShardedClassifier:
         self.dist.all_to_all_single(out, src, output_split_sizes=recv_counts, input_split_sizes=list(send_counts))
         return out.to(self.device), recv_counts
 
-    def classify(self, d_bases, d_offsets, R, total_bases, thresholds=(0.0,), min_hit_groups=2):
+    def classify(self, d_bases, d_offsets, R, total_bases, thresholds=(0.0,), min_hit_groups=2, fast=True):
         """d_bases uint8 [total_bases + >=16 pad], d_offsets int64 [R+1] (device tensors). Single-end fragments."""
+        if fast:
+            out = self._classify_fast(d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups)
+            if out is not None:
+                return out
+        return self._classify_staged(d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups)
+
+    def _any_rank(self, flag):
+        """logical OR of a host flag over all ranks (every rank must take the same sequence of collectives)"""
+        if self.world == 1 or self.dist is None:
+            return bool(flag)
+        t = self.torch.tensor([1 if flag else 0], dtype=self.torch.int64, device="cpu" if self.on_cpu else self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return bool(int(t.item()))
+
+    def _classify_fast(self, d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups):
+        import slacken_amd
+        torch, dev, W = self.torch, self.device, self.world
+        # about 0.26 probes per base on random sequence, spread evenly by the hash over W owners and by the wave index over
+        # SUB sub-lists per owner: 0.6 / (W * SUB) per base leaves 2x headroom
+        SUB = 256
+        cap = int(total_bases * 0.6 / (W * SUB)) + (1 << 12)
+        send_keys = torch.empty(W * SUB * cap, dtype=torch.int64, device=dev)
+        send_slots = torch.empty(W * SUB * cap, dtype=torch.int64, device=dev)
+        counts = torch.zeros(W * SUB, dtype=torch.int64, device=dev)
+        defer = torch.empty(max(R, 1), dtype=torch.int32, device=dev)
+        try:
+            self.st.shard_emit_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, W, SUB, send_keys.data_ptr(),
+                                      send_slots.data_ptr(), cap, counts.data_ptr(), defer.data_ptr())
+            self.st.synchronize()
+            unsupported = False
+        except slacken_amd.SlackenError as e:
+            if e.code != -4:   # SLK_E_UNSUPPORTED: this splitter only has the staged route
+                raise
+            unsupported = True
+        if self._any_rank(unsupported):
+            return None
+        sub_counts = [int(v) for v in counts.tolist()]          # [owner][sub-list], owner-major: concatenation order
+        send_counts = [sum(sub_counts[g * SUB:(g + 1) * SUB]) for g in range(W)]
+        keys = torch.cat([send_keys[i * cap:i * cap + n] for i, n in enumerate(sub_counts)])
+        slots = torch.cat([send_slots[i * cap:i * cap + n] for i, n in enumerate(sub_counts)])
+        del send_keys, send_slots
+        recv_keys, recv_counts = self._all_to_all(keys, send_counts)
+        found = torch.zeros(max(recv_keys.numel(), 1), dtype=torch.int32, device=dev)
+        if recv_keys.numel():
+            recv_keys = recv_keys.contiguous()
+            self.st.lookup_device(recv_keys.data_ptr(), recv_keys.numel(), found.data_ptr())
+            self.st.synchronize()
+        back, _ = self._all_to_all(found[:recv_keys.numel()].contiguous(), recv_counts)
+        by_slot = torch.empty(total_bases + R + 1, dtype=torch.int32, device=dev)
+        back = back.contiguous()
+        self.st.shard_scatter_device(slots.data_ptr(), back.data_ptr(), back.numel(), by_slot.data_ptr())
+        C = len(thresholds)
+        out = dict(taxon=torch.zeros(C * max(R, 1), dtype=torch.int32, device=dev),
+                   classified=torch.zeros(C * max(R, 1), dtype=torch.uint8, device=dev),
+                   num_distinct=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
+                   total_kmers=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
+                   num_hits=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
+                   exchanged_keys=int(keys.numel()))
+        self.st.shard_apply_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, by_slot.data_ptr(), out["taxon"].data_ptr(),
+                                   out["classified"].data_ptr(), defer.data_ptr(), out["num_distinct"].data_ptr(),
+                                   out["total_kmers"].data_ptr(), out["num_hits"].data_ptr(), min_hit_groups=min_hit_groups,
+                                   thresholds=thresholds)
+        self.st.synchronize()
+        # fragments the fused kernel does not take: a compacted batch through the staged route (all ranks, also with none)
+        idx = torch.nonzero(defer[:R]).flatten() if R else torch.zeros(0, dtype=torch.int64, device=dev)
+        out["deferred"] = int(idx.numel())
+        if self._any_rank(idx.numel() > 0):
+            lens = d_offsets[idx + 1] - d_offsets[idx]
+            sub_off = torch.zeros(idx.numel() + 1, dtype=torch.int64, device=dev)
+            sub_off[1:] = torch.cumsum(lens, 0)
+            sub_total = int(sub_off[-1].item()) if idx.numel() else 0
+            src = torch.repeat_interleave(d_offsets[idx], lens) + (torch.arange(sub_total, device=dev) -
+                                                                   torch.repeat_interleave(sub_off[:-1], lens))
+            sub_bases = torch.cat([d_bases[src], torch.zeros(64, dtype=torch.uint8, device=dev)])
+            sub = self._classify_staged(sub_bases, sub_off, int(idx.numel()), sub_total, thresholds, min_hit_groups)
+            n = int(idx.numel())
+            if n:
+                for c in range(C):
+                    out["taxon"][c * R + idx] = sub["taxon"][c * n:(c + 1) * n]
+                    out["classified"][c * R + idx] = sub["classified"][c * n:(c + 1) * n]
+                for k in ("num_distinct", "total_kmers", "num_hits"):
+                    out[k][idx] = sub[k][:n]
+            out["exchanged_keys"] += sub["exchanged_keys"]
+        return out
+
+    def _classify_staged(self, d_bases, d_offsets, R, total_bases, thresholds=(0.0,), min_hit_groups=2):
         torch, dev = self.torch, self.device
         slots = total_bases + 1
         keys = torch.empty(slots, dtype=torch.int64, device=dev)

@@ -30,7 +30,7 @@ def _free_port():
     return p
 
 
-def _rank(rank, world, port, payload, outdir):
+def _rank(rank, world, port, payload, outdir, fast):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -47,7 +47,8 @@ def _rank(rank, world, port, payload, outdir):
     d_bases = torch.cat([torch.from_numpy(bases[b0:b1]), torch.full((64,), 65, dtype=torch.uint8)]).to(dev)
     d_off = torch.from_numpy((offsets[lo:hi + 1] - offsets[lo]).astype(np.int64)).to(dev)
     sc = sharded.ShardedClassifier(ix, rank, world, dist, dev, exchange_on_cpu=True)
-    out = sc.classify(d_bases, d_off, hi - lo, b1 - b0, thresholds=(0.0, 0.2))
+    out = sc.classify(d_bases, d_off, hi - lo, b1 - b0, thresholds=(0.0, 0.2), fast=fast)
+    assert ("deferred" in out) == fast
     np.savez(os.path.join(outdir, f"r{rank}.npz"), lo=lo, hi=hi, **{k: v.cpu().numpy() for k, v in out.items()
                                                                      if hasattr(v, "cpu")})
     dist.barrier()
@@ -55,7 +56,8 @@ def _rank(rank, world, port, payload, outdir):
 
 
 @pytest.mark.gpu
-def test_two_ranks_half_table_each(orc, tmp_path):
+@pytest.mark.parametrize("fast", [True, False], ids=["fast", "staged"])
+def test_two_ranks_half_table_each(orc, tmp_path, fast):
     import torch.multiprocessing as mp
     import synth
     import taxgen
@@ -64,9 +66,12 @@ def test_two_ranks_half_table_each(orc, tmp_path):
     p = orc.params()
     lib = synth.Library(orc, p, parents, n_genomes=8, genome_len=10000, pad_records=20000)
     reads = synth.make_reads(lib, 3000, rng, n_single=0.1, n_run=0.05, vary_length=True)
+    reads += synth.make_reads(lib, 40, rng, length=1500, short=0)     # longer than the fused kernel takes: deferred
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
     bases, offsets = synth.pack(reads)
     want = orc.classify_batch(p, orc.Index(1, lib.keys, lib.taxa), parents, bases, offsets, thresholds=(0.0, 0.2))
-    mp.spawn(_rank, args=(2, _free_port(), (lib.keys, lib.taxa, parents, bases, offsets), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_rank, args=(2, _free_port(), (lib.keys, lib.taxa, parents, bases, offsets), str(tmp_path), fast), nprocs=2, join=True)
     R = len(reads)
     got = {k: np.zeros((2, R), np.int64) if k in ("taxon", "classified") else np.zeros(R, np.int64)
            for k in ("taxon", "classified", "num_distinct", "total_kmers", "num_hits")}
@@ -81,3 +86,39 @@ def test_two_ranks_half_table_each(orc, tmp_path):
             got[k][lo:hi] = z[k][:n]
     for k in got:
         assert np.array_equal(got[k], want[k]), k
+
+
+@pytest.mark.gpu
+def test_single_rank_fast_route_with_deferrals(orc):
+    """world = 1: no exchange, but the same emit -> lookup -> scatter -> apply pipeline, incl. fragments the fused kernel
+    hands back (longer than 1000 bases; more than 8 distinct taxa) and empty / vanishing fragments."""
+    import synth
+    import taxgen
+    rng = np.random.default_rng(43)
+    parents = taxgen.taxonomy(8 * 64, rng)
+    taxa = np.array(taxgen.defined_taxa(parents))
+    p = orc.params()
+    reads = synth.make_reads(synth.Library(orc, p, parents, n_genomes=4, genome_len=8000), 500, rng, vary_length=True)
+    reads += [synth.random_dna(400, rng) for _ in range(30)] + [synth.random_dna(2500, rng) for _ in range(5)]
+    reads += [np.zeros(0, np.uint8), np.frombuffer(b"ACGT" * 5, np.uint8)]
+    keys = np.unique(np.concatenate([orc.minimizer_keys(p, r.tobytes()) for r in reads]))
+    tx = rng.choice(taxa, size=len(keys)).astype(np.int32)       # every minimizer its own random taxon: many taxa per read
+    ix = slacken_amd.Index(expected_records=len(keys), max_taxon=len(parents) - 1)
+    ix.append(keys, tx)
+    ix.set_taxonomy(parents)
+    ix.finalize()
+    bases, offsets = synth.pack(reads)
+    dev = torch.device("cuda", 0)
+    d_bases = torch.cat([torch.from_numpy(bases), torch.full((64,), 65, dtype=torch.uint8)]).to(dev)
+    d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    sc = sharded.ShardedClassifier(ix, 0, 1, None, dev)
+    R = len(reads)
+    want = orc.classify_batch(p, orc.Index(1, keys, tx), parents, bases, offsets, thresholds=(0.0, 0.1))
+    for fast in (True, False):
+        out = sc.classify(d_bases, d_off, R, int(offsets[-1]), thresholds=(0.0, 0.1), fast=fast)
+        assert np.array_equal(out["taxon"].cpu().numpy().reshape(2, R), want["taxon"]), fast
+        assert np.array_equal(out["classified"].cpu().numpy().reshape(2, R), want["classified"]), fast
+        for k in ("num_distinct", "total_kmers", "num_hits"):
+            assert np.array_equal(out[k].cpu().numpy()[:R], want[k]), (k, fast)
+        if fast:
+            assert out["deferred"] >= 35

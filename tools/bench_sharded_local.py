@@ -14,18 +14,19 @@ ix = slacken_amd.Index(expected_records=int(G * L * 0.4), max_taxon=len(parents)
 ix.set_taxonomy(parents)
 ix.add_sequences(bases, offsets, rng.choice(taxa[len(taxa)//2:], G).astype(np.int32))
 ix.finalize()
-R = 2_000_000
+R = int(os.environ.get('R', 2_000_000))
 starts = rng.integers(0, G * L - 150, R)
 d_all = torch.from_numpy(bases).cuda()
 idx = torch.from_numpy(starts).cuda()[:, None] + torch.arange(150, device="cuda")[None, :]
 d_b = torch.cat([d_all[idx.reshape(-1)], torch.zeros(64, dtype=torch.uint8, device="cuda")])
 d_o = torch.arange(0, (R + 1) * 150, 150, dtype=torch.int64, device="cuda")
 sc = ShardedClassifier(ix, 0, 1, None, torch.device("cuda", 0))
-for _ in range(3):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    out = sc.classify(d_b, d_o, R, R * 150)
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print("sharded world=1:", round(dt * 1e3, 1), "ms", round(R / dt / 1e6, 1), "M reads/s")
+for fast in (False, True):
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = sc.classify(d_b, d_o, R, R * 150, fast=fast)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("sharded world=1", "fast" if fast else "staged", round(dt * 1e3, 1), "ms", round(R / dt / 1e6, 1), "M reads/s", out.get("deferred"))
 st = ix.stream()
 d_t = torch.zeros(R, dtype=torch.int32, device="cuda"); d_c = torch.zeros(R, dtype=torch.uint8, device="cuda")
 for _ in range(3):
