@@ -74,13 +74,15 @@ class ShardedClassifier:
         self.dist.all_to_all_single(out, src, output_split_sizes=recv_counts, input_split_sizes=list(send_counts))
         return out.to(self.device), recv_counts
 
-    def classify(self, d_bases, d_offsets, R, total_bases, thresholds=(0.0,), min_hit_groups=2, fast=True):
-        """d_bases uint8 [total_bases + >=16 pad], d_offsets int64 [R+1] (device tensors). Single-end fragments."""
+    def classify(self, d_bases, d_offsets, R, total_bases, thresholds=(0.0,), min_hit_groups=2, fast=True, d_mate_bases=None,
+                 d_mate_offsets=None, total_mate_bases=0):
+        """d_bases uint8 [total_bases + >=16 pad], d_offsets int64 [R+1] (device tensors); second mates likewise (optional)."""
+        mates = (d_mate_bases, d_mate_offsets, total_mate_bases) if d_mate_bases is not None else None
         if fast:
-            out = self._classify_fast(d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups)
+            out = self._classify_fast(d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups, mates)
             if out is not None:
                 return out
-        return self._classify_staged(d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups)
+        return self._classify_staged(d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups, mates)
 
     def _any_rank(self, flag):
         """logical OR of a host flag over all ranks (every rank must take the same sequence of collectives)"""
@@ -90,26 +92,39 @@ class ShardedClassifier:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return bool(int(t.item()))
 
-    def _classify_fast(self, d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups):
+    def _classify_fast(self, d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups, mates=None):
         import slacken_amd
         torch, dev, W = self.torch, self.device, self.world
         # about 0.26 probes per base on random sequence, spread evenly by the hash over W owners and by the wave index over
-        # SUB sub-lists per owner: 0.6 / (W * SUB) per base leaves 2x headroom
-        SUB = 256
-        cap = int(total_bases * 0.6 / (W * SUB)) + (1 << 12)
-        send_keys = torch.empty(W * SUB * cap, dtype=torch.int64, device=dev)
-        send_slots = torch.empty(W * SUB * cap, dtype=torch.int64, device=dev)
-        counts = torch.zeros(W * SUB, dtype=torch.int64, device=dev)
+        # SUB sub-lists per owner (each fed by at least 64 waves, so that the spread holds): 0.6 / (W * SUB) per base leaves 2x
+        # headroom; a list that overflows all the same makes the engine say so, and the batch is emitted again with twice the room
+        mb, mo, mtotal = mates if mates is not None else (None, None, 0)
+        mkw = dict(d_mate_bases=mb.data_ptr(), d_mate_offsets=mo.data_ptr()) if mates is not None else {}
+        tiles = (R + 63) // 64
+        SUB = 1
+        while SUB < 256 and SUB * 2 * 64 <= tiles:
+            SUB *= 2
+        cap = int((total_bases + mtotal) * 0.6 / (W * SUB)) + (1 << 12)
         defer = torch.empty(max(R, 1), dtype=torch.int32, device=dev)
-        try:
-            self.st.shard_emit_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, W, SUB, send_keys.data_ptr(),
-                                      send_slots.data_ptr(), cap, counts.data_ptr(), defer.data_ptr())
-            self.st.synchronize()
-            unsupported = False
-        except slacken_amd.SlackenError as e:
-            if e.code != -4:   # SLK_E_UNSUPPORTED: this splitter only has the staged route
-                raise
-            unsupported = True
+        unsupported = False
+        while True:
+            send_keys = torch.empty(W * SUB * cap, dtype=torch.int64, device=dev)
+            send_slots = torch.empty(W * SUB * cap, dtype=torch.int64, device=dev)
+            counts = torch.zeros(W * SUB, dtype=torch.int64, device=dev)
+            try:
+                self.st.shard_emit_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, W, SUB, send_keys.data_ptr(),
+                                          send_slots.data_ptr(), cap, counts.data_ptr(), defer.data_ptr(), **mkw)
+                self.st.synchronize()
+                break
+            except slacken_amd.SlackenError as e:
+                if e.code == -5:     # SLK_E_CAPACITY
+                    del send_keys, send_slots
+                    cap *= 2
+                    continue
+                if e.code != -4:     # SLK_E_UNSUPPORTED: this splitter only has the staged route
+                    raise
+                unsupported = True
+                break
         if self._any_rank(unsupported):
             return None
         sub_counts = [int(v) for v in counts.tolist()]          # [owner][sub-list], owner-major: concatenation order
@@ -124,7 +139,7 @@ class ShardedClassifier:
             self.st.lookup_device(recv_keys.data_ptr(), recv_keys.numel(), found.data_ptr())
             self.st.synchronize()
         back, _ = self._all_to_all(found[:recv_keys.numel()].contiguous(), recv_counts)
-        by_slot = torch.empty(total_bases + R + 1, dtype=torch.int32, device=dev)
+        by_slot = torch.empty(total_bases + mtotal + R + 1, dtype=torch.int32, device=dev)
         back = back.contiguous()
         self.st.shard_scatter_device(slots.data_ptr(), back.data_ptr(), back.numel(), by_slot.data_ptr())
         C = len(thresholds)
@@ -137,20 +152,26 @@ class ShardedClassifier:
         self.st.shard_apply_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, by_slot.data_ptr(), out["taxon"].data_ptr(),
                                    out["classified"].data_ptr(), defer.data_ptr(), out["num_distinct"].data_ptr(),
                                    out["total_kmers"].data_ptr(), out["num_hits"].data_ptr(), min_hit_groups=min_hit_groups,
-                                   thresholds=thresholds)
+                                   thresholds=thresholds, **mkw)
         self.st.synchronize()
         # fragments the fused kernel does not take: a compacted batch through the staged route (all ranks, also with none)
         idx = torch.nonzero(defer[:R]).flatten() if R else torch.zeros(0, dtype=torch.int64, device=dev)
         out["deferred"] = int(idx.numel())
         if self._any_rank(idx.numel() > 0):
-            lens = d_offsets[idx + 1] - d_offsets[idx]
-            sub_off = torch.zeros(idx.numel() + 1, dtype=torch.int64, device=dev)
-            sub_off[1:] = torch.cumsum(lens, 0)
-            sub_total = int(sub_off[-1].item()) if idx.numel() else 0
-            src = torch.repeat_interleave(d_offsets[idx], lens) + (torch.arange(sub_total, device=dev) -
-                                                                   torch.repeat_interleave(sub_off[:-1], lens))
-            sub_bases = torch.cat([d_bases[src], torch.zeros(64, dtype=torch.uint8, device=dev)])
-            sub = self._classify_staged(sub_bases, sub_off, int(idx.numel()), sub_total, thresholds, min_hit_groups)
+            def compact(bases, offsets):
+                lens = offsets[idx + 1] - offsets[idx]
+                sub_off = torch.zeros(idx.numel() + 1, dtype=torch.int64, device=dev)
+                sub_off[1:] = torch.cumsum(lens, 0)
+                sub_total = int(sub_off[-1].item()) if idx.numel() else 0
+                src = torch.repeat_interleave(offsets[idx], lens) + (torch.arange(sub_total, device=dev) -
+                                                                     torch.repeat_interleave(sub_off[:-1], lens))
+                return torch.cat([bases[src], torch.zeros(64, dtype=torch.uint8, device=dev)]), sub_off, sub_total
+            sub_bases, sub_off, sub_total = compact(d_bases, d_offsets)
+            sub_mates = None
+            if mates is not None:
+                smb, smo, smt = compact(mb, mo)
+                sub_mates = (smb, smo, smt)
+            sub = self._classify_staged(sub_bases, sub_off, int(idx.numel()), sub_total, thresholds, min_hit_groups, sub_mates)
             n = int(idx.numel())
             if n:
                 for c in range(C):
@@ -161,20 +182,22 @@ class ShardedClassifier:
             out["exchanged_keys"] += sub["exchanged_keys"]
         return out
 
-    def _classify_staged(self, d_bases, d_offsets, R, total_bases, thresholds=(0.0,), min_hit_groups=2):
+    def _classify_staged(self, d_bases, d_offsets, R, total_bases, thresholds=(0.0,), min_hit_groups=2, mates=None):
         torch, dev = self.torch, self.device
-        slots = total_bases + 1
+        mb, mo, mtotal = mates if mates is not None else (None, None, 0)
+        mkw = dict(d_mate_bases=mb.data_ptr(), d_mate_offsets=mo.data_ptr()) if mates is not None else {}
+        slots = total_bases + mtotal + R + 1
         keys = torch.empty(slots, dtype=torch.int64, device=dev)
         meta = torch.empty(slots, dtype=torch.int32, device=dev)
         count = torch.zeros(max(R, 1), dtype=torch.int32, device=dev)
         taxon = torch.zeros(slots, dtype=torch.int32, device=dev)
-        self.st.scan_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, keys.data_ptr(), meta.data_ptr(), count.data_ptr())
+        self.st.scan_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, keys.data_ptr(), meta.data_ptr(), count.data_ptr(), **mkw)
         self.st.synchronize()
         cnt = count[:R].long()
         total = int(cnt.sum().item())
         starts = torch.cumsum(cnt, 0) - cnt
-        slot = torch.repeat_interleave(d_offsets[:R], cnt) + (torch.arange(total, device=dev) -
-                                                              torch.repeat_interleave(starts, cnt))
+        region = d_offsets[:R] if mates is None else d_offsets[:R] + mo[:R] + torch.arange(R, device=dev)  # engine.h span_region
+        slot = torch.repeat_interleave(region, cnt) + (torch.arange(total, device=dev) - torch.repeat_interleave(starts, cnt))
         seq = ((meta[slot] >> 1) & 7) == 1
         seq_slot = slot[seq]
         k = keys[seq_slot]
@@ -202,6 +225,7 @@ class ShardedClassifier:
         self.st.classify_hits_device(d_offsets.data_ptr(), R, meta.data_ptr(), taxon.data_ptr(), count.data_ptr(),
                                      scratch.data_ptr(), out["taxon"].data_ptr(), out["classified"].data_ptr(),
                                      out["num_distinct"].data_ptr(), out["total_kmers"].data_ptr(),
-                                     out["num_hits"].data_ptr(), min_hit_groups=min_hit_groups, thresholds=thresholds)
+                                     out["num_hits"].data_ptr(), min_hit_groups=min_hit_groups, thresholds=thresholds,
+                                     **({"d_mate_offsets": mo.data_ptr()} if mates is not None else {}))
         self.st.synchronize()
         return out

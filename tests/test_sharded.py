@@ -122,3 +122,39 @@ def test_single_rank_fast_route_with_deferrals(orc):
             assert np.array_equal(out[k].cpu().numpy()[:R], want[k]), (k, fast)
         if fast:
             assert out["deferred"] >= 35
+
+
+@pytest.mark.gpu
+def test_single_rank_paired(orc):
+    """paired fragments through both sharded routes: the slot of a probe is offsets[r] + mate_offsets[r] + r + ordinal"""
+    import synth
+    import taxgen
+    rng = np.random.default_rng(44)
+    parents = taxgen.taxonomy(8 * 32, rng)
+    p = orc.params()
+    lib = synth.Library(orc, p, parents, n_genomes=6, genome_len=9000, pad_records=5000)
+    r1 = synth.make_reads(lib, 1200, rng, n_single=0.1)
+    r2 = synth.make_reads(lib, 1200, rng, vary_length=True, short=0.1)
+    r1[7], r2[7] = synth.make_reads(lib, 1, rng, length=900, short=0)[0], synth.make_reads(lib, 1, rng, length=700, short=0)[0]  # > 1000 together
+    ix = slacken_amd.Index(expected_records=len(lib.keys), max_taxon=len(parents) - 1)
+    ix.append(lib.keys, lib.taxa)
+    ix.set_taxonomy(parents)
+    ix.finalize()
+    b1, o1 = synth.pack(r1)
+    b2, o2 = synth.pack(r2)
+    dev = torch.device("cuda", 0)
+    pad = torch.full((64,), 65, dtype=torch.uint8)
+    d = [torch.cat([torch.from_numpy(b1), pad]).to(dev), torch.from_numpy(o1.astype(np.int64)).to(dev),
+         torch.cat([torch.from_numpy(b2), pad]).to(dev), torch.from_numpy(o2.astype(np.int64)).to(dev)]
+    R = len(r1)
+    want = orc.classify_batch(p, orc.Index(1, lib.keys, lib.taxa), parents, b1, o1, b2, o2, thresholds=(0.0, 0.15))
+    sc = sharded.ShardedClassifier(ix, 0, 1, None, dev)
+    for fast in (True, False):
+        out = sc.classify(d[0], d[1], R, int(o1[-1]), thresholds=(0.0, 0.15), fast=fast, d_mate_bases=d[2], d_mate_offsets=d[3],
+                          total_mate_bases=int(o2[-1]))
+        assert np.array_equal(out["taxon"].cpu().numpy().reshape(2, R), want["taxon"]), fast
+        assert np.array_equal(out["classified"].cpu().numpy().reshape(2, R), want["classified"]), fast
+        for k in ("num_distinct", "total_kmers", "num_hits"):
+            assert np.array_equal(out[k].cpu().numpy()[:R], want[k]), (k, fast)
+        if fast:
+            assert out["deferred"] >= 1
