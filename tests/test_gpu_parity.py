@@ -266,3 +266,36 @@ def test_many_taxa_per_read_take_the_deferred_path(orc):
     want = orc.classify_batch(p, world2["oix"], parents, bases, offsets, thresholds=(0.0,))
     assert np.array_equal(outs[0].cpu().numpy(), want["taxon"][0]) and np.array_equal(d_c.cpu().numpy(), want["classified"][0])
     assert np.array_equal(outs[1].cpu().numpy(), want["num_distinct"]) and np.array_equal(outs[3].cpu().numpy(), want["num_hits"])
+
+
+def test_streams_on_threads_share_one_index(orc, world):
+    """The reference calls the path from many task threads with shared read-only state: one finalized index, one
+    stream per thread, concurrent slk_classify_batch calls (ctypes drops the GIL) -- every thread gets the oracle's answers."""
+    import threading
+    rng = np.random.default_rng(77)
+    ix = world["ix"]
+    jobs = []
+    for t in range(6):
+        reads = synth.make_reads(world["lib"], 1500 + 100 * t, rng, vary_length=bool(t % 2))
+        bases, offsets = synth.pack(reads)
+        want = orc.classify_batch(world["p"], world["oix"], world["parents"], bases, offsets, thresholds=(0.0, 0.15))
+        jobs.append((bases, offsets, want))
+    errors = []
+
+    def work(job, with_hits):
+        try:
+            st = ix.stream()
+            for _ in range(5):
+                got = st.classify_batch(job[0], job[1], thresholds=(0.0, 0.15), with_hits=with_hits)
+                for key in ("taxon", "classified", "num_distinct", "total_kmers"):
+                    assert np.array_equal(got[key], job[2][key]), key
+            st.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(job, i % 2 == 0)) for i, job in enumerate(jobs)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
