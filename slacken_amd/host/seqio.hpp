@@ -197,6 +197,80 @@ class RecordStream {
   bool next(std::string_view &header, std::string_view &seq) { return fastq_ ? next_fastq(header, seq) : next_fasta(header, seq); }
 };
 
+// A RecordStream read ahead on its own thread (decompression and line splitting of one file), handed over in chunks of a few
+// thousand records.  Paired input runs two of these side by side; a gzip stream inflates at a few hundred MB/s on one core,
+// so the two files of a pair are best inflated concurrently.  The views stay valid until the next call.
+class AsyncRecordStream {
+  struct Chunk {
+    std::string blob;
+    std::vector<uint32_t> pos;  // 4 per record: header offset, header length, sequence offset, sequence length
+  };
+  std::deque<std::unique_ptr<Chunk>> q_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  bool done_ = false, stop_ = false;
+  std::string error_;
+  std::unique_ptr<Chunk> cur_;
+  size_t cur_i_ = 0;
+  std::thread th_;
+
+  void run(std::string file) {
+    try {
+      RecordStream rs(file);
+      std::string_view h, sq;
+      auto c = std::make_unique<Chunk>();
+      auto flush = [&]() {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return q_.size() < 4 || stop_; });
+        if (stop_) return false;
+        q_.push_back(std::move(c));
+        cv_.notify_all();
+        c = std::make_unique<Chunk>();
+        return true;
+      };
+      while (rs.next(h, sq)) {
+        if (c->blob.size() + h.size() + sq.size() > 0xF0000000u) throw std::runtime_error("record too large: " + file);
+        c->pos.push_back((uint32_t)c->blob.size()); c->pos.push_back((uint32_t)h.size());
+        c->blob.append(h);
+        c->pos.push_back((uint32_t)c->blob.size()); c->pos.push_back((uint32_t)sq.size());
+        c->blob.append(sq);
+        if (c->pos.size() >= 4 * 4096 || c->blob.size() >= ((size_t)4 << 20)) if (!flush()) return;
+      }
+      if (!c->pos.empty()) flush();
+    } catch (const std::exception &e) {
+      std::lock_guard<std::mutex> lk(mu_);
+      error_ = e.what();
+    }
+    std::lock_guard<std::mutex> lk(mu_);
+    done_ = true;
+    cv_.notify_all();
+  }
+
+ public:
+  explicit AsyncRecordStream(const std::string &file) : th_([this, file] { run(file); }) {}
+  ~AsyncRecordStream() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; cv_.notify_all(); }
+    th_.join();
+  }
+  bool next(std::string_view &header, std::string_view &seq) {
+    if (!cur_ || cur_i_ * 4 >= cur_->pos.size()) {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&] { return !q_.empty() || done_; });
+      if (!error_.empty()) throw std::runtime_error(error_);
+      if (q_.empty()) { cur_.reset(); return false; }
+      cur_ = std::move(q_.front());
+      q_.pop_front();
+      cur_i_ = 0;
+      cv_.notify_all();
+    }
+    const uint32_t *p = &cur_->pos[cur_i_ * 4];
+    header = std::string_view(cur_->blob).substr(p[0], p[1]);
+    seq = std::string_view(cur_->blob).substr(p[2], p[3]);
+    cur_i_++;
+    return true;
+  }
+};
+
 inline std::string_view remove_suffix(std::string_view h, const char *suf) {  // header.replaceAll(suffix + "$", "")
   size_t n = strlen(suf);
   return (h.size() >= n && h.compare(h.size() - n, n, suf) == 0) ? h.substr(0, h.size() - n) : h;
@@ -230,15 +304,15 @@ class FragmentSource {
   std::vector<std::string> files_;
   bool paired_;
   size_t next_file_ = 0;
-  std::unique_ptr<RecordStream> s1_, s2_;
+  std::unique_ptr<AsyncRecordStream> s1_, s2_;
   bool joined_ = false;  // the rest of the mate file has been loaded into mates_ (its order differs from the first file's)
   std::unordered_map<std::string, std::string> mates_;
   std::string h1_, seq1_;
 
   bool open_next() {
     if (next_file_ >= files_.size()) return false;
-    s1_ = std::make_unique<RecordStream>(files_[next_file_]);
-    if (paired_) s2_ = std::make_unique<RecordStream>(files_[next_file_ + 1]);
+    s1_ = std::make_unique<AsyncRecordStream>(files_[next_file_]);
+    if (paired_) s2_ = std::make_unique<AsyncRecordStream>(files_[next_file_ + 1]);
     next_file_ += paired_ ? 2 : 1;
     joined_ = false;
     mates_.clear();
