@@ -459,7 +459,9 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
                                  (MODE == LANE_APPLY ? (uint32_t)(np - 1) << 17 : 0u);
         }
         qn += __popcll(E);
-        if (qn >= 64) {
+        // (a loop, not an if: a batch can hand entries back -- bucket overflows re-queued with a larger displacement -- and
+        // the next step may push 64 more; fewer than 64 must be left so that the 128-entry ring cannot overflow)
+        while (qn >= 64) {
           lane_wave_sync();
           int back = 0;
           if (MODE == LANE_EMIT) emit_batch(L, S, A.status, qhead, 64, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1));

@@ -11,7 +11,17 @@ import taxgen
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", range(16))
+import os
+
+N_SEEDS = int(os.environ.get("SLK_FUZZ_SEEDS", 16))   # (a longer soak: SLK_FUZZ_SEEDS=300)
+
+
+# seed 295 (k = m = 13: every k-mer its own window, 64 queue pushes per step) once overflowed the lane kernel's probe ring
+# when a batch handed re-queued entries back; it stays in the default set
+SEEDS = sorted(set(range(N_SEEDS)) | {295})
+
+
+@pytest.mark.parametrize("seed", SEEDS)
 def test_differential(orc, seed):
     import slacken_amd
     rng = np.random.default_rng(9000 + seed)
