@@ -11,6 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 DEFAULT_TOGGLE_MASK = 0xE37E28C4271B5A2D
+E_INVALID, E_UNSUPPORTED, E_HIP, E_NO_GPU, E_CAPACITY, E_STATE = -1, -2, -3, -4, -5, -6   # SLK_E_* of the header
 TAXON_NONE, TAXON_ROOT, TAXON_AMBIGUOUS, TAXON_MATE_PAIR_BORDER = 0, 1, -1, -2
 FLAG_SEQUENCE, FLAG_AMBIGUOUS, FLAG_MATE_PAIR_BORDER = 1, 2, 3
 

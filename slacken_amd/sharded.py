@@ -94,6 +94,7 @@ class ShardedClassifier:
 
     def _classify_fast(self, d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups, mates=None):
         import slacken_amd
+        from slacken_amd import capi
         torch, dev, W = self.torch, self.device, self.world
         # about 0.26 probes per base on random sequence, spread evenly by the hash over W owners and by the wave index over
         # SUB sub-lists per owner (each fed by at least 64 waves, so that the spread holds): 0.6 / (W * SUB) per base leaves 2x
@@ -117,11 +118,11 @@ class ShardedClassifier:
                 self.st.synchronize()
                 break
             except slacken_amd.SlackenError as e:
-                if e.code == -5:     # SLK_E_CAPACITY
+                if e.code == capi.E_CAPACITY:
                     del send_keys, send_slots
                     cap *= 2
                     continue
-                if e.code != -4:     # SLK_E_UNSUPPORTED: this splitter only has the staged route
+                if e.code != capi.E_UNSUPPORTED:   # (unsupported: this splitter only has the staged route)
                     raise
                 unsupported = True
                 break

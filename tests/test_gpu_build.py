@@ -31,7 +31,16 @@ def genomes(rng, parents, n, lo, hi, shared=400):
     return seqs, tx
 
 
-@pytest.mark.parametrize("k,m,spaces", [(35, 31, 7), (31, 12, 0), (35, 31, 0), (40, 32, 4)])
+def _build_param_sets():
+    sets = [(35, 31, 7), (31, 12, 0), (35, 31, 0), (40, 32, 4)]
+    rng = np.random.default_rng(4242)
+    for _ in range(int(__import__("os").environ.get("SLK_FUZZ_SEEDS", 0)) // 4):   # soak: random splitters
+        m = int(rng.integers(8, 33))
+        sets.append((int(rng.integers(m, m + 28)), m, int(rng.integers(0, m // 2 + 1))))
+    return sets
+
+
+@pytest.mark.parametrize("k,m,spaces", _build_param_sets())
 def test_build_matches_oracle(orc, k, m, spaces):
     import slacken_amd
     rng = np.random.default_rng(k * 100 + m)
@@ -134,7 +143,7 @@ def test_append_then_add_sequences_and_errors(orc):
         ix.add_sequences(bases, offsets, [3])
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(max(6, int(__import__("os").environ.get("SLK_FUZZ_SEEDS", 0)) // 4)))
 def test_random_genomes_classify_to_ancestor_or_self(orc, seed):
     """The reference's end-to-end property (T/slacken/ClassifierTest.scala:75-124): ~100 random genomes (1-10 kb) on leaf
     taxa, library built from them (here: on the device), 1000 simulated 200 bp reads, minHitGroups = 1, confidence 0; random

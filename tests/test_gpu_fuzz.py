@@ -76,3 +76,49 @@ def test_differential(orc, seed):
         g = sp[int(off[i]):int(off[i + 1])]
         assert [(int(x["key"]), int(x["kmers"]), int(x["flag"]), bool(x["distinct"])) for x in g] == \
                [((s["key"][0] - (1 << 64)) if s["key"][0] >= (1 << 63) else s["key"][0], s["kmers"], s["flag"], s["distinct"]) for s in ws], (i, ctx)
+
+
+@pytest.mark.parametrize("seed", range(max(6, N_SEEDS // 4)))
+def test_sharded_routes_differential(orc, seed):
+    """The table-sharded pipeline (world = 1: emit -> lookup -> scatter -> apply, with deferrals through the staged route)
+    over random splitters and read shapes, single and paired, against the oracle."""
+    import torch
+    import slacken_amd
+    from slacken_amd import sharded
+    rng = np.random.default_rng(7000 + seed)
+    m = int(rng.integers(8, 33))
+    k = int(rng.integers(m, m + (40 if seed % 5 == 0 else 16)))      # windows wider than 16: staged route only
+    spaces = int(rng.integers(0, m // 2 + 1))
+    p = orc.params(k=k, m=m, spaces=spaces)
+    parents = taxgen.taxonomy(8 * int(rng.integers(4, 64)), rng)
+    lib = synth.Library(orc, p, parents, n_genomes=int(rng.integers(2, 10)), genome_len=int(rng.integers(3000, 9000)),
+                        pad_records=int(rng.integers(0, 3000)), seed=seed)
+    ix = slacken_amd.Index(k=k, m=m, spaces=spaces, expected_records=len(lib.keys), max_taxon=len(parents) - 1)
+    ix.append(lib.keys, lib.taxa)
+    ix.set_taxonomy(parents)
+    ix.finalize()
+    n = int(rng.integers(1, 1200))
+    reads = synth.make_reads(lib, n, rng, length=int(rng.integers(50, 1200)), vary_length=True, n_single=0.1, n_run=0.05, short=0.05)
+    paired = seed % 2 == 1
+    b1, o1 = synth.pack(reads)
+    dev = torch.device("cuda", 0)
+    pad = torch.full((64,), 65, dtype=torch.uint8)
+    kw, mb, mo = {}, None, None
+    if paired:
+        mates = synth.make_reads(lib, n, rng, length=int(rng.integers(40, 500)), vary_length=True, short=0.1)
+        mb, mo = synth.pack(mates)
+        kw = dict(d_mate_bases=torch.cat([torch.from_numpy(mb), pad]).to(dev), d_mate_offsets=torch.from_numpy(mo.astype(np.int64)).to(dev),
+                  total_mate_bases=int(mo[-1]))
+    thr = (0.0, float(rng.choice([0.05, 0.15, 0.5])))
+    mhg = int(rng.integers(1, 4))
+    want = orc.classify_batch(p, orc.Index(1, lib.keys, lib.taxa), parents, b1, o1, mb, mo, min_hit_groups=mhg, thresholds=thr)
+    sc = sharded.ShardedClassifier(ix, 0, 1, None, dev)
+    d_b = torch.cat([torch.from_numpy(b1), pad]).to(dev)
+    d_o = torch.from_numpy(o1.astype(np.int64)).to(dev)
+    for fast in (True, False):
+        out = sc.classify(d_b, d_o, n, int(o1[-1]), thresholds=thr, min_hit_groups=mhg, fast=fast, **kw)
+        ctx = dict(k=k, m=m, spaces=spaces, paired=paired, fast=fast, n=n)
+        assert np.array_equal(out["taxon"].cpu().numpy()[:2 * n].reshape(2, n), want["taxon"]), ctx
+        assert np.array_equal(out["classified"].cpu().numpy()[:2 * n].reshape(2, n), want["classified"]), ctx
+        for key in ("num_distinct", "total_kmers", "num_hits"):
+            assert np.array_equal(out[key].cpu().numpy()[:n], want[key]), (key, ctx)

@@ -159,3 +159,39 @@ def test_parquet_roundtrip(tmp_path):
     # the streaming converter (what the command line runs) writes the same file, whatever the batch size
     assert conv.convert(loc, batch_rows=77) == 1000
     assert open(loc + ".slkrec", "rb").read() == raw
+
+
+@pytest.mark.gpu
+def test_cli_many_reads_cross_slice_and_thread_borders(tmp_path, orc):
+    """70 000 reads: several formatting slices (32 768 reads each) on several threads, gzip members appended in read order;
+    every line equals the oracle's and the order is the input order."""
+    import synth
+    g, loc, tax, _ = make_library(tmp_path, convert=False)
+    lib = np.load(os.path.join(GOLD, "library.npz"))
+    p = orc.params(k=g["k"], m=g["m"], spaces=g["spaces"])
+    oix = orc.Index(1, lib["keys"], lib["taxa"])
+    base_reads = [line.rstrip("\n").split("\t")[1] for line in open(os.path.join(GOLD, "reads.tsv"))][:300]
+    rng = np.random.default_rng(8)
+    n = 70_000
+    pick = rng.integers(0, len(base_reads), n)
+    cut = rng.integers(40, 101, n)
+    fq = tmp_path / "many.fq"
+    with open(fq, "w") as f:
+        for i in range(n):
+            s = base_reads[pick[i]][:cut[i]]
+            f.write(f"@q{i}\n{s}\n+\n{'I' * len(s)}\n")
+    out = tmp_path / "many"
+    classify("-i", loc, "-o", out, "-c", "0.05", fq)
+    lines = read_out(f"{out}_c0.05")
+    cache = {}
+    want = []
+    for i in range(n):
+        key = (int(pick[i]), int(cut[i]))
+        if key not in cache:
+            res, hits = orc.classify_read(p, oix, lib["parents"], base_reads[key[0]][:key[1]], None, 2, 0.05)
+            cache[key] = (res, hits)
+        res, hits = cache[key]
+        if hits:
+            want.append(orc.output_line(res["classified"], f"q{i}", res["taxon"], hits, g["k"]))
+    assert len(lines) == len(want)
+    assert lines == want
