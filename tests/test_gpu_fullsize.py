@@ -1,5 +1,5 @@
-"""Size-independent properties of the classify path at sizes the CPU oracle cannot reach (default: 2^30-record table,
-2M x 150 bp reads; SLK_FULLSIZE=1: BASELINE.json's 1e10 records / 1e7 reads).  Integer work => exact equality everywhere.
+"""Size-independent properties of the classify path at BASELINE.json's full sizes, which the CPU oracle cannot reach: a
+1.0e10-record table (128 GiB) and 1.0e7 x 150 bp reads (SLK_FULLSIZE=0: a 2^30-record table and 2M reads).  Integer work => exact equality everywhere.
   * determinism and batch-split invariance
   * reverse-complement invariance (canonical minimizers: MinSplitterProps.scala:101-114 lifted to the whole path)
   * the two independently written kernels (lane-per-read hot path, wave-per-read path) agree read for read
@@ -17,7 +17,7 @@ def big():
     import torch
     import bench
     import slacken_amd
-    full = os.environ.get("SLK_FULLSIZE") == "1"
+    full = os.environ.get("SLK_FULLSIZE", "1") == "1"
     n_records, n_reads = (int(1e10), int(1e7)) if full else (1 << 30, 2_000_000)
     dev = torch.device("cuda", 0)
     parents, taxa, leaves = bench.build_taxonomy()
