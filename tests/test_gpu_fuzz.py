@@ -35,9 +35,14 @@ def test_differential(orc, seed):
     parents = taxgen.taxonomy(8 * int(rng.integers(4, 64)), rng)
     lib = synth.Library(orc, p, parents, n_genomes=int(rng.integers(2, 12)), genome_len=int(rng.integers(3000, 12000)),
                         pad_records=int(rng.integers(0, 3000)), seed=seed)
-    ix = slacken_amd.Index(k=k, m=m, spaces=spaces, xor_mask=xor_mask, canonical=canonical,
-                           expected_records=len(lib.keys), max_taxon=len(parents) - 1)
-    ix.append(lib.keys, lib.taxa)
+    for lf in (float(rng.choice([0.0, 0.3, 0.9, 0.95])), 0.0):   # dense tables: long displacement chains
+        ix = slacken_amd.Index(k=k, m=m, spaces=spaces, xor_mask=xor_mask, canonical=canonical,
+                               expected_records=len(lib.keys), max_taxon=len(parents) - 1, load_factor=lf)
+        try:
+            ix.append(lib.keys, lib.taxa)
+            break
+        except slacken_amd.SlackenError as e:    # a table this dense may refuse records -- loudly; then use the default
+            assert e.code == slacken_amd.capi.E_CAPACITY and lf >= 0.9
     ix.set_taxonomy(parents)
     ix.finalize()
     st = ix.stream()
