@@ -158,11 +158,15 @@ class OutputSink {
   std::map<Key, FILE *> files_;
   std::map<Key, std::map<Taxon, long>> counts_;
 
-  std::string sample_of(std::string_view title) const {  // Classifier.scala:138-142
+  // Per-read output: group 1 of the first match, else "other" (Classifier.classifyHits, Classifier.scala:138-142).
+  // Reports only (--nodetailed): the reference takes the SQL route, ifnull(regexp_extract(title, re, 1), "other")
+  // (SQLClassifier, Classifier.scala:297-300) -- and regexp_extract yields "" rather than null without a match, so there the
+  // unmatched titles form the sample "" (report file "_kreport.txt").  Mirrored as is.
+  std::string sample_of(std::string_view title) const {
     if (o_.sample_regex.empty()) return "all";
     std::cmatch m;
     if (std::regex_search(title.data(), title.data() + title.size(), m, re_) && m.size() > 1) return m[1].str();
-    return "other";
+    return o_.detailed ? "other" : "";
   }
 
   SliceOut do_slice(std::shared_ptr<const ClassifiedBatch> b, size_t i0, size_t i1) const {
