@@ -19,7 +19,9 @@
  *     slk_stream (call slk_stream_synchronize before reading results);
  *   - an slk_index is immutable after slk_index_finalize() and may be shared by many threads; an slk_stream holds
  *     one HIP stream plus the scratch of ONE in-flight batch: use one per calling thread.
- *   - minimizers wider than 32 nt (id_longs > 1) are not supported by this engine: slk_index_create fails loudly.
+ *   - minimizers of up to 128 nt (id_longs = ceil(m/32) <= 4 key words per record, row-major) are supported by
+ *     slk_index_create / append / lookup and the classify entry points; the spans, staged, sharded and library-construction
+ *     entry points take one-word keys (m <= 32) and return SLK_E_UNSUPPORTED otherwise.
  */
 #ifndef SLACKEN_AMD_H
 #define SLACKEN_AMD_H
@@ -62,7 +64,7 @@ typedef struct {
   int32_t spaces;
   int32_t canonical;
   uint64_t xor_mask;
-  int32_t id_longs; /* ceil(m/32), S/slacken/KeyValueIndex.scala:49; must be 1 */
+  int32_t id_longs; /* ceil(m/32) <= 4, S/slacken/KeyValueIndex.scala:49: key words per record */
   int32_t reserved;
 } slk_params;
 

@@ -144,6 +144,7 @@ class Index:
     def __init__(self, k=35, m=31, spaces=7, xor_mask=DEFAULT_TOGGLE_MASK, canonical=True, expected_records=1 << 20,
                  max_taxon=0, load_factor=0.0, device=0):
         self.k, self.m, self.spaces = k, m, spaces
+        self.W = (m + 31) // 32   # id columns: keys are rows of W int64 words
         p = _Params(k, m, spaces, int(bool(canonical)), C.c_uint64(xor_mask & (2**64 - 1)), (m + 31) // 32, 0)
         cfg = _TableConfig(int(expected_records), int(max_taxon), float(load_factor))
         h = C.c_void_p()
@@ -152,8 +153,8 @@ class Index:
 
     def append(self, keys, taxa):
         keys, taxa = _np(keys, np.int64), _np(taxa, np.int32)
-        assert keys.shape == taxa.shape
-        _check(lib().slk_index_append(self.h, _ptr(keys), _ptr(taxa), keys.size))
+        assert keys.size == taxa.size * self.W
+        _check(lib().slk_index_append(self.h, _ptr(keys), _ptr(taxa), taxa.size))
 
     def append_device(self, d_keys_ptr, d_taxa_ptr, n):
         _check(lib().slk_index_append_device(self.h, d_keys_ptr, d_taxa_ptr, n))
@@ -188,8 +189,8 @@ class Index:
 
     def lookup(self, keys):
         keys = _np(keys, np.int64)
-        out = np.zeros(keys.size, np.int32)
-        _check(lib().slk_index_lookup(self.h, _ptr(keys), keys.size, _ptr(out)))
+        out = np.zeros(keys.size // self.W, np.int32)
+        _check(lib().slk_index_lookup(self.h, _ptr(keys), out.size, _ptr(out)))
         return out
 
     def stream(self):

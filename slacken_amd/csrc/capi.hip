@@ -70,6 +70,9 @@ struct slk_index {
   uint64_t records = 0, dups = 0;
   hipStream_t build_stream = nullptr;
   DevBuf stage_keys, stage_taxa;
+  int W = 1;          // id columns; > 1: the wide path (wide.hip) with its own table
+  WideParams wp{};
+  WideTable wt{};
 
   TableView view() const {
     TableView v;
@@ -141,10 +144,12 @@ int32_t slk_index_create(const slk_params *p, const slk_table_config *cfg, int32
   *out = nullptr;
   if (p->m < 1 || p->k < p->m || p->spaces < 0 || p->spaces > p->m / 2)
     return fail(SLK_E_INVALID, "invalid splitter parameters k=%d m=%d spaces=%d", p->k, p->m, p->spaces);
-  if (p->m > 32 || p->id_longs != 1)
-    return fail(SLK_E_UNSUPPORTED, "minimizer width m=%d (id_longs=%d): this engine supports m <= 32 (one id column)",
-                p->m, p->id_longs);
+  const int W = (p->m + 31) / 32;
+  if (W > WIDE_MAXW) return fail(SLK_E_UNSUPPORTED, "minimizer width m=%d: at most %d nt (%d id columns)", p->m, 32 * WIDE_MAXW, WIDE_MAXW);
+  if (p->id_longs != W) return fail(SLK_E_INVALID, "id_longs=%d but m=%d needs %d id columns", p->id_longs, p->m, W);
   if (p->k - p->m + 1 > 512) return fail(SLK_E_UNSUPPORTED, "k - m + 1 = %d > 512 m-mers per window", p->k - p->m + 1);
+  if (W > 1 && (p->k - p->m + 1) * W > 128)
+    return fail(SLK_E_UNSUPPORTED, "k - m + 1 = %d m-mers per window with %d id columns: at most %d", p->k - p->m + 1, W, 128 / W);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(SLK_E_NO_GPU, "no HIP device available; this engine has no CPU fallback");
@@ -161,7 +166,7 @@ int32_t slk_index_create(const slk_params *p, const slk_table_config *cfg, int32
   ix->params = *p;
   ScanParams &sp = ix->sp;
   sp.k = p->k; sp.m = p->m; sp.w = p->k - p->m + 1; sp.canonical = p->canonical ? 1 : 0;
-  sp.sh = (32 - p->m) * 2;
+  sp.sh = W == 1 ? (32 - p->m) * 2 : 0;   // (the one-word fields are unused with several id columns)
   sp.keep = (sp.sh == 0) ? ~0ULL : (~0ULL << sp.sh);
   // RandomXOR.mask (MinimizerPriorities.scala:146-160): one word; partial word => xorMask << (64 - (m%32)*2)
   sp.xmask = (p->m % 32 != 0) ? (p->xor_mask << (64 - (p->m % 32) * 2)) : p->xor_mask;
@@ -171,6 +176,44 @@ int32_t slk_index_create(const slk_params *p, const slk_table_config *cfg, int32
   for (int i = 0; i < p->spaces; i++) sm = (sm << 4) | finalBits;
   sp.smask = sm;
 
+  if (W > 1) {
+    // several id columns: the staged kernels of wide.hip over an open-addressing table of (W key words, taxon) slots
+    ix->W = W;
+    WideParams &wp = ix->wp;
+    wp.k = p->k; wp.m = p->m; wp.w = p->k - p->m + 1; wp.canonical = p->canonical ? 1 : 0; wp.W = W;
+    wp.last_sh = ((32 - p->m % 32) % 32) * 2;
+    for (int i = 0; i < W; i++) {   // RandomXOR.mask :146-160; NTBitArray.fill(-1, m) for the space mask
+      wp.xmask[i] = (i == W - 1 && p->m % 32 != 0) ? (p->xor_mask << (64 - (p->m % 32) * 2)) : p->xor_mask;
+      wp.smask[i] = ~0ULL;
+    }
+    if (wp.last_sh) wp.smask[W - 1] = ~0ULL << wp.last_sh;
+    const uint64_t fb = 3ULL << ((64 - (p->m % 32) * 2) & 63);
+    for (int s = 0; s < p->spaces; s++) {   // SpacedSeed.spaceMask :285-300: s times { <<= 4 over all words ; |= finalBits }
+      for (int i = 0; i < W; i++) wp.smask[i] = (wp.smask[i] << 4) | (i + 1 < W ? wp.smask[i + 1] >> 60 : 0);
+      wp.smask[W - 1] |= fb;
+    }
+    uint64_t cap = 1ULL << ceil_log2_u64(std::max<uint64_t>(cfg->expected_records, 8) * 2);
+    ix->wt.mask = cap - 1;
+    ix->taxon_bits = 31;
+    hipError_t e1 = hipMalloc((void **)&ix->wt.keys, cap * W * 8);
+    hipError_t e2 = e1 == hipSuccess ? hipMalloc((void **)&ix->wt.taxa, cap * 4) : e1;
+    if (e2 != hipSuccess) {
+      (void)hipGetLastError();
+      if (ix->wt.keys) (void)hipFree(ix->wt.keys);
+      delete ix;
+      return fail(SLK_E_HIP, "hipMalloc of the %llu-slot table failed: %s", (unsigned long long)cap, hipGetErrorString(e2));
+    }
+    HIPCHK(hipStreamCreate(&ix->build_stream));
+    HIPCHK(hipMemsetAsync(ix->wt.taxa, 0, cap * 4, ix->build_stream));
+    HIPCHK(hipMalloc((void **)&ix->d_max_disp, sizeof(int32_t)));
+    HIPCHK(hipMalloc((void **)&ix->d_counters, 3 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(ix->d_max_disp, 0, sizeof(int32_t), ix->build_stream));
+    HIPCHK(hipMemsetAsync(ix->d_counters, 0, 3 * sizeof(unsigned long long), ix->build_stream));
+    HIPCHK(hipStreamSynchronize(ix->build_stream));
+    ix->nbuckets = cap;
+    *out = ix;
+    return SLK_OK;
+  }
   int32_t max_taxon = cfg->max_taxon > 0 ? cfg->max_taxon : ((1 << 22) - 1);
   int tb = 1;
   while (tb < 31 && (1LL << tb) <= (long long)max_taxon) tb++;
@@ -209,6 +252,7 @@ static int32_t read_build_counters(slk_index *ix) {
   ix->records = c[0];
   ix->dups = c[1];
   ix->max_disp = md;
+  if (c[2] != 0 && ix->W > 1) return fail(SLK_E_CAPACITY, "%llu records found no free slot: raise expected_records", c[2]);
   if (c[2] != 0)
     return fail(SLK_E_CAPACITY,
                 "%llu records could not be placed within %d buckets of their home bucket: raise expected_records "
@@ -237,7 +281,8 @@ int32_t slk_index_append_device(slk_index *ix, const int64_t *d_keys, const int3
   if (ix->finalized) return fail(SLK_E_STATE, "index is finalized");
   int32_t rc = set_device(ix);
   if (rc) return rc;
-  launch_table_insert(build_view(ix), d_keys, d_taxa, n, ix->build_stream);
+  if (ix->W > 1) launch_wide_insert(ix->wt, ix->W, d_keys, d_taxa, n, ix->d_counters, ix->build_stream);
+  else launch_table_insert(build_view(ix), d_keys, d_taxa, n, ix->build_stream);
   HIPCHK(hipGetLastError());
   return read_build_counters(ix);
 }
@@ -248,6 +293,22 @@ int32_t slk_index_append(slk_index *ix, const int64_t *keys, const int32_t *taxa
   int32_t rc = set_device(ix);
   if (rc) return rc;
   const uint64_t CH = 1ULL << 24;
+  if (ix->W > 1) {  // keys: n rows of W words (id1..idW)
+    const int W = ix->W;
+    for (uint64_t o = 0; o < n; o += CH) {
+      uint64_t c = std::min(CH, n - o);
+      for (uint64_t i = 0; i < c; i++)
+        if (taxa[o + i] < 0) return fail(SLK_E_INVALID, "record %llu: negative taxon %d", (unsigned long long)(o + i), taxa[o + i]);
+      HIPCHK(ix->stage_keys.ensure(c * 8 * W));
+      HIPCHK(ix->stage_taxa.ensure(c * 4));
+      HIPCHK(hipMemcpyAsync(ix->stage_keys.p, keys + o * W, c * 8 * W, hipMemcpyHostToDevice, ix->build_stream));
+      HIPCHK(hipMemcpyAsync(ix->stage_taxa.p, taxa + o, c * 4, hipMemcpyHostToDevice, ix->build_stream));
+      launch_wide_insert(ix->wt, W, ix->stage_keys.as<int64_t>(), ix->stage_taxa.as<int32_t>(), c, ix->d_counters, ix->build_stream);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(ix->build_stream));
+    }
+    return read_build_counters(ix);
+  }
   for (uint64_t o = 0; o < n; o += CH) {
     uint64_t c = std::min(CH, n - o);
     HIPCHK(ix->stage_keys.ensure(c * 8));
@@ -299,6 +360,7 @@ int32_t slk_index_add_sequences(slk_index *ix, const uint8_t *bases, const uint6
                                 uint64_t S) {
   if (!ix || (S && (!bases || !offsets || !taxa))) return fail(SLK_E_INVALID, "null argument");
   if (ix->finalized) return fail(SLK_E_STATE, "index is finalized");
+  if (ix->W > 1) return fail(SLK_E_UNSUPPORTED, "library construction supports minimizers of up to 32 nt (one id column)");
   if (!ix->d_parents) return fail(SLK_E_STATE, "slk_index_add_sequences needs the taxonomy (LCA merging): call slk_index_set_taxonomy first");
   if (ix->sp.w > BUILD_MAX_W) return fail(SLK_E_UNSUPPORTED, "library construction supports windows of up to %d m-mers (k - m + 1 = %d)", BUILD_MAX_W, ix->sp.w);
   int32_t rc = set_device(ix);
@@ -357,6 +419,7 @@ int32_t slk_index_add_sequences(slk_index *ix, const uint8_t *bases, const uint6
 
 int32_t slk_index_export(const slk_index *ix, int64_t *keys, int32_t *taxa, uint64_t capacity, uint64_t *n_records) {
   if (!ix || !n_records || (capacity && (!keys || !taxa))) return fail(SLK_E_INVALID, "null argument");
+  if (ix->W > 1) return fail(SLK_E_UNSUPPORTED, "slk_index_export supports minimizers of up to 32 nt (one id column)");
   (void)hipSetDevice(ix->device);
   DevBuf dk, dt, dc;
   HIPCHK(dk.ensure(std::max<uint64_t>(capacity, 1) * 8));
@@ -397,7 +460,7 @@ int32_t slk_index_get_info(const slk_index *ix, slk_index_info *out) {
   memset(out, 0, sizeof(*out));
   out->records = ix->records;
   out->buckets = ix->nbuckets;
-  out->table_bytes = ix->nbuckets * 64;
+  out->table_bytes = ix->W > 1 ? ix->nbuckets * (8 * ix->W + 4) : ix->nbuckets * 64;
   out->bucket_bits = ix->bucket_bits;
   out->taxon_bits = ix->taxon_bits;
   out->disp_bits = ix->disp_bits;
@@ -415,10 +478,11 @@ int32_t slk_index_lookup(const slk_index *ix, const int64_t *keys, uint64_t n, i
   if (rc) return rc;
   if (n == 0) return SLK_OK;
   DevBuf k, o;
-  HIPCHK(k.ensure(n * 8));
+  HIPCHK(k.ensure(n * 8 * ix->W));
   HIPCHK(o.ensure(n * 4));
-  HIPCHK(hipMemcpy(k.p, keys, n * 8, hipMemcpyHostToDevice));
-  launch_table_lookup(ix->view(), k.as<int64_t>(), n, o.as<int32_t>(), nullptr);
+  HIPCHK(hipMemcpy(k.p, keys, n * 8 * ix->W, hipMemcpyHostToDevice));
+  if (ix->W > 1) launch_wide_lookup(ix->wt, ix->W, k.as<int64_t>(), n, o.as<int32_t>(), nullptr);
+  else launch_table_lookup(ix->view(), k.as<int64_t>(), n, o.as<int32_t>(), nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(out_taxa, o.p, n * 4, hipMemcpyDeviceToHost));
   k.release();
@@ -430,6 +494,8 @@ void slk_index_destroy(slk_index *ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
   if (ix->cells) (void)hipFree(ix->cells);
+  if (ix->wt.keys) (void)hipFree(ix->wt.keys);
+  if (ix->wt.taxa) (void)hipFree(ix->wt.taxa);
   if (ix->d_max_disp) (void)hipFree(ix->d_max_disp);
   if (ix->d_counters) (void)hipFree(ix->d_counters);
   if (ix->d_parents) (void)hipFree(ix->d_parents);
@@ -491,7 +557,7 @@ static uint64_t span_slots(uint64_t total_bases, uint64_t total_mate_bases, uint
 }
 
 static int32_t ensure_scratch(slk_stream *st, uint64_t slots, uint64_t R) {
-  HIPCHK(st->span_keys.ensure(slots * 8));
+  HIPCHK(st->span_keys.ensure(slots * 8 * st->ix->W));
   HIPCHK(st->span_meta.ensure(slots * 4));
   HIPCHK(st->span_taxon.ensure(slots * 4));
   HIPCHK(st->span_count.ensure((R + 1) * 4));
@@ -510,7 +576,7 @@ static int32_t check_ready(const slk_index *ix, const slk_stream *st, bool need_
 // A/B switch for tests) run the three separate lane-per-read kernels of kernels.hip.  Both are HIP: no CPU path.
 static bool use_fused(const slk_index *ix) {
   static const bool force_v1 = getenv("SLK_FORCE_V1") != nullptr && getenv("SLK_FORCE_V1")[0] == '1';
-  return !force_v1 && ix->sp.w <= 32;
+  return !force_v1 && ix->W == 1 && ix->sp.w <= 32;
 }
 
 static bool force_wave() {  // SLK_FORCE_WAVE=1: A/B switch, classify with the wave-per-read kernel only
@@ -607,11 +673,19 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
     HIPCHK(hipEventRecord(st->ev[1], st->s));
     HIPCHK(hipEventRecord(st->ev[2], st->s));
   } else {
-    launch_scan(ix->sp, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, st->span_keys.as<uint64_t>(),
-                st->span_meta.as<int32_t>(), st->span_count.as<int32_t>(), st->s);
-    HIPCHK(hipEventRecord(st->ev[1], st->s));
-    launch_probe(ix->view(), d_offsets, d_mate_offsets, R, st->span_keys.as<uint64_t>(), st->span_meta.as<int32_t>(),
-                 st->span_count.as<int32_t>(), st->span_taxon.as<int32_t>(), st->s);
+    if (ix->W > 1) {
+      launch_wide_scan(ix->wp, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, st->span_keys.as<uint64_t>(),
+                       st->span_meta.as<int32_t>(), st->span_count.as<int32_t>(), st->s);
+      HIPCHK(hipEventRecord(st->ev[1], st->s));
+      launch_wide_probe(ix->wt, ix->W, d_offsets, d_mate_offsets, R, st->span_keys.as<uint64_t>(), st->span_meta.as<int32_t>(),
+                        st->span_count.as<int32_t>(), st->span_taxon.as<int32_t>(), st->s);
+    } else {
+      launch_scan(ix->sp, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, st->span_keys.as<uint64_t>(),
+                  st->span_meta.as<int32_t>(), st->span_count.as<int32_t>(), st->s);
+      HIPCHK(hipEventRecord(st->ev[1], st->s));
+      launch_probe(ix->view(), d_offsets, d_mate_offsets, R, st->span_keys.as<uint64_t>(), st->span_meta.as<int32_t>(),
+                   st->span_count.as<int32_t>(), st->span_taxon.as<int32_t>(), st->s);
+    }
     HIPCHK(hipEventRecord(st->ev[2], st->s));
     // the key slots are dead after the probe: the per-read taxon->count map reuses them
     launch_classify(ix->d_parents, ix->T, d_offsets, d_mate_offsets, R, st->span_meta.as<int32_t>(),
@@ -651,6 +725,7 @@ int32_t slk_scan_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, c
                         uint64_t *d_span_keys, int32_t *d_span_meta, int32_t *d_span_count) {
   int32_t rc = check_ready(ix, st, false);
   if (rc) return rc;
+  if (ix->W > 1) return fail(SLK_E_UNSUPPORTED, "the staged and sharded entry points support minimizers of up to 32 nt (one id column)");
   if (R && (!d_bases || !d_offsets || !d_span_keys || !d_span_meta || !d_span_count)) return fail(SLK_E_INVALID, "null argument");
   if ((d_mate_bases == nullptr) != (d_mate_offsets == nullptr))
     return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
@@ -671,6 +746,7 @@ int32_t slk_scan_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, c
 int32_t slk_lookup_device(slk_index *ix, slk_stream *st, const int64_t *d_keys, uint64_t n, int32_t *d_out_taxa) {
   int32_t rc = check_ready(ix, st, false);
   if (rc) return rc;
+  if (ix->W > 1) return fail(SLK_E_UNSUPPORTED, "the staged and sharded entry points support minimizers of up to 32 nt (one id column)");
   if (n && (!d_keys || !d_out_taxa)) return fail(SLK_E_INVALID, "null argument");
   rc = set_device(ix);
   if (rc) return rc;
@@ -766,6 +842,7 @@ int32_t slk_classify_hits_device(slk_index *ix, slk_stream *st, const uint64_t *
                                  int32_t *d_out_num_hits) {
   int32_t rc = check_ready(ix, st, true);
   if (rc) return rc;
+  if (ix->W > 1) return fail(SLK_E_UNSUPPORTED, "the staged and sharded entry points support minimizers of up to 32 nt (one id column)");
   if (C < 1 || C > MAX_THRESHOLDS || !thresholds) return fail(SLK_E_INVALID, "need 1..%d thresholds", MAX_THRESHOLDS);
   if (R && (!d_offsets || !d_span_meta || !d_span_taxon || !d_span_count || !d_scratch || !d_out_taxon || !d_out_classified))
     return fail(SLK_E_INVALID, "null argument");
@@ -836,6 +913,7 @@ int32_t slk_spans_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, con
                         uint64_t *out_span_offsets, slk_span *out_spans, uint64_t spans_capacity) {
   int32_t rc = check_ready(ix, st, false);
   if (rc) return rc;
+  if (ix->W > 1) return fail(SLK_E_UNSUPPORTED, "slk_spans_batch returns one key word per span: minimizers of up to 32 nt (one id column)");
   if (!offsets || !out_span_offsets || (R && !bases)) return fail(SLK_E_INVALID, "null argument");
   if ((mate_bases == nullptr) != (mate_offsets == nullptr))
     return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");

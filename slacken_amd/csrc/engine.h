@@ -15,6 +15,31 @@ struct ScanParams {
   uint64_t keep;      // ~0 << sh: the 2m bits an m-mer occupies
 };
 
+// Minimizers wider than 32 nt (2..4 id columns, KeyValueIndex.scala:49; NTBitArray with several longs): wide.hip
+constexpr int WIDE_MAXW = 4;
+struct WideParams {
+  int32_t k, m, w, canonical;
+  int32_t W;                     // 64-bit words per m-mer = ceil(m / 32)
+  int32_t last_sh;               // (32 - m % 32) % 32 * 2: unused low bits of the last word
+  uint64_t xmask[WIDE_MAXW];     // RandomXOR.mask (MinimizerPriorities.scala:146-160)
+  uint64_t smask[WIDE_MAXW];     // SpacedSeed.spaceMask (:285-300)
+};
+// Records with W-word keys: open addressing, linear probing by slot; a slot is taken when its taxon is non-zero.
+struct WideTable {
+  uint64_t *keys;   // [capacity][W]
+  int32_t *taxa;    // [capacity]
+  uint64_t mask;    // capacity - 1 (capacity is a power of two, load <= 0.5)
+};
+void launch_wide_insert(const WideTable &t, int W, const int64_t *keys, const int32_t *taxa, uint64_t n, unsigned long long *counters,
+                        hipStream_t s);
+void launch_wide_lookup(const WideTable &t, int W, const int64_t *keys, uint64_t n, int32_t *out, hipStream_t s);
+void launch_wide_scan(const WideParams &P, const uint8_t *bases, const uint64_t *offsets, const uint8_t *mate_bases,
+                      const uint64_t *mate_offsets, uint64_t R, uint64_t *span_keys, int32_t *span_meta, int32_t *span_count,
+                      hipStream_t s);
+void launch_wide_probe(const WideTable &t, int W, const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R,
+                       const uint64_t *span_keys, const int32_t *span_meta, const int32_t *span_count, int32_t *span_taxon,
+                       hipStream_t s);
+
 // HBM-resident record table: 64-byte buckets of eight 8-byte cells, bucket-level linear probing.
 //   h      = fmix64(key)                       (bijective, so (home bucket, remainder) identifies the key: lossless)
 //   home   = h >> (64 - bucket_bits)

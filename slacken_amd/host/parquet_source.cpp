@@ -26,16 +26,19 @@ static std::vector<std::string> parquet_files(const std::string &dir) {
 
 bool parquet_available() { return true; }
 
-static void check_schema(const parquet::SchemaDescriptor *schema, const std::string &file, int *c_id, int *c_tax) {
-  if (schema->ColumnIndex("id2") >= 0) throw std::runtime_error(file + ": several id columns; this engine supports minimizers up to 32 nt (one column)");
-  *c_id = schema->ColumnIndex("id1");
+static void check_schema(const parquet::SchemaDescriptor *schema, const std::string &file, int W, int *c_id, int *c_tax) {
+  if (schema->ColumnIndex("id" + std::to_string(W + 1)) >= 0)
+    throw std::runtime_error(file + ": more id columns than the index parameters imply (" + std::to_string(W) + ")");
+  for (int i = 0; i < W; i++) {
+    c_id[i] = schema->ColumnIndex("id" + std::to_string(i + 1));
+    if (c_id[i] < 0) throw std::runtime_error(file + ": expected columns id1..id" + std::to_string(W) + " and taxon");
+    if (schema->Column(c_id[i])->physical_type() != parquet::Type::INT64) throw std::runtime_error(file + ": id columns must be int64");
+  }
   *c_tax = schema->ColumnIndex("taxon");
-  if (*c_id < 0 || *c_tax < 0) throw std::runtime_error(file + ": expected columns id1 and taxon");
-  if (schema->Column(*c_id)->physical_type() != parquet::Type::INT64 || schema->Column(*c_tax)->physical_type() != parquet::Type::INT32)
-    throw std::runtime_error(file + ": expected id1: int64 and taxon: int32");
+  if (*c_tax < 0 || schema->Column(*c_tax)->physical_type() != parquet::Type::INT32) throw std::runtime_error(file + ": expected taxon: int32");
 }
 
-uint64_t parquet_count_rows(const std::string &dir, int64_t *max_taxon) {
+uint64_t parquet_count_rows(const std::string &dir, int W, int64_t *max_taxon) {
   uint64_t n = 0;
   int64_t mt = 0;
   bool have_stats = true;
@@ -44,8 +47,8 @@ uint64_t parquet_count_rows(const std::string &dir, int64_t *max_taxon) {
   for (auto &f : files) {
     auto reader = parquet::ParquetFileReader::OpenFile(f, false);
     auto md = reader->metadata();
-    int c_id, c_tax;
-    check_schema(md->schema(), f, &c_id, &c_tax);
+    int c_id[4], c_tax;
+    check_schema(md->schema(), f, W, c_id, &c_tax);
     n += (uint64_t)md->num_rows();
     for (int g = 0; g < md->num_row_groups(); g++) {
       auto cc = md->RowGroup(g)->ColumnChunk(c_tax);
@@ -66,29 +69,34 @@ static int64_t read_values(Reader *r, int64_t want, std::vector<int16_t> &def, T
   return values;
 }
 
-void parquet_for_each_batch(const std::string &dir, const std::function<void(const int64_t *, const int32_t *, uint64_t)> &fn) {
+void parquet_for_each_batch(const std::string &dir, int W, const std::function<void(const int64_t *, const int32_t *, uint64_t)> &fn) {
   const int64_t B = 1 << 22;
-  std::vector<int64_t> keys((size_t)B);
+  std::vector<int64_t> col((size_t)B), keys((size_t)B * W);
   std::vector<int32_t> taxa((size_t)B);
   std::vector<int16_t> def((size_t)B);
   for (auto &f : parquet_files(dir)) {
     auto reader = parquet::ParquetFileReader::OpenFile(f, false);
     auto md = reader->metadata();
-    int c_id, c_tax;
-    check_schema(md->schema(), f, &c_id, &c_tax);
+    int c_id[4], c_tax;
+    check_schema(md->schema(), f, W, c_id, &c_tax);
     for (int g = 0; g < md->num_row_groups(); g++) {
       auto rg = reader->RowGroup(g);
-      auto col_id = rg->Column(c_id);
+      std::shared_ptr<parquet::ColumnReader> cols[4];
+      for (int i = 0; i < W; i++) cols[i] = rg->Column(c_id[i]);
       auto col_tax = rg->Column(c_tax);
-      auto *rid = static_cast<parquet::Int64Reader *>(col_id.get());
       auto *rtx = static_cast<parquet::Int32Reader *>(col_tax.get());
-      while (rid->HasNext()) {
-        int64_t nk = 0;
-        while (nk < B && rid->HasNext()) nk += read_values(rid, B - nk, def, keys.data() + nk);
+      while (rtx->HasNext()) {
         int64_t nt = 0;
-        while (nt < nk && rtx->HasNext()) nt += read_values(rtx, nk - nt, def, taxa.data() + nt);
-        if (nt != nk) throw std::runtime_error(f + ": id1 and taxon columns differ in length");
-        fn(keys.data(), taxa.data(), (uint64_t)nk);
+        while (nt < B && rtx->HasNext()) nt += read_values(rtx, B - nt, def, taxa.data() + nt);
+        for (int i = 0; i < W; i++) {
+          auto *rid = static_cast<parquet::Int64Reader *>(cols[i].get());
+          int64_t nk = 0;
+          int64_t *dst = W == 1 ? keys.data() : col.data();
+          while (nk < nt && rid->HasNext()) nk += read_values(rid, nt - nk, def, dst + nk);
+          if (nk != nt) throw std::runtime_error(f + ": id and taxon columns differ in length");
+          if (W > 1) for (int64_t r = 0; r < nt; r++) keys[(size_t)r * W + i] = col[(size_t)r];
+        }
+        fn(keys.data(), taxa.data(), (uint64_t)nt);
       }
     }
   }
@@ -100,8 +108,8 @@ void parquet_for_each_batch(const std::string &dir, const std::function<void(con
 
 namespace slk_host {
 bool parquet_available() { return false; }
-uint64_t parquet_count_rows(const std::string &, int64_t *) { throw std::runtime_error("built without Parquet support"); }
-void parquet_for_each_batch(const std::string &, const std::function<void(const int64_t *, const int32_t *, uint64_t)> &) {
+uint64_t parquet_count_rows(const std::string &, int, int64_t *) { throw std::runtime_error("built without Parquet support"); }
+void parquet_for_each_batch(const std::string &, int, const std::function<void(const int64_t *, const int32_t *, uint64_t)> &) {
   throw std::runtime_error("built without Parquet support");
 }
 }  // namespace slk_host

@@ -12,9 +12,11 @@ namespace slk_host {
 
 bool parquet_available();
 // Row count of all *.parquet files under dir (footers only) and the largest taxon according to the column statistics
-// (-1 if some file carries none).  Throws std::runtime_error on unreadable files or an unsupported schema.
-uint64_t parquet_count_rows(const std::string &dir, int64_t *max_taxon);
-// Streams the records in batches.
-void parquet_for_each_batch(const std::string &dir, const std::function<void(const int64_t *, const int32_t *, uint64_t)> &fn);
+// (-1 if some file carries none).  id_columns = number of id columns the index parameters imply (id1..idN, ceil(m / 32)).
+// Throws std::runtime_error on unreadable files or a schema that does not match.
+uint64_t parquet_count_rows(const std::string &dir, int id_columns, int64_t *max_taxon);
+// Streams the records in batches: keys are rows of id_columns words.
+void parquet_for_each_batch(const std::string &dir, int id_columns,
+                            const std::function<void(const int64_t *, const int32_t *, uint64_t)> &fn);
 
 }  // namespace slk_host

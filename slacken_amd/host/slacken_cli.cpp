@@ -79,21 +79,21 @@ static IndexParams read_index_params(const std::string &location) {  // IndexPar
 }
 
 // ---- records (<idx>.slkrec written by tools/parquet_to_slkrec.py) ----
-// <idx>.slkrec: "SLKREC1\0", u64 n, u32 id columns (1), u32 largest taxon (0 = not recorded), int64 keys[n], int32 taxa[n].
+// <idx>.slkrec: "SLKREC1\0", u64 n, u32 id columns W, u32 largest taxon (0 = not recorded), int64 keys[n][W], int32 taxa[n].
 // Streamed into the device table in chunks: a standard library is ~120 GB of records, which must not need as much host memory.
 struct RecordFile {
   FILE *f = nullptr;
   std::string path;
   uint64_t n = 0;
-  uint32_t max_taxon = 0;
-  explicit RecordFile(const std::string &location) : path(location + ".slkrec") {
+  uint32_t max_taxon = 0, id_columns = 1;
+  RecordFile(const std::string &location, int expect_columns) : path(location + ".slkrec") {
     f = fopen(path.c_str(), "rb");
     if (!f) die("cannot open " + path + " (this build reads Parquet " + (parquet_available() ? "natively, but " + location + "/ holds no *.parquet" : "only through tools/parquet_to_slkrec.py " + location) + ")");
     char magic[8];
-    uint32_t idl;
     if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "SLKREC1", 8) != 0) die(path + ": bad magic");
-    if (fread(&n, 8, 1, f) != 1 || fread(&idl, 4, 1, f) != 1 || fread(&max_taxon, 4, 1, f) != 1) die(path + ": truncated header");
-    if (idl != 1) die(path + ": " + std::to_string(idl) + " id columns; this engine supports minimizers up to 32 nt (one column)");
+    if (fread(&n, 8, 1, f) != 1 || fread(&id_columns, 4, 1, f) != 1 || fread(&max_taxon, 4, 1, f) != 1) die(path + ": truncated header");
+    if ((int)id_columns != expect_columns)
+      die(path + ": " + std::to_string(id_columns) + " id columns, the index parameters imply " + std::to_string(expect_columns));
   }
   ~RecordFile() { if (f) fclose(f); }
   void read_at(uint64_t off, void *dst, size_t bytes) {
@@ -101,12 +101,13 @@ struct RecordFile {
   }
   static constexpr uint64_t CHUNK = 1ull << 24;
   template <class F> void for_each_chunk(bool with_keys, F fn) {  // fn(keys or null, taxa, count)
-    std::vector<int64_t> keys(with_keys ? std::min(n, CHUNK) : 0);
+    const uint64_t W = id_columns;
+    std::vector<int64_t> keys(with_keys ? std::min(n, CHUNK) * W : 0);
     std::vector<int32_t> taxa(std::min(n, CHUNK));
     for (uint64_t o = 0; o < n; o += CHUNK) {
       uint64_t c = std::min(CHUNK, n - o);
-      if (with_keys) read_at(24 + o * 8, keys.data(), c * 8);
-      read_at(24 + n * 8 + o * 4, taxa.data(), c * 4);
+      if (with_keys) read_at(24 + o * 8 * W, keys.data(), c * 8 * W);
+      read_at(24 + n * 8 * W + o * 4, taxa.data(), c * 4);
       fn(with_keys ? keys.data() : nullptr, taxa.data(), c);
     }
   }
@@ -142,15 +143,17 @@ static int cmd_parse(int argc, char **argv) {  // parse <file> [<file2>]: header
 static int cmd_records(int argc, char **argv) {
   if (argc < 1) die("usage: records INDEX_LOCATION");
   std::string location = argv[0];
+  const int W = (read_index_params(location).m + 31) / 32;
   auto report = [](const char *src, uint64_t n, uint64_t kx, int64_t ts, int32_t mt) {
     std::cout << src << " n=" << n << " key_xor=" << kx << " taxon_sum=" << ts << " max_taxon=" << mt << '\n';
   };
   if (parquet_available() && fs::is_directory(location)) {
     uint64_t n = 0, kx = 0; int64_t ts = 0; int32_t mt = 0;
     int64_t stat_max = -1;
-    uint64_t rows = parquet_count_rows(location, &stat_max);
-    parquet_for_each_batch(location, [&](const int64_t *k, const int32_t *t, uint64_t c) {
-      for (uint64_t i = 0; i < c; i++) { kx ^= (uint64_t)k[i] * 0x9E3779B97F4A7C15ull; ts += t[i]; mt = std::max(mt, t[i]); }
+    uint64_t rows = parquet_count_rows(location, W, &stat_max);
+    parquet_for_each_batch(location, W, [&](const int64_t *k, const int32_t *t, uint64_t c) {
+      for (uint64_t i = 0; i < c; i++) { ts += t[i]; mt = std::max(mt, t[i]); }
+      for (uint64_t i = 0; i < c * W; i++) kx ^= ((uint64_t)k[i] + i % W) * 0x9E3779B97F4A7C15ull;
       n += c;
     });
     if (rows != n) die("row count of the footers differs from the rows read");
@@ -158,10 +161,11 @@ static int cmd_records(int argc, char **argv) {
     report("parquet", n, kx, ts, mt);
   }
   if (fs::exists(location + ".slkrec")) {
-    RecordFile rec(location);
+    RecordFile rec(location, W);
     uint64_t n = 0, kx = 0; int64_t ts = 0; int32_t mt = 0;
     rec.for_each_chunk(true, [&](const int64_t *k, const int32_t *t, uint64_t c) {
-      for (uint64_t i = 0; i < c; i++) { kx ^= (uint64_t)k[i] * 0x9E3779B97F4A7C15ull; ts += t[i]; mt = std::max(mt, t[i]); }
+      for (uint64_t i = 0; i < c; i++) { ts += t[i]; mt = std::max(mt, t[i]); }
+      for (uint64_t i = 0; i < c * W; i++) kx ^= ((uint64_t)k[i] + i % W) * 0x9E3779B97F4A7C15ull;
       n += c;
     });
     report("slkrec", n, kx, ts, mt);
@@ -310,17 +314,18 @@ static void load_index(const std::string &location, IndexParams &ip, Taxonomy &t
   ip = read_index_params(location);
   tax = Taxonomy::load(location + "_taxonomy");
   // records: the flat <idx>.slkrec if it exists, else Slacken's Parquet table itself
+  const int W = (ip.m + 31) / 32;   // id columns (KeyValueIndex.scala:49)
   uint64_t n_records = 0;
   if (!fs::exists(location + ".slkrec") && parquet_available() && fs::is_directory(location)) {
     int64_t mt = -1;
-    n_records = parquet_count_rows(location, &mt);
+    n_records = parquet_count_rows(location, W, &mt);
     int32_t max_taxon = std::max<int32_t>(tax.size() - 1, (int32_t)std::max<int64_t>(mt, 0));
     if (mt < 0)  // no column statistics: one pass over the taxon column
-      parquet_for_each_batch(location, [&](const int64_t *, const int32_t *taxa, uint64_t c) { for (uint64_t i = 0; i < c; i++) max_taxon = std::max(max_taxon, taxa[i]); });
+      parquet_for_each_batch(location, W, [&](const int64_t *, const int32_t *taxa, uint64_t c) { for (uint64_t i = 0; i < c; i++) max_taxon = std::max(max_taxon, taxa[i]); });
     dev.create(ip, tax, n_records, max_taxon);
-    parquet_for_each_batch(location, [&](const int64_t *keys, const int32_t *taxa, uint64_t c) { SLK_CALL(slk_index_append(dev.ix, keys, taxa, c)); });
+    parquet_for_each_batch(location, W, [&](const int64_t *keys, const int32_t *taxa, uint64_t c) { SLK_CALL(slk_index_append(dev.ix, keys, taxa, c)); });
   } else {
-    RecordFile rec(location);
+    RecordFile rec(location, W);
     n_records = rec.n;
     int32_t max_taxon = std::max<int32_t>(tax.size() - 1, (int32_t)rec.max_taxon);
     if (rec.max_taxon == 0)  // an older file without the recorded maximum: one pass over the taxon column

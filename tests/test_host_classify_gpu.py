@@ -117,24 +117,32 @@ def test_cli_paired_samples_and_flags(tmp_path):
         assert os.path.exists(f"{out4}_c0.0/{s}_kreport.txt")
 
 
-def test_native_parquet_reader_matches_converter(tmp_path):
+@pytest.mark.parametrize("m", [31, 40, 100])
+def test_native_parquet_reader_matches_converter(tmp_path, m):
     """`slacken-amd records`: the C++ Parquet reader (Arrow C++ from the pyarrow wheel) and the flat file written by the
-    converter hold the same records; snappy-compressed bucket files as Spark writes them, several row groups."""
+    converter hold the same records; snappy-compressed bucket files as Spark writes them, several row groups; one id column
+    per 32 nt of minimizer (id1..idN, KeyValueIndex.scala:49)."""
     import pyarrow as pa
     import pyarrow.parquet as pq
     rng = np.random.default_rng(2)
-    n = 50_000
-    keys = rng.integers(-2**62, 2**62, n).astype(np.int64)
+    n, W = 50_000, (m + 31) // 32
+    keys = rng.integers(-2**62, 2**62, (n, W)).astype(np.int64)
     taxa = rng.integers(1, 3_000_000, n).astype(np.int32)
     loc = str(tmp_path / "lib")
     os.makedirs(loc)
+    with open(loc + ".properties", "w") as f:
+        f.write(f"k={m + 4}\nm={m}\nversion=1\nsplitter=randomXOR\n")
     for b in range(4):
         sel = np.arange(n) % 4 == b
-        tab = pa.table({"id1": pa.array(keys[sel], pa.int64()), "taxon": pa.array(taxa[sel], pa.int32())})
-        pq.write_table(tab, os.path.join(loc, f"part-00000-x_{b:05d}.c000.snappy.parquet"), compression="snappy", row_group_size=3000)
+        cols = {f"id{i + 1}": pa.array(keys[sel, i], pa.int64()) for i in range(W)}
+        cols["taxon"] = pa.array(taxa[sel], pa.int32())
+        pq.write_table(pa.table(cols), os.path.join(loc, f"part-00000-x_{b:05d}.c000.snappy.parquet"), compression="snappy",
+                       row_group_size=3000)
     open(os.path.join(loc, "_SUCCESS"), "w").close()
     import parquet_to_slkrec as conv
     conv.convert(loc)
+    k2, t2 = conv.read_parquet_dir(loc)
+    assert np.array_equal(np.sort(t2), np.sort(taxa)) and k2.reshape(n, -1).shape == (n, W)
     out = subprocess.run([CLI, "records", loc], check=True, capture_output=True, text=True).stdout.strip().split("\n")
     if len(out) == 1:
         pytest.skip("CLI built without Parquet support")

@@ -13,10 +13,12 @@ import pyarrow.parquet as pq
 
 
 def write_slkrec(path, keys, taxa):
+    """keys: int64 [n] (one id column) or [n, W] (id1..idW)"""
     keys = np.ascontiguousarray(keys, np.int64)
     taxa = np.ascontiguousarray(taxa, np.int32)
+    W = 1 if keys.ndim == 1 else keys.shape[1]
     with open(path, "wb") as f:
-        f.write(b"SLKREC1\0" + struct.pack("<QII", len(keys), 1, int(taxa.max()) if len(taxa) else 0))
+        f.write(b"SLKREC1\0" + struct.pack("<QII", len(taxa), W, int(taxa.max()) if len(taxa) else 0))
         f.write(keys.tobytes())
         f.write(taxa.tobytes())
 
@@ -28,9 +30,9 @@ def read_parquet_dir(location):
     keys, taxa = [], []
     for fn in files:
         t = pq.read_table(fn)
-        if "id2" in t.column_names:
-            raise SystemExit("this engine supports minimizers up to 32 nt (one id column)")
-        keys.append(t.column("id1").to_numpy())
+        ids = sorted((c for c in t.column_names if c.startswith("id")), key=lambda c: int(c[2:]))
+        k = np.stack([t.column(c).to_numpy() for c in ids], axis=1)
+        keys.append(k[:, 0] if len(ids) == 1 else k)
         taxa.append(t.column("taxon").to_numpy())
     return np.concatenate(keys), np.concatenate(taxa)
 
@@ -38,10 +40,14 @@ def read_parquet_dir(location):
 def write_parquet_dir(location, keys, taxa, buckets):
     """bucketed like Spark's bucketBy would name them (the assignment itself is a Spark internal and irrelevant for reading)"""
     os.makedirs(location, exist_ok=True)
-    order = np.arange(len(keys)) % buckets
+    keys = np.asarray(keys, np.int64)
+    k2 = keys.reshape(len(taxa), -1)
+    order = np.arange(len(taxa)) % buckets
     for b in range(buckets):
         sel = order == b
-        tab = pa.table({"id1": pa.array(keys[sel], pa.int64()), "taxon": pa.array(taxa[sel], pa.int32())})
+        cols = {f"id{i + 1}": pa.array(k2[sel, i], pa.int64()) for i in range(k2.shape[1])}
+        cols["taxon"] = pa.array(np.asarray(taxa)[sel], pa.int32())
+        tab = pa.table(cols)
         pq.write_table(tab, os.path.join(location, f"part-00000-test_{b:05d}.c000.snappy.parquet"), compression="snappy")
 
 
@@ -51,21 +57,25 @@ def convert(location, batch_rows=1 << 22):
     if not files:
         raise SystemExit(f"no *.parquet under {location}")
     n = 0
+    ids = None
     for fn in files:
         pf = pq.ParquetFile(fn)
-        if "id2" in pf.schema_arrow.names:
-            raise SystemExit("this engine supports minimizers up to 32 nt (one id column)")
+        these = sorted((c for c in pf.schema_arrow.names if c.startswith("id")), key=lambda c: int(c[2:]))
+        if ids is not None and these != ids:
+            raise SystemExit(f"{fn}: id columns {these} differ from {ids}")
+        ids = these
         n += pf.metadata.num_rows
+    W = len(ids)
     pos, max_taxon = 0, 0
     with open(location + ".slkrec", "wb") as f:
-        f.write(b"SLKREC1\0" + struct.pack("<QII", n, 1, 0))
+        f.write(b"SLKREC1\0" + struct.pack("<QII", n, W, 0))
         for fn in files:
-            for batch in pq.ParquetFile(fn).iter_batches(batch_size=batch_rows, columns=["id1", "taxon"]):
-                k = np.ascontiguousarray(batch.column("id1").to_numpy(zero_copy_only=False), np.int64)
+            for batch in pq.ParquetFile(fn).iter_batches(batch_size=batch_rows, columns=ids + ["taxon"]):
+                k = np.ascontiguousarray(np.stack([batch.column(c).to_numpy(zero_copy_only=False) for c in ids], axis=1), np.int64)
                 t = np.ascontiguousarray(batch.column("taxon").to_numpy(zero_copy_only=False), np.int32)
-                f.seek(24 + pos * 8)
+                f.seek(24 + pos * 8 * W)
                 f.write(k.tobytes())
-                f.seek(24 + n * 8 + pos * 4)
+                f.seek(24 + n * 8 * W + pos * 4)
                 f.write(t.tobytes())
                 pos += len(k)
                 if len(t):
