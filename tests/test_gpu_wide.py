@@ -30,9 +30,19 @@ def build_world(orc, k, m, spaces, canonical, rng, n_genomes=6, genome_len=4000)
     return p, W, parents, genomes, keys, tx
 
 
-@pytest.mark.parametrize("k,m,spaces,canonical", [(40, 33, 0, True), (45, 40, 7, True), (70, 63, 10, True), (64, 64, 0, True),
-                                                  (80, 65, 16, False), (110, 100, 20, True), (158, 128, 64, True), (130, 128, 0, True),
-                                                  (96, 96, 48, True)])
+def _param_sets():
+    import os
+    sets = [(40, 33, 0, True), (45, 40, 7, True), (70, 63, 10, True), (64, 64, 0, True), (80, 65, 16, False), (110, 100, 20, True),
+            (158, 128, 64, True), (130, 128, 0, True), (96, 96, 48, True)]
+    rng = np.random.default_rng(99)
+    for _ in range(int(os.environ.get("SLK_FUZZ_SEEDS", 0)) // 8):      # soak: random wide splitters
+        m = int(rng.integers(33, 129))
+        W = (m + 31) // 32
+        sets.append((int(rng.integers(m, m + 128 // W)), m, int(rng.integers(0, m // 2 + 1)), bool(rng.integers(0, 4))))
+    return sets
+
+
+@pytest.mark.parametrize("k,m,spaces,canonical", _param_sets())
 def test_wide_classify_parity(orc, k, m, spaces, canonical):
     import slacken_amd
     rng = np.random.default_rng(k * 1000 + m)
