@@ -93,7 +93,7 @@ struct slk_stream {
   hipStream_t s = nullptr;
   DevBuf span_keys, span_meta, span_taxon, span_count;  // per-batch scratch (sparse per-read regions)
   DevBuf bases, offsets, mate_bases, mate_offsets;      // staging for the host-pointer entry points
-  DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items, defer;
+  DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items, defer, defer_list;
   double *d_thresholds = nullptr;
   double *h_thresholds = nullptr;  // pinned
   int32_t *d_status = nullptr;     // device error bits of the fused kernels
@@ -540,7 +540,7 @@ void slk_stream_destroy(slk_stream *st) {
   (void)hipStreamSynchronize(st->s);
   DevBuf *bufs[] = {&st->span_keys, &st->span_meta, &st->span_taxon, &st->span_count, &st->bases, &st->offsets,
                     &st->mate_bases, &st->mate_offsets, &st->out_taxon, &st->out_cls, &st->out_nd, &st->out_tk,
-                    &st->out_nh, &st->out_offsets, &st->out_items, &st->defer};
+                    &st->out_nh, &st->out_offsets, &st->out_items, &st->defer, &st->defer_list};
   for (DevBuf *b : bufs) b->release();
   if (st->d_thresholds) (void)hipFree(st->d_thresholds);
   if (st->h_thresholds) (void)hipHostFree(st->h_thresholds);
@@ -661,13 +661,19 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
     A.span_taxon = want_hits ? st->span_taxon.as<int32_t>() : nullptr;
     A.span_count = want_hits ? st->span_count.as<int32_t>() : nullptr;
     A.status = st->d_status;
-    A.only_flagged = nullptr;
+    A.work_list = nullptr; A.work_count = nullptr;
     if (!want_hits && ix->sp.w <= 16 && !force_wave()) {
       // hot path: one lane per fragment; long fragments and map overflows are deferred to the wave-per-read kernel
       HIPCHK(st->defer.ensure((R + 64) * sizeof(int32_t)));
       HIPCHK(hipMemsetAsync(st->defer.p, 0, (R + 64) * sizeof(int32_t), st->s));
       launch_lane(A, st->defer.as<int32_t>(), 1000, st->s);  // queue entries carry 10-bit k-mer counts
-      A.only_flagged = st->defer.as<int32_t>();
+      // the deferred fragments, compacted: [0] = their number, [1..] = their indices
+      HIPCHK(st->defer_list.ensure((R + 1) * sizeof(uint64_t)));
+      HIPCHK(hipMemsetAsync(st->defer_list.p, 0, sizeof(uint64_t), st->s));
+      launch_compact_flags(st->defer.as<int32_t>(), R, st->defer_list.as<uint64_t>() + 1,
+                           (unsigned long long *)st->defer_list.p, st->s);
+      A.work_list = st->defer_list.as<uint64_t>() + 1;
+      A.work_count = (const unsigned long long *)st->defer_list.p;
     }
     launch_fused(want_hits ? MODE_HITS : MODE_CLASSIFY, A, st->s);
     HIPCHK(hipEventRecord(st->ev[1], st->s));

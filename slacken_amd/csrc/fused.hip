@@ -402,18 +402,13 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
   const int w = P.w;
   const uint32_t STEP = 64 - (w - 1);  // k-mer windows resolved per round
   const uint64_t nwaves = (uint64_t)gridDim.x * FW;
-  // Work list: every fragment, or (only_flagged) the fragments the lane kernel deferred -- found 64 at a time by ballot.
-  const uint64_t nunits = A.only_flagged ? (A.R + 63) / 64 : A.R;
+  // Work list: every fragment, or (work_list) the fragments the lane kernel deferred, one per wave iteration.  (They used to
+  // be found 64 flags at a time by ballot, each wave working through its 64 one after the other: with most fragments
+  // deferred -- a batch of long reads -- that left most of the chip idle.)
+  const uint64_t nunits = A.work_list ? (uint64_t)*A.work_count : A.R;
   for (uint64_t unit = (uint64_t)blockIdx.x * FW + wib; unit < nunits; unit += nwaves) {
-   uint64_t pending = 1;
-   if (A.only_flagged) {
-     uint64_t rr = unit * 64 + lane;
-     pending = __ballot(rr < A.R && A.only_flagged[rr] != 0);
-   }
-   while (pending) {
-    uint64_t r = unit;
-    if (A.only_flagged) r = unit * 64 + __builtin_ctzll(pending);
-    pending &= pending - 1;
+   {
+    const uint64_t r = A.work_list ? A.work_list[unit] : unit;
     // ---- per-fragment state (wave-uniform unless noted) ----
     int nbuf = 0, n_out = 0;
     bool first = true, have_last = false;   // Supermers.spans :72-73
@@ -622,6 +617,30 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
     wave_sync();
    }
   }
+}
+
+__global__ void __launch_bounds__(256) compact_flags_kernel(const int32_t *__restrict__ flags, uint64_t R, uint64_t *__restrict__ list,
+                                                            unsigned long long *__restrict__ count) {
+  const int lane = threadIdx.x & 63;
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t base = i - lane; base < R; base += step) {  // wave-uniform trip count
+    const uint64_t r = base + lane;
+    const bool f = r < R && flags[r] != 0;
+    const uint64_t m = __ballot(f);
+    if (m == 0) continue;
+    unsigned long long first = 0;
+    const int leader = __ffsll((long long)m) - 1;
+    if (lane == leader) first = atomicAdd(count, (unsigned long long)__popcll(m));
+    first = ((unsigned long long)(uint32_t)__shfl((int)(first >> 32), leader) << 32) | (uint32_t)__shfl((int)first, leader);
+    if (f) list[first + lanes_below(m)] = r;
+  }
+}
+
+void launch_compact_flags(const int32_t *flags, uint64_t R, uint64_t *list, unsigned long long *count, hipStream_t s) {
+  if (R == 0) return;
+  uint64_t blocks = std::min<uint64_t>((R + 255) / 256, 256 * 8);
+  hipLaunchKernelGGL(compact_flags_kernel, dim3((unsigned)blocks), dim3(256), 0, s, flags, R, list, count);
 }
 
 void launch_fused(int mode, const FusedArgs &A, hipStream_t s) {

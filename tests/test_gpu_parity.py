@@ -172,7 +172,7 @@ def test_classify_edge_batches(orc, world):
 def test_api_errors(world):
     import slacken_amd
     with pytest.raises(slacken_amd.SlackenError) as e:
-        slacken_amd.Index(k=63, m=33, spaces=0)
+        slacken_amd.Index(k=150, m=140, spaces=0)      # five id columns (m <= 128 is served, tests/test_gpu_wide.py)
     assert e.value.code == -2
     with pytest.raises(slacken_amd.SlackenError):
         slacken_amd.Index(k=10, m=12)
