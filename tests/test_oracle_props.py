@@ -203,3 +203,15 @@ def test_spans_quirks(orc):
     n1 = b[0]["ordinal"]
     assert pair[n1 + 1]["distinct"] == (pair[n1 + 1]["key"] != pair[n1 - 1]["key"])  # lastMinimizer survives border
     assert orc.spans(p, "", "") == [dict(key=(0,), kmers=-34, flag=3, ordinal=0, distinct=False)]
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(97, 128).flatmap(lambda m: st.tuples(st.just(m), st.integers(m, m + 31), priorities(m, True), dna(m + 31, 400))))
+def test_four_word_minimizers_match_the_python_model(orc, c):
+    # m in 97..128 (four id columns; the reference's ClassifierTest draws m up to 128): the C restatement's multi-word
+    # arithmetic against the pure-Python-integer model
+    m, k, pri, x = c
+    p = orc.params(k=k, **pri)
+    got = orc.split_encode(p, x)
+    want = [(pymodel.left_align(v, p.m), s, l) for v, s, l in pymodel.supermers(x, k, **pri)]
+    assert got == want
