@@ -58,6 +58,23 @@ def main():
         assert r.returncode == 0, r.stderr
         out[name + "_log"] = [l for l in r.stderr.split("\n") if "task" in l or "fragments" in l]
         out[name] = dict(reads=R, seconds=round(dt, 2), M_reads_per_s=round(R / dt / 1e6, 3))
+    # classify2: the two-step run with a dynamic library built on the device from the genome FASTA files
+    libdir = os.path.join(d, "k2")
+    os.makedirs(os.path.join(libdir, "library", "bacteria"))
+    gtaxa = rng.choice(taxa[len(taxa) // 2:], G).astype(np.int32)   # (labels only: the base index above has its own)
+    with open(os.path.join(libdir, "library", "bacteria", "library.fna"), "wb") as f, open(os.path.join(libdir, "seqid2taxid.map"), "w") as mp:
+        for gi in range(G):
+            f.write(b">G%d synthetic genome\n" % gi)
+            g = bases[gi * L:(gi + 1) * L]
+            f.write(b"\n".join(g[j:j + 80].tobytes() for j in range(0, L, 80)) + b"\n")
+            mp.write(f"G{gi}\t{int(gtaxa[gi])}\n")
+    t0 = time.perf_counter()
+    r = subprocess.run([os.path.join(ROOT, "slacken_amd", "bin", "slacken-amd"), "classify2", "-i", loc, "-o", os.path.join(d, "out2"),
+                        "--library", libdir, "-R", "100", "--rank", "superkingdom", fq], capture_output=True, text=True)
+    dt = time.perf_counter() - t0
+    assert r.returncode == 0, r.stderr
+    out["classify2"] = dict(reads=R, library_Mbp=G * L // 1000000, seconds=round(dt, 2), M_reads_per_s=round(R / dt / 1e6, 3),
+                            log=[l for l in r.stderr.split("\n") if "task" in l or "Detected" in l or "dynamic" in l or "Construct" in l])
     out["fastq_MB"] = round(os.path.getsize(fq) / 1e6)
     out["records"] = len(keys)
     print(json.dumps(out))
