@@ -57,7 +57,7 @@ def test_build_matches_oracle(orc, k, m, spaces):
     want_k, want_t = orc.build_records(p, parents, wb, wo, [tx[i] for i in keep])
 
     def build(parts):
-        ix = slacken_amd.Index(k=k, m=m, spaces=spaces, expected_records=int(offsets[-1]) // 2 + 1000, max_taxon=len(parents) - 1)
+        ix = slacken_amd.Index(k=k, m=m, spaces=spaces, expected_records=int(offsets[-1]) + 1000, max_taxon=len(parents) - 1)
         ix.set_taxonomy(parents)
         for idx in parts:
             b, o = pack([seqs[i] for i in idx])
