@@ -69,37 +69,41 @@ static int64_t read_values(Reader *r, int64_t want, std::vector<int16_t> &def, T
   return values;
 }
 
-void parquet_for_each_batch(const std::string &dir, int W, const std::function<void(const int64_t *, const int32_t *, uint64_t)> &fn) {
-  const int64_t B = 1 << 22;
+std::vector<std::string> parquet_list_files(const std::string &dir) { return parquet_files(dir); }
+
+void parquet_read_file(const std::string &f, int W, const std::function<void(const int64_t *, const int32_t *, uint64_t)> &fn) {
+  const int64_t B = 1 << 20;
   std::vector<int64_t> col((size_t)B), keys((size_t)B * W);
   std::vector<int32_t> taxa((size_t)B);
   std::vector<int16_t> def((size_t)B);
-  for (auto &f : parquet_files(dir)) {
-    auto reader = parquet::ParquetFileReader::OpenFile(f, false);
-    auto md = reader->metadata();
-    int c_id[4], c_tax;
-    check_schema(md->schema(), f, W, c_id, &c_tax);
-    for (int g = 0; g < md->num_row_groups(); g++) {
-      auto rg = reader->RowGroup(g);
-      std::shared_ptr<parquet::ColumnReader> cols[4];
-      for (int i = 0; i < W; i++) cols[i] = rg->Column(c_id[i]);
-      auto col_tax = rg->Column(c_tax);
-      auto *rtx = static_cast<parquet::Int32Reader *>(col_tax.get());
-      while (rtx->HasNext()) {
-        int64_t nt = 0;
-        while (nt < B && rtx->HasNext()) nt += read_values(rtx, B - nt, def, taxa.data() + nt);
-        for (int i = 0; i < W; i++) {
-          auto *rid = static_cast<parquet::Int64Reader *>(cols[i].get());
-          int64_t nk = 0;
-          int64_t *dst = W == 1 ? keys.data() : col.data();
-          while (nk < nt && rid->HasNext()) nk += read_values(rid, nt - nk, def, dst + nk);
-          if (nk != nt) throw std::runtime_error(f + ": id and taxon columns differ in length");
-          if (W > 1) for (int64_t r = 0; r < nt; r++) keys[(size_t)r * W + i] = col[(size_t)r];
-        }
-        fn(keys.data(), taxa.data(), (uint64_t)nt);
+  auto reader = parquet::ParquetFileReader::OpenFile(f, false);
+  auto md = reader->metadata();
+  int c_id[4], c_tax;
+  check_schema(md->schema(), f, W, c_id, &c_tax);
+  for (int g = 0; g < md->num_row_groups(); g++) {
+    auto rg = reader->RowGroup(g);
+    std::shared_ptr<parquet::ColumnReader> cols[4];
+    for (int i = 0; i < W; i++) cols[i] = rg->Column(c_id[i]);
+    auto col_tax = rg->Column(c_tax);
+    auto *rtx = static_cast<parquet::Int32Reader *>(col_tax.get());
+    while (rtx->HasNext()) {
+      int64_t nt = 0;
+      while (nt < B && rtx->HasNext()) nt += read_values(rtx, B - nt, def, taxa.data() + nt);
+      for (int i = 0; i < W; i++) {
+        auto *rid = static_cast<parquet::Int64Reader *>(cols[i].get());
+        int64_t nk = 0;
+        int64_t *dst = W == 1 ? keys.data() : col.data();
+        while (nk < nt && rid->HasNext()) nk += read_values(rid, nt - nk, def, dst + nk);
+        if (nk != nt) throw std::runtime_error(f + ": id and taxon columns differ in length");
+        if (W > 1) for (int64_t r = 0; r < nt; r++) keys[(size_t)r * W + i] = col[(size_t)r];
       }
+      fn(keys.data(), taxa.data(), (uint64_t)nt);
     }
   }
+}
+
+void parquet_for_each_batch(const std::string &dir, int W, const std::function<void(const int64_t *, const int32_t *, uint64_t)> &fn) {
+  for (auto &f : parquet_files(dir)) parquet_read_file(f, W, fn);
 }
 
 }  // namespace slk_host
@@ -110,6 +114,10 @@ namespace slk_host {
 bool parquet_available() { return false; }
 uint64_t parquet_count_rows(const std::string &, int, int64_t *) { throw std::runtime_error("built without Parquet support"); }
 void parquet_for_each_batch(const std::string &, int, const std::function<void(const int64_t *, const int32_t *, uint64_t)> &) {
+  throw std::runtime_error("built without Parquet support");
+}
+std::vector<std::string> parquet_list_files(const std::string &) { return {}; }
+void parquet_read_file(const std::string &, int, const std::function<void(const int64_t *, const int32_t *, uint64_t)> &) {
   throw std::runtime_error("built without Parquet support");
 }
 }  // namespace slk_host

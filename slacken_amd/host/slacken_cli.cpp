@@ -323,7 +323,28 @@ static void load_index(const std::string &location, IndexParams &ip, Taxonomy &t
     if (mt < 0)  // no column statistics: one pass over the taxon column
       parquet_for_each_batch(location, W, [&](const int64_t *, const int32_t *taxa, uint64_t c) { for (uint64_t i = 0; i < c; i++) max_taxon = std::max(max_taxon, taxa[i]); });
     dev.create(ip, tax, n_records, max_taxon);
-    parquet_for_each_batch(location, W, [&](const int64_t *keys, const int32_t *taxa, uint64_t c) { SLK_CALL(slk_index_append(dev.ix, keys, taxa, c)); });
+    // bucket files are decoded on several threads (whole files: a bucket file of a standard library is ~60 MB) and appended
+    // here in file order
+    struct FileRecords { std::vector<int64_t> keys; std::vector<int32_t> taxa; };
+    ThreadPool pool(host_threads());
+    std::deque<std::future<FileRecords>> pending;
+    auto drain_one = [&]() {
+      FileRecords fr = pending.front().get();
+      pending.pop_front();
+      SLK_CALL(slk_index_append(dev.ix, fr.keys.data(), fr.taxa.data(), fr.taxa.size()));
+    };
+    for (auto &file : parquet_list_files(location)) {
+      pending.push_back(pool.submit([file, W]() {
+        FileRecords fr;
+        parquet_read_file(file, W, [&](const int64_t *keys, const int32_t *taxa, uint64_t c) {
+          fr.keys.insert(fr.keys.end(), keys, keys + c * W);
+          fr.taxa.insert(fr.taxa.end(), taxa, taxa + c);
+        });
+        return fr;
+      }));
+      while (pending.size() >= 2 * pool.size()) drain_one();
+    }
+    while (!pending.empty()) drain_one();
   } else {
     RecordFile rec(location, W);
     n_records = rec.n;
