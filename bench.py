@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+GATHER_CEILING_GLPS = 48.5
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 K, M, SPACES = 35, 31, 7
 READ_LEN = 150
@@ -254,7 +255,12 @@ def main():
         },
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": round(dom_ms, 3)},
+                     "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": round(dom_ms, 3),
+                     # the part's measured rate of random 64-byte line reads on a 128 GiB table (tools/gather_bench.hip,
+                     # profiles/r01_gather_microbench.txt): what a hash-table probe can reach, as opposed to the streaming peak
+                     "random_line_ceiling_Glines_per_s": GATHER_CEILING_GLPS,
+                     "probe_lines_per_s_G": round(probes / (dom_ms * 1e-3) / 1e9, 2),
+                     "frac_of_random_line_ceiling": round(probes / (dom_ms * 1e-3) / 1e9 / GATHER_CEILING_GLPS, 3)},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
