@@ -1,0 +1,112 @@
+/* slacken_jni.c -- JNI shim between the reference (Scala on Spark) and libslacken_amd.so.
+ * Class: com.jnpersson.slacken.gpu.Native (integration/GpuClassifier.scala).  NOT COMPILED IN THIS REPOSITORY'S BUILD IMAGE
+ * (it has no JDK, hence no jni.h); build where the reference builds:
+ *   cc -O2 -fPIC -shared -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude integration/slacken_jni.c \
+ *      -Lslacken_amd/lib -lslacken_amd -o libslacken_jni.so
+ * Rules (include/slacken_amd.h): plain pointers and sizes, int32 status + thread-local slk_last_error(), no callbacks, no
+ * ownership transfer; one slk_index per executor JVM shared by all task threads, one slk_stream per task thread. */
+#include <jni.h>
+#include <stdint.h>
+
+#include "slacken_amd.h"
+
+static void throw_state(JNIEnv *e) {
+  (*e)->ThrowNew(e, (*e)->FindClass(e, "java/lang/IllegalStateException"), slk_last_error());
+}
+#define H(x) ((slk_index *)(intptr_t)(x))
+#define S(x) ((slk_stream *)(intptr_t)(x))
+
+JNIEXPORT jint JNICALL Java_com_jnpersson_slacken_gpu_Native_deviceCount(JNIEnv *e, jclass c) { return slk_device_count(); }
+
+/* KeyValueIndex.load: parameters of IndexParams + MinSplitter (k, m, spaces, XOR mask, canonical) */
+JNIEXPORT jlong JNICALL Java_com_jnpersson_slacken_gpu_Native_indexCreate(JNIEnv *e, jclass c, jint k, jint m, jint spaces,
+                                                                         jlong xorMask, jboolean canonical,
+                                                                         jlong expectedRecords, jint maxTaxon, jint device) {
+  slk_params p = {k, m, spaces, canonical ? 1 : 0, (uint64_t)xorMask, (m + 31) / 32, 0};
+  slk_table_config cfg = {(uint64_t)expectedRecords, maxTaxon, 0.0f};
+  slk_index *ix = NULL;
+  if (slk_index_create(&p, &cfg, device, &ix) != SLK_OK) { throw_state(e); return 0; }
+  return (jlong)(intptr_t)ix;
+}
+
+/* one Parquet bucket file = one call; ids holds n rows of idLongs words (row-major), pinned, not copied */
+JNIEXPORT void JNICALL Java_com_jnpersson_slacken_gpu_Native_indexAppend(JNIEnv *e, jclass c, jlong h, jlongArray ids,
+                                                                        jintArray taxa, jint n) {
+  jlong *k = (*e)->GetPrimitiveArrayCritical(e, ids, NULL);
+  jint *t = (*e)->GetPrimitiveArrayCritical(e, taxa, NULL);
+  int32_t rc = slk_index_append(H(h), (const int64_t *)k, (const int32_t *)t, (uint64_t)n);
+  (*e)->ReleasePrimitiveArrayCritical(e, taxa, t, JNI_ABORT);
+  (*e)->ReleasePrimitiveArrayCritical(e, ids, k, JNI_ABORT);
+  if (rc != SLK_OK) throw_state(e);
+}
+
+/* Taxonomy.parents (Taxonomy.scala:159) */
+JNIEXPORT void JNICALL Java_com_jnpersson_slacken_gpu_Native_setTaxonomy(JNIEnv *e, jclass c, jlong h, jintArray parents) {
+  jsize T = (*e)->GetArrayLength(e, parents);
+  jint *p = (*e)->GetPrimitiveArrayCritical(e, parents, NULL);
+  int32_t rc = slk_index_set_taxonomy(H(h), (const int32_t *)p, (int32_t)T);
+  (*e)->ReleasePrimitiveArrayCritical(e, parents, p, JNI_ABORT);
+  if (rc != SLK_OK) throw_state(e);
+}
+
+JNIEXPORT void JNICALL Java_com_jnpersson_slacken_gpu_Native_indexFinalize(JNIEnv *e, jclass c, jlong h) {
+  if (slk_index_finalize(H(h)) != SLK_OK) throw_state(e);
+}
+JNIEXPORT void JNICALL Java_com_jnpersson_slacken_gpu_Native_indexDestroy(JNIEnv *e, jclass c, jlong h) { slk_index_destroy(H(h)); }
+
+/* KeyValueIndex.makeRecords(library, Some(taxonSet)) for the dynamic library (Dynamic.scala:362-374): bases = direct
+ * ByteBuffer of concatenated, whitespace-free sequences */
+JNIEXPORT void JNICALL Java_com_jnpersson_slacken_gpu_Native_addSequences(JNIEnv *e, jclass c, jlong h, jobject bases,
+                                                                         jlongArray offsets, jintArray taxa, jint n) {
+  const uint8_t *b = (const uint8_t *)(*e)->GetDirectBufferAddress(e, bases);
+  jlong *o = (*e)->GetPrimitiveArrayCritical(e, offsets, NULL);
+  jint *t = (*e)->GetPrimitiveArrayCritical(e, taxa, NULL);
+  int32_t rc = slk_index_add_sequences(H(h), b, (const uint64_t *)o, (const int32_t *)t, (uint64_t)n);
+  (*e)->ReleasePrimitiveArrayCritical(e, taxa, t, JNI_ABORT);
+  (*e)->ReleasePrimitiveArrayCritical(e, offsets, o, JNI_ABORT);
+  if (rc != SLK_OK) throw_state(e);
+}
+
+JNIEXPORT jlong JNICALL Java_com_jnpersson_slacken_gpu_Native_streamCreate(JNIEnv *e, jclass c, jlong h) {
+  slk_stream *st = NULL;
+  if (slk_stream_create(H(h), &st) != SLK_OK) { throw_state(e); return 0; }
+  return (jlong)(intptr_t)st;
+}
+JNIEXPORT void JNICALL Java_com_jnpersson_slacken_gpu_Native_streamDestroy(JNIEnv *e, jclass c, jlong s) { slk_stream_destroy(S(s)); }
+
+/* Classifier.classify for one batch.  bases / mateBases: direct ByteBuffers (mateBases null for single-end); offsets,
+ * mateOffsets: long[R+1]; thresholds: double[C]; outputs are caller-owned arrays: outTaxon int[C*R], outClassified byte[C*R],
+ * outNumDistinct / outTotalKmers int[R], outHitOffsets long[R+1] (null: no hit lists), outHits direct ByteBuffer of
+ * {int taxon; int count} with room for hitsCapacity entries.  A fragment r with outHitOffsets[r+1] == outHitOffsets[r]
+ * produced no span: the reference emits no row for it. */
+JNIEXPORT void JNICALL Java_com_jnpersson_slacken_gpu_Native_classifyBatch(
+    JNIEnv *e, jclass c, jlong h, jlong s, jobject bases, jlongArray offsets, jobject mateBases, jlongArray mateOffsets, jint R,
+    jint minHitGroups, jdoubleArray thresholds, jintArray outTaxon, jbyteArray outClassified, jintArray outNumDistinct,
+    jintArray outTotalKmers, jlongArray outHitOffsets, jobject outHits, jlong hitsCapacity) {
+  const uint8_t *b = (const uint8_t *)(*e)->GetDirectBufferAddress(e, bases);
+  const uint8_t *mb = mateBases ? (const uint8_t *)(*e)->GetDirectBufferAddress(e, mateBases) : NULL;
+  slk_hit *hits = outHits ? (slk_hit *)(*e)->GetDirectBufferAddress(e, outHits) : NULL;
+  jsize C = (*e)->GetArrayLength(e, thresholds);
+  jdouble thr[16];
+  if (C > 16) C = 16;
+  (*e)->GetDoubleArrayRegion(e, thresholds, 0, C, thr);
+  /* the call below blocks on the GPU: no critical sections are held across it; primitive arrays are copied in and out */
+  jlong *o = (*e)->GetLongArrayElements(e, offsets, NULL);
+  jlong *mo = mateOffsets ? (*e)->GetLongArrayElements(e, mateOffsets, NULL) : NULL;
+  jint *t = (*e)->GetIntArrayElements(e, outTaxon, NULL);
+  jbyte *cl = (*e)->GetByteArrayElements(e, outClassified, NULL);
+  jint *nd = (*e)->GetIntArrayElements(e, outNumDistinct, NULL);
+  jint *tk = (*e)->GetIntArrayElements(e, outTotalKmers, NULL);
+  jlong *ho = outHitOffsets ? (*e)->GetLongArrayElements(e, outHitOffsets, NULL) : NULL;
+  int32_t rc = slk_classify_batch(H(h), S(s), b, (const uint64_t *)o, mb, (const uint64_t *)mo, (uint64_t)R, minHitGroups, thr, C,
+                                  (int32_t *)t, (uint8_t *)cl, (int32_t *)nd, (int32_t *)tk, (uint64_t *)ho, hits,
+                                  (uint64_t)hitsCapacity);
+  if (ho) (*e)->ReleaseLongArrayElements(e, outHitOffsets, ho, 0);
+  (*e)->ReleaseIntArrayElements(e, outTotalKmers, tk, 0);
+  (*e)->ReleaseIntArrayElements(e, outNumDistinct, nd, 0);
+  (*e)->ReleaseByteArrayElements(e, outClassified, cl, 0);
+  (*e)->ReleaseIntArrayElements(e, outTaxon, t, 0);
+  if (mo) (*e)->ReleaseLongArrayElements(e, mateOffsets, mo, JNI_ABORT);
+  (*e)->ReleaseLongArrayElements(e, offsets, o, JNI_ABORT);
+  if (rc != SLK_OK) throw_state(e);
+}
