@@ -625,6 +625,8 @@ static int32_t check_status(slk_stream *st) {  // call after the stream has been
   return SLK_OK;
 }
 
+static bool lane_path_ok(const slk_index *ix) { return use_fused(ix) && ix->sp.w <= 16 && ix->taxon_bits <= 22; }
+
 static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
                             const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
                             uint64_t total_bases, uint64_t total_mate_bases, int32_t min_hit_groups,
@@ -662,7 +664,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
     A.span_count = want_hits ? st->span_count.as<int32_t>() : nullptr;
     A.status = st->d_status;
     A.work_list = nullptr; A.work_count = nullptr;
-    if (!want_hits && ix->sp.w <= 16 && !force_wave()) {
+    if (lane_path_ok(ix) && !force_wave()) {  // (window of at most 16 m-mers, taxon ids of at most 22 bits)
       // hot path: one lane per fragment; long fragments and map overflows are deferred to the wave-per-read kernel
       HIPCHK(st->defer.ensure((R + 64) * sizeof(int32_t)));
       HIPCHK(hipMemsetAsync(st->defer.p, 0, (R + 64) * sizeof(int32_t), st->s));
@@ -765,7 +767,6 @@ uint32_t slk_shard_of(int64_t key, uint32_t n_shards) {
   return n_shards ? (uint32_t)(fmix64((uint64_t)key) % n_shards) : 0;
 }
 
-static bool lane_path_ok(const slk_index *ix) { return use_fused(ix) && ix->sp.w <= 16 && ix->taxon_bits <= 22; }
 
 int32_t slk_shard_emit_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
                               const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,

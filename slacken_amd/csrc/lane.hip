@@ -20,7 +20,8 @@
 //           Reference: TaxonCounts.toMap/totalKmers (S/slacken/TaxonCounts.scala:70-87), LowestCommonAncestor
 //           (S/slacken/LowestCommonAncestor.scala:49-146), Classifier.classify (S/slacken/Classifier.scala:439-454).
 // Fragments longer than LANE_MAX_LEN, and fragments whose 8-slot map overflows, are flagged in `defer` and re-done by the
-// wave-per-read kernel of fused.hip in the same stream.
+// wave-per-read kernel of fused.hip in the same stream.  With A.span_taxon set the kernel also writes the un-merged hit lists
+// (TaxonHit per span, ordinal order) into the fragments' span regions, the layout fused.hip's MODE_HITS uses.
 #include "engine.h"
 
 #include <cstdio>
@@ -48,6 +49,8 @@ struct __attribute__((aligned(16))) LaneLds {
   uint4 sbuf[(SBLK - 1) * 64];    // read stream: the staged 16-byte sub-blocks 1.. of every lane, [sub-block - 1][lane]
   uint32_t omap[OMAP * 64];       // [slot][owner lane]: taxon << 10 | k-mer count; 0 = empty (NONE hits are not stored)
   uint32_t o_flags[64];           // low bits: hits with distinct && taxon != NONE (Classifier.scala:94); bit 31: map overflow
+  uint64_t rb[64];                // hit-list output only: every lane's span region (engine.h span_region)
+  uint16_t q_ord[QCAP];           // hit-list output only: the queue entry's ordinal among its fragment's spans
 };
 
 #ifndef SLK_PROBE_NT
@@ -97,12 +100,15 @@ __device__ __forceinline__ void fold_hit(LaneLds *L, bool in, uint32_t meta, int
 //      instructions in flight before the first compare; the lane that finds the key writes the taxon to result[entry];
 //   3. lane i folds entry i's hit into its owner's 8-slot map: ONE round of LDS atomics per batch (NONE hits carry no
 //      information for resolveTree and are dropped).
-__device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int qhead, int qn, int cnt, int lane, int dbg) {
+template <bool HITS>
+__device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int qhead, int qn, int cnt, int lane, int dbg,
+                                           int32_t *hit_meta, int32_t *hit_taxon) {
   const uint64_t NO_TAG = ~0ULL;
   const bool in = lane < cnt;
   const int qi = (qhead + lane) & (QCAP - 1);
   const uint64_t key = L->q_key[qi];
   const uint32_t meta = L->q_meta[qi];
+  const uint32_t ord = HITS ? L->q_ord[qi] : 0u;  // (in a register now: re-queued entries may wrap onto this batch's slots)
   const uint64_t h = fmix64(key);
   uint4 st;
   const uint32_t disp = (meta >> 17) & 63;                                // > 0 for an entry re-queued after a full bucket
@@ -144,12 +150,14 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int q
       const uint32_t m_old = L->q_meta[qj];
       const bool again = c == 0 && ((B >> (g * 4)) & 0xF) == 0 && (int)((m_old >> 17) & 63) < T.max_disp;
       const uint64_t k_old = L->q_key[qj];
+      const uint16_t o_old = HITS ? L->q_ord[qj] : (uint16_t)0;
       const uint64_t R = __ballot(again);
       lane_wave_sync();  // every key is in registers before a tail slot (which may wrap onto this batch) is written
       if (again) {
         const int slot = (qhead + qn + requeued + __builtin_amdgcn_mbcnt_hi((uint32_t)(R >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)R, 0))) & (QCAP - 1);
         L->q_key[slot] = k_old;
         L->q_meta[slot] = m_old + (1u << 17);
+        if (HITS) L->q_ord[slot] = o_old;
       }
       requeued += __popcll(R);
     }
@@ -158,6 +166,13 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int q
   // step 3: one lane per entry
   const int32_t taxon = (int32_t)((const uint4 *)L->stash)[lane].y;
   if (!(dbg & 2)) fold_hit(L, in, meta, taxon);
+  if (HITS && in) {
+    // the un-merged hit list (TaxonHit, KeyValueIndex.scala:436-441) in the fragment's span region.  An entry handed back
+    // to the queue writes NONE here and its final taxon when a later batch resolves it.
+    const uint64_t at = L->rb[meta & 63] + ord;
+    hit_taxon[at] = taxon;
+    hit_meta[at] = pack_meta((int32_t)((meta >> 7) & 0x3FF), 1, (meta >> 6) & 1);
+  }
   lane_wave_sync();
   return requeued;
 }
@@ -271,7 +286,7 @@ __device__ __forceinline__ uint4 stream_refill(LaneLds *L, int lane, const uint8
 #define LANE_BOUNDS __launch_bounds__(LW * 64)
 #endif
 
-template <bool W5, int MODE>
+template <bool W5, int MODE, bool HITS>
 __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, uint32_t max_len, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
@@ -308,6 +323,8 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     bool too_long = have && ((uint64_t)n + n2 > max_len);
     bool fin = !have || too_long;
     if (MODE != LANE_LOCAL) L->stash[lane] = have ? span_region(A.offsets, A.mate_offsets, r) : 0;  // (read after a wave sync)
+    const uint64_t rbase = (HITS && have) ? span_region(A.offsets, A.mate_offsets, r) : 0;
+    if (HITS) L->rb[lane] = rbase;
     // ---- per-lane LDS state ----
 #pragma unroll
     for (int s = 0; s < OMAP; s++) L->omap[s * 64 + lane] = 0;
@@ -352,7 +369,12 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       const bool seqrun = run_class == 1 && nvalid >= (uint32_t)k;
       const bool seq_close = run_end && seqrun;                              // last super-mer of a SEQUENCE_FLAG run
       const bool amb_close = run_end && !seqrun && run_len >= (uint32_t)k;   // AMBIGUOUS_FLAG run >= k: one span, no lookup
+      const int32_t ord0 = nhits;  // ordinal of the span (if any) that closes in this step
       total += amb_close ? (int32_t)run_len - (k - 1) : 0;                   // Supermers.scala:116-119
+      if (HITS && amb_close) {
+        A.span_meta[rbase + ord0] = pack_meta((int32_t)run_len - (k - 1), 2, 0);
+        A.span_taxon[rbase + ord0] = -1;                                     // spanToHit: AMBIGUOUS_SPAN
+      }
       nhits += amb_close ? 1 : 0;
       first = first && !amb_close;
       const uint64_t ekey = cur_val;   // what a super-mer closing in this step carries
@@ -418,6 +440,11 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       if (__ballot(at_end) != 0) {
         if (at_end) {
           if (mate == 0 && paired) {  // MATE_PAIR_BORDER pseudo-span (Supermers.scala:53-57): no k-mers, no lookup
+            if (HITS) {  // it follows the span that closes in this step, if there is one
+              const int32_t ordb = ord0 + ((amb_close || emit) ? 1 : 0);
+              A.span_meta[rbase + ordb] = pack_meta(-(k - 1), 3, 0);
+              A.span_taxon[rbase + ordb] = -2;
+            }
             nhits++;
             first = false;
             mate = 1;
@@ -454,6 +481,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
         if (emit) {
           int slot = (qhead + qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(E >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)E, 0))) & (QCAP - 1);
           L->q_key[slot] = ekey;
+          if (HITS) L->q_ord[slot] = (uint16_t)ord0;
           if (MODE == LANE_EMIT) L->q_meta[slot] = (uint32_t)lane | ((uint32_t)(np - 1) << 7);
           else L->q_meta[slot] = (uint32_t)lane | (distinct ? 64u : 0u) | ((uint32_t)ekmers << 7) |
                                  (MODE == LANE_APPLY ? (uint32_t)(np - 1) << 17 : 0u);
@@ -466,7 +494,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
           int back = 0;
           if (MODE == LANE_EMIT) emit_batch(L, S, A.status, qhead, 64, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1));
           else if (MODE == LANE_APPLY) apply_batch(L, S, qhead, 64, lane);
-          else if (!(dbg & 1)) back = probe_batch(L, A.T, qhead, qn, 64, lane, dbg);
+          else if (!(dbg & 1)) back = probe_batch<HITS>(L, A.T, qhead, qn, 64, lane, dbg, A.span_meta, A.span_taxon);
           qhead = (qhead + 64) & (QCAP - 1);
           qn += back - 64;
         }
@@ -478,7 +506,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       int back = 0;
       if (MODE == LANE_EMIT) emit_batch(L, S, A.status, qhead, cnt, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1));
       else if (MODE == LANE_APPLY) apply_batch(L, S, qhead, cnt, lane);
-      else if (!(dbg & 1)) back = probe_batch(L, A.T, qhead, qn, cnt, lane, dbg);
+      else if (!(dbg & 1)) back = probe_batch<HITS>(L, A.T, qhead, qn, cnt, lane, dbg, A.span_meta, A.span_taxon);
       qhead = (qhead + cnt) & (QCAP - 1);
       qn += back - cnt;
     }
@@ -534,6 +562,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
         if (A.out_nd) A.out_nd[r] = nd;
         if (A.out_tk) A.out_tk[r] = total;
         if (A.out_nh) A.out_nh[r] = nhits;
+        if (HITS) A.span_count[r] = nhits;
         if (A.out_np) A.out_np[r] = np;
       }
     }
@@ -541,7 +570,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
   }
 }
 
-template <int MODE>
+template <int MODE, bool HITS>
 static void launch_lane_mode(const FusedArgs &A, const ShardIO &S, int32_t *defer, uint32_t max_len, hipStream_t s) {
   if (A.R == 0) return;
   const bool w5 = A.P.w == 5;
@@ -558,19 +587,21 @@ static void launch_lane_mode(const FusedArgs &A, const ShardIO &S, int32_t *defe
   if (getenv("SLK_DEBUG_OCC") && !occ_printed) {  // (tuning aid)
     occ_printed = true;
     int nb = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, w5 ? (const void *)lane_kernel<true, MODE> : (const void *)lane_kernel<false, MODE>, LW * 64, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, w5 ? (const void *)lane_kernel<true, MODE, HITS> : (const void *)lane_kernel<false, MODE, HITS>, LW * 64, lds);
     fprintf(stderr, "[slk] lane kernel: %zu B LDS per block, %d blocks (%d waves) resident per CU\n", lds, nb, nb * LW);
   }
-  if (w5) hipLaunchKernelGGL((lane_kernel<true, MODE>), g, b, lds, s, A, S, defer, max_len, dbg);
-  else hipLaunchKernelGGL((lane_kernel<false, MODE>), g, b, lds, s, A, S, defer, max_len, dbg);
+  if (w5) hipLaunchKernelGGL((lane_kernel<true, MODE, HITS>), g, b, lds, s, A, S, defer, max_len, dbg);
+  else hipLaunchKernelGGL((lane_kernel<false, MODE, HITS>), g, b, lds, s, A, S, defer, max_len, dbg);
 }
 
+// A.span_taxon set: the hit lists are written too (span_meta / span_taxon / span_count, the layout of MODE_HITS)
 void launch_lane(const FusedArgs &A, int32_t *defer, uint32_t max_len, hipStream_t s) {
-  launch_lane_mode<LANE_LOCAL>(A, ShardIO{}, defer, max_len, s);
+  if (A.span_taxon) launch_lane_mode<LANE_LOCAL, true>(A, ShardIO{}, defer, max_len, s);
+  else launch_lane_mode<LANE_LOCAL, false>(A, ShardIO{}, defer, max_len, s);
 }
 void launch_lane_sharded(int mode, const FusedArgs &A, const ShardIO &S, int32_t *defer, uint32_t max_len, hipStream_t s) {
-  if (mode == LANE_EMIT) launch_lane_mode<LANE_EMIT>(A, S, defer, max_len, s);
-  else launch_lane_mode<LANE_APPLY>(A, S, defer, max_len, s);
+  if (mode == LANE_EMIT) launch_lane_mode<LANE_EMIT, false>(A, S, defer, max_len, s);
+  else launch_lane_mode<LANE_APPLY, false>(A, S, defer, max_len, s);
 }
 
 }  // namespace slk

@@ -299,3 +299,35 @@ def test_streams_on_threads_share_one_index(orc, world):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+def test_taxon_ids_beyond_22_bits(orc):
+    """The lane kernel packs (taxon << 10 | count) into one LDS word: taxon ids of 2^22 and more must take the wave kernel."""
+    import slacken_amd
+    rng = np.random.default_rng(2222)
+    small = taxgen.taxonomy(8 * 16, rng)
+    parents, remap = taxgen.sparse_relabel(small, 6_000_000, rng)
+    p = orc.params()
+
+    class L:
+        pass
+    L.genomes = [synth.random_dna(6000, rng) for _ in range(5)]
+    big_taxa = np.nonzero(parents)[0]
+    big_taxa = big_taxa[big_taxa > (1 << 22)]
+    assert len(big_taxa) >= 5
+    keys, tx = [], []
+    for g, t in zip(L.genomes, big_taxa[:5]):
+        kk = orc.minimizer_keys(p, g.tobytes())
+        keys.append(kk)
+        tx.append(np.full(len(kk), t, np.int32))
+    keys, idx = np.unique(np.concatenate(keys), return_index=True)
+    tx = np.concatenate(tx)[idx]
+    ix = slacken_amd.Index(expected_records=len(keys), max_taxon=len(parents) - 1)
+    assert ix.info().taxon_bits > 22
+    ix.append(keys, tx)
+    ix.set_taxonomy(parents)
+    ix.finalize()
+    reads = synth.make_reads(L, 800, rng)
+    world = dict(p=p, st=ix.stream(), oix=orc.Index(1, keys, tx), parents=parents)
+    got = check_classify(orc, world, reads, thresholds=(0.0, 0.2))
+    assert (got["taxon"][0] > (1 << 22)).any()
