@@ -5,9 +5,11 @@
 // the taxon map) is cheap per lane but expensive per wave; with one lane per read it costs nothing in scalar instructions
 // and every vector instruction does 64 reads' worth of work.  What a lane cannot do efficiently alone is the table probe
 // (a whole 64-byte bucket per lane costs 4x the address-unit work), so minimizers are pushed into a wave-shared LDS queue
-// and probed cooperatively: 8 lanes read one bucket (8 x 8 B = one HBM line), 8 probes per wave instruction.
+// and probed cooperatively: 4 lanes read one bucket (4 x 16 B = one HBM line), 16 probes per wave instruction, four
+// instructions in flight per batch of 64.
 //
-//   scan    each lane streams its read 16 bytes at a time (prefetched), rolls the forward and reverse-complement m-mer,
+//   scan    each lane consumes its read 16 bytes at a time (fetched 80 at a time, see stream_refill), rolls the forward and
+//           reverse-complement m-mer,
 //           takes the canonical / XOR / spaced-seed key, a width-w sliding minimum (registers for w = 5, a van-Herk
 //           prefix/suffix ring in LDS otherwise) and merges equal consecutive minima into super-mer spans.
 //           Reference: KeyValueIndex.getSpans (S/slacken/KeyValueIndex.scala:163-173) = Supermers.splitByAmbiguity /
