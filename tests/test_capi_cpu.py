@@ -58,3 +58,13 @@ def test_product_does_not_touch_the_oracle():
 
 def test_struct_layouts():
     assert capi.SPAN_DTYPE.itemsize == 16 and capi.HIT_DTYPE.itemsize == 8
+
+
+def test_header_is_plain_c(tmp_path):
+    """The ABI header must be consumable from C (a JNI shim, cgo, ...): C99, no warnings."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "slacken_amd.h"\nint main(void) { slk_params p = {35, 31, 7, 1, SLK_DEFAULT_TOGGLE_MASK, 1, 0}; '
+                   'slk_hit h = {0, 0}; (void)p; (void)h; return slk_device_count() < 0; }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)])
