@@ -181,3 +181,52 @@ def test_random_genomes_classify_to_ancestor_or_self(orc, seed):
     p = orc.params(k=k, m=m, spaces=spaces)
     want = orc.classify_batch(p, orc.Index(1, rec_k, rec_t), parents, rb, ro, thresholds=(0.0,), min_hit_groups=1)
     assert np.array_equal(got["taxon"], want["taxon"]) and np.array_equal(got["classified"], want["classified"])
+
+
+def test_real_contig_with_long_n_runs(orc):
+    """The reference's testData/Akashinriki_10k.fasta (one 599 940-base barley contig, 112 822 of them N in long runs; kept as
+    data under tests/golden): device library construction equals the oracle's, and the contig classifies identically as ONE
+    fragment (wave-per-read path, ~150 000 spans incl. ambiguous ones of thousands of k-mers) and cut into pieces."""
+    import gzip
+    import os
+    import hostmodel
+    import slacken_amd
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    (_, contig), = hostmodel.parse_fasta(gzip.open(os.path.join(gold, "akashinriki_10k.fasta.gz"), "rt").read())
+    assert len(contig) == 599940 and contig.count("N") == 112822
+    rng = np.random.default_rng(31)
+    parents = taxgen.taxonomy(8 * 8, rng)
+    p = orc.params()
+    other = bytearray(contig[100_000:400_000].encode())          # a relative: a stretch of the contig with 2 % substitutions
+    for i in rng.choice(len(other), len(other) // 50, replace=False):
+        other[i] = b"ACGT"[rng.integers(0, 4)]
+    seqs = [contig, other.decode()]
+    tx = [10, 20]
+    bases, offsets = pack(seqs)
+    want_k, want_t = orc.build_records(p, parents, bases, offsets, tx)
+    ix = slacken_amd.Index(expected_records=len(want_k) * 2, max_taxon=len(parents) - 1)
+    ix.set_taxonomy(parents)
+    ix.add_sequences(bases, offsets, tx)
+    got_k, got_t = ix.export()
+    assert np.array_equal(got_k, want_k) and np.array_equal(got_t, want_t)
+    ix.finalize()
+    oix = orc.Index(1, want_k, want_t)
+    st = ix.stream()
+    cuts = np.sort(rng.choice(len(contig), 400, replace=False))
+    pieces = [contig[a:b] for a, b in zip(np.concatenate([[0], cuts]), np.concatenate([cuts, [len(contig)]]))]
+    frags = [contig] + pieces + [contig[200_000:260_000].lower()]
+    fb, fo = pack(frags)
+    want = orc.classify_batch(p, oix, parents, fb, fo, thresholds=(0.0, 0.3))
+    for with_hits in (True, False):
+        got = st.classify_batch(fb, fo, thresholds=(0.0, 0.3), with_hits=with_hits)
+        for key in ("taxon", "classified", "num_distinct", "total_kmers"):
+            assert np.array_equal(got[key], want[key]), (key, with_hits)
+    full = st.classify_batch(fb, fo, thresholds=(0.0,), with_hits=True)
+    assert np.array_equal(full["num_hits"], want["num_hits"]) and want["num_hits"][0] > 100_000
+    ho = full["hit_offsets"].astype(np.int64)
+    for i in (0, 1, 57, len(frags) - 1):
+        _, hits = orc.classify_read(p, oix, parents, frags[i], None, 2, 0.0)
+        g = full["hits"][ho[i]:ho[i + 1]]
+        assert [(int(t), int(c)) for t, c in zip(g["taxon"], g["count"])] == hits
+        if i == 0:
+            assert any(t == -1 and c > 1000 for t, c in hits)       # an ambiguous span of thousands of k-mers
