@@ -142,11 +142,12 @@ struct Taxonomy {
   }
 
   // Taxonomy.children :186-195: built by PREPENDING while iterating taxids upward => each list is in descending id order
+  // (here: appended while iterating downward -- the same lists without the quadratic cost for taxa with 1e5 children)
   const std::vector<std::vector<Taxon>> &children() const {
     if (children_.empty()) {
       children_.assign(parents.size(), {});
-      for (Taxon t = 0; t < size(); t++)
-        if (isDefined(t)) children_[parents[t]].insert(children_[parents[t]].begin(), t);
+      for (Taxon t = size() - 1; t >= 0; t--)
+        if (isDefined(t)) children_[parents[t]].push_back(t);
     }
     return children_;
   }
