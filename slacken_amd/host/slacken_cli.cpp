@@ -486,11 +486,32 @@ static int cmd_classify2(int argc, char **argv) {
   return 0;
 }
 
+static const char *HELP =
+    "slacken-amd -- Slacken's classify path on an MI355X (libslacken_amd.so)\n"
+    "  slacken-amd [--partitions N] classify  -i INDEX -o OUTPUT [options] FILES...\n"
+    "  slacken-amd [--partitions N] classify2 -i INDEX -o OUTPUT --library DIR [options] FILES...\n"
+    "options of both (the reference's `classify`, Slacken.scala:66-100):\n"
+    "  -i, --index LOC        library location: LOC.properties, LOC_taxonomy/{nodes,names}.dmp, LOC/*.parquet (or LOC.slkrec)\n"
+    "  -o, --output PREFIX    writes PREFIX_c<threshold>/sample=<id>/part-*.txt.gz and PREFIX_c<threshold>/<id>_kreport.txt\n"
+    "  -c, --confidence T...  confidence thresholds in [0, 1] (default 0.0)\n"
+    "      --min-hits N       distinct minimizer hits needed to classify (default 2)\n"
+    "  -p, --paired           FILES are pairs (file_1 file_2 ...), joined by read id without /1 /2\n"
+    "      --sample-regex RE  group 1 of the first match in the read id names the sample\n"
+    "      --[no]unclassified keep (default) or drop unclassified reads\n"
+    "      --[no]detailed     per-read output (default) or reports only\n"
+    "  FILES                  FASTA / FASTQ, plain, .gz or .bz2; @list.txt names a file of file names\n"
+    "options of classify2 (Slacken.scala:199-260): --library DIR (DIR/library/**/*.fna, DIR/seqid2taxid.map), --rank RANK (species),\n"
+    "  -R, --reads N (100) | -C, --min-count N | -D, --min-distinct N, --init-confidence X (0.15)\n"
+    "host-only helpers: report TAXONOMY_DIR COUNTS_TSV | parse FILE [MATE_FILE] | props INDEX | records INDEX\n"
+    "environment: SLK_HOST_THREADS (formatting/decoding threads)\n";
+
 int main(int argc, char **argv) {
   int i = 1;
   while (i < argc && std::string(argv[i]) == "--partitions") i += 2;  // global Spark option of the reference: accepted, unused
-  if (i >= argc) die("usage: slacken-amd [--partitions N] classify|classify2|report|parse|props|records ...");
+  if (i >= argc) die("usage: slacken-amd [--partitions N] classify|classify2|report|parse|props|records ... (--help for the options)");
   std::string cmd = argv[i++];
+  if (cmd == "--help" || cmd == "-h" || cmd == "help") { std::cout << HELP; return 0; }
+  if (cmd == "--version") { std::cout << slk_version() << "\n"; return 0; }
   try {
     if (cmd == "classify") return cmd_classify(argc - i, argv + i);
     if (cmd == "classify2") return cmd_classify2(argc - i, argv + i);
