@@ -123,6 +123,29 @@ static int cmd_report(int argc, char **argv) {  // report <taxonomy dir> <counts
   KrakenReport(tax, counts).print(std::cout);
   return 0;
 }
+// taxonomy <taxonomy dir> <rank> <threshold> <counts.tsv>: the dynamic library's taxon selection on its own (Dynamic.scala
+// CountFilter :174-185 + Taxonomy.taxaWithDescendants :304-311): line 1 = the kept taxa, line 2 = with descendants
+static int cmd_taxonomy(int argc, char **argv) {
+  if (argc < 4) die("usage: taxonomy TAXONOMY_DIR RANK THRESHOLD COUNTS_TSV");
+  Taxonomy tax = Taxonomy::load(argv[0]);
+  int rank = rank_index(argv[1]);
+  if (rank == NO_RANK) die(std::string("unknown rank ") + argv[1]);
+  long threshold = std::stol(argv[2]);
+  std::ifstream f(argv[3]);
+  std::vector<std::pair<Taxon, long>> counts;
+  Taxon t; long c;
+  while (f >> t >> c) counts.emplace_back(t, c);
+  KrakenReport agg(tax, counts);
+  std::vector<Taxon> keep;
+  for (auto &kv : agg.taxonCounts)
+    if (tax.depth(kv.first) >= rank - 1 && agg.clade(kv.first) >= threshold) keep.push_back(kv.first);
+  for (Taxon k : keep) std::cout << k << ' ';
+  std::cout << '\n';
+  auto in = tax.withDescendants(keep);
+  for (Taxon i = 0; i < tax.size(); i++) if (in[i]) std::cout << i << ' ';
+  std::cout << '\n';
+  return 0;
+}
 static int cmd_parse(int argc, char **argv) {  // parse <file> [<file2>]: header \t nucleotides [\t nucleotides2]
   if (argc < 1) die("usage: parse FILE [MATE_FILE]");
   std::vector<std::string> files(argv, argv + std::min(argc, 2));
@@ -519,6 +542,7 @@ int main(int argc, char **argv) {
     if (cmd == "parse") return cmd_parse(argc - i, argv + i);
     if (cmd == "props") return cmd_props(argc - i, argv + i);
     if (cmd == "records") return cmd_records(argc - i, argv + i);
+    if (cmd == "taxonomy") return cmd_taxonomy(argc - i, argv + i);
   } catch (const std::exception &e) {
     die(e.what());
   }

@@ -233,3 +233,30 @@ def test_streaming_parser_is_chunk_border_proof(tmp_path, chunk):
     b.write_text("".join(f"@{i}/2\n{'TTGA' * 2}{ids.index(i)}\n+\nIIII\n" for i in order))
     got = parse(a, b)
     assert got == [(i, f"{'ACGT' * 3}{n}", f"{'TTGA' * 2}{n}") for n, i in enumerate(ids) if i != "p7"]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_dynamic_taxon_selection_matches_restatement(tmp_path, seed):
+    """`slacken-amd taxonomy`: Taxonomy.depth (nearest ranked ancestor-or-self), CountFilter and taxaWithDescendants of the C++
+    host against tests/hostmodel.py, on random taxonomies with unranked nodes (Dynamic.scala:174-185, Taxonomy.scala:217-224,
+    304-311; the reference's TaxonomyProps.scala checks the same invariants on its own implementation)."""
+    rng = np.random.default_rng(seed)
+    parents = taxgen.taxonomy(300, rng)
+    tax = write_taxonomy(str(tmp_path / "tax"), parents, rng, ranked=0.6)
+    defined = [t for t in range(1, len(parents)) if t == 1 or parents[t] != 0]
+    counts = sorted({int(t): int(rng.integers(1, 60)) for t in rng.choice(defined, size=60, replace=False)}.items())
+    with open(tmp_path / "c.tsv", "w") as f:
+        for t, c in counts:
+            f.write(f"{t}\t{c}\n")
+    for rank in ("species", "genus", "phylum"):
+        rd = hostmodel.RANKS.index(rank) - 1
+        for threshold in (1, 25, 100):
+            out = run("taxonomy", tmp_path / "tax", rank, threshold, tmp_path / "c.tsv").split("\n")
+            keep = [int(x) for x in out[0].split()]
+            full = [int(x) for x in out[1].split()]
+            want = hostmodel.count_filter(tax, counts, rd, threshold)
+            assert keep == want
+            assert full == sorted(hostmodel.with_descendants(tax, want))
+            # TaxonomyProps-style invariants: every kept taxon is in the closure; the closure is closed under children
+            assert set(keep) <= set(full)
+            assert all(c in set(full) for t in full for c in tax.children[t])
