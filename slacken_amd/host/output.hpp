@@ -131,7 +131,7 @@ struct ClassifiedBatch {
   std::vector<int32_t> taxon;
   std::vector<uint8_t> classified;
   std::vector<uint64_t> hit_offs;
-  std::vector<slk_hit> hits;
+  std::unique_ptr<slk_hit[]> hits;  // hit_offs[n] entries (allocated uninitialised: zero-filling 8 bytes per base per batch showed)
   std::vector<uint64_t> span_offs;  // only when spans were requested
   std::vector<slk_span> spans;
 };

@@ -280,11 +280,38 @@ struct DeviceIndex {
 template <class F>
 static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &files, bool paired, int min_hits,
                             const std::vector<double> &thresholds, bool want_spans, F f) {
-  BatchPrefetcher reader(files, paired);
+  // Several input files (or pairs) are read side by side, each on its own threads -- a gzip stream inflates on one core -- and
+  // their batches are taken in turn: the order of the output is deterministic, though interleaved between files at batch
+  // granularity (the reference's output order is whatever Spark's partitions give).
+  const size_t unit = paired ? 2 : 1;
+  const size_t nsrc = files.size() / unit;
+  const char *cenv = getenv("SLK_INPUT_STREAMS");
+  const size_t conc = std::max<size_t>(1, std::min<size_t>(nsrc, cenv ? (size_t)atol(cenv) : 8));
+  std::vector<std::unique_ptr<BatchPrefetcher>> active;
+  size_t next_src = 0;
+  auto open_next = [&]() -> std::unique_ptr<BatchPrefetcher> {
+    if (next_src >= nsrc) return nullptr;
+    std::vector<std::string> fs(files.begin() + next_src * unit, files.begin() + (next_src + 1) * unit);
+    next_src++;
+    return std::make_unique<BatchPrefetcher>(fs, paired);
+  };
+  while (active.size() < conc) { auto r = open_next(); if (!r) break; active.push_back(std::move(r)); }
+  size_t turn = 0;
+  auto next_batch = [&]() -> std::unique_ptr<FragmentBatch> {
+    while (!active.empty()) {
+      if (turn >= active.size()) turn = 0;
+      auto b = active[turn]->next();
+      if (b) { turn++; return b; }
+      auto r = open_next();  // this file is exhausted: the next unopened one takes its place in the rotation
+      if (r) active[turn] = std::move(r);
+      else active.erase(active.begin() + turn);
+    }
+    return nullptr;
+  };
   const int C = (int)thresholds.size();
   std::vector<int32_t> nd, tk;
   size_t total = 0;
-  while (auto frags = reader.next()) {
+  while (auto frags = next_batch()) {
     auto b = std::make_shared<ClassifiedBatch>();
     b->frags = std::move(frags);
     b->C = C;
@@ -294,13 +321,11 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
     b->taxon.resize((size_t)C * n); b->classified.resize((size_t)C * n); nd.resize(n); tk.resize(n);
     b->hit_offs.resize(n + 1);
     const size_t cap = fb.bases.size() + fb.mate_bases.size() + n + 1;
-    b->hits.resize(cap);
+    b->hits.reset(new slk_hit[cap]);  // (no zero-fill; the untouched tail of the allocation is never paged in)
     const uint8_t *mb = fb.paired ? fb.mate_bases.data() : nullptr;
     const uint64_t *mo = fb.paired ? fb.mate_offs.data() : nullptr;
     SLK_CALL(slk_classify_batch(dev.ix, dev.st, fb.bases.data(), fb.offs.data(), mb, mo, n, min_hits, thresholds.data(), C,
-                                b->taxon.data(), b->classified.data(), nd.data(), tk.data(), b->hit_offs.data(), b->hits.data(), cap));
-    b->hits.resize(b->hit_offs[n]);
-    b->hits.shrink_to_fit();
+                                b->taxon.data(), b->classified.data(), nd.data(), tk.data(), b->hit_offs.data(), b->hits.get(), cap));
     if (want_spans) {
       b->span_offs.resize(n + 1);
       b->spans.resize(cap);
@@ -526,7 +551,7 @@ static const char *HELP =
     "options of classify2 (Slacken.scala:199-260): --library DIR (DIR/library/**/*.fna, DIR/seqid2taxid.map), --rank RANK (species),\n"
     "  -R, --reads N (100) | -C, --min-count N | -D, --min-distinct N, --init-confidence X (0.15)\n"
     "host-only helpers: report TAXONOMY_DIR COUNTS_TSV | parse FILE [MATE_FILE] | props INDEX | records INDEX\n"
-    "environment: SLK_HOST_THREADS (formatting/decoding threads)\n";
+    "environment: SLK_HOST_THREADS (formatting/decoding threads), SLK_INPUT_STREAMS (input files read side by side, default 8)\n";
 
 int main(int argc, char **argv) {
   int i = 1;

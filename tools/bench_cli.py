@@ -58,6 +58,24 @@ def main():
         assert r.returncode == 0, r.stderr
         out[name + "_log"] = [l for l in r.stderr.split("\n") if "task" in l or "fragments" in l]
         out[name] = dict(reads=R, seconds=round(dt, 2), M_reads_per_s=round(R / dt / 1e6, 3))
+    # the same reads as one gzip file and as eight: input files are inflated and parsed side by side
+    import gzip
+    parts = [os.path.join(d, f"part{i}.fq.gz") for i in range(8)]
+    lines = open(fq, "rb").read().split(b"\n")
+    per = (len(lines) // 4 + 7) // 8 * 4
+    for i, pth in enumerate(parts):
+        with gzip.open(pth, "wb", compresslevel=1) as f:
+            f.write(b"\n".join(lines[i * per:(i + 1) * per]) + b"\n")
+    one = os.path.join(d, "all.fq.gz")
+    with gzip.open(one, "wb", compresslevel=1) as f:
+        f.write(open(fq, "rb").read())
+    for name, inputs in (("gz_one_file", [one]), ("gz_eight_files", parts)):
+        t0 = time.perf_counter()
+        r = subprocess.run([os.path.join(ROOT, "slacken_amd", "bin", "slacken-amd"), "classify", "-i", loc, "-o",
+                            os.path.join(d, "out_" + name), *inputs], capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        assert r.returncode == 0, r.stderr
+        out[name] = dict(reads=R, seconds=round(dt, 2), M_reads_per_s=round(R / dt / 1e6, 3))
     # classify2: the two-step run with a dynamic library built on the device from the genome FASTA files
     libdir = os.path.join(d, "k2")
     os.makedirs(os.path.join(libdir, "library", "bacteria"))
