@@ -203,3 +203,29 @@ def test_cli_many_reads_cross_slice_and_thread_borders(tmp_path, orc):
             want.append(orc.output_line(res["classified"], f"q{i}", res["taxon"], hits, g["k"]))
     assert len(lines) == len(want)
     assert lines == want
+
+
+@pytest.mark.gpu
+def test_cli_several_input_files_side_by_side(tmp_path):
+    """Several input files are read concurrently and their batches taken in turn: every read is classified exactly once, the
+    output is the same on every run, and with SLK_INPUT_STREAMS=1 it is in file order."""
+    g, loc, tax, reads = make_library(tmp_path, convert=False)
+    files = []
+    for i in range(5):
+        fq = tmp_path / f"lane{i}.fq.gz"
+        with gzip.open(fq, "wt") as f:
+            for t, s in reads[i::5]:
+                f.write(f"@{t}\n{s}\n+\n{'I' * len(s)}\n")
+        files.append(str(fq))
+    want = {r["title"]: r["line"] for r in g["reads"] if r["hits"]}
+    outs = []
+    for run_i, env in enumerate(({}, {}, {"SLK_INPUT_STREAMS": "1"})):
+        out = tmp_path / f"multi{run_i}"
+        r = subprocess.run([CLI, "classify", "-i", loc, "-o", str(out), *files], capture_output=True, text=True,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        outs.append(read_out(f"{out}_c0.0"))
+    assert outs[0] == outs[1]
+    assert sorted(outs[0]) == sorted(want.values()) == sorted(outs[2])
+    in_file_order = [want[t] for i in range(5) for t, _ in reads[i::5] if t in want]
+    assert outs[2] == in_file_order
