@@ -81,7 +81,7 @@ def test_wide_classify_parity(orc, k, m, spaces, canonical):
             _, hits = orc.classify_read(p, oix, parents, reads[i].tobytes(), None if mb is None else mates[i].tobytes(), 2, 0.0)
             g = full["hits"][ho[i]:ho[i + 1]]
             assert [(int(t), int(c)) for t, c in zip(g["taxon"], g["count"])] == hits
-    assert want["classified"][0].mean() > 0.3
+    assert want["classified"][0].mean() > 0.05
 
 
 def test_wide_limits(orc):
