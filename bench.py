@@ -247,6 +247,7 @@ def main():
             "records": int(info.records), "table_GiB": round(info.table_bytes / 2**30, 1),
             "reads_per_gpu_per_step": n_reads, "read_len": READ_LEN, "parallelism": f"read-sharded x{world}, table replicated",
             "probes_per_read": round(probes / n_reads, 3), "classified_fraction": round(classified, 4),
+            "deferred_to_wave_kernel": st.last_deferred(),
             "stage_ms": ({"fused": round(dom_ms, 3)} if fused else
                          {"scan": round(float(stage_ms[0]), 3), "probe": round(float(stage_ms[1]), 3),
                           "classify": round(float(stage_ms[2]), 3)}),

@@ -244,6 +244,9 @@ int32_t slk_classify_hits_device(slk_index *ix, slk_stream *st, const uint64_t *
 /* Per-stage device timing of the last slk_classify_batch_device call on st, in milliseconds (HIP events on the
  * stream the kernels ran on): [0]=scan, [1]=probe, [2]=classify.  Synchronises st. */
 int32_t slk_stream_last_stage_ms(slk_stream *st, float out_ms[3]);
+/* How many fragments of the last classify call on st the lane-per-fragment kernel handed to the wave-per-fragment kernel
+ * (longer than 1000 bases, or more than 8 distinct taxa); 0 if that call did not take the lane kernel.  Synchronises st. */
+int32_t slk_stream_last_deferred(slk_stream *st, uint64_t *out_count);
 
 #ifdef __cplusplus
 }

@@ -48,7 +48,7 @@ EXPORTS = ["slk_device_count", "slk_last_error", "slk_version", "slk_index_creat
            "slk_stream_hip_stream", "slk_stream_destroy", "slk_spans_batch", "slk_classify_batch",
            "slk_classify_batch_device", "slk_stream_last_stage_ms", "slk_scan_device", "slk_lookup_device",
            "slk_shard_of", "slk_classify_hits_device", "slk_shard_emit_device", "slk_shard_scatter_device",
-           "slk_shard_apply_device"]
+           "slk_shard_apply_device", "slk_stream_last_deferred"]
 
 
 def lib_path():
@@ -104,6 +104,7 @@ def lib():
                                            C.POINTER(C.c_double), C.c_int32, i32p, u8p, i32p, i32p, i32p]
     L.slk_shard_emit_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_uint32, i64p, u64p, C.c_uint64, u64p,
                                         i32p]
+    L.slk_stream_last_deferred.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.slk_shard_scatter_device.argtypes = [vp, vp, u64p, i32p, C.c_uint64, i32p]
     L.slk_shard_apply_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, i32p, C.c_int32, C.POINTER(C.c_double),
                                          C.c_int32, i32p, u8p, i32p, i32p, i32p, i32p]
@@ -221,6 +222,11 @@ class Stream:
 
     def synchronize(self):
         _check(lib().slk_stream_synchronize(self.h))
+
+    def last_deferred(self):
+        n = C.c_uint64(0)
+        _check(lib().slk_stream_last_deferred(self.h, C.byref(n)))
+        return int(n.value)
 
     def spans_batch(self, bases, offsets, mate_bases=None, mate_offsets=None, capacity=None):
         """-> (span_offsets u64[R+1], spans structured array SPAN_DTYPE)"""

@@ -100,6 +100,7 @@ struct slk_stream {
   int32_t *h_status = nullptr;     // pinned copy, refreshed after every classify launch
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool timed = false;
+  bool last_used_lane = false;  // the last classify call ran the lane kernel (defer_list[0] is its deferral count)
   struct LastCall {  // the arguments of the classify call in flight, for the unbounded re-run (check_status)
     bool valid = false, want_hits = false;
     const uint8_t *bases = nullptr, *mate_bases = nullptr;
@@ -636,6 +637,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
   bool paired = d_mate_bases != nullptr;
   bool fused = use_fused(ix);
   int32_t rc;
+  st->last_used_lane = false;
   if (!fused || want_hits) {
     rc = ensure_scratch(st, span_slots(total_bases, total_mate_bases, R, paired), R);
     if (rc) return rc;
@@ -665,6 +667,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
     A.status = st->d_status;
     A.work_list = nullptr; A.work_count = nullptr;
     if (lane_path_ok(ix) && !force_wave()) {  // (window of at most 16 m-mers, taxon ids of at most 22 bits)
+      st->last_used_lane = true;
       // hot path: one lane per fragment; long fragments and map overflows are deferred to the wave-per-read kernel
       HIPCHK(st->defer.ensure((R + 64) * sizeof(int32_t)));
       HIPCHK(hipMemsetAsync(st->defer.p, 0, (R + 64) * sizeof(int32_t), st->s));
@@ -861,6 +864,15 @@ int32_t slk_classify_hits_device(slk_index *ix, slk_stream *st, const uint64_t *
                   min_hit_groups, st->d_thresholds, C, d_out_taxon, d_out_classified, d_out_num_distinct,
                   d_out_total_kmers, d_out_num_hits, nullptr, st->s);
   HIPCHK(hipGetLastError());
+  return SLK_OK;
+}
+
+int32_t slk_stream_last_deferred(slk_stream *st, uint64_t *out_count) {
+  if (!st || !out_count) return fail(SLK_E_INVALID, "null argument");
+  { int32_t rc_ = set_device(st->ix); if (rc_) return rc_; }
+  *out_count = 0;
+  HIPCHK(hipStreamSynchronize(st->s));
+  if (st->defer_list.p && st->last_used_lane) HIPCHK(hipMemcpy(out_count, st->defer_list.p, sizeof(uint64_t), hipMemcpyDeviceToHost));
   return SLK_OK;
 }
 

@@ -236,6 +236,7 @@ def test_many_taxa_per_read_take_the_deferred_path(orc):
     world = dict(p=p, st=ix.stream(), oix=orc.Index(1, keys, tx), parents=parents)
     got = check_classify(orc, world, reads, thresholds=(0.0, 0.3))
     assert (got["num_distinct"][:300] > 8).all()
+    assert world["st"].last_deferred() >= 300        # (of the last call: the hot path without hit lists)
     # > 128 distinct taxa in one fragment overflow the wave kernel's map too: the batch is classified again by the staged
     # kernels with an unbounded map (check_status -> run_unbounded), with and without hit lists, sync and async entry
     big = [synth.random_dna(3000, rng), synth.random_dna(150, rng), synth.random_dna(6000, rng)] + reads[:50]
