@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Hot-path throughput on a library with phylogenetic structure: genomes evolve along the taxonomy (each child = its parent with
+a few per cent substitutions), so minimizers carry LCA taxa at every rank and a read hits several distinct taxa -- the per-read
+resolveTree really walks the tree, unlike on bench.py's independent random genomes (one taxon per read).  GPU box."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import slacken_amd
+    rng = np.random.default_rng(11)
+    # a regular tree: 8 ranks, fan-out 2 below the root's 2 children => 256 leaves
+    parents = [0, 0]
+    level = [1]
+    for d in range(8):
+        nxt = []
+        for p in level:
+            for _ in range(2):
+                parents.append(p)
+                nxt.append(len(parents) - 1)
+        level = nxt
+    parents = np.array(parents, np.int32)
+    leaves = level
+    L = 1 << 18
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    genome = {1: acgt[rng.integers(0, 4, L, dtype=np.uint8)]}
+    order = [t for t in range(2, len(parents))]
+    rate = float(os.environ.get("RATE", 0.02))
+    for t in order:                               # parents precede children by construction
+        g = genome[int(parents[t])].copy()
+        sub = rng.random(L) < rate
+        g[sub] = acgt[rng.integers(0, 4, int(sub.sum()), dtype=np.uint8)]
+        genome[t] = g
+    bases = np.concatenate([genome[t] for t in leaves])
+    offsets = np.arange(len(leaves) + 1, dtype=np.uint64) * np.uint64(L)
+    ix = slacken_amd.Index(expected_records=int(len(leaves) * L * 0.4), max_taxon=len(parents) - 1)
+    ix.set_taxonomy(parents)
+    ix.add_sequences(bases, offsets, np.array(leaves, np.int32))
+    ix.finalize()
+    _, taxa = ix.export()
+    depth = np.zeros(len(parents), np.int32)
+    for t in range(2, len(parents)):
+        depth[t] = depth[parents[t]] + 1
+    hist = np.bincount(depth[taxa], minlength=9)
+    R = 4_000_000
+    d_all = torch.from_numpy(bases).cuda()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1)
+    stt = torch.randint(0, len(bases) - 150, (R,), generator=g, device="cuda")
+    d_b = torch.cat([d_all[(stt[:, None] + torch.arange(150, device="cuda")[None, :]).reshape(-1)], torch.zeros(64, dtype=torch.uint8, device="cuda")])
+    d_o = torch.arange(0, (R + 1) * 150, 150, dtype=torch.int64, device="cuda")
+    d_t = torch.zeros(2 * R, dtype=torch.int32, device="cuda")
+    d_c = torch.zeros(2 * R, dtype=torch.uint8, device="cuda")
+    d_nd = torch.zeros(R, dtype=torch.int32, device="cuda")
+    st = ix.stream()
+    out = {}
+    for thr in ((0.0,), (0.0, 0.15)):
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st.classify_batch_device(d_b.data_ptr(), d_o.data_ptr(), R, R * 150, d_t.data_ptr(), d_c.data_ptr(), d_nd.data_ptr(), thresholds=thr)
+            st.synchronize()
+            dt = time.perf_counter() - t0
+        out[f"thresholds_{len(thr)}"] = dict(ms=round(dt * 1e3, 2), M_reads_per_s=round(R / dt / 1e6, 1), deferred=st.last_deferred())
+    lvl = depth[d_t[:R].cpu().numpy()]
+    out.update(records=int(ix.info().records), records_by_depth=hist.tolist(), classified=float(d_c[:R].float().mean()),
+               calls_by_depth=np.bincount(lvl, minlength=9).tolist(), substitution_rate_per_level=rate)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
