@@ -217,7 +217,7 @@ uint32_t slk_shard_of(int64_t key, uint32_t n_shards);
  *   slk_shard_apply_device  scans again and classifies, taking probe j of fragment r from d_taxa_by_slot: same outputs
  *                           as slk_classify_batch_device.
  * d_defer[R] (zeroed by slk_shard_emit_device) is set to 1 for fragments this path does not take (longer than 1000 bases,
- * or more than 8 distinct taxa): classify those with the staged calls above.  SLK_E_UNSUPPORTED if the index's splitter
+ * or more than 12 distinct taxa): classify those with the staged calls above.  SLK_E_UNSUPPORTED if the index's splitter
  * is outside the fused kernel's range (window wider than 16 m-mers or taxon ids beyond 22 bits): use the staged calls. */
 int32_t slk_shard_emit_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
                               const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
@@ -245,7 +245,7 @@ int32_t slk_classify_hits_device(slk_index *ix, slk_stream *st, const uint64_t *
  * stream the kernels ran on): [0]=scan, [1]=probe, [2]=classify.  Synchronises st. */
 int32_t slk_stream_last_stage_ms(slk_stream *st, float out_ms[3]);
 /* How many fragments of the last classify call on st the lane-per-fragment kernel handed to the wave-per-fragment kernel
- * (longer than 1000 bases, or more than 8 distinct taxa); 0 if that call did not take the lane kernel.  Synchronises st. */
+ * (longer than 1000 bases, or more than 12 distinct taxa); 0 if that call did not take the lane kernel.  Synchronises st. */
 int32_t slk_stream_last_deferred(slk_stream *st, uint64_t *out_count);
 
 #ifdef __cplusplus

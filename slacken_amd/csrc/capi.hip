@@ -588,7 +588,7 @@ static bool force_wave() {  // SLK_FORCE_WAVE=1: A/B switch, classify with the w
 static int32_t ensure_scratch(slk_stream *st, uint64_t slots, uint64_t R);
 static uint64_t span_slots(uint64_t total_bases, uint64_t total_mate_bases, uint64_t R, bool paired);
 
-// The fused kernels keep a fragment's taxon -> count map in LDS (8 slots per lane, 128 per wave).  A fragment that hits more
+// The fused kernels keep a fragment's taxon -> count map in LDS (12 slots per lane, 128 per wave).  A fragment that hits more
 // distinct taxa than that (long reads across conserved regions can) raises status bit 1; the batch is then classified again
 // by the staged kernels, whose per-fragment map lives in HBM scratch and is unbounded -- the same three kernels that serve
 // windows wider than 32 m-mers.  Slower (HBM intermediates), rare, and bit-identical for every other fragment.

@@ -1,5 +1,5 @@
 // fused.hip -- ONE WAVEFRONT PER FRAGMENT (the lane-per-fragment kernel of lane.hip takes the short fragments; this one takes
-// what that one hands back -- fragments over 1000 bases or with more than 8 distinct taxa -- windows of 17..32 m-mers, and the
+// what that one hands back -- fragments over 1000 bases or with more than 12 distinct taxa -- windows of 17..32 m-mers, and the
 // span output): scan -> probe -> per-read LCA fused in one launch, no
 // HBM intermediates (spans, hits and the per-read taxon map live in registers / LDS).  gfx950, wave64.  Integer/byte
 // work bounded by random 64-byte HBM probes: no MFMA.

@@ -17,15 +17,16 @@
 //           (S/kmers/minimizer/MinSplitter.scala:133-172), PosRankWindow (PosRankWindow.scala:33-97), ShiftScanner.allMatches
 //           (ShiftScanner.scala:90-159), RandomXOR/SpacedSeed (MinimizerPriorities.scala:144-321).
 //   probe   the left join + spanToHit (S/slacken/Classifier.scala:84-88, KeyValueIndex.scala:176-185).
-//   LCA     hits are folded (LDS atomics) into an 8-slot taxon->count map per read; NONE hits are never needed by
+//   LCA     hits are folded (LDS atomics) into a 12-slot taxon->count map per read; NONE hits are never needed by
 //           resolveTree and are only counted; one distinct taxon is resolved without touching the tree.
 //           Reference: TaxonCounts.toMap/totalKmers (S/slacken/TaxonCounts.scala:70-87), LowestCommonAncestor
 //           (S/slacken/LowestCommonAncestor.scala:49-146), Classifier.classify (S/slacken/Classifier.scala:439-454).
-// Fragments longer than LANE_MAX_LEN, and fragments whose 8-slot map overflows, are flagged in `defer` and re-done by the
+// Fragments longer than LANE_MAX_LEN, and fragments whose 12-slot map overflows, are flagged in `defer` and re-done by the
 // wave-per-read kernel of fused.hip in the same stream.  With A.span_taxon set the kernel also writes the un-merged hit lists
 // (TaxonHit per span, ordinal order) into the fragments' span regions, the layout fused.hip's MODE_HITS uses.
 #include "engine.h"
 
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 
@@ -40,7 +41,10 @@ constexpr int QCAP = 128;         // probe queue entries per wave (64 buffered +
 #define SLK_SBLK 5
 #endif
 constexpr int SBLK = SLK_SBLK;           // read stream: 16-byte sub-blocks fetched per refill (48 bytes per lane)
-constexpr int OMAP = 8;           // taxon map slots per fragment
+#ifndef SLK_OMAP
+#define SLK_OMAP 12
+#endif
+constexpr int OMAP = SLK_OMAP;    // taxon map slots per fragment (any number; 12 is what the LDS left at four blocks per CU holds)
 constexpr int OMAP_CNT_BITS = 10; // a fragment the lane kernel takes has <= LANE_MAX_LEN (1000) k-mers; taxon ids need <= 22 bits
 constexpr uint32_t OMAP_CNT_MASK = (1u << OMAP_CNT_BITS) - 1;
 
@@ -76,21 +80,21 @@ __device__ __forceinline__ void lane_wave_sync() {
 }
 __device__ __forceinline__ uint64_t lmin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
 
-// Fold entry `meta`'s hit into its owner's 8-slot map: ONE round of LDS atomics per batch (NONE hits carry no information
+// Fold entry `meta`'s hit into its owner's 12-slot map: ONE round of LDS atomics per batch (NONE hits carry no information
 // for resolveTree and are dropped).
 __device__ __forceinline__ void fold_hit(LaneLds *L, bool in, uint32_t meta, int32_t taxon) {
   if (in && taxon != 0) {
     const int owner = meta & 63;
     const int32_t kmers = (int32_t)((meta >> 7) & 0x3FF);
     if (meta & 64) atomicAdd(&L->o_flags[owner], 1u);  // distinct && taxon != NONE (Classifier.scala:94)
-    uint32_t slot = ((uint32_t)taxon * 0x9E3779B1u) >> 29;
+    uint32_t slot = (uint32_t)(((uint64_t)((uint32_t)taxon * 0x9E3779B1u) * (uint32_t)OMAP) >> 32);  // hash -> [0, OMAP)
     const uint32_t fresh = ((uint32_t)taxon << OMAP_CNT_BITS) | (uint32_t)kmers;
     int p = 0;
     for (; p < OMAP; p++) {
       uint32_t old = atomicCAS(&L->omap[slot * 64 + owner], 0u, fresh);
       if (old == 0u) break;
       if ((old >> OMAP_CNT_BITS) == (uint32_t)taxon) { atomicAdd(&L->omap[slot * 64 + owner], (uint32_t)kmers); break; }
-      slot = (slot + 1) & (OMAP - 1);
+      slot = (slot + 1 == (uint32_t)OMAP) ? 0u : slot + 1;
     }
     if (p == OMAP) atomicOr(&L->o_flags[owner], 0x80000000u);
   }
@@ -100,7 +104,7 @@ __device__ __forceinline__ void fold_hit(LaneLds *L, bool in, uint32_t meta, int
 //   1. lane i hashes entry i and parks (home bucket, tag) in LDS;
 //   2. FOUR lanes read one 64-byte bucket (4 x 16 B = one HBM line), sixteen probes per wave instruction, four
 //      instructions in flight before the first compare; the lane that finds the key writes the taxon to result[entry];
-//   3. lane i folds entry i's hit into its owner's 8-slot map: ONE round of LDS atomics per batch (NONE hits carry no
+//   3. lane i folds entry i's hit into its owner's 12-slot map: ONE round of LDS atomics per batch (NONE hits carry no
 //      information for resolveTree and are dropped).
 template <bool HITS>
 __device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int qhead, int qn, int cnt, int lane, int dbg,
@@ -296,9 +300,11 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
   const ScanParams P = A.P;
   const int k = P.k, m = P.m, w = P.w;
   // per-wave LDS: fixed part, then (generic w only) the key ring and the suffix-minimum ring, [w][64] each
-  const size_t per_wave = sizeof(LaneLds) + (W5 ? 0 : (size_t)2 * w * 64 * sizeof(uint64_t));
+  // (the hit-list fields are the struct's tail: kernels that do not write hit lists leave them out of their footprint)
+  const size_t fixed = HITS ? sizeof(LaneLds) : offsetof(LaneLds, rb);
+  const size_t per_wave = fixed + (W5 ? 0 : (size_t)2 * w * 64 * sizeof(uint64_t));
   LaneLds *L = (LaneLds *)(lds_raw + (size_t)wib * per_wave);
-  uint64_t *ring = (uint64_t *)((unsigned char *)L + sizeof(LaneLds));
+  uint64_t *ring = (uint64_t *)((unsigned char *)L + fixed);
   uint64_t *suf = ring + (size_t)w * 64;
   const bool paired = A.mate_bases != nullptr;
   const uint64_t ntiles = (A.R + 63) / 64;
@@ -576,7 +582,7 @@ template <int MODE, bool HITS>
 static void launch_lane_mode(const FusedArgs &A, const ShardIO &S, int32_t *defer, uint32_t max_len, hipStream_t s) {
   if (A.R == 0) return;
   const bool w5 = A.P.w == 5;
-  size_t per_wave = sizeof(LaneLds) + (w5 ? 0 : (size_t)2 * A.P.w * 64 * sizeof(uint64_t));
+  size_t per_wave = (HITS ? sizeof(LaneLds) : offsetof(LaneLds, rb)) + (w5 ? 0 : (size_t)2 * A.P.w * 64 * sizeof(uint64_t));
   static const int extra_lds = getenv("SLK_LANE_EXTRA_LDS") ? atoi(getenv("SLK_LANE_EXTRA_LDS")) : 0;  // (occupancy experiment)
   size_t lds = per_wave * LW + (size_t)extra_lds;
   uint64_t tiles = (A.R + 63) / 64;

@@ -8,7 +8,7 @@ mode (no collective at all).
 Host plumbing only: torch for device buffers and the collectives, the engine for all compute.  Two routes:
   fast    slk_shard_emit_device -> all-to-all -> slk_lookup_device -> all-to-all -> slk_shard_scatter_device ->
           slk_shard_apply_device: the fused lane-per-fragment kernel runs on both sides of the exchange, no span arrays;
-          takes fragments of up to 1000 bases with at most 8 distinct taxa;
+          takes fragments of up to 1000 bases with at most 12 distinct taxa;
   staged  slk_scan_device / slk_lookup_device / slk_classify_hits_device with the exchange lists built by torch ops: takes
           everything, and the fragments the fast route hands back (`defer`)."""
 import numpy as np

@@ -91,7 +91,7 @@ def test_two_ranks_half_table_each(orc, tmp_path, fast):
 @pytest.mark.gpu
 def test_single_rank_fast_route_with_deferrals(orc):
     """world = 1: no exchange, but the same emit -> lookup -> scatter -> apply pipeline, incl. fragments the fused kernel
-    hands back (longer than 1000 bases; more than 8 distinct taxa) and empty / vanishing fragments."""
+    hands back (longer than 1000 bases; more than 12 distinct taxa) and empty / vanishing fragments."""
     import synth
     import taxgen
     rng = np.random.default_rng(43)
