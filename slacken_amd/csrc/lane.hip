@@ -237,9 +237,27 @@ struct OwnerMap {  // this lane's column of the LDS maps
   int lane;
   __device__ __forceinline__ int32_t key(int s) const { return (int32_t)(L->omap[s * 64 + lane] >> OMAP_CNT_BITS); }  // 0 = empty
   __device__ __forceinline__ int32_t cnt(int s) const { return (int32_t)(L->omap[s * 64 + lane] & OMAP_CNT_MASK); }
+  // the map is a hash table (fold_hit): follow t's probe sequence to its entry or to the first empty slot -- one or two LDS
+  // reads instead of a scan of all slots, for every node of every root path resolveTree walks
   __device__ __forceinline__ int32_t get(int32_t t) const {
-    for (int s = 0; s < OMAP; s++) if (key(s) == t) return cnt(s);
+    uint32_t slot = (uint32_t)(((uint64_t)((uint32_t)t * 0x9E3779B1u) * (uint32_t)OMAP) >> 32);
+    for (int p = 0; p < OMAP; p++) {
+      const uint32_t e = L->omap[slot * 64 + lane];
+      if (e == 0) return 0;
+      if ((int32_t)(e >> OMAP_CNT_BITS) == t) return (int32_t)(e & OMAP_CNT_MASK);
+      slot = (slot + 1 == (uint32_t)OMAP) ? 0u : slot + 1;
+    }
     return 0;
+  }
+  __device__ __forceinline__ int find(int32_t t) const {  // slot of taxon t, or -1
+    uint32_t slot = (uint32_t)(((uint64_t)((uint32_t)t * 0x9E3779B1u) * (uint32_t)OMAP) >> 32);
+    for (int p = 0; p < OMAP; p++) {
+      const uint32_t e = L->omap[slot * 64 + lane];
+      if (e == 0) return -1;
+      if ((int32_t)(e >> OMAP_CNT_BITS) == t) return (int)slot;
+      slot = (slot + 1 == (uint32_t)OMAP) ? 0u : slot + 1;
+    }
+    return -1;
   }
 };
 
@@ -535,14 +553,27 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
           if (kk != 0) { D++; t0 = kk; c0 = M.cnt(s); }
         }
         int32_t maxTaxon = t0;  // D <= 1: the single taxon (or NONE)
-        if (D >= 2) {           // resolveTree step 1 (:101-123): LCA of the taxa with the maximal root-path score
+        if (D >= 2 && !(dbg & 16)) {  // resolveTree step 1 (:101-123): LCA of the taxa with the maximal root-path score  (16: timing experiment)
+          // A taxon's score is the k-mer count of the map taxa on its root path.  Instead of walking every root path to
+          // the end (distinct taxa x depth parent loads), each taxon walks only to its NEAREST ancestor that is in the map;
+          // the score is then the sum along those links, which stay in LDS.  (The probe queue's LDS is idle by now: it
+          // holds the links.)  On a lineage -- the usual shape of a read's hits -- that is one or two loads per taxon.
+          uint8_t *link = (uint8_t *)L->stash;  // [slot][lane]: slot of the nearest map ancestor, 255 = none
+          for (int s = 0; s < OMAP; s++) {
+            const int32_t taxon = M.key(s);
+            if (taxon == 0) continue;
+            int up = -1;
+            for (int32_t node = lane_parent(A.parents, A.ntax, taxon); node != 0 && up < 0; node = lane_parent(A.parents, A.ntax, node))
+              up = M.find(node);
+            link[s * 64 + lane] = (uint8_t)(up < 0 ? 255 : up);
+          }
           maxTaxon = 0;
           int32_t best = 0;
           for (int s = 0; s < OMAP; s++) {
-            int32_t taxon = M.key(s);
+            const int32_t taxon = M.key(s);
             if (taxon == 0) continue;
             int32_t score = 0;
-            for (int32_t node = taxon; node != 0; node = lane_parent(A.parents, A.ntax, node)) score += M.get(node);
+            for (int u = s, guard = 0; u != 255 && guard < OMAP; u = link[u * 64 + lane], guard++) score += M.cnt(u);
             if (score > best) { maxTaxon = taxon; best = score; }
             else if (score == best) maxTaxon = lane_lca(A.parents, A.ntax, maxTaxon, taxon);
           }
@@ -551,14 +582,27 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
           double required = ceil(__dmul_rn(A.thresholds[c], (double)total));  // Math.ceil(confidence * totalKmers) :94
           int32_t mt = maxTaxon;
           int32_t ms = (D >= 2) ? M.get(mt) : c0;                             // :125
+          bool first_candidate = true;
           while (mt != 0 && (double)ms < required) {                          // :126-144
             if (D < 2) { mt = 0; break; }  // one taxon: its clade sum never grows (NONE is in no clade)
             ms = 0;
-            for (int s = 0; s < OMAP; s++) {
-              int32_t taxon = M.key(s);
-              if (taxon == 0) continue;
-              for (int32_t x = taxon; x != 0; x = lane_parent(A.parents, A.ntax, x))
-                if (x == mt) { ms += M.cnt(s); break; }                       // Taxonomy.hasAncestor :236-244
+            const int sm = first_candidate ? M.find(mt) : -1;
+            first_candidate = false;
+            if (sm >= 0) {
+              // mt is a map taxon (the usual first candidate): the map taxa below it are those whose links lead to it
+              const uint8_t *link = (const uint8_t *)L->stash;
+              for (int s = 0; s < OMAP; s++) {
+                if (M.key(s) == 0) continue;
+                for (int u = s, guard = 0; u != 255 && guard < OMAP; u = link[u * 64 + lane], guard++)
+                  if (u == sm) { ms += M.cnt(s); break; }
+              }
+            } else {
+              for (int s = 0; s < OMAP; s++) {
+                int32_t taxon = M.key(s);
+                if (taxon == 0) continue;
+                for (int32_t x = taxon; x != 0; x = lane_parent(A.parents, A.ntax, x))
+                  if (x == mt) { ms += M.cnt(s); break; }                     // Taxonomy.hasAncestor :236-244
+              }
             }
             if ((double)ms >= required) break;
             mt = lane_parent(A.parents, A.ntax, mt);

@@ -42,11 +42,27 @@ def main():
         genome[t] = g
     bases = np.concatenate([genome[t] for t in leaves])
     offsets = np.arange(len(leaves) + 1, dtype=np.uint64) * np.uint64(L)
-    ix = slacken_amd.Index(expected_records=int(len(leaves) * L * 0.4), max_taxon=len(parents) - 1)
+    pad = int(float(os.environ.get("PAD", 0)))     # PAD=1e10: random records up to the standard-library scale (128 GiB table)
+    ix = slacken_amd.Index(expected_records=max(int(len(leaves) * L * 0.4), pad), max_taxon=len(parents) - 1)
     ix.set_taxonomy(parents)
     ix.add_sequences(bases, offsets, np.array(leaves, np.int32))
+    tmp = slacken_amd.Index(expected_records=int(len(leaves) * L * 0.4), max_taxon=len(parents) - 1)
+    tmp.set_taxonomy(parents)
+    tmp.add_sequences(bases, offsets, np.array(leaves, np.int32))
+    _, taxa = tmp.export()
+    tmp.close()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3)
+    smask = (((2**62 - 1) & ~0x0CCCCCCC) << 2) - (1 << 64)
+    for s0 in range(0, max(0, pad - len(taxa)), 1 << 27):
+        n = min(1 << 27, pad - len(taxa) - s0)
+        keys = ((torch.randint(0, 2**32, (n,), generator=gen, device="cuda", dtype=torch.int64) << 32) |
+                torch.randint(0, 2**32, (n,), generator=gen, device="cuda", dtype=torch.int64)) & smask
+        tx = torch.randint(2, len(parents), (n,), generator=gen, device="cuda", dtype=torch.int32)
+        torch.cuda.synchronize()
+        ix.append_device(keys.data_ptr(), tx.data_ptr(), n)
+        del keys, tx
     ix.finalize()
-    _, taxa = ix.export()
     depth = np.zeros(len(parents), np.int32)
     for t in range(2, len(parents)):
         depth[t] = depth[parents[t]] + 1
