@@ -1,6 +1,8 @@
 """GPU parity: every result of the HIP engine, obtained through the C ABI, is compared bit for bit with the CPU oracle
 on the same seeded inputs (integer/byte/index work => exact equality; the only floating point is one binary64
 multiply + ceil per read and threshold, also compared exactly)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -332,3 +334,17 @@ def test_taxon_ids_beyond_22_bits(orc):
     world = dict(p=p, st=ix.stream(), oix=orc.Index(1, keys, tx), parents=parents)
     got = check_classify(orc, world, reads, thresholds=(0.0, 0.2))
     assert (got["taxon"][0] > (1 << 22)).any()
+
+
+def test_c_example_runs(tmp_path):
+    """examples/classify_minimal.c: the ABI from plain C (device library construction + classify with hit lists)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "classify_minimal"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "classify_minimal.c"), "-L", os.path.join(root, "slacken_amd", "lib"),
+                           "-lslacken_amd", "-Wl,-rpath," + os.path.join(root, "slacken_amd", "lib"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    assert out[1].startswith("read 0: taxon 2 classified 1")      # the shared stretch: the genus (LCA of both species)
+    assert out[2].startswith("read 1: taxon 3 classified 1")      # species 3's own sequence
+    assert out[3].startswith("read 2: taxon 0 classified 0")
