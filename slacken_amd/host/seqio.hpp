@@ -10,11 +10,16 @@
 // records are not in the same order as the first file's.
 #pragma once
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -197,80 +202,6 @@ class RecordStream {
   bool next(std::string_view &header, std::string_view &seq) { return fastq_ ? next_fastq(header, seq) : next_fasta(header, seq); }
 };
 
-// A RecordStream read ahead on its own thread (decompression and line splitting of one file), handed over in chunks of a few
-// thousand records.  Paired input runs two of these side by side; a gzip stream inflates at a few hundred MB/s on one core,
-// so the two files of a pair are best inflated concurrently.  The views stay valid until the next call.
-class AsyncRecordStream {
-  struct Chunk {
-    std::string blob;
-    std::vector<uint32_t> pos;  // 4 per record: header offset, header length, sequence offset, sequence length
-  };
-  std::deque<std::unique_ptr<Chunk>> q_;
-  std::mutex mu_;
-  std::condition_variable cv_;
-  bool done_ = false, stop_ = false;
-  std::string error_;
-  std::unique_ptr<Chunk> cur_;
-  size_t cur_i_ = 0;
-  std::thread th_;
-
-  void run(std::string file) {
-    try {
-      RecordStream rs(file);
-      std::string_view h, sq;
-      auto c = std::make_unique<Chunk>();
-      auto flush = [&]() {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return q_.size() < 4 || stop_; });
-        if (stop_) return false;
-        q_.push_back(std::move(c));
-        cv_.notify_all();
-        c = std::make_unique<Chunk>();
-        return true;
-      };
-      while (rs.next(h, sq)) {
-        if (c->blob.size() + h.size() + sq.size() > 0xF0000000u) throw std::runtime_error("record too large: " + file);
-        c->pos.push_back((uint32_t)c->blob.size()); c->pos.push_back((uint32_t)h.size());
-        c->blob.append(h);
-        c->pos.push_back((uint32_t)c->blob.size()); c->pos.push_back((uint32_t)sq.size());
-        c->blob.append(sq);
-        if (c->pos.size() >= 4 * 4096 || c->blob.size() >= ((size_t)4 << 20)) if (!flush()) return;
-      }
-      if (!c->pos.empty()) flush();
-    } catch (const std::exception &e) {
-      std::lock_guard<std::mutex> lk(mu_);
-      error_ = e.what();
-    }
-    std::lock_guard<std::mutex> lk(mu_);
-    done_ = true;
-    cv_.notify_all();
-  }
-
- public:
-  explicit AsyncRecordStream(const std::string &file) : th_([this, file] { run(file); }) {}
-  ~AsyncRecordStream() {
-    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; cv_.notify_all(); }
-    th_.join();
-  }
-  bool next(std::string_view &header, std::string_view &seq) {
-    if (!cur_ || cur_i_ * 4 >= cur_->pos.size()) {
-      std::unique_lock<std::mutex> lk(mu_);
-      cv_.wait(lk, [&] { return !q_.empty() || done_; });
-      if (!error_.empty()) throw std::runtime_error(error_);
-      if (q_.empty()) { cur_.reset(); return false; }
-      cur_ = std::move(q_.front());
-      q_.pop_front();
-      cur_i_ = 0;
-      cv_.notify_all();
-    }
-    const uint32_t *p = &cur_->pos[cur_i_ * 4];
-    header = std::string_view(cur_->blob).substr(p[0], p[1]);
-    seq = std::string_view(cur_->blob).substr(p[2], p[3]);
-    cur_i_++;
-    return true;
-  }
-};
-
 inline std::string_view remove_suffix(std::string_view h, const char *suf) {  // header.replaceAll(suffix + "$", "")
   size_t n = strlen(suf);
   return (h.size() >= n && h.compare(h.size() - n, n, suf) == 0) ? h.substr(0, h.size() - n) : h;
@@ -297,6 +228,282 @@ struct FragmentBatch {
       mate_offs.push_back(mate_bases.size());
     }
   }
+  // records [i, i + n) of c as one run; strip: a suffix to drop from the titles (the "/1" of paired input) or nullptr
+  void append(const FragmentBatch &c, size_t i, size_t n, const char *strip) {
+    if (!strip) {
+      const uint64_t t0 = c.title_off[i], shift = titles.size() - t0;
+      titles.append(c.titles, t0, c.title_off[i + n] - t0);
+      for (size_t r = 1; r <= n; r++) title_off.push_back(c.title_off[i + r] + shift);
+    } else {
+      for (size_t r = 0; r < n; r++) {
+        titles.append(remove_suffix(c.title(i + r), strip));
+        title_off.push_back(titles.size());
+      }
+    }
+    const uint64_t b0 = c.offs[i], shift = bases.size() - b0;
+    bases.insert(bases.end(), c.bases.begin() + b0, c.bases.begin() + c.offs[i + n]);
+    for (size_t r = 1; r <= n; r++) offs.push_back(c.offs[i + r] + shift);
+  }
+  void append_mates(const FragmentBatch &c, size_t i, size_t n) {  // the sequences of c's records [i, i + n) as mates
+    const uint64_t b0 = c.offs[i], shift = mate_bases.size() - b0;
+    mate_bases.insert(mate_bases.end(), c.bases.begin() + b0, c.bases.begin() + c.offs[i + n]);
+    for (size_t r = 1; r <= n; r++) mate_offs.push_back(c.offs[i + r] + shift);
+  }
+};
+
+// ---- plain (uncompressed) files: mapped into memory and cut into segments that are parsed on several threads ----
+// Both record rules of the reference are local -- a FASTQ record starts at every line that begins with '@' and whose second
+// successor begins with '+' (the sliding window of next_fastq above), a FASTA record at the start of the file and after every
+// '>' -- so a file can be cut anywhere: a segment owns the records that START inside it and reads as far past its end as they
+// reach.  The records of the segments, taken in segment order, are those of the serial reader.
+class PlainSegmentParser {
+  const char *d_;
+  size_t n_;
+  bool fastq_;
+  struct Line { size_t s, e, next; };  // [s, e) without its terminator; next = start of the following line
+
+  Line line(size_t p) const {  // p < n_
+    const char *a = (const char *)memchr(d_ + p, '\n', n_ - p);
+    size_t j = a ? (size_t)(a - d_) : n_;
+    const char *b = (const char *)memchr(d_ + p, '\r', j - p);
+    if (b) j = (size_t)(b - d_);
+    if (j == n_) return {p, n_, n_};
+    return {p, j, (d_[j] == '\r' && j + 1 < n_ && d_[j + 1] == '\n') ? j + 2 : j + 1};
+  }
+  bool is_line_start(size_t p) const { return p == 0 || d_[p - 1] == '\n' || (d_[p - 1] == '\r' && d_[p] != '\n'); }
+  static std::string_view first_token(std::string_view s) { return s.substr(0, s.find(' ')); }
+
+  void fastq(size_t a, size_t b, FragmentBatch &out) const {
+    if (a >= n_) return;
+    const size_t p = is_line_start(a) ? a : line(a).next;  // (from inside a line, line() finds where that line ends)
+    if (p >= b || p >= n_) return;
+    Line l0 = line(p);
+    if (l0.next >= n_) return;
+    Line l1 = line(l0.next);
+    while (l1.next < n_) {  // (fewer than three lines left: no window can start here or later)
+      Line l2 = line(l1.next);
+      if (l0.e > l0.s && d_[l0.s] == '@' && l2.e > l2.s && d_[l2.s] == '+')
+        out.add(first_token(std::string_view(d_ + l0.s, l0.e - l0.s)).substr(1), std::string_view(d_ + l1.s, l1.e - l1.s), nullptr);
+      l0 = l1;
+      l1 = l2;
+      if (l0.s >= b) return;  // the window slides by one line; the next segment owns this one
+    }
+  }
+
+  void fasta(size_t a, size_t b, FragmentBatch &out) const {
+    size_t s = 0;
+    if (a > 0) {
+      const char *q = (const char *)memchr(d_ + a - 1, '>', n_ - (a - 1));
+      if (!q) return;
+      s = (size_t)(q - d_) + 1;
+    }
+    while (s < b) {
+      const char *q = (const char *)memchr(d_ + s, '>', n_ - s);
+      const size_t end = q ? (size_t)(q - d_) : n_;
+      // String.split("[\n\r]+"): a leading empty string is kept, trailing ones are dropped; the first line is the header
+      size_t i = s, nlines = 0;
+      std::string_view first;
+      while (i < end) {
+        const char *x = (const char *)memchr(d_ + i, '\n', end - i);
+        size_t j = x ? (size_t)(x - d_) : end;
+        const char *y = (const char *)memchr(d_ + i, '\r', j - i);
+        if (y) j = (size_t)(y - d_);
+        if (j > i || nlines == 0) {
+          if (nlines == 0) first = std::string_view(d_ + i, j - i);
+          else out.bases.insert(out.bases.end(), d_ + i, d_ + j);
+          nlines++;
+        }
+        while (j < end && (d_[j] == '\n' || d_[j] == '\r')) j++;
+        i = j;
+      }
+      if (nlines >= 2) {
+        out.titles.append(first_token(first));
+        out.title_off.push_back(out.titles.size());
+        out.offs.push_back(out.bases.size());
+      }
+      if (end == n_) return;
+      s = end + 1;
+    }
+  }
+
+ public:
+  PlainSegmentParser(const char *d, size_t n, bool fastq) : d_(d), n_(n), fastq_(fastq) {}
+  void parse(size_t a, size_t b, FragmentBatch &out) const {  // the records starting in [a, b)
+    if (fastq_) fastq(a, b, out); else fasta(a, b, out);
+  }
+};
+
+inline size_t parse_threads() {  // SLK_PARSE_THREADS: threads that parse one plain input file
+  const char *e = getenv("SLK_PARSE_THREADS");
+  long v = e ? atol(e) : 0;
+  if (v > 0) return (size_t)v;
+  unsigned hc = std::thread::hardware_concurrency();
+  return std::min<size_t>(8, std::max<unsigned>(2, hc / 2));
+}
+
+// The records of one file, read ahead and handed over in chunks, in file order.  Compressed input is inflated and split on one
+// thread (a gzip stream is serial; paired input runs two of these side by side); a plain file is mapped and its segments are
+// parsed on several threads.  The views of next() stay valid until the next call.
+class AsyncRecordStream {
+  std::deque<std::unique_ptr<FragmentBatch>> q_;  // serial producer: finished chunks
+  std::map<size_t, std::unique_ptr<FragmentBatch>> done_;  // parallel producers: finished segments by number
+  size_t nseg_ = 0, seg_bytes_ = 0, next_claim_ = 0, next_out_ = 0, depth_ = 0;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  bool done_flag_ = false, stop_ = false, parallel_ = false;
+  std::string error_;
+  std::unique_ptr<FragmentBatch> cur_;
+  size_t cur_i_ = 0;
+  std::vector<std::thread> th_;
+  const char *map_ = nullptr;
+  size_t map_len_ = 0;
+
+  void run_serial(std::string file) {
+    try {
+      RecordStream rs(file);
+      std::string_view h, sq;
+      auto c = std::make_unique<FragmentBatch>();
+      auto flush = [&]() {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return q_.size() < 4 || stop_; });
+        if (stop_) return false;
+        q_.push_back(std::move(c));
+        cv_.notify_all();
+        c = std::make_unique<FragmentBatch>();
+        return true;
+      };
+      while (rs.next(h, sq)) {
+        c->add(h, sq, nullptr);
+        if (c->size() >= 4096 || c->bases.size() >= ((size_t)4 << 20)) if (!flush()) return;
+      }
+      if (c->size()) flush();
+    } catch (const std::exception &e) {
+      std::lock_guard<std::mutex> lk(mu_);
+      error_ = e.what();
+    }
+    std::lock_guard<std::mutex> lk(mu_);
+    done_flag_ = true;
+    cv_.notify_all();
+  }
+
+  void run_segments(bool fastq) {
+    PlainSegmentParser parser(map_, map_len_, fastq);
+    for (;;) {
+      size_t i;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || next_claim_ >= nseg_ || next_claim_ < next_out_ + depth_; });
+        if (stop_ || next_claim_ >= nseg_) return;
+        i = next_claim_++;
+      }
+      auto c = std::make_unique<FragmentBatch>();
+      try {
+        const size_t a = i * seg_bytes_, b = std::min(map_len_, a + seg_bytes_);
+        c->bases.reserve((b - a) / 2 + 256);
+        parser.parse(a, b, *c);
+      } catch (const std::exception &e) {
+        std::lock_guard<std::mutex> lk(mu_);
+        error_ = e.what();
+      }
+      std::lock_guard<std::mutex> lk(mu_);
+      done_[i] = std::move(c);
+      cv_.notify_all();
+    }
+  }
+
+  static bool is_compressed(const std::string &file) {  // by name, or by the gzip magic (zlib would inflate it either way)
+    if (ends_with(file, ".gz") || ends_with(file, ".bz2")) return true;
+    FILE *f = fopen(file.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + file);
+    unsigned char m[2] = {0, 0};
+    size_t k = fread(m, 1, 2, f);
+    fclose(f);
+    return k == 2 && m[0] == 0x1f && m[1] == 0x8b;
+  }
+
+  std::unique_ptr<FragmentBatch> pop() {  // the next non-empty chunk, nullptr at the end
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu_);
+      std::unique_ptr<FragmentBatch> c;
+      if (parallel_) {
+        cv_.wait(lk, [&] { return !error_.empty() || next_out_ >= nseg_ || done_.count(next_out_); });
+        if (!error_.empty()) throw std::runtime_error(error_);
+        if (next_out_ >= nseg_) return nullptr;
+        auto it = done_.find(next_out_);
+        c = std::move(it->second);
+        done_.erase(it);
+        next_out_++;
+      } else {
+        cv_.wait(lk, [&] { return !q_.empty() || done_flag_; });
+        if (!error_.empty()) throw std::runtime_error(error_);
+        if (q_.empty()) return nullptr;
+        c = std::move(q_.front());
+        q_.pop_front();
+      }
+      cv_.notify_all();
+      if (c->size()) return c;
+    }
+  }
+
+ public:
+  explicit AsyncRecordStream(const std::string &file) {
+    if (is_compressed(file)) {
+      th_.emplace_back([this, file] { run_serial(file); });
+      return;
+    }
+    parallel_ = true;
+    int fd = open(file.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("cannot open " + file);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); throw std::runtime_error("cannot stat " + file); }
+    map_len_ = (size_t)sb.st_size;
+    if (map_len_) {
+      void *m = mmap(nullptr, map_len_, PROT_READ, MAP_PRIVATE, fd, 0);
+      close(fd);
+      if (m == MAP_FAILED) throw std::runtime_error("cannot map " + file);
+      madvise(m, map_len_, MADV_SEQUENTIAL);
+      map_ = (const char *)m;
+    } else {
+      close(fd);
+    }
+    const char *e = getenv("SLK_IO_CHUNK");  // (the tests put segment borders everywhere with it)
+    seg_bytes_ = e && atol(e) > 0 ? (size_t)atol(e) : (size_t)16 << 20;
+    nseg_ = (map_len_ + seg_bytes_ - 1) / seg_bytes_;
+    const size_t nt = std::max<size_t>(1, std::min(parse_threads(), nseg_));
+    depth_ = nt + 2;
+    const bool fastq = RecordStream::is_fastq_name(file);
+    for (size_t t = 0; t < nt; t++) th_.emplace_back([this, fastq] { run_segments(fastq); });
+  }
+  AsyncRecordStream(const AsyncRecordStream &) = delete;
+  ~AsyncRecordStream() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; cv_.notify_all(); }
+    for (auto &t : th_) t.join();
+    if (map_) munmap((void *)map_, map_len_);
+  }
+  bool next(std::string_view &header, std::string_view &seq) {
+    if (!cur_ || cur_i_ >= cur_->size()) {
+      cur_ = pop();
+      cur_i_ = 0;
+      if (!cur_) return false;
+    }
+    header = cur_->title(cur_i_);
+    seq = cur_->seq(cur_i_);
+    cur_i_++;
+    return true;
+  }
+  // Chunk-wise access: the current chunk and the position in it (nullptr at the end of the file); advance(n) consumes n of its
+  // records, take() the whole chunk when nothing of it has been consumed.
+  const FragmentBatch *current(size_t &i) {
+    if (!cur_ || cur_i_ >= cur_->size()) {
+      cur_ = pop();
+      cur_i_ = 0;
+    }
+    i = cur_i_;
+    return cur_.get();
+  }
+  void advance(size_t n) { cur_i_ += n; }
+  std::unique_ptr<FragmentBatch> take() { cur_i_ = 0; return std::move(cur_); }
+  bool whole_chunks() const { return parallel_; }  // chunks are batch-sized (the segments of a plain file)
 };
 
 // All fragments of a list of input files (or of pairs of files), in file order.
@@ -307,7 +514,6 @@ class FragmentSource {
   std::unique_ptr<AsyncRecordStream> s1_, s2_;
   bool joined_ = false;  // the rest of the mate file has been loaded into mates_ (its order differs from the first file's)
   std::unordered_map<std::string, std::string> mates_;
-  std::string h1_, seq1_;
 
   bool open_next() {
     if (next_file_ >= files_.size()) return false;
@@ -323,31 +529,56 @@ class FragmentSource {
   FragmentSource(std::vector<std::string> files, bool paired) : files_(std::move(files)), paired_(paired) {}
 
   // Appends up to max_fragments (and about max_bases) to b; false when every file is exhausted and nothing was added.
+  // Records move a run at a time (one copy of the bases of the run, not one per record).
   bool fill(FragmentBatch &b, size_t max_fragments, size_t max_bases) {
     b.paired = paired_;
     size_t added = 0;
     while (added < max_fragments && b.bases.size() + b.mate_bases.size() < max_bases) {
       if (!s1_ && !open_next()) break;
-      std::string_view h, s;
-      if (!s1_->next(h, s)) { s1_.reset(); s2_.reset(); continue; }
-      if (!paired_) { b.add(h, s, nullptr); added++; continue; }
+      size_t i1 = 0, i2 = 0;
+      const FragmentBatch *c1 = s1_->current(i1);
+      if (!c1) { s1_.reset(); s2_.reset(); continue; }
+      if (!paired_) {
+        if (b.size() == 0 && i1 == 0 && s1_->whole_chunks()) {  // a parsed segment of a plain file is a batch as it stands
+          b = std::move(*s1_->take());
+          b.paired = false;
+          return true;
+        }
+        const size_t n = std::min(c1->size() - i1, max_fragments - added);
+        b.append(*c1, i1, n, nullptr);
+        s1_->advance(n);
+        added += n;
+        continue;
+      }
       // Paired: the reference joins the two files on the header.  While both files list their records in the same order
       // the join is a lockstep walk; at the first disagreement the rest of the mate file becomes the join's hash side.
-      h1_.assign(remove_suffix(h, "/1"));
-      seq1_.assign(s);
       if (!joined_) {
-        std::string_view h2, m;
-        if (s2_->next(h2, m)) {
-          if (remove_suffix(h2, "/2") == std::string_view(h1_)) { b.add(h1_, seq1_, &m); added++; continue; }
-          mates_.emplace(std::string(remove_suffix(h2, "/2")), std::string(m));
+        const FragmentBatch *c2 = s2_->current(i2);
+        if (c2) {
+          const size_t n = std::min({c1->size() - i1, c2->size() - i2, max_fragments - added});
+          size_t ok = 0;
+          while (ok < n && remove_suffix(c1->title(i1 + ok), "/1") == remove_suffix(c2->title(i2 + ok), "/2")) ok++;
+          if (ok) {
+            b.append(*c1, i1, ok, "/1");
+            b.append_mates(*c2, i2, ok);
+            s1_->advance(ok);
+            s2_->advance(ok);
+            added += ok;
+          }
+          if (ok == n) continue;
         }
+        std::string_view h2, m;
         while (s2_->next(h2, m)) mates_.emplace(std::string(remove_suffix(h2, "/2")), std::string(m));
         joined_ = true;
+        continue;
       }
-      auto it = mates_.find(h1_);
+      std::string_view h, sq;
+      s1_->next(h, sq);
+      h = remove_suffix(h, "/1");
+      auto it = mates_.find(std::string(h));
       if (it == mates_.end()) continue;  // inner join: no mate, no fragment
       std::string_view m(it->second);
-      b.add(h1_, seq1_, &m);
+      b.add(h, sq, &m);
       added++;
     }
     return added > 0;

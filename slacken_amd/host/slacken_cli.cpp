@@ -147,7 +147,21 @@ static int cmd_taxonomy(int argc, char **argv) {
   return 0;
 }
 static int cmd_parse(int argc, char **argv) {  // parse <file> [<file2>]: header \t nucleotides [\t nucleotides2]
-  if (argc < 1) die("usage: parse FILE [MATE_FILE]");
+  if (argc < 1) die("usage: parse [--count] FILE [MATE_FILE]");
+  if (std::string(argv[0]) == "--count") {  // read through the batch reader only: fragments, bases, a checksum, seconds
+    std::vector<std::string> files(argv + 1, argv + std::min(argc, 3));
+    auto t0 = std::chrono::steady_clock::now();
+    BatchPrefetcher pf(files, files.size() >= 2);
+    uint64_t n = 0, nb = 0, sum = 0;
+    while (auto b = pf.next()) {
+      n += b->size();
+      nb += b->bases.size() + b->mate_bases.size();
+      for (size_t i = 0; i < b->size(); i += 97) sum = sum * 31 + std::hash<std::string_view>()(b->title(i)) + b->seq(i).size();
+    }
+    double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::cout << n << " fragments, " << nb << " bases, checksum " << sum << ", " << dt << " s\n";
+    return 0;
+  }
   std::vector<std::string> files(argv, argv + std::min(argc, 2));
   FragmentSource src(files, argc >= 2);
   for (;;) {
@@ -279,7 +293,7 @@ struct DeviceIndex {
 // handed to f (shared ownership: output formatting keeps them alive on its own threads).
 template <class F>
 static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &files, bool paired, int min_hits,
-                            const std::vector<double> &thresholds, bool want_spans, F f) {
+                            const std::vector<double> &thresholds, bool want_spans, bool want_hits, F f) {
   // Several input files (or pairs) are read side by side, each on its own threads -- a gzip stream inflates on one core -- and
   // their batches are taken in turn: the order of the output is deterministic, though interleaved between files at batch
   // granularity (the reference's output order is whatever Spark's partitions give).
@@ -310,8 +324,17 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
   };
   const int C = (int)thresholds.size();
   std::vector<int32_t> nd, tk;
-  size_t total = 0;
-  while (auto frags = next_batch()) {
+  size_t total = 0, n_batches = 0;
+  const bool timing = getenv("SLK_HOST_TIMING") != nullptr;  // where the wall clock of the run goes, by stage
+  double t_input = 0, t_device = 0, t_hand_over = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  for (;;) {
+    double t0 = now();
+    auto frags = next_batch();
+    if (!frags) break;
+    double t1 = now();
+    t_input += t1 - t0;
+    n_batches++;
     auto b = std::make_shared<ClassifiedBatch>();
     b->frags = std::move(frags);
     b->C = C;
@@ -321,7 +344,7 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
     b->taxon.resize((size_t)C * n); b->classified.resize((size_t)C * n); nd.resize(n); tk.resize(n);
     b->hit_offs.resize(n + 1);
     const size_t cap = fb.bases.size() + fb.mate_bases.size() + n + 1;
-    b->hits.reset(new slk_hit[cap]);  // (no zero-fill; the untouched tail of the allocation is never paged in)
+    if (want_hits) b->hits.reset(new slk_hit[cap]);  // (no zero-fill; the untouched tail of the allocation is never paged in)
     const uint8_t *mb = fb.paired ? fb.mate_bases.data() : nullptr;
     const uint64_t *mo = fb.paired ? fb.mate_offs.data() : nullptr;
     SLK_CALL(slk_classify_batch(dev.ix, dev.st, fb.bases.data(), fb.offs.data(), mb, mo, n, min_hits, thresholds.data(), C,
@@ -331,8 +354,14 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
       b->spans.resize(cap);
       SLK_CALL(slk_spans_batch(dev.ix, dev.st, fb.bases.data(), fb.offs.data(), mb, mo, n, b->span_offs.data(), b->spans.data(), cap));
     }
+    double t2 = now();
+    t_device += t2 - t1;
     f(std::shared_ptr<const ClassifiedBatch>(b));
+    t_hand_over += now() - t2;
   }
+  if (timing)
+    std::cerr << "host timing: " << n_batches << " batches; waiting for input " << t_input << " s, upload+kernels+download " << t_device
+              << " s, handing over to the output threads " << t_hand_over << " s" << std::endl;
   std::cerr << total << " fragments" << std::endl;
 }
 
@@ -351,7 +380,7 @@ static void classify_and_write(DeviceIndex &dev, const IndexParams &ip, const Ta
   oo.with_unclassified = o.with_unclassified; oo.detailed = o.detailed; oo.k = ip.k;
   Timer t("Classify reads");
   OutputSink sink(oo, tax, host_threads());
-  classify_stream(dev, o.files, o.paired, o.min_hits, o.thresholds, false,
+  classify_stream(dev, o.files, o.paired, o.min_hits, o.thresholds, false, o.detailed,   // (hit lists only feed the per-read lines)
                   [&](std::shared_ptr<const ClassifiedBatch> b) { sink.submit(std::move(b)); });
   sink.finish();
 }
@@ -444,7 +473,7 @@ static int cmd_classify2(int argc, char **argv) {
     if (o.min_count >= 0 || o.min_distinct >= 0) {
       // MinimizerTotalCount / MinimizerDistinctCount: hits with a true taxon at depth >= rank (minimizersInSubjects :73-86)
       std::vector<std::pair<Taxon, int64_t>> pairs;
-      classify_stream(base, o.files, o.paired, o.min_hits, {0.0}, o.min_distinct >= 0, [&](std::shared_ptr<const ClassifiedBatch> b) {
+      classify_stream(base, o.files, o.paired, o.min_hits, {0.0}, o.min_distinct >= 0, true, [&](std::shared_ptr<const ClassifiedBatch> b) {
         for (size_t i = 0; i < b->frags->size(); i++)
           for (size_t j = b->hit_offs[i]; j < b->hit_offs[i + 1]; j++) {
             Taxon t = b->hits[j].taxon;
@@ -460,7 +489,7 @@ static int cmd_classify2(int argc, char **argv) {
       }
     } else {
       // ClassifiedReadCount(threshold, confidence): classified reads per taxon (classifiedReadsPerTaxon :133-141)
-      classify_stream(base, o.files, o.paired, o.min_hits, {o.init_confidence}, false, [&](std::shared_ptr<const ClassifiedBatch> b) {
+      classify_stream(base, o.files, o.paired, o.min_hits, {o.init_confidence}, false, false, [&](std::shared_ptr<const ClassifiedBatch> b) {
         for (size_t i = 0; i < b->frags->size(); i++)
           if (b->hit_offs[i + 1] > b->hit_offs[i] && b->classified[i]) m[b->taxon[i]] += 1;
       });
@@ -502,7 +531,7 @@ static int cmd_classify2(int argc, char **argv) {
   std::vector<int32_t> taxa;
   size_t n_titles = 0;
   for (auto &file : fna) {
-    RecordStream rs(file);
+    AsyncRecordStream rs(file);  // (plain .fna files are parsed on several threads)
     std::string_view h, sq;
     while (rs.next(h, sq)) {
       auto it = labels.find(std::string(h));

@@ -260,3 +260,36 @@ def test_dynamic_taxon_selection_matches_restatement(tmp_path, seed):
             # TaxonomyProps-style invariants: every kept taxon is in the closure; the closure is closed under children
             assert set(keep) <= set(full)
             assert all(c in set(full) for t in full for c in tax.children[t])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SLK_PARSE_SEEDS", 6))))
+def test_segment_parallel_parser_on_adversarial_text(tmp_path, seed):
+    """Plain files are mapped and cut into segments parsed on several threads (seqio.hpp, PlainSegmentParser): on text made of
+    the characters the two record rules look at ('@', '+', '>', the three line ends, ' '), with segment borders at every
+    granularity, the records are those of the restatement and of the serial reader (the same bytes gzip-compressed)."""
+    rng = np.random.default_rng(100 + seed)
+    alphabet = np.array(list("@+>\n\r ACx"))
+    weights = np.array([3, 3, 2, 6, 3, 1, 4, 4, 2], float)
+    text = "".join(rng.choice(alphabet, size=int(rng.integers(1, 300)), p=weights / weights.sum()))
+    # ... followed by lines that often start with '@' or '+', so that FASTQ windows match, overlap and nest
+    for _ in range(int(rng.integers(5, 60))):
+        body = "".join(rng.choice(list("AC@+> x"), size=int(rng.integers(0, 6))))
+        text += str(rng.choice(["@", "+", "", ">"], p=[0.4, 0.35, 0.2, 0.05])) + body + str(rng.choice(["\n", "\r\n", "\r", "\n\n"]))
+    if rng.integers(0, 2):
+        text = text.rstrip("\r\n")          # no line end after the last line
+
+    def parse(path, chunk, threads):
+        env = dict(os.environ, SLK_IO_CHUNK=str(chunk), SLK_PARSE_THREADS=str(threads))
+        out = subprocess.run([CLI, "parse", str(path)], check=True, capture_output=True, env=env).stdout.decode()
+        return [tuple(l.split("\t")) for l in out.split("\n")[:-1]]
+
+    for ext, model in (("fastq", hostmodel.parse_fastq), ("fasta", hostmodel.parse_fasta)):
+        p = tmp_path / f"t.{ext}"
+        p.write_bytes(text.encode())
+        gz = tmp_path / f"t.{ext}.gz"
+        with gzip.open(gz, "wb") as f:
+            f.write(text.encode())
+        want = [tuple(r) for r in model(text)]
+        assert parse(gz, 5, 1) == want
+        for chunk, threads in ((1, 3), (2, 2), (3, 4), (7, 1), (64, 5), (1 << 20, 2)):
+            assert parse(p, chunk, threads) == want, (ext, chunk, threads)

@@ -50,14 +50,28 @@ def main():
             blk = bases[(starts[s:e, None] + np.arange(150)[None, :])]
             f.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (s + i, blk[i].tobytes(), qual) for i in range(e - s)))
     out = {}
-    for name, extra in (("detailed", []), ("reports_only", ["--nodetailed"])):
+    os.environ["SLK_HOST_TIMING"] = "1"
+    # a paired sample: the first half of the reads as /1, the second half as /2
+    half = R // 2
+    p1, p2 = os.path.join(d, "pair_1.fq"), os.path.join(d, "pair_2.fq")
+    with open(p1, "wb") as f1, open(p2, "wb") as f2:
+        CH = 100000
+        qual = b"I" * 150
+        for s in range(0, half, CH):
+            e = min(half, s + CH)
+            blk = bases[(starts[s:e, None] + np.arange(150)[None, :])]
+            blk2 = bases[(starts[half + s:half + e, None] + np.arange(150)[None, :])]
+            f1.write(b"".join(b"@r%d/1\n%s\n+\n%s\n" % (s + i, blk[i].tobytes(), qual) for i in range(e - s)))
+            f2.write(b"".join(b"@r%d/2\n%s\n+\n%s\n" % (s + i, blk2[i].tobytes(), qual) for i in range(e - s)))
+    for name, extra, inputs, n in (("detailed", [], [fq], R), ("reports_only", ["--nodetailed"], [fq], R),
+                                   ("paired_detailed", ["-p"], [p1, p2], half)):
         t0 = time.perf_counter()
         r = subprocess.run([os.path.join(ROOT, "slacken_amd", "bin", "slacken-amd"), "classify", "-i", loc, "-o",
-                            os.path.join(d, "out_" + name), *extra, fq], capture_output=True, text=True)
+                            os.path.join(d, "out_" + name), *extra, *inputs], capture_output=True, text=True)
         dt = time.perf_counter() - t0
         assert r.returncode == 0, r.stderr
-        out[name + "_log"] = [l for l in r.stderr.split("\n") if "task" in l or "fragments" in l]
-        out[name] = dict(reads=R, seconds=round(dt, 2), M_reads_per_s=round(R / dt / 1e6, 3))
+        out[name + "_log"] = [l for l in r.stderr.split("\n") if "task" in l or "fragments" in l or "host timing" in l]
+        out[name] = dict(fragments=n, seconds=round(dt, 2), M_fragments_per_s=round(n / dt / 1e6, 3))
     # the same reads as one gzip file and as eight: input files are inflated and parsed side by side
     import gzip
     parts = [os.path.join(d, f"part{i}.fq.gz") for i in range(8)]
@@ -75,6 +89,7 @@ def main():
                             os.path.join(d, "out_" + name), *inputs], capture_output=True, text=True)
         dt = time.perf_counter() - t0
         assert r.returncode == 0, r.stderr
+        out[name + "_log"] = [l for l in r.stderr.split("\n") if "host timing" in l]
         out[name] = dict(reads=R, seconds=round(dt, 2), M_reads_per_s=round(R / dt / 1e6, 3))
     # classify2: the two-step run with a dynamic library built on the device from the genome FASTA files
     libdir = os.path.join(d, "k2")
