@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -99,6 +100,13 @@ struct slk_stream {
   int32_t *d_status = nullptr;     // device error bits of the fused kernels
   int32_t *h_status = nullptr;     // pinned copy, refreshed after every classify launch
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // Two pinned buffers: every copy between the caller's memory and HBM goes through them (copy_in / copy_out), so the
+  // runtime never has to pin the caller's pages for DMA -- that path took tens of ms per call once an application with many
+  // threads was mapping and unmapping memory around it.
+  void *stage[2] = {nullptr, nullptr};
+  hipEvent_t stage_ev[2] = {nullptr, nullptr};
+  bool stage_busy[2] = {false, false};
+  int stage_next = 0;
   bool timed = false;
   bool last_used_lane = false;  // the last classify call ran the lane kernel (defer_list[0] is its deferral count)
   struct LastCall {  // the arguments of the classify call in flight, for the unbounded re-run (check_status)
@@ -113,6 +121,61 @@ struct slk_stream {
 };
 
 static int32_t check_status(slk_stream *st);
+
+static const size_t STAGE_BYTES = (size_t)4 << 20;
+
+static int32_t stage_ready(slk_stream *st) {
+  if (st->stage[0]) return SLK_OK;
+  for (int i = 0; i < 2; i++) {
+    HIPCHK(hipHostMalloc(&st->stage[i], STAGE_BYTES, hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&st->stage_ev[i], hipEventDisableTiming));
+  }
+  return SLK_OK;
+}
+
+// caller memory -> HBM, ordered on st->s.  The caller's buffer is free on return; the last DMA may still be in flight.
+static int32_t copy_in(slk_stream *st, void *d_dst, const void *h_src, size_t n) {
+  int32_t rc = stage_ready(st);
+  if (rc) return rc;
+  for (size_t o = 0; o < n; o += STAGE_BYTES) {
+    const size_t len = std::min(STAGE_BYTES, n - o);
+    const int b = st->stage_next;
+    st->stage_next ^= 1;
+    if (st->stage_busy[b]) HIPCHK(hipEventSynchronize(st->stage_ev[b]));  // the DMA that last read this buffer
+    memcpy(st->stage[b], (const char *)h_src + o, len);
+    HIPCHK(hipMemcpyAsync((char *)d_dst + o, st->stage[b], len, hipMemcpyHostToDevice, st->s));
+    HIPCHK(hipEventRecord(st->stage_ev[b], st->s));
+    st->stage_busy[b] = true;
+  }
+  return SLK_OK;
+}
+
+// HBM -> caller memory, after everything queued on st->s; complete on return.  The DMA of one piece overlaps the copy of
+// the piece before it into the caller's buffer.
+static int32_t copy_out(slk_stream *st, void *h_dst, const void *d_src, size_t n) {
+  int32_t rc = stage_ready(st);
+  if (rc) return rc;
+  size_t prev_o = 0, prev_len = 0;
+  int prev_b = -1;
+  for (size_t o = 0; o < n; o += STAGE_BYTES) {
+    const size_t len = std::min(STAGE_BYTES, n - o);
+    const int b = prev_b < 0 ? 0 : prev_b ^ 1;
+    // (stream order protects the buffer: an earlier copy_in DMA out of it is queued before this write into it)
+    HIPCHK(hipMemcpyAsync(st->stage[b], (const char *)d_src + o, len, hipMemcpyDeviceToHost, st->s));
+    HIPCHK(hipEventRecord(st->stage_ev[b], st->s));
+    st->stage_busy[b] = true;
+    if (prev_b >= 0) {
+      HIPCHK(hipEventSynchronize(st->stage_ev[prev_b]));
+      memcpy((char *)h_dst + prev_o, st->stage[prev_b], prev_len);
+    }
+    prev_b = b; prev_o = o; prev_len = len;
+  }
+  if (prev_b >= 0) {
+    HIPCHK(hipEventSynchronize(st->stage_ev[prev_b]));
+    memcpy((char *)h_dst + prev_o, st->stage[prev_b], prev_len);
+  }
+  return SLK_OK;
+}
 
 // Every entry point that launches kernels starts here: select the index's device and drop whatever error code an earlier,
 // unrelated HIP call of this thread (this library's or the application's) left behind, so that the hipGetLastError()
@@ -547,6 +610,10 @@ void slk_stream_destroy(slk_stream *st) {
   if (st->h_thresholds) (void)hipHostFree(st->h_thresholds);
   if (st->d_status) (void)hipFree(st->d_status);
   if (st->h_status) (void)hipHostFree(st->h_status);
+  for (int i = 0; i < 2; i++) {
+    if (st->stage[i]) (void)hipHostFree(st->stage[i]);
+    if (st->stage_ev[i]) (void)hipEventDestroy(st->stage_ev[i]);
+  }
   for (int i = 0; i < 4; i++) if (st->ev[i]) (void)hipEventDestroy(st->ev[i]);
   if (st->s) (void)hipStreamDestroy(st->s);
   delete st;
@@ -900,13 +967,15 @@ static int32_t upload_reads(slk_stream *st, const uint8_t *bases, const uint64_t
   *mate_total = mate_offsets ? mate_offsets[R] : 0;
   HIPCHK(st->bases.ensure(*total + 16));
   HIPCHK(st->offsets.ensure((R + 1) * 8));
-  if (*total) HIPCHK(hipMemcpyAsync(st->bases.p, bases, *total, hipMemcpyHostToDevice, st->s));
-  HIPCHK(hipMemcpyAsync(st->offsets.p, offsets, (R + 1) * 8, hipMemcpyHostToDevice, st->s));
+  int32_t rc = copy_in(st, st->bases.p, bases, *total);
+  if (!rc) rc = copy_in(st, st->offsets.p, offsets, (R + 1) * 8);
+  if (rc) return rc;
   if (mate_offsets) {
     HIPCHK(st->mate_bases.ensure(*mate_total + 16));
     HIPCHK(st->mate_offsets.ensure((R + 1) * 8));
-    if (*mate_total) HIPCHK(hipMemcpyAsync(st->mate_bases.p, mate_bases, *mate_total, hipMemcpyHostToDevice, st->s));
-    HIPCHK(hipMemcpyAsync(st->mate_offsets.p, mate_offsets, (R + 1) * 8, hipMemcpyHostToDevice, st->s));
+    rc = copy_in(st, st->mate_bases.p, mate_bases, *mate_total);
+    if (!rc) rc = copy_in(st, st->mate_offsets.p, mate_offsets, (R + 1) * 8);
+    if (rc) return rc;
   }
   return SLK_OK;
 }
@@ -915,16 +984,15 @@ static int32_t upload_reads(slk_stream *st, const uint8_t *bases, const uint64_t
 static int32_t counts_to_offsets(slk_stream *st, const int32_t *d_counts, uint64_t R, uint64_t *out_offsets,
                                  uint64_t capacity) {
   std::vector<int32_t> counts(R);
-  HIPCHK(hipMemcpyAsync(counts.data(), d_counts, R * 4, hipMemcpyDeviceToHost, st->s));
-  HIPCHK(hipStreamSynchronize(st->s));
+  int32_t rc = copy_out(st, counts.data(), d_counts, R * 4);
+  if (rc) return rc;
   out_offsets[0] = 0;
   for (uint64_t r = 0; r < R; r++) out_offsets[r + 1] = out_offsets[r] + (uint64_t)counts[r];
   if (out_offsets[R] > capacity)
     return fail(SLK_E_CAPACITY, "output needs %llu entries, capacity is %llu", (unsigned long long)out_offsets[R],
                 (unsigned long long)capacity);
   HIPCHK(st->out_offsets.ensure((R + 1) * 8));
-  HIPCHK(hipMemcpyAsync(st->out_offsets.p, out_offsets, (R + 1) * 8, hipMemcpyHostToDevice, st->s));
-  return SLK_OK;
+  return copy_in(st, st->out_offsets.p, out_offsets, (R + 1) * 8);
 }
 
 int32_t slk_spans_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, const uint64_t *offsets,
@@ -969,7 +1037,8 @@ int32_t slk_spans_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, con
     launch_gather_spans(d_off, d_moff, R, st->span_keys.as<uint64_t>(), st->span_meta.as<int32_t>(),
                         st->out_offsets.as<uint64_t>(), st->out_items.p, st->s);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out_spans, st->out_items.p, n * sizeof(slk_span), hipMemcpyDeviceToHost, st->s));
+    rc = copy_out(st, out_spans, st->out_items.p, n * sizeof(slk_span));
+    if (rc) return rc;
   }
   HIPCHK(hipStreamSynchronize(st->s));
   return SLK_OK;
@@ -990,9 +1059,13 @@ int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, 
   if (rc) return rc;
   if (out_hit_offsets) out_hit_offsets[0] = 0;
   if (R == 0) return SLK_OK;
+  static const bool call_timing = getenv("SLK_DEBUG_CALL_TIMING") != nullptr;  // tuning aid: wall clock of the phases of a call
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tp[6] = {now(), 0, 0, 0, 0, 0};
   uint64_t total, mate_total;
   rc = upload_reads(st, bases, offsets, mate_bases, mate_offsets, R, &total, &mate_total);
   if (rc) return rc;
+  if (call_timing) { (void)hipStreamSynchronize(st->s); tp[1] = now(); }
   bool paired = mate_offsets != nullptr;
   HIPCHK(st->out_taxon.ensure((size_t)C * R * 4));
   HIPCHK(st->out_cls.ensure((size_t)C * R));
@@ -1007,12 +1080,15 @@ int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, 
                     st->out_nh.as<int32_t>(), nullptr, out_hit_offsets != nullptr);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(st->s));
+  tp[2] = now();
   rc = check_status(st);  // (re-runs the batch through the unbounded path if a taxon map overflowed)
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(out_taxon, st->out_taxon.p, (size_t)C * R * 4, hipMemcpyDeviceToHost, st->s));
-  HIPCHK(hipMemcpyAsync(out_classified, st->out_cls.p, (size_t)C * R, hipMemcpyDeviceToHost, st->s));
-  if (out_num_distinct) HIPCHK(hipMemcpyAsync(out_num_distinct, st->out_nd.p, R * 4, hipMemcpyDeviceToHost, st->s));
-  if (out_total_kmers) HIPCHK(hipMemcpyAsync(out_total_kmers, st->out_tk.p, R * 4, hipMemcpyDeviceToHost, st->s));
+  rc = copy_out(st, out_taxon, st->out_taxon.p, (size_t)C * R * 4);
+  if (!rc) rc = copy_out(st, out_classified, st->out_cls.p, (size_t)C * R);
+  if (!rc && out_num_distinct) rc = copy_out(st, out_num_distinct, st->out_nd.p, R * 4);
+  if (!rc && out_total_kmers) rc = copy_out(st, out_total_kmers, st->out_tk.p, R * 4);
+  if (rc) return rc;
+  if (call_timing) { (void)hipStreamSynchronize(st->s); tp[3] = now(); }
   if (out_hit_offsets) {
     rc = counts_to_offsets(st, st->out_nh.as<int32_t>(), R, out_hit_offsets, out_hits ? hits_capacity : ~0ULL);
     if (rc) return rc;
@@ -1022,10 +1098,14 @@ int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, 
       launch_gather_hits(d_off, d_moff, R, st->span_meta.as<int32_t>(), st->span_taxon.as<int32_t>(),
                          st->out_offsets.as<uint64_t>(), st->out_items.p, st->s);
       HIPCHK(hipGetLastError());
-      HIPCHK(hipMemcpyAsync(out_hits, st->out_items.p, n * sizeof(slk_hit), hipMemcpyDeviceToHost, st->s));
+      rc = copy_out(st, out_hits, st->out_items.p, n * sizeof(slk_hit));
+      if (rc) return rc;
     }
   }
   HIPCHK(hipStreamSynchronize(st->s));
+  if (call_timing)
+    fprintf(stderr, "slk_classify_batch R=%llu: upload %.2f ms, kernels %.2f, results %.2f, hit lists %.2f\n", (unsigned long long)R,
+            tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], now() - tp[3]);
   return check_status(st);
 }
 
