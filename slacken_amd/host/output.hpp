@@ -68,10 +68,19 @@ inline void append_pairs_in_order(std::string &s, const slk_hit *h, size_t n) {
   }
 }
 
+inline int gzip_level() {  // SLK_GZIP_LEVEL: 1..9; default = zlib's default level, as java.util.zip's Deflater behind Hadoop's GzipCodec
+  static const int level = [] {
+    const char *e = getenv("SLK_GZIP_LEVEL");
+    int v = e ? atoi(e) : 0;
+    return v >= 1 && v <= 9 ? v : Z_DEFAULT_COMPRESSION;
+  }();
+  return level;
+}
+
 inline std::string gzip_member(const std::string &text) {
   z_stream zs;
   memset(&zs, 0, sizeof zs);
-  if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
+  if (deflateInit2(&zs, gzip_level(), Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
   std::string out;
   out.resize(deflateBound(&zs, (uLong)text.size()) + 32);
   zs.next_in = (Bytef *)text.data();
@@ -126,15 +135,27 @@ class ThreadPool {
 
 // One classified batch: the fragments and what slk_classify_batch returned for them (threshold-major taxon / classified).
 struct ClassifiedBatch {
-  std::unique_ptr<FragmentBatch> frags;
+  FragmentBatchPtr frags;
   int C = 0;
   std::vector<int32_t> taxon;
   std::vector<uint8_t> classified;
   std::vector<uint64_t> hit_offs;
   std::unique_ptr<slk_hit[]> hits;  // hit_offs[n] entries (allocated uninitialised: zero-filling 8 bytes per base per batch showed)
+  size_t hits_capacity = 0;
   std::vector<uint64_t> span_offs;  // only when spans were requested
   std::vector<slk_span> spans;
+  void reserve_hits(size_t cap) {  // (the untouched tail of the allocation is never paged in)
+    if (cap <= hits_capacity) return;
+    hits_capacity = cap + cap / 8;
+    hits.reset(new slk_hit[hits_capacity]);
+  }
+  void recycle() { frags.reset(); }  // the fragments go back to their own pool; the result buffers keep their memory
+  size_t footprint() const { return hits_capacity * sizeof(slk_hit) / 8 + spans.capacity() * sizeof(slk_span); }
 };
+inline std::shared_ptr<ClassifiedBatch> new_classified_batch() {
+  static auto *pool = new Recycler<ClassifiedBatch>(64, (size_t)256 << 20);
+  return std::shared_ptr<ClassifiedBatch>(pool->acquire(), [](ClassifiedBatch *b) { pool->release(b); });
+}
 
 struct OutputOptions {
   std::string output, sample_regex;

@@ -214,6 +214,7 @@ struct FragmentBatch {
   std::string titles;
   std::vector<uint64_t> title_off{0};
   bool paired = false;
+  int pool = 0;  // which recycler it came from: 0 = batches assembled from runs of records, 1 = parsed chunks
   size_t size() const { return offs.size() - 1; }
   std::string_view title(size_t i) const { return std::string_view(titles).substr(title_off[i], title_off[i + 1] - title_off[i]); }
   std::string_view seq(size_t i) const { return std::string_view((const char *)bases.data() + offs[i], offs[i + 1] - offs[i]); }
@@ -249,7 +250,54 @@ struct FragmentBatch {
     mate_bases.insert(mate_bases.end(), c.bases.begin() + b0, c.bases.begin() + c.offs[i + n]);
     for (size_t r = 1; r <= n; r++) mate_offs.push_back(c.offs[i + r] + shift);
   }
+  void recycle() {  // empty, with the memory kept
+    bases.clear(); mate_bases.clear(); titles.clear();
+    offs.assign(1, 0); mate_offs.assign(1, 0); title_off.assign(1, 0);
+    paired = false;
+  }
+  size_t footprint() const { return bases.capacity() + mate_bases.capacity() + titles.capacity() + 8 * (offs.capacity() + mate_offs.capacity() + title_off.capacity()); }
 };
+
+// Batches travel from the parsing threads through the classify loop to the output threads and die there; their buffers are
+// tens of MB, which the allocator would map, fault in page by page and unmap again for every batch.  Finished objects come
+// back here instead and are handed out again with their memory (and its pages) in place.
+template <class T>
+class Recycler {
+  std::mutex mu_;
+  std::vector<T *> free_;
+  const size_t max_objects_, max_footprint_;
+
+ public:
+  Recycler(size_t max_objects, size_t max_footprint) : max_objects_(max_objects), max_footprint_(max_footprint) {}
+  T *acquire() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (!free_.empty()) { T *p = free_.back(); free_.pop_back(); return p; }
+    }
+    return new T();
+  }
+  void release(T *p) {
+    if (!p) return;
+    if (p->footprint() <= max_footprint_) {
+      p->recycle();
+      std::lock_guard<std::mutex> lk(mu_);
+      if (free_.size() < max_objects_) { free_.push_back(p); return; }
+    }
+    delete p;
+  }
+};
+// (two pools, as the two kinds differ in size; never destroyed: threads may still hand objects back during exit())
+inline Recycler<FragmentBatch> &fragment_batches(int pool) {
+  static Recycler<FragmentBatch> *r[2] = {new Recycler<FragmentBatch>(24, (size_t)256 << 20), new Recycler<FragmentBatch>(48, (size_t)256 << 20)};
+  return *r[pool];
+}
+struct FragmentBatchReturn { void operator()(FragmentBatch *b) const { if (b) fragment_batches(b->pool).release(b); } };
+using FragmentBatchPtr = std::unique_ptr<FragmentBatch, FragmentBatchReturn>;
+inline FragmentBatchPtr new_fragment_batch(int pool = 0) {
+  FragmentBatch *b = fragment_batches(pool).acquire();
+  b->pool = pool;
+  return FragmentBatchPtr(b);
+}
 
 // ---- plain (uncompressed) files: mapped into memory and cut into segments that are parsed on several threads ----
 // Both record rules of the reference are local -- a FASTQ record starts at every line that begins with '@' and whose second
@@ -345,14 +393,14 @@ inline size_t parse_threads() {  // SLK_PARSE_THREADS: threads that parse one pl
 // thread (a gzip stream is serial; paired input runs two of these side by side); a plain file is mapped and its segments are
 // parsed on several threads.  The views of next() stay valid until the next call.
 class AsyncRecordStream {
-  std::deque<std::unique_ptr<FragmentBatch>> q_;  // serial producer: finished chunks
-  std::map<size_t, std::unique_ptr<FragmentBatch>> done_;  // parallel producers: finished segments by number
+  std::deque<FragmentBatchPtr> q_;  // serial producer: finished chunks
+  std::map<size_t, FragmentBatchPtr> done_;  // parallel producers: finished segments by number
   size_t nseg_ = 0, seg_bytes_ = 0, next_claim_ = 0, next_out_ = 0, depth_ = 0;
   std::mutex mu_;
   std::condition_variable cv_;
   bool done_flag_ = false, stop_ = false, parallel_ = false;
   std::string error_;
-  std::unique_ptr<FragmentBatch> cur_;
+  FragmentBatchPtr cur_;
   size_t cur_i_ = 0;
   std::vector<std::thread> th_;
   const char *map_ = nullptr;
@@ -362,14 +410,14 @@ class AsyncRecordStream {
     try {
       RecordStream rs(file);
       std::string_view h, sq;
-      auto c = std::make_unique<FragmentBatch>();
+      auto c = new_fragment_batch(1);
       auto flush = [&]() {
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [&] { return q_.size() < 4 || stop_; });
         if (stop_) return false;
         q_.push_back(std::move(c));
         cv_.notify_all();
-        c = std::make_unique<FragmentBatch>();
+        c = new_fragment_batch(1);
         return true;
       };
       while (rs.next(h, sq)) {
@@ -396,7 +444,7 @@ class AsyncRecordStream {
         if (stop_ || next_claim_ >= nseg_) return;
         i = next_claim_++;
       }
-      auto c = std::make_unique<FragmentBatch>();
+      auto c = new_fragment_batch(1);
       try {
         const size_t a = i * seg_bytes_, b = std::min(map_len_, a + seg_bytes_);
         c->bases.reserve((b - a) / 2 + 256);
@@ -421,10 +469,10 @@ class AsyncRecordStream {
     return k == 2 && m[0] == 0x1f && m[1] == 0x8b;
   }
 
-  std::unique_ptr<FragmentBatch> pop() {  // the next non-empty chunk, nullptr at the end
+  FragmentBatchPtr pop() {  // the next non-empty chunk, nullptr at the end
     for (;;) {
       std::unique_lock<std::mutex> lk(mu_);
-      std::unique_ptr<FragmentBatch> c;
+      FragmentBatchPtr c;
       if (parallel_) {
         cv_.wait(lk, [&] { return !error_.empty() || next_out_ >= nseg_ || done_.count(next_out_); });
         if (!error_.empty()) throw std::runtime_error(error_);
@@ -502,7 +550,7 @@ class AsyncRecordStream {
     return cur_.get();
   }
   void advance(size_t n) { cur_i_ += n; }
-  std::unique_ptr<FragmentBatch> take() { cur_i_ = 0; return std::move(cur_); }
+  FragmentBatchPtr take() { cur_i_ = 0; return std::move(cur_); }
   bool whole_chunks() const { return parallel_; }  // chunks are batch-sized (the segments of a plain file)
 };
 
@@ -530,22 +578,23 @@ class FragmentSource {
 
   // Appends up to max_fragments (and about max_bases) to b; false when every file is exhausted and nothing was added.
   // Records move a run at a time (one copy of the bases of the run, not one per record).
-  bool fill(FragmentBatch &b, size_t max_fragments, size_t max_bases) {
-    b.paired = paired_;
+  bool fill(FragmentBatchPtr &bp, size_t max_fragments, size_t max_bases) {
+    if (!bp) bp = new_fragment_batch();
+    bp->paired = paired_;
     size_t added = 0;
-    while (added < max_fragments && b.bases.size() + b.mate_bases.size() < max_bases) {
+    while (added < max_fragments && bp->bases.size() + bp->mate_bases.size() < max_bases) {
       if (!s1_ && !open_next()) break;
       size_t i1 = 0, i2 = 0;
       const FragmentBatch *c1 = s1_->current(i1);
       if (!c1) { s1_.reset(); s2_.reset(); continue; }
       if (!paired_) {
-        if (b.size() == 0 && i1 == 0 && s1_->whole_chunks()) {  // a parsed segment of a plain file is a batch as it stands
-          b = std::move(*s1_->take());
-          b.paired = false;
+        if (bp->size() == 0 && i1 == 0 && s1_->whole_chunks()) {  // a parsed segment of a plain file is a batch as it stands
+          bp = s1_->take();
+          bp->paired = false;
           return true;
         }
         const size_t n = std::min(c1->size() - i1, max_fragments - added);
-        b.append(*c1, i1, n, nullptr);
+        bp->append(*c1, i1, n, nullptr);
         s1_->advance(n);
         added += n;
         continue;
@@ -559,8 +608,8 @@ class FragmentSource {
           size_t ok = 0;
           while (ok < n && remove_suffix(c1->title(i1 + ok), "/1") == remove_suffix(c2->title(i2 + ok), "/2")) ok++;
           if (ok) {
-            b.append(*c1, i1, ok, "/1");
-            b.append_mates(*c2, i2, ok);
+            bp->append(*c1, i1, ok, "/1");
+            bp->append_mates(*c2, i2, ok);
             s1_->advance(ok);
             s2_->advance(ok);
             added += ok;
@@ -578,7 +627,7 @@ class FragmentSource {
       auto it = mates_.find(std::string(h));
       if (it == mates_.end()) continue;  // inner join: no mate, no fragment
       std::string_view m(it->second);
-      b.add(h, sq, &m);
+      bp->add(h, sq, &m);
       added++;
     }
     return added > 0;
@@ -589,7 +638,7 @@ class FragmentSource {
 class BatchPrefetcher {
   FragmentSource src_;
   size_t max_fragments_, max_bases_, depth_;
-  std::deque<std::unique_ptr<FragmentBatch>> q_;
+  std::deque<FragmentBatchPtr> q_;
   std::mutex mu_;
   std::condition_variable cv_;
   bool done_ = false, stop_ = false;
@@ -599,8 +648,8 @@ class BatchPrefetcher {
   void run() {
     try {
       for (;;) {
-        auto b = std::make_unique<FragmentBatch>();
-        if (!src_.fill(*b, max_fragments_, max_bases_)) break;
+        auto b = new_fragment_batch();
+        if (!src_.fill(b, max_fragments_, max_bases_)) break;
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [&] { return q_.size() < depth_ || stop_; });
         if (stop_) return;
@@ -617,14 +666,14 @@ class BatchPrefetcher {
   }
 
  public:
-  BatchPrefetcher(std::vector<std::string> files, bool paired, size_t max_fragments = (size_t)1 << 20,
+  BatchPrefetcher(std::vector<std::string> files, bool paired, size_t max_fragments = (size_t)1 << 17,
                   size_t max_bases = (size_t)512 << 20, size_t depth = 2)
       : src_(std::move(files), paired), max_fragments_(max_fragments), max_bases_(max_bases), depth_(depth), th_([this] { run(); }) {}
   ~BatchPrefetcher() {
     { std::lock_guard<std::mutex> lk(mu_); stop_ = true; cv_.notify_all(); }
     th_.join();
   }
-  std::unique_ptr<FragmentBatch> next() {  // nullptr at the end of the input
+  FragmentBatchPtr next() {  // nullptr at the end of the input
     std::unique_lock<std::mutex> lk(mu_);
     cv_.wait(lk, [&] { return !q_.empty() || done_; });
     if (!error_.empty()) throw std::runtime_error(error_);

@@ -165,8 +165,9 @@ static int cmd_parse(int argc, char **argv) {  // parse <file> [<file2>]: header
   std::vector<std::string> files(argv, argv + std::min(argc, 2));
   FragmentSource src(files, argc >= 2);
   for (;;) {
-    FragmentBatch b;
-    if (!src.fill(b, 4096, (size_t)64 << 20)) break;
+    FragmentBatchPtr bp;
+    if (!src.fill(bp, 4096, (size_t)64 << 20)) break;
+    const FragmentBatch &b = *bp;
     for (size_t i = 0; i < b.size(); i++) {
       std::cout << b.title(i) << '\t' << b.seq(i);
       if (b.paired) std::cout << '\t' << b.mate(i);
@@ -311,7 +312,7 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
   };
   while (active.size() < conc) { auto r = open_next(); if (!r) break; active.push_back(std::move(r)); }
   size_t turn = 0;
-  auto next_batch = [&]() -> std::unique_ptr<FragmentBatch> {
+  auto next_batch = [&]() -> FragmentBatchPtr {
     while (!active.empty()) {
       if (turn >= active.size()) turn = 0;
       auto b = active[turn]->next();
@@ -335,7 +336,7 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
     double t1 = now();
     t_input += t1 - t0;
     n_batches++;
-    auto b = std::make_shared<ClassifiedBatch>();
+    auto b = new_classified_batch();
     b->frags = std::move(frags);
     b->C = C;
     const FragmentBatch &fb = *b->frags;
@@ -344,11 +345,11 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
     b->taxon.resize((size_t)C * n); b->classified.resize((size_t)C * n); nd.resize(n); tk.resize(n);
     b->hit_offs.resize(n + 1);
     const size_t cap = fb.bases.size() + fb.mate_bases.size() + n + 1;
-    if (want_hits) b->hits.reset(new slk_hit[cap]);  // (no zero-fill; the untouched tail of the allocation is never paged in)
+    if (want_hits) b->reserve_hits(cap);
     const uint8_t *mb = fb.paired ? fb.mate_bases.data() : nullptr;
     const uint64_t *mo = fb.paired ? fb.mate_offs.data() : nullptr;
     SLK_CALL(slk_classify_batch(dev.ix, dev.st, fb.bases.data(), fb.offs.data(), mb, mo, n, min_hits, thresholds.data(), C,
-                                b->taxon.data(), b->classified.data(), nd.data(), tk.data(), b->hit_offs.data(), b->hits.get(), cap));
+                                b->taxon.data(), b->classified.data(), nd.data(), tk.data(), b->hit_offs.data(), want_hits ? b->hits.get() : nullptr, cap));
     if (want_spans) {
       b->span_offs.resize(n + 1);
       b->spans.resize(cap);
@@ -580,7 +581,9 @@ static const char *HELP =
     "options of classify2 (Slacken.scala:199-260): --library DIR (DIR/library/**/*.fna, DIR/seqid2taxid.map), --rank RANK (species),\n"
     "  -R, --reads N (100) | -C, --min-count N | -D, --min-distinct N, --init-confidence X (0.15)\n"
     "host-only helpers: report TAXONOMY_DIR COUNTS_TSV | parse FILE [MATE_FILE] | props INDEX | records INDEX\n"
-    "environment: SLK_HOST_THREADS (formatting/decoding threads), SLK_INPUT_STREAMS (input files read side by side, default 8)\n";
+    "environment: SLK_HOST_THREADS (formatting/decoding threads), SLK_INPUT_STREAMS (input files read side by side, default 8),\n"
+    "             SLK_PARSE_THREADS (threads parsing one plain input file, default min(8, cores/2)), SLK_GZIP_LEVEL (1..9, default zlib's),\n"
+    "             SLK_HOST_TIMING (report where the wall clock of the classify loop went)\n";
 
 int main(int argc, char **argv) {
   int i = 1;
