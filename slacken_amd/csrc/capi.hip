@@ -693,7 +693,7 @@ static int32_t check_status(slk_stream *st) {  // call after the stream has been
   return SLK_OK;
 }
 
-static bool lane_path_ok(const slk_index *ix) { return use_fused(ix) && ix->sp.w <= 16 && ix->taxon_bits <= 22; }
+static bool lane_path_ok(const slk_index *ix) { return use_fused(ix) && ix->sp.w <= 32 && ix->taxon_bits <= 22; }
 
 static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
                             const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
@@ -733,7 +733,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
     A.span_count = want_hits ? st->span_count.as<int32_t>() : nullptr;
     A.status = st->d_status;
     A.work_list = nullptr; A.work_count = nullptr;
-    if (lane_path_ok(ix) && !force_wave()) {  // (window of at most 16 m-mers, taxon ids of at most 22 bits)
+    if (lane_path_ok(ix) && !force_wave()) {  // (window of at most 32 m-mers, taxon ids of at most 22 bits)
       st->last_used_lane = true;
       // hot path: one lane per fragment; long fragments and map overflows are deferred to the wave-per-read kernel
       HIPCHK(st->defer.ensure((R + 64) * sizeof(int32_t)));

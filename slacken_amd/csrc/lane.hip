@@ -317,13 +317,13 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const ScanParams P = A.P;
   const int k = P.k, m = P.m, w = P.w;
-  // per-wave LDS: fixed part, then (generic w only) the key ring and the suffix-minimum ring, [w][64] each
+  // per-wave LDS: fixed part, then (generic w only) the window array, [w][64]: the keys of the current w-block in its first
+  // rows, the suffix minima of the previous block in the rows the current block has not reached yet
   // (the hit-list fields are the struct's tail: kernels that do not write hit lists leave them out of their footprint)
   const size_t fixed = HITS ? sizeof(LaneLds) : offsetof(LaneLds, rb);
-  const size_t per_wave = fixed + (W5 ? 0 : (size_t)2 * w * 64 * sizeof(uint64_t));
+  const size_t per_wave = fixed + (W5 ? 0 : (size_t)w * 64 * sizeof(uint64_t));
   LaneLds *L = (LaneLds *)(lds_raw + (size_t)wib * per_wave);
-  uint64_t *ring = (uint64_t *)((unsigned char *)L + fixed);
-  uint64_t *suf = ring + (size_t)w * 64;
+  uint64_t *win = (uint64_t *)((unsigned char *)L + fixed);
   const bool paired = A.mate_bases != nullptr;
   const uint64_t ntiles = (A.R + 63) / 64;
   const uint64_t nwaves = (uint64_t)gridDim.x * LW;
@@ -433,9 +433,9 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       } else {
         // van Herk: window = suffix of the previous w-block  U  prefix of the current one (blocks on the step counter)
         const uint64_t kk = havekey ? key : ~0ULL;
-        ring[tphase * 64 + lane] = kk;
         pre = lmin64(pre, kk);
-        minv = (tphase == w - 1) ? pre : lmin64(pre, suf[(tphase + 1) * 64 + lane]);
+        minv = (tphase == w - 1) ? pre : lmin64(pre, win[(tphase + 1) * 64 + lane]);  // row tphase + 1: still the previous block's
+        win[tphase * 64 + lane] = kk;                                                  // row tphase: its suffix minimum was used last step
       }
       const bool havewin = havekey && nvalid >= (uint32_t)k;  // a k-mer window is complete: its minimizer VALUE is minv
       const bool start = havewin && cur_run == 0;
@@ -488,7 +488,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       if (!W5) {  // end of a w-block: rebuild the suffix minima of the block just completed (wave-uniform control flow)
         if (tphase == w - 1) {
           uint64_t sm = ~0ULL;
-          for (int j = w - 1; j >= 0; j--) { sm = lmin64(sm, ring[j * 64 + lane]); suf[j * 64 + lane] = sm; }
+          for (int j = w - 1; j >= 0; j--) { sm = lmin64(sm, win[j * 64 + lane]); win[j * 64 + lane] = sm; }  // in place
           tphase = 0;
         } else {
           tphase++;
@@ -626,7 +626,7 @@ template <int MODE, bool HITS>
 static void launch_lane_mode(const FusedArgs &A, const ShardIO &S, int32_t *defer, uint32_t max_len, hipStream_t s) {
   if (A.R == 0) return;
   const bool w5 = A.P.w == 5;
-  size_t per_wave = (HITS ? sizeof(LaneLds) : offsetof(LaneLds, rb)) + (w5 ? 0 : (size_t)2 * A.P.w * 64 * sizeof(uint64_t));
+  size_t per_wave = (HITS ? sizeof(LaneLds) : offsetof(LaneLds, rb)) + (w5 ? 0 : (size_t)A.P.w * 64 * sizeof(uint64_t));
   static const int extra_lds = getenv("SLK_LANE_EXTRA_LDS") ? atoi(getenv("SLK_LANE_EXTRA_LDS")) : 0;  // (occupancy experiment)
   size_t lds = per_wave * LW + (size_t)extra_lds;
   uint64_t tiles = (A.R + 63) / 64;

@@ -92,7 +92,7 @@ def test_sharded_routes_differential(orc, seed):
     from slacken_amd import sharded
     rng = np.random.default_rng(7000 + seed)
     m = int(rng.integers(8, 33))
-    k = int(rng.integers(m, m + (40 if seed % 5 == 0 else 16)))      # windows wider than 16: staged route only
+    k = int(rng.integers(m, m + (40 if seed % 5 == 0 else 16)))      # windows wider than 32: staged route only
     spaces = int(rng.integers(0, m // 2 + 1))
     p = orc.params(k=k, m=m, spaces=spaces)
     parents = taxgen.taxonomy(8 * int(rng.integers(4, 64)), rng)

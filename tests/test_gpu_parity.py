@@ -194,10 +194,11 @@ def test_api_errors(world):
 
 
 @pytest.mark.parametrize("ps", [dict(k=31, m=31, spaces=0), dict(k=21, m=12, spaces=5), dict(k=45, m=32, spaces=16),
-                                dict(k=35, m=31, spaces=7, canonical=False), dict(k=40, m=25, spaces=3)],
+                                dict(k=35, m=31, spaces=7, canonical=False), dict(k=40, m=25, spaces=3),
+                                dict(k=31, m=15, spaces=0), dict(k=51, m=20, spaces=2)],
                          ids=lambda ps: f"k{ps['k']}m{ps['m']}s{ps['spaces']}")
 def test_classify_parity_other_splitters(orc, ps):
-    """Window widths other than 5 run the van-Herk variant of the lane kernel (w <= 16); non-canonical and full-width
+    """Window widths other than 5 run the van-Herk variant of the lane kernel (w <= 32); non-canonical and full-width
     keys exercise the key arithmetic.  Hot path and hit-list path against the oracle."""
     import slacken_amd
     ps = full(ps)

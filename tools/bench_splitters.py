@@ -16,7 +16,7 @@ stt = torch.randint(0, G * L - 150, (R,), generator=g, device="cuda")
 d_b = torch.cat([d_all[(stt[:, None] + torch.arange(150, device="cuda")[None, :]).reshape(-1)], torch.zeros(64, dtype=torch.uint8, device="cuda")])
 d_o = torch.arange(0, (R + 1) * 150, 150, dtype=torch.int64, device="cuda")
 d_t = torch.zeros(R, dtype=torch.int32, device="cuda"); d_c = torch.zeros(R, dtype=torch.uint8, device="cuda")
-for k, m, s in ((35, 31, 7), (31, 27, 0), (31, 25, 4), (31, 21, 0), (35, 20, 0), (25, 25, 0), (31, 15, 0)):
+for k, m, s in ((35, 31, 7), (31, 27, 0), (31, 25, 4), (31, 21, 0), (35, 20, 0), (25, 25, 0), (31, 15, 0), (45, 20, 2)):
     ix = slacken_amd.Index(k=k, m=m, spaces=s, expected_records=int(G * L * 0.7), max_taxon=len(parents) - 1)
     ix.set_taxonomy(parents)
     ix.add_sequences(bases, offsets, rng.choice(taxa[len(taxa)//2:], G).astype(np.int32))
