@@ -243,7 +243,7 @@ class Stream:
         return out_off, out[:int(out_off[R])]
 
     def classify_batch(self, bases, offsets, mate_bases=None, mate_offsets=None, min_hit_groups=2,
-                       thresholds=(0.0,), with_hits=True, hits_capacity=None):
+                       thresholds=(0.0,), with_hits=True, hits_capacity=None, with_num_hits=False):
         bases, offsets = _np(bases, np.uint8), _np(offsets, np.uint64)
         R = offsets.size - 1
         if mate_bases is not None:
@@ -260,6 +260,8 @@ class Stream:
                 int(bases.size + (mate_bases.size + R if mate_bases is not None else 0)) + 1
             hit_off = np.zeros(R + 1, np.uint64)
             hits = np.zeros(cap, HIT_DTYPE)
+        elif with_num_hits:   # the number of spans per fragment without the lists: offsets only
+            hit_off = np.zeros(R + 1, np.uint64)
         _check(lib().slk_classify_batch(self.index.h, self.h, _ptr(bases), _ptr(offsets), _ptr(mate_bases),
                                         _ptr(mate_offsets), R, min_hit_groups, thr, Cn, _ptr(taxon), _ptr(cls),
                                         _ptr(nd), _ptr(tk), _ptr(hit_off), _ptr(hits), cap))
@@ -267,6 +269,8 @@ class Stream:
         if with_hits:
             out["hit_offsets"] = hit_off
             out["hits"] = hits[:int(hit_off[R])]
+            out["num_hits"] = np.diff(hit_off.astype(np.int64)).astype(np.int32)
+        elif with_num_hits:
             out["num_hits"] = np.diff(hit_off.astype(np.int64)).astype(np.int32)
         return out
 

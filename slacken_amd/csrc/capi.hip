@@ -746,6 +746,12 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
                            (unsigned long long *)st->defer_list.p, st->s);
       A.work_list = st->defer_list.as<uint64_t>() + 1;
       A.work_count = (const unsigned long long *)st->defer_list.p;
+      // of the deferred fragments, the long unpaired ones go to the lane-per-segment kernel (classification only, w = 5)
+      static const int seg_min = getenv("SLK_SEG_MIN_LEN") ? atoi(getenv("SLK_SEG_MIN_LEN")) : 3000;  // 0: wave kernel only
+      if (!want_hits && !paired && ix->sp.w == 5 && seg_min > 0) {
+        A.seg_min_len = (uint32_t)std::max(seg_min, 1001);
+        launch_segments(A, st->s);
+      }
     }
     launch_fused(want_hits ? MODE_HITS : MODE_CLASSIFY, A, st->s);
     HIPCHK(hipEventRecord(st->ev[1], st->s));
@@ -1077,7 +1083,7 @@ int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, 
   rc = run_classify(ix, st, st->bases.as<uint8_t>(), d_off, paired ? st->mate_bases.as<uint8_t>() : nullptr, d_moff, R,
                     total, mate_total, min_hit_groups, thresholds, C, st->out_taxon.as<int32_t>(),
                     st->out_cls.as<uint8_t>(), st->out_nd.as<int32_t>(), st->out_tk.as<int32_t>(),
-                    st->out_nh.as<int32_t>(), nullptr, out_hit_offsets != nullptr);
+                    st->out_nh.as<int32_t>(), nullptr, out_hit_offsets != nullptr && out_hits != nullptr);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(st->s));
   tp[2] = now();

@@ -413,6 +413,7 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
   for (uint64_t unit = (uint64_t)blockIdx.x * FW + wib; unit < nunits; unit += nwaves) {
    {
     const uint64_t r = A.work_list ? A.work_list[unit] : unit;
+    if (A.seg_min_len && A.offsets[r + 1] - A.offsets[r] >= A.seg_min_len) continue;  // the segment kernel's (launch_segments)
     // ---- per-fragment state (wave-uniform unless noted) ----
     int nbuf = 0, n_out = 0;
     bool first = true, have_last = false;   // Supermers.spans :72-73
@@ -621,6 +622,283 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
     wave_sync();
    }
   }
+}
+
+
+// ---- long unpaired fragments: ONE WAVE PER FRAGMENT, ONE LANE PER SEGMENT ---------------------------------------------------
+// The wave-wide scan above spends a few hundred instructions per 60 windows; a lane that walks its own stretch of the read
+// with the lane kernel's state machine (lane.hip) needs a fraction of that per base, and 64 of them run side by side.  The
+// fragment's k-mer windows are cut into 64 contiguous segments (of at least 64 windows), lane j scans the bases of segment j
+// (its windows + k - 1) and pushes its super-mers into the wave's span buffer; probing, the taxon map and resolveTree are the
+// wave kernel's.  Everything the classification needs is additive over windows -- a window's minimizer depends on its own
+// bases only, super-mers and ambiguous spans partition the windows of their runs (Supermers.scala:116-119) -- except what
+// looks across a segment border, which is settled at the end from what each lane saw at its two ends:
+//   * `distinct` of a segment's first super-mer (Supermers.spans :84-90) compares with the last super-mer BEFORE it, which
+//     another lane produced: it is counted as distinct first and taken back if the keys turn out equal;
+//   * a super-mer or an ambiguous span cut by a border was counted twice in the number of spans (out_nh).
+// The order of the spans is not kept: classification only (no hit lists), window width 5 (the register window of lane.hip).
+constexpr int SEG_SBLK = 5;       // 16-byte sub-blocks fetched per refill of a lane's read stream (as lane.hip)
+constexpr uint32_t SEG_MIN_WINDOWS = 64;
+struct __attribute__((aligned(16))) SegLds {
+  uint4 sbuf[(SEG_SBLK - 1) * 64];
+  uint64_t first_key[64], last_key[64];
+  uint32_t flags[64];
+};
+enum { SEGF_HAS = 1, SEGF_ENDS_OPEN = 2, SEGF_END_AMB = 4 };
+
+__device__ __forceinline__ uint4 seg_refill(SegLds *G, int lane, const uint8_t *seq, uint32_t p, uint32_t n) {
+  uint4 v[SEG_SBLK];
+#pragma unroll
+  for (int i = 0; i < SEG_SBLK; i++) {
+    v[i] = make_uint4(0, 0, 0, 0);
+    if (p + 16u * i < n) __builtin_memcpy(&v[i], seq + p + 16u * i, 16);
+  }
+#pragma unroll
+  for (int i = 1; i < SEG_SBLK; i++) G->sbuf[(i - 1) * 64 + lane] = v[i];
+  return v[0];
+}
+
+__global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
+  __shared__ WaveLds lds[FW];
+  __shared__ SegLds seg[FW];
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  WaveLds *L = &lds[wib];
+  SegLds *G = &seg[wib];
+  const ScanParams P = A.P;
+  const int k = P.k, m = P.m;
+  const uint64_t nwaves = (uint64_t)gridDim.x * FW;
+  const uint64_t nunits = (uint64_t)*A.work_count;
+  const uint32_t VM = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20) | (1u << 21);  // A C G T U, either case
+  for (uint64_t unit = (uint64_t)blockIdx.x * FW + wib; unit < nunits; unit += nwaves) {
+    const uint64_t r = A.work_list[unit];
+    const uint64_t o = A.offsets[r];
+    const uint32_t n_all = (uint32_t)(A.offsets[r + 1] - o);
+    if (n_all < A.seg_min_len) continue;  // the wave kernel's
+    // ---- this lane's segment ----
+    const uint32_t nwin = n_all - (uint32_t)k + 1;  // (seg_min_len > k)
+    const uint32_t S = max(SEG_MIN_WINDOWS, (nwin + 63) / 64);
+    const uint32_t w0 = (uint32_t)lane * S;
+    const bool exists = w0 < nwin;
+    const uint8_t *seq = A.bases + o + (exists ? w0 : 0);
+    const uint32_t n = exists ? (min(nwin, w0 + S) - w0) + (uint32_t)k - 1 : 0;
+    // ---- wave state (as fused_kernel) ----
+    int nbuf = 0, n_out = 0;
+    int32_t nd = 0, np = 0, t0 = 0;
+    bool map_mode = false;
+    int32_t acc_t0 = 0, acc_none = 0;
+    L->map_key[lane] = MAP_EMPTY; L->map_key[lane + 64] = MAP_EMPTY;
+    L->map_cnt[lane] = 0; L->map_cnt[lane + 64] = 0;
+    // ---- lane state (as lane_kernel, window width 5) ----
+    bool fin = !exists;
+    uint32_t pos = 0;
+    uint32_t cur = 0, b1 = 0, b2 = 0, b3 = 0;
+    int sb = 1;
+    if (!fin) {
+      uint4 v = seg_refill(G, lane, seq, 0, n);
+      cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
+    }
+    int run_class = 0;
+    uint32_t run_len = 0, nvalid = 0;
+    uint64_t fwd = 0, rc = 0;
+    uint64_t k1 = ~0ULL, p1 = ~0ULL, p2 = ~0ULL, m41 = ~0ULL;
+    uint64_t cur_val = 0;
+    int32_t cur_run = 0;
+    bool have_last = false;
+    uint64_t last_key = 0, first_key = 0;
+    int32_t total = 0, namb = 0;
+    // what the borders need
+    bool seen_win = false, starts_seq = false, first_run_done = false, first_run_amb = false;
+    bool ends_open = false, end_amb = false;
+    int first_slot = -1;       // where this lane's first super-mer sits in the span buffer until its taxon is known
+    bool first_nz = false;     // ... and whether that taxon is a real one
+    bool done = false;
+
+    while (true) {
+      // ================= producer: every lane takes one step; at most 64 spans per step =================
+      while (!done && nbuf <= SPAN_CAP - 64) {
+        if (__ballot(!fin) == 0) { done = true; break; }
+        const bool act = !fin;
+        const bool is_end = pos >= n;
+        const uint32_t c = cur & 0xFF;
+        const bool okc = ((c & 0xC0) == 0x40) && ((VM >> (c & 31)) & 1);
+        uint32_t t = (c >> 1) & 3;
+        t ^= t >> 1;
+        const int cls = is_end ? -1 : (okc ? 1 : 0);
+        const bool run_end = act && run_len > 0 && cls != run_class;
+        const bool seqrun = run_class == 1 && nvalid >= (uint32_t)k;
+        const bool seq_close = run_end && seqrun;
+        const bool amb_close = run_end && !seqrun && run_len >= (uint32_t)k;
+        total += amb_close ? (int32_t)run_len - (k - 1) : 0;
+        namb += amb_close ? 1 : 0;
+        first_run_amb = (run_end && !first_run_done) ? amb_close : first_run_amb;
+        first_run_done = first_run_done || run_end;
+        ends_open = (act && is_end) ? seq_close : ends_open;
+        end_amb = (act && is_end) ? amb_close : end_amb;
+        const uint64_t ekey = cur_val;
+        const int32_t ekmers = cur_run;
+        run_len = run_end ? 0u : run_len;
+        const bool proc = act && !is_end;
+        const bool new_run = proc && run_len == 0;
+        run_class = new_run ? cls : run_class;
+        nvalid = new_run ? 0u : nvalid;
+        cur_run = (new_run || seq_close) ? 0 : cur_run;
+        run_len += proc ? 1u : 0u;
+        const bool nt = proc && okc;
+        nvalid += nt ? 1u : 0u;
+        fwd = (fwd << 2) | ((uint64_t)t << P.sh);
+        rc = ((rc >> 2) | ((uint64_t)(3 - t) << 62)) & P.keep;
+        const bool havekey = nt && nvalid >= (uint32_t)m;
+        const uint64_t canon = (P.canonical && rc < fwd) ? rc : fwd;
+        const uint64_t key = (canon ^ P.xmask) & P.smask;
+        const uint64_t pm = umin64(key, k1);
+        const uint64_t m4 = umin64(pm, p2);
+        const uint64_t minv = umin64(key, m41);
+        k1 = key; p2 = p1; p1 = pm; m41 = m4;
+        const bool havewin = havekey && nvalid >= (uint32_t)k;
+        starts_seq = (havewin && !seen_win) ? (pos == (uint32_t)k - 1) : starts_seq;  // the segment's first window is a k-mer
+        seen_win = seen_win || havewin;
+        const bool start = havewin && cur_run == 0;
+        const bool same = havewin && cur_run != 0 && minv == cur_val;
+        const bool change = havewin && cur_run != 0 && minv != cur_val;
+        const bool emit = seq_close || change;
+        cur_val = (start || change) ? minv : cur_val;
+        cur_run = (start || change) ? 1 : (same ? cur_run + 1 : cur_run);
+        pos += proc ? 1u : 0u;
+        const bool nextdw = proc && (pos & 3) == 0;
+        cur = nextdw ? b1 : (proc ? (cur >> 8) : cur);
+        b1 = nextdw ? b2 : b1;
+        b2 = nextdw ? b3 : b2;
+        const bool refill = proc && (pos & 15) == 0;
+        if (__ballot(refill) != 0) {
+          if (refill && pos < n) {
+            uint4 v;
+            if (sb < SEG_SBLK) { v = G->sbuf[(sb - 1) * 64 + lane]; sb++; }
+            else { v = seg_refill(G, lane, seq, pos, n); sb = 1; }
+            cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
+          }
+        }
+        fin = fin || (act && is_end);
+        const bool distinct = emit && !(have_last && ekey == last_key);  // (a segment's first: provisionally distinct)
+        const bool is_first = emit && !have_last;
+        first_key = is_first ? ekey : first_key;
+        last_key = emit ? ekey : last_key;
+        have_last = have_last || emit;
+        total += emit ? ekmers : 0;
+        const uint64_t E = __ballot(emit);
+        if (E != 0) {
+          if (emit) {
+            const int slot = nbuf + lanes_below(E);
+            put_span(L, slot, ekey, ekmers, 1, distinct);
+            if (is_first && lane > 0) first_slot = slot;
+          }
+          nbuf += __popcll(E);
+        }
+      }
+
+      // ================= consumer: whole chunks of 64 (everything at the end) =================
+      wave_sync();
+      const int nflush = done ? nbuf : (nbuf & ~63);
+      for (int s0 = 0; s0 < nflush; s0 += 64) {
+        const int cnt = min(64, nflush - s0);
+        const bool in = lane < cnt;
+        const int32_t meta = in ? L->span_meta[s0 + lane] : 0;
+        const int32_t taxon = probe_chunk(L, A.T, s0, cnt, lane, meta);
+        const int32_t count = meta_kmers(meta);
+        const bool real = in && taxon >= 0;
+        nd += __popcll(__ballot(in && meta_distinct(meta) && taxon != 0));
+        np += __popcll(__ballot(real));
+        {  // the lanes whose first super-mer is in this chunk learn its taxon
+          const int src = first_slot - s0;
+          const bool mine = first_slot >= 0 && src >= 0 && src < cnt;
+          const int32_t tf = __shfl(taxon, mine ? src : 0);
+          if (mine) { first_nz = tf != 0; first_slot = -1; }
+        }
+        if (!map_mode) {
+          uint64_t nz = __ballot(real && taxon != 0);
+          if (nz != 0) {
+            if (t0 == 0) t0 = __builtin_amdgcn_readlane(taxon, __builtin_ctzll(nz));
+            if (__ballot(real && taxon != 0 && taxon != t0) != 0) {
+              int32_t c0 = wave_sum(acc_t0), cn = wave_sum(acc_none);
+              if (lane == 0 && c0 != 0) map_insert(L, t0, c0, A.status);
+              if (lane == 1 && cn != 0) map_insert(L, 0, cn, A.status);
+              map_mode = true;
+            }
+          }
+        }
+        if (map_mode) {
+          if (real) map_insert(L, taxon, count, A.status);
+        } else if (real) {
+          if (taxon != 0) acc_t0 += count;
+          else acc_none += count;
+        }
+        n_out += cnt;
+      }
+      wave_sync();
+      if (done) break;
+      // the spans short of a whole chunk move to the front of the buffer
+      const int rest = nbuf - nflush;
+      if (nflush > 0 && rest > 0) {
+        uint64_t kk = 0; int32_t mm = 0;
+        if (lane < rest) { kk = L->span_key[nflush + lane]; mm = L->span_meta[nflush + lane]; }
+        wave_sync();
+        if (lane < rest) { L->span_key[lane] = kk; L->span_meta[lane] = mm; }
+        if (first_slot >= 0) first_slot -= nflush;
+        wave_sync();
+      }
+      nbuf = rest;
+    }
+
+    // ---- the borders ----
+    G->first_key[lane] = first_key;
+    G->last_key[lane] = last_key;
+    G->flags[lane] = (have_last ? SEGF_HAS : 0) | (ends_open ? SEGF_ENDS_OPEN : 0) | (end_amb ? SEGF_END_AMB : 0);
+    wave_sync();
+    bool undo_distinct = false;
+    int merged = 0;
+    if (lane > 0 && exists) {
+      if (have_last && first_nz) {  // the super-mer before this segment's first one: the nearest earlier lane that has any
+        int q = lane - 1;
+        while (q >= 0 && !(G->flags[q] & SEGF_HAS)) q--;
+        undo_distinct = q >= 0 && G->last_key[q] == first_key;
+      }
+      const uint32_t fp = G->flags[lane - 1];
+      if ((fp & SEGF_ENDS_OPEN) && starts_seq && G->last_key[lane - 1] == first_key) merged = 1;  // one super-mer, cut
+      if ((fp & SEGF_END_AMB) && first_run_amb) merged = 1;                                      // one ambiguous span, cut
+    }
+    nd -= __popcll(__ballot(undo_distinct));
+    n_out += wave_sum(namb) - wave_sum(merged);
+    total = wave_sum(total);
+
+    // ---- per-read classification (as fused_kernel) ----
+    if (map_mode) {
+      resolve_map(L, A, r, lane, total, nd);
+    } else {
+      bool need_count = false;
+      for (int32_t c = 0; c < A.C; c++) need_count |= A.thresholds[c] > 0.0;
+      int32_t c0 = (need_count && t0 != 0) ? wave_sum(acc_t0) : 0;
+      for (int32_t c = 0; c < A.C; c++) {
+        double required = ceil(__dmul_rn(A.thresholds[c], (double)total));
+        int32_t mt = (t0 != 0 && !((double)c0 < required)) ? t0 : 0;
+        bool classified = (mt != 0) && (nd >= A.min_hit_groups);
+        if (lane == 0) {
+          A.out_taxon[(uint64_t)c * A.R + r] = classified ? mt : 0;
+          A.out_classified[(uint64_t)c * A.R + r] = classified ? 1 : 0;
+        }
+      }
+    }
+    if (lane == 0) {
+      if (A.out_nd) A.out_nd[r] = nd;
+      if (A.out_tk) A.out_tk[r] = total;
+      if (A.out_nh) A.out_nh[r] = n_out;
+      if (A.out_np) A.out_np[r] = np;
+    }
+    wave_sync();
+  }
+}
+
+void launch_segments(const FusedArgs &A, hipStream_t s) {  // work-list pass; A.seg_min_len set, unpaired, window width 5
+  hipLaunchKernelGGL(segment_kernel, dim3(256 * 8), dim3(FW * 64), 0, s, A);
 }
 
 __global__ void __launch_bounds__(256) compact_flags_kernel(const int32_t *__restrict__ flags, uint64_t R, uint64_t *__restrict__ list,

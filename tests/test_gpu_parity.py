@@ -124,8 +124,8 @@ def check_classify(orc, world, reads, mates=None, thresholds=(0.0, 0.07, 0.15, 0
         assert np.array_equal(got[key], want[key]), key
     # without the hit lists the engine takes its hot path (lane-per-read kernel + deferral): same answers required
     fast = st.classify_batch(bases, offsets, mb, mo, min_hit_groups=min_hit_groups, thresholds=thresholds,
-                             with_hits=False)
-    for key in ("taxon", "classified", "num_distinct", "total_kmers"):
+                             with_hits=False, with_num_hits=True)
+    for key in ("taxon", "classified", "num_distinct", "total_kmers", "num_hits"):
         assert np.array_equal(fast[key], want[key]), "hot path: " + key
     # un-merged hit lists (what hitDetails / lengthString are formatted from)
     ho = got["hit_offsets"].astype(np.int64)

@@ -1,0 +1,116 @@
+"""Long unpaired fragments on the hot path run with one lane per SEGMENT of the fragment (fused.hip: segment_kernel): what a
+lane cannot see -- whether its first super-mer equals the last one before it, whether a super-mer or an ambiguous span was cut
+by a segment border -- is settled at the end.  Reads built to hit those borders, against the oracle: taxon, classified,
+distinct hit groups, k-mer total and the number of spans (classification only; the hit lists keep the wave kernel)."""
+import numpy as np
+import pytest
+
+import synth
+import taxgen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world(orc):
+    import slacken_amd
+    p = orc.params()
+    rng = np.random.default_rng(77)
+    parents = taxgen.taxonomy(8 * 32, rng)
+    lib = synth.Library(orc, p, parents, n_genomes=12, genome_len=30000, pad_records=20000)
+    # low-complexity sequence is in the library too, so that long super-mers with equal keys carry real taxa
+    units = [synth.random_dna(int(rng.integers(1, 7)), rng) for _ in range(24)] + [np.frombuffer(b"AC", np.uint8), np.frombuffer(b"ACGGT", np.uint8)]
+    keys, taxa = [lib.keys], [lib.taxa]
+    for u in units:
+        kk = np.setdiff1d(np.unique(orc.minimizer_keys(p, np.tile(u, 40).tobytes())), np.concatenate(keys))
+        keys.append(kk)
+        taxa.append(np.full(len(kk), int(rng.choice(lib.genome_taxa)), np.int32))
+    keys, taxa = np.concatenate(keys), np.concatenate(taxa).astype(np.int32)
+    lib.units = units
+    ix = slacken_amd.Index(expected_records=len(keys), max_taxon=len(parents) - 1)
+    ix.append(keys, taxa)
+    ix.set_taxonomy(parents)
+    ix.finalize()
+    return dict(p=p, lib=lib, parents=parents, st=ix.stream(), oix=orc.Index(1, keys, taxa), ix=ix)
+
+
+def long_read(lib, rng, length):
+    """pieces of several genomes (several taxa per read), substitutions, single Ns, N runs shorter and longer than k,
+    repeats whose windows share one minimizer for hundreds of bases"""
+    parts, have = [], 0
+    while have < length:
+        kind = rng.random()
+        if kind < 0.70:
+            g = lib.genomes[rng.integers(0, len(lib.genomes))]
+            L = int(rng.integers(100, 4000))
+            a = int(rng.integers(0, len(g) - L))
+            piece = g[a:a + L].copy()
+            if rng.random() < 0.5:
+                piece = synth.revcomp(piece).copy()
+            subs = rng.random(L) < 0.01
+            piece[subs] = synth.random_dna(int(subs.sum()), rng)
+        elif kind < 0.80:
+            piece = np.full(int(rng.choice([1, 2, 5, 30, 34, 35, 36, 40, 64, 70, 100, 200])), ord("N"), np.uint8)
+        elif kind < 0.90:
+            unit = lib.units[rng.integers(0, len(lib.units))]
+            piece = np.tile(unit, int(rng.integers(20, 400)))
+        else:
+            piece = synth.random_dna(int(rng.integers(10, 500)), rng)
+        parts.append(piece)
+        have += len(piece)
+    return np.concatenate(parts)[:length].copy()
+
+
+def check(orc, world, reads, thresholds=(0.0, 0.1, 0.5), min_hit_groups=2):
+    bases, offsets = synth.pack(reads)
+    got = world["st"].classify_batch(bases, offsets, thresholds=thresholds, min_hit_groups=min_hit_groups, with_hits=False,
+                                     with_num_hits=True)
+    want = orc.classify_batch(world["p"], world["oix"], world["parents"], bases, offsets, None, None,
+                              min_hit_groups=min_hit_groups, thresholds=thresholds)
+    for key in ("total_kmers", "num_hits", "num_distinct", "taxon", "classified"):
+        bad = np.nonzero(np.atleast_2d(got[key] != want[key]).any(axis=0))[0]
+        assert bad.size == 0, (key, bad[:5].tolist(), [len(reads[i]) for i in bad[:5]],
+                               np.atleast_2d(got[key])[:, bad[:5]].tolist(), np.atleast_2d(want[key])[:, bad[:5]].tolist())
+    return got
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_long_reads_with_cut_spans(orc, world, seed):
+    rng = np.random.default_rng(500 + seed)
+    # 3000..4200 bases: segments of 64 windows, a border every 64 bases; longer reads: longer segments
+    reads = [long_read(world["lib"], rng, int(rng.integers(3000, 4200))) for _ in range(120)]
+    reads += [long_read(world["lib"], rng, int(rng.integers(4200, 30000))) for _ in range(40)]
+    reads += synth.make_reads(world["lib"], 300, rng, vary_length=True)      # short ones in the same batch (lane kernel)
+    reads += [long_read(world["lib"], rng, int(rng.integers(1001, 3000))) for _ in range(40)]   # the wave kernel's share
+    order = rng.permutation(len(reads))
+    got = check(orc, world, [reads[i] for i in order], min_hit_groups=int(rng.integers(1, 4)))
+    assert got["classified"][0].mean() > 0.3
+
+
+def test_segment_borders_one_by_one(orc, world):
+    """One read, then the same read with a run of Ns (shorter than, equal to, longer than k) or a repeat slid base by base
+    across a segment border."""
+    rng = np.random.default_rng(9)
+    g = world["lib"].genomes[0]
+    base = g[:3300].copy()
+    reads = [base]
+    for ins_len in (1, 34, 35, 36, 70):
+        for at in range(1000, 1000 + 70, 3):
+            r = base.copy()
+            r[at:at + ins_len] = ord("N")
+            reads.append(r)
+    unit = np.frombuffer(b"AC", np.uint8)
+    for at in range(1900, 1900 + 70, 5):
+        r = base.copy()
+        r[at:at + 300] = np.tile(unit, 150)
+        reads.append(r)
+    reads.append(np.full(5000, ord("N"), np.uint8))                   # nothing but one ambiguous span, cut 63 times
+    reads.append(np.tile(np.frombuffer(b"ACGGT", np.uint8), 1000))    # one minimizer value throughout
+    reads.append(np.full(3000, ord("A"), np.uint8))
+    check(orc, world, reads, thresholds=(0.0, 0.3))
+
+
+def test_very_long_read(orc, world):
+    rng = np.random.default_rng(3)
+    reads = [long_read(world["lib"], rng, 400_000), long_read(world["lib"], rng, 70_000)]
+    check(orc, world, reads)
