@@ -2,6 +2,8 @@
 lane cannot see -- whether its first super-mer equals the last one before it, whether a super-mer or an ambiguous span was cut
 by a segment border -- is settled at the end.  Reads built to hit those borders, against the oracle: taxon, classified,
 distinct hit groups, k-mer total and the number of spans (classification only; the hit lists keep the wave kernel)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,13 @@ import synth
 import taxgen
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def segments_from_1001_bases(monkeypatch):
+    # the engine's default hands fragments of 4000 bases and more to the segment kernel; here everything over 1000 goes there,
+    # which makes the segments short (64 windows) and the borders many
+    monkeypatch.setenv("SLK_SEG_MIN_LEN", "1001")
 
 
 @pytest.fixture(scope="module")
@@ -71,17 +80,25 @@ def check(orc, world, reads, thresholds=(0.0, 0.1, 0.5), min_hit_groups=2):
         bad = np.nonzero(np.atleast_2d(got[key] != want[key]).any(axis=0))[0]
         assert bad.size == 0, (key, bad[:5].tolist(), [len(reads[i]) for i in bad[:5]],
                                np.atleast_2d(got[key])[:, bad[:5]].tolist(), np.atleast_2d(want[key])[:, bad[:5]].tolist())
+    # the same batch with every deferred fragment on the wave kernel
+    os.environ["SLK_SEG_MIN_LEN"] = "0"
+    try:
+        wave = world["st"].classify_batch(bases, offsets, thresholds=thresholds, min_hit_groups=min_hit_groups, with_hits=False,
+                                          with_num_hits=True)
+    finally:
+        os.environ["SLK_SEG_MIN_LEN"] = "1001"
+    for key in ("total_kmers", "num_hits", "num_distinct", "taxon", "classified"):
+        assert np.array_equal(wave[key], got[key]), "wave kernel vs segment kernel: " + key
     return got
 
 
 @pytest.mark.parametrize("seed", range(4))
 def test_long_reads_with_cut_spans(orc, world, seed):
     rng = np.random.default_rng(500 + seed)
-    # 3000..4200 bases: segments of 64 windows, a border every 64 bases; longer reads: longer segments
-    reads = [long_read(world["lib"], rng, int(rng.integers(3000, 4200))) for _ in range(120)]
+    # up to 4200 bases: segments of 64 windows, a border every 64 bases; longer reads: longer segments
+    reads = [long_read(world["lib"], rng, int(rng.integers(1001, 4200))) for _ in range(120)]
     reads += [long_read(world["lib"], rng, int(rng.integers(4200, 30000))) for _ in range(40)]
     reads += synth.make_reads(world["lib"], 300, rng, vary_length=True)      # short ones in the same batch (lane kernel)
-    reads += [long_read(world["lib"], rng, int(rng.integers(1001, 3000))) for _ in range(40)]   # the wave kernel's share
     order = rng.permutation(len(reads))
     got = check(orc, world, [reads[i] for i in order], min_hit_groups=int(rng.integers(1, 4)))
     assert got["classified"][0].mean() > 0.3
