@@ -427,7 +427,7 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
       L->map_cnt[lane] = 0; L->map_cnt[lane + 64] = 0;
     }
     int mate = 0, phase = PH_START;
-    bool done = false;
+    bool done = false, handed_over = false;
     const uint8_t *seq = nullptr;
     uint32_t n = 0;
     // fast-path state
@@ -447,7 +447,13 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
           bool bad = false;
           uint32_t nblk = (n + 255) / 256;
           for (uint32_t b = nblk; b-- > 0;) bad |= stage_block(L, seq, n, b, lane);
-          if (__ballot(bad) != 0) {
+          if (__ballot(bad) != 0 && MODE == MODE_CLASSIFY && A.handover_list && !A.mate_bases && n > 1000) {
+            // a long fragment with ambiguous characters: the segment kernel scans it with 64 lanes, this path with one
+            if (lane == 0) A.handover_list[atomicAdd(A.handover_count, 1ULL)] = r;
+            handed_over = true;
+            done = true;
+            break;
+          } else if (__ballot(bad) != 0) {
             if (lane == 0) {
               SeqState S{};
               S.first = first; S.have_last = have_last; S.last_key = last_key;
@@ -589,6 +595,7 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
       if (done) break;
     }
 
+    if (handed_over) { wave_sync(); continue; }
     if (MODE != MODE_CLASSIFY) {
       if (lane == 0) A.span_count[r] = n_out;
     }

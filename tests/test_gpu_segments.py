@@ -131,3 +131,24 @@ def test_very_long_read(orc, world):
     rng = np.random.default_rng(3)
     reads = [long_read(world["lib"], rng, 400_000), long_read(world["lib"], rng, 70_000)]
     check(orc, world, reads)
+
+
+def test_fragments_with_ambiguous_characters_are_handed_over(orc, world, monkeypatch):
+    """Default threshold: fragments of 1001..3999 bases stay on the wave kernel, unless it finds a character outside ACGTU in
+    them -- those come back to the segment kernel in a second pass instead of being scanned by a single lane."""
+    monkeypatch.setenv("SLK_SEG_MIN_LEN", "4000")
+    rng = np.random.default_rng(12)
+    reads = []
+    for _ in range(150):
+        r = long_read(world["lib"], rng, int(rng.integers(1001, 4000)))
+        if rng.random() < 0.5:
+            r = np.where(r == ord("N"), ord("A"), r).astype(np.uint8)    # a clean one: the wave kernel's own
+        reads.append(r)
+    reads += synth.make_reads(world["lib"], 200, rng, vary_length=True)
+    reads += [long_read(world["lib"], rng, int(rng.integers(4000, 9000))) for _ in range(20)]
+    bases, offsets = synth.pack(reads)
+    got = world["st"].classify_batch(bases, offsets, thresholds=(0.0, 0.2), with_hits=False, with_num_hits=True)
+    want = orc.classify_batch(world["p"], world["oix"], world["parents"], bases, offsets, None, None, min_hit_groups=2,
+                              thresholds=(0.0, 0.2))
+    for key in ("total_kmers", "num_hits", "num_distinct", "taxon", "classified"):
+        assert np.array_equal(got[key], want[key]), key
