@@ -229,3 +229,47 @@ def test_cli_several_input_files_side_by_side(tmp_path):
     assert sorted(outs[0]) == sorted(want.values()) == sorted(outs[2])
     in_file_order = [want[t] for i in range(5) for t, _ in reads[i::5] if t in want]
     assert outs[2] == in_file_order
+
+
+@pytest.mark.gpu
+def test_cli_long_reads_all_routes_agree(tmp_path, orc):
+    """Long reads (the golden reads chained to 1.5-40 kbp, some with Ns) through the CLI: with per-read lines the deferred
+    fragments take the wave kernel (hit lists), with --nodetailed the segment kernel; each line equals the oracle's and the two
+    reports are the same file."""
+    g, loc, tax, reads = make_library(tmp_path, convert=False)
+    lib = np.load(os.path.join(GOLD, "library.npz"))
+    p = orc.params(k=g["k"], m=g["m"], spaces=g["spaces"])
+    oix = orc.Index(1, lib["keys"], lib["taxa"])
+    rng = np.random.default_rng(21)
+    seqs = [r[1] for r in reads]
+    fq = tmp_path / "long.fq"
+    longs = []
+    with open(fq, "w") as f:
+        for i in range(120):
+            want_len = int(rng.choice([1500, 3000, 4500, 8000, 40000]))
+            parts, have = [], 0
+            while have < want_len:
+                s = seqs[rng.integers(0, len(seqs))]
+                if rng.random() < 0.1:
+                    s = "N" * int(rng.choice([1, 10, 35, 80]))
+                parts.append(s)
+                have += len(s)
+            s = "".join(parts)
+            longs.append(s)
+            f.write(f"@long{i}\n{s}\n+\n{'I' * len(s)}\n")
+        for i in range(200):   # and short ones around them
+            s = seqs[rng.integers(0, len(seqs))]
+            longs.append(s)
+            f.write(f"@short{i}\n{s}\n+\n{'I' * len(s)}\n")
+    out = tmp_path / "long"
+    classify("-i", loc, "-o", out, "-c", "0.1", fq)
+    lines = read_out(f"{out}_c0.1")
+    want = []
+    for i, s in enumerate(longs):
+        res, hits = orc.classify_read(p, oix, lib["parents"], s, None, 2, 0.1)
+        if hits:
+            want.append(orc.output_line(res["classified"], f"long{i}" if i < 120 else f"short{i - 120}", res["taxon"], hits, g["k"]))
+    assert lines == want
+    out2 = tmp_path / "long_reports"
+    classify("-i", loc, "-o", out2, "-c", "0.1", "--nodetailed", fq)
+    assert open(f"{out2}_c0.1/all_kreport.txt").read() == open(f"{out}_c0.1/all_kreport.txt").read()
