@@ -1,6 +1,6 @@
 // fused.hip -- ONE WAVEFRONT PER FRAGMENT (the lane-per-fragment kernel of lane.hip takes the short fragments; this one takes
-// what that one hands back -- fragments over 1000 bases or with more than 12 distinct taxa -- windows of 17..32 m-mers, and the
-// span output): scan -> probe -> per-read LCA fused in one launch, no
+// what that one hands back -- fragments over 1000 bases or with more than 12 distinct taxa -- and the span output; long
+// unpaired fragments go on to segment_kernel below, one lane per segment): scan -> probe -> per-read LCA fused in one launch, no
 // HBM intermediates (spans, hits and the per-read taxon map live in registers / LDS).  gfx950, wave64.  Integer/byte
 // work bounded by random 64-byte HBM probes: no MFMA.
 //
