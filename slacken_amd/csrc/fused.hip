@@ -193,28 +193,27 @@ __device__ __forceinline__ int32_t probe_chunk(WaveLds *L, const TableView &T, i
   const int g = lane >> 3, c = lane & 7;
   const uint64_t tmask = (1ULL << T.taxon_bits) - 1;
   const char *cellbase = (const char *)T.cells + c * 8;
-  // displacement 0: four steps' loads (32 HBM lines per wave) in flight before the first compare, twice
+  // displacement 0: all eight steps' loads (64 HBM lines per wave) in flight before the first compare
   uint32_t more = 0;  // bit s: my group's span s*8+g overflowed its home bucket and is still unresolved
+  {
+    uint64_t cell[8];
 #pragma unroll
-  for (int h4 = 0; h4 < 8; h4 += 4) {
-    uint64_t cell[4];
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-      ulonglong2 e = ((const ulonglong2 *)L->stash)[(h4 + s) * 8 + g];
+    for (int s = 0; s < 8; s++) {
+      ulonglong2 e = ((const ulonglong2 *)L->stash)[s * 8 + g];
       cell[s] = 0;
       if (e.y != NO_TAG) cell[s] = *(const uint64_t *)(cellbase + e.x);
     }
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-      uint64_t want = L->stash[2 * ((h4 + s) * 8 + g) + 1];
+    for (int s = 0; s < 8; s++) {
+      uint64_t want = L->stash[2 * (s * 8 + g) + 1];
       bool act = want != NO_TAG;
       bool empty = cell[s] == 0;
       bool match = !empty && (cell[s] >> T.taxon_bits) == want;
-      if (match) L->result[(h4 + s) * 8 + g] = (int32_t)(cell[s] & tmask);
+      if (match) L->result[s * 8 + g] = (int32_t)(cell[s] & tmask);
       // a group is resolved once one of its lanes matched or saw an empty cell (cells are never freed)
       uint64_t B = __ballot(match || empty || !act);
       if (((B - 0x0101010101010101ULL) & ~B & 0x8080808080808080ULL) != 0) {  // some group's byte is zero (rare)
-        if (((B >> (g * 8)) & 0xFF) == 0) more |= 1u << (h4 + s);
+        if (((B >> (g * 8)) & 0xFF) == 0) more |= 1u << s;
       }
     }
   }
