@@ -10,6 +10,7 @@
 //   per-read output  S/slacken/Classifier.scala:41-44,124-147,184-227, S/slacken/TaxonCounts.scala:94-121
 //   report           S/slacken/KrakenReport.scala (taxonomy.hpp)
 // Host-only subcommands (`report`, `parse`, `props`) exist so that this layer can be tested without a GPU.
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <filesystem>
@@ -323,46 +324,92 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
     }
     return nullptr;
   };
+  // The batches are classified by a few worker threads, each with a stream of its own (its scratch, its staging buffers, its
+  // HIP stream): one worker's copies overlap another's kernels.  Batches are taken and handed to f in input order.
   const int C = (int)thresholds.size();
-  std::vector<int32_t> nd, tk;
-  size_t total = 0, n_batches = 0;
-  const bool timing = getenv("SLK_HOST_TIMING") != nullptr;  // where the wall clock of the run goes, by stage
+  const char *wenv = getenv("SLK_CLASSIFY_THREADS");
+  const size_t n_workers = std::max<size_t>(1, std::min<size_t>(8, wenv ? (size_t)atol(wenv) : 2));
+  std::vector<slk_stream *> streams(n_workers, nullptr);
+  streams[0] = dev.st;
+  for (size_t i = 1; i < n_workers; i++) SLK_CALL(slk_stream_create(dev.ix, &streams[i]));
+  std::atomic<size_t> total{0}, n_batches{0};
+  const bool timing = getenv("SLK_HOST_TIMING") != nullptr;  // where the wall clock of the workers goes, by stage
+  std::mutex mu_in, mu_out, mu_stat;
+  std::condition_variable cv_out;
+  size_t next_ticket = 0, next_out = 0;
   double t_input = 0, t_device = 0, t_hand_over = 0;
+  std::exception_ptr failure;
+  std::atomic<bool> failed{false};
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  for (;;) {
-    double t0 = now();
-    auto frags = next_batch();
-    if (!frags) break;
-    double t1 = now();
-    t_input += t1 - t0;
-    n_batches++;
-    auto b = new_classified_batch();
-    b->frags = std::move(frags);
-    b->C = C;
-    const FragmentBatch &fb = *b->frags;
-    const size_t n = fb.size();
-    total += n;
-    b->taxon.resize((size_t)C * n); b->classified.resize((size_t)C * n); nd.resize(n); tk.resize(n);
-    b->hit_offs.resize(n + 1);
-    const size_t cap = fb.bases.size() + fb.mate_bases.size() + n + 1;
-    if (want_hits) b->reserve_hits(cap);
-    const uint8_t *mb = fb.paired ? fb.mate_bases.data() : nullptr;
-    const uint64_t *mo = fb.paired ? fb.mate_offs.data() : nullptr;
-    SLK_CALL(slk_classify_batch(dev.ix, dev.st, fb.bases.data(), fb.offs.data(), mb, mo, n, min_hits, thresholds.data(), C,
-                                b->taxon.data(), b->classified.data(), nd.data(), tk.data(), b->hit_offs.data(), want_hits ? b->hits.get() : nullptr, cap));
-    if (want_spans) {
-      b->span_offs.resize(n + 1);
-      b->spans.resize(cap);
-      SLK_CALL(slk_spans_batch(dev.ix, dev.st, fb.bases.data(), fb.offs.data(), mb, mo, n, b->span_offs.data(), b->spans.data(), cap));
+  auto work = [&](slk_stream *st) {
+    std::vector<int32_t> nd, tk;
+    double w_input = 0, w_device = 0, w_hand_over = 0;
+    try {
+      for (;;) {
+        double t0 = now();
+        FragmentBatchPtr frags;
+        size_t ticket;
+        if (failed) break;
+        {
+          std::lock_guard<std::mutex> lk(mu_in);
+          frags = next_batch();
+          ticket = next_ticket;
+          if (frags) next_ticket++;
+        }
+        if (!frags) break;
+        double t1 = now();
+        w_input += t1 - t0;
+        n_batches++;
+        auto b = new_classified_batch();
+        b->frags = std::move(frags);
+        b->C = C;
+        const FragmentBatch &fb = *b->frags;
+        const size_t n = fb.size();
+        total += n;
+        b->taxon.resize((size_t)C * n); b->classified.resize((size_t)C * n); nd.resize(n); tk.resize(n);
+        b->hit_offs.resize(n + 1);
+        const size_t cap = fb.bases.size() + fb.mate_bases.size() + n + 1;
+        if (want_hits) b->reserve_hits(cap);
+        const uint8_t *mb = fb.paired ? fb.mate_bases.data() : nullptr;
+        const uint64_t *mo = fb.paired ? fb.mate_offs.data() : nullptr;
+        SLK_CALL(slk_classify_batch(dev.ix, st, fb.bases.data(), fb.offs.data(), mb, mo, n, min_hits, thresholds.data(), C,
+                                    b->taxon.data(), b->classified.data(), nd.data(), tk.data(), b->hit_offs.data(), want_hits ? b->hits.get() : nullptr, cap));
+        if (want_spans) {
+          b->span_offs.resize(n + 1);
+          b->spans.resize(cap);
+          SLK_CALL(slk_spans_batch(dev.ix, st, fb.bases.data(), fb.offs.data(), mb, mo, n, b->span_offs.data(), b->spans.data(), cap));
+        }
+        double t2 = now();
+        w_device += t2 - t1;
+        {
+          std::unique_lock<std::mutex> lk(mu_out);
+          cv_out.wait(lk, [&] { return next_out == ticket || failure; });
+          if (!failure) f(std::shared_ptr<const ClassifiedBatch>(b));
+          next_out = ticket + 1;
+          cv_out.notify_all();
+        }
+        w_hand_over += now() - t2;
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(mu_out);
+      if (!failure) failure = std::current_exception();
+      failed = true;
+      next_out = (size_t)-1;  // (nobody waits for a ticket any more)
+      cv_out.notify_all();
     }
-    double t2 = now();
-    t_device += t2 - t1;
-    f(std::shared_ptr<const ClassifiedBatch>(b));
-    t_hand_over += now() - t2;
-  }
+    std::lock_guard<std::mutex> lk(mu_stat);
+    t_input += w_input; t_device += w_device; t_hand_over += w_hand_over;
+  };
+  std::vector<std::thread> workers;
+  for (size_t i = 1; i < n_workers; i++) workers.emplace_back(work, streams[i]);
+  work(streams[0]);
+  for (auto &t : workers) t.join();
+  for (size_t i = 1; i < n_workers; i++) slk_stream_destroy(streams[i]);
+  if (failure) std::rethrow_exception(failure);
   if (timing)
-    std::cerr << "host timing: " << n_batches << " batches; waiting for input " << t_input << " s, upload+kernels+download " << t_device
-              << " s, handing over to the output threads " << t_hand_over << " s" << std::endl;
+    std::cerr << "host timing: " << n_batches << " batches on " << n_workers << " classify thread(s); summed over them: waiting for input "
+              << t_input << " s, upload+kernels+download " << t_device << " s, waiting for their turn and handing over to the output threads "
+              << t_hand_over << " s" << std::endl;
   std::cerr << total << " fragments" << std::endl;
 }
 
@@ -583,6 +630,7 @@ static const char *HELP =
     "host-only helpers: report TAXONOMY_DIR COUNTS_TSV | parse FILE [MATE_FILE] | props INDEX | records INDEX\n"
     "environment: SLK_HOST_THREADS (formatting/decoding threads), SLK_INPUT_STREAMS (input files read side by side, default 8),\n"
     "             SLK_PARSE_THREADS (threads parsing one plain input file, default min(8, cores/2)), SLK_GZIP_LEVEL (1..9, default zlib's),\n"
+    "             SLK_CLASSIFY_THREADS (threads classifying batches, each with its own stream, default 2),\n"
     "             SLK_HOST_TIMING (report where the wall clock of the classify loop went)\n";
 
 int main(int argc, char **argv) {
