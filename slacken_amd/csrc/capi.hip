@@ -55,6 +55,23 @@ struct DevBuf {
   template <class T> T *as() const { return (T *)p; }
 };
 
+// Two pinned buffers: every copy between the caller's memory and HBM goes through them (copy_in / copy_out), so the
+// runtime never has to pin the caller's pages for DMA -- that path took tens of ms per call once an application with many
+// threads was mapping and unmapping memory around it.
+struct Staging {
+  void *buf[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  bool busy[2] = {false, false};
+  int next = 0;
+  void release() {
+    for (int i = 0; i < 2; i++) {
+      if (buf[i]) (void)hipHostFree(buf[i]);
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+      buf[i] = nullptr; ev[i] = nullptr; busy[i] = false;
+    }
+  }
+};
+
 struct slk_index {
   int32_t device = 0;
   slk_params params{};
@@ -71,6 +88,7 @@ struct slk_index {
   uint64_t records = 0, dups = 0;
   hipStream_t build_stream = nullptr;
   DevBuf stage_keys, stage_taxa;
+  Staging staging;    // host -> HBM copies of the build calls
   int W = 1;          // id columns; > 1: the wide path (wide.hip) with its own table
   WideParams wp{};
   WideTable wt{};
@@ -100,13 +118,7 @@ struct slk_stream {
   int32_t *d_status = nullptr;     // device error bits of the fused kernels
   int32_t *h_status = nullptr;     // pinned copy, refreshed after every classify launch
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  // Two pinned buffers: every copy between the caller's memory and HBM goes through them (copy_in / copy_out), so the
-  // runtime never has to pin the caller's pages for DMA -- that path took tens of ms per call once an application with many
-  // threads was mapping and unmapping memory around it.
-  void *stage[2] = {nullptr, nullptr};
-  hipEvent_t stage_ev[2] = {nullptr, nullptr};
-  bool stage_busy[2] = {false, false};
-  int stage_next = 0;
+  Staging staging;
   bool timed = false;
   bool last_used_lane = false;  // the last classify call ran the lane kernel (defer_list[0] is its deferral count)
   struct LastCall {  // the arguments of the classify call in flight, for the unbounded re-run (check_status)
@@ -124,36 +136,36 @@ static int32_t check_status(slk_stream *st);
 
 static const size_t STAGE_BYTES = (size_t)4 << 20;
 
-static int32_t stage_ready(slk_stream *st) {
-  if (st->stage[0]) return SLK_OK;
+static int32_t stage_ready(Staging *g) {
+  if (g->buf[0]) return SLK_OK;
   for (int i = 0; i < 2; i++) {
-    HIPCHK(hipHostMalloc(&st->stage[i], STAGE_BYTES, hipHostMallocDefault));
-    HIPCHK(hipEventCreateWithFlags(&st->stage_ev[i], hipEventDisableTiming));
+    HIPCHK(hipHostMalloc(&g->buf[i], STAGE_BYTES, hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming));
   }
   return SLK_OK;
 }
 
-// caller memory -> HBM, ordered on st->s.  The caller's buffer is free on return; the last DMA may still be in flight.
-static int32_t copy_in(slk_stream *st, void *d_dst, const void *h_src, size_t n) {
-  int32_t rc = stage_ready(st);
+// caller memory -> HBM, ordered on s.  The caller's buffer is free on return; the last DMA may still be in flight.
+static int32_t copy_in(Staging *g, hipStream_t s, void *d_dst, const void *h_src, size_t n) {
+  int32_t rc = stage_ready(g);
   if (rc) return rc;
   for (size_t o = 0; o < n; o += STAGE_BYTES) {
     const size_t len = std::min(STAGE_BYTES, n - o);
-    const int b = st->stage_next;
-    st->stage_next ^= 1;
-    if (st->stage_busy[b]) HIPCHK(hipEventSynchronize(st->stage_ev[b]));  // the DMA that last read this buffer
-    memcpy(st->stage[b], (const char *)h_src + o, len);
-    HIPCHK(hipMemcpyAsync((char *)d_dst + o, st->stage[b], len, hipMemcpyHostToDevice, st->s));
-    HIPCHK(hipEventRecord(st->stage_ev[b], st->s));
-    st->stage_busy[b] = true;
+    const int b = g->next;
+    g->next ^= 1;
+    if (g->busy[b]) HIPCHK(hipEventSynchronize(g->ev[b]));  // the DMA that last read this buffer
+    memcpy(g->buf[b], (const char *)h_src + o, len);
+    HIPCHK(hipMemcpyAsync((char *)d_dst + o, g->buf[b], len, hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(g->ev[b], s));
+    g->busy[b] = true;
   }
   return SLK_OK;
 }
 
-// HBM -> caller memory, after everything queued on st->s; complete on return.  The DMA of one piece overlaps the copy of
-// the piece before it into the caller's buffer.
-static int32_t copy_out(slk_stream *st, void *h_dst, const void *d_src, size_t n) {
-  int32_t rc = stage_ready(st);
+// HBM -> caller memory, after everything queued on s; complete on return.  The DMA of one piece overlaps the copy of the
+// piece before it into the caller's buffer.
+static int32_t copy_out(Staging *g, hipStream_t s, void *h_dst, const void *d_src, size_t n) {
+  int32_t rc = stage_ready(g);
   if (rc) return rc;
   size_t prev_o = 0, prev_len = 0;
   int prev_b = -1;
@@ -161,21 +173,23 @@ static int32_t copy_out(slk_stream *st, void *h_dst, const void *d_src, size_t n
     const size_t len = std::min(STAGE_BYTES, n - o);
     const int b = prev_b < 0 ? 0 : prev_b ^ 1;
     // (stream order protects the buffer: an earlier copy_in DMA out of it is queued before this write into it)
-    HIPCHK(hipMemcpyAsync(st->stage[b], (const char *)d_src + o, len, hipMemcpyDeviceToHost, st->s));
-    HIPCHK(hipEventRecord(st->stage_ev[b], st->s));
-    st->stage_busy[b] = true;
+    HIPCHK(hipMemcpyAsync(g->buf[b], (const char *)d_src + o, len, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(g->ev[b], s));
+    g->busy[b] = true;
     if (prev_b >= 0) {
-      HIPCHK(hipEventSynchronize(st->stage_ev[prev_b]));
-      memcpy((char *)h_dst + prev_o, st->stage[prev_b], prev_len);
+      HIPCHK(hipEventSynchronize(g->ev[prev_b]));
+      memcpy((char *)h_dst + prev_o, g->buf[prev_b], prev_len);
     }
     prev_b = b; prev_o = o; prev_len = len;
   }
   if (prev_b >= 0) {
-    HIPCHK(hipEventSynchronize(st->stage_ev[prev_b]));
-    memcpy((char *)h_dst + prev_o, st->stage[prev_b], prev_len);
+    HIPCHK(hipEventSynchronize(g->ev[prev_b]));
+    memcpy((char *)h_dst + prev_o, g->buf[prev_b], prev_len);
   }
   return SLK_OK;
 }
+static int32_t copy_in(slk_stream *st, void *d_dst, const void *h_src, size_t n) { return copy_in(&st->staging, st->s, d_dst, h_src, n); }
+static int32_t copy_out(slk_stream *st, void *h_dst, const void *d_src, size_t n) { return copy_out(&st->staging, st->s, h_dst, d_src, n); }
 
 // Every entry point that launches kernels starts here: select the index's device and drop whatever error code an earlier,
 // unrelated HIP call of this thread (this library's or the application's) left behind, so that the hipGetLastError()
@@ -365,8 +379,9 @@ int32_t slk_index_append(slk_index *ix, const int64_t *keys, const int32_t *taxa
         if (taxa[o + i] < 0) return fail(SLK_E_INVALID, "record %llu: negative taxon %d", (unsigned long long)(o + i), taxa[o + i]);
       HIPCHK(ix->stage_keys.ensure(c * 8 * W));
       HIPCHK(ix->stage_taxa.ensure(c * 4));
-      HIPCHK(hipMemcpyAsync(ix->stage_keys.p, keys + o * W, c * 8 * W, hipMemcpyHostToDevice, ix->build_stream));
-      HIPCHK(hipMemcpyAsync(ix->stage_taxa.p, taxa + o, c * 4, hipMemcpyHostToDevice, ix->build_stream));
+      rc = copy_in(&ix->staging, ix->build_stream, ix->stage_keys.p, keys + o * W, c * 8 * W);
+      if (!rc) rc = copy_in(&ix->staging, ix->build_stream, ix->stage_taxa.p, taxa + o, c * 4);
+      if (rc) return rc;
       launch_wide_insert(ix->wt, W, ix->stage_keys.as<int64_t>(), ix->stage_taxa.as<int32_t>(), c, ix->d_counters, ix->build_stream);
       HIPCHK(hipGetLastError());
       HIPCHK(hipStreamSynchronize(ix->build_stream));
@@ -382,8 +397,9 @@ int32_t slk_index_append(slk_index *ix, const int64_t *keys, const int32_t *taxa
       if (taxa[o + i] < 0 || taxa[o + i] > max_t)
         return fail(SLK_E_INVALID, "record %llu: taxon %d outside [0, %d] (slk_table_config.max_taxon)",
                     (unsigned long long)(o + i), taxa[o + i], max_t);
-    HIPCHK(hipMemcpyAsync(ix->stage_keys.p, keys + o, c * 8, hipMemcpyHostToDevice, ix->build_stream));
-    HIPCHK(hipMemcpyAsync(ix->stage_taxa.p, taxa + o, c * 4, hipMemcpyHostToDevice, ix->build_stream));
+    rc = copy_in(&ix->staging, ix->build_stream, ix->stage_keys.p, keys + o, c * 8);
+    if (!rc) rc = copy_in(&ix->staging, ix->build_stream, ix->stage_taxa.p, taxa + o, c * 4);
+    if (rc) return rc;
     launch_table_insert(build_view(ix), ix->stage_keys.as<int64_t>(), ix->stage_taxa.as<int32_t>(), c,
                         ix->build_stream);
     HIPCHK(hipGetLastError());
@@ -465,11 +481,12 @@ int32_t slk_index_add_sequences(slk_index *ix, const uint8_t *bases, const uint6
       HIPCHK(d_start.ensure(nc * 8));
       HIPCHK(d_len.ensure(nc * 4));
       HIPCHK(d_tax.ensure(nc * 4));
-      HIPCHK(hipMemcpyAsync(d_bases.p, bases + g0, gbytes, hipMemcpyHostToDevice, ix->build_stream));
+      rc = copy_in(&ix->staging, ix->build_stream, d_bases.p, bases + g0, gbytes);
       HIPCHK(hipMemsetAsync((uint8_t *)d_bases.p + gbytes, 0, 16, ix->build_stream));
-      HIPCHK(hipMemcpyAsync(d_start.p, cstart.data(), nc * 8, hipMemcpyHostToDevice, ix->build_stream));
-      HIPCHK(hipMemcpyAsync(d_len.p, clen.data(), nc * 4, hipMemcpyHostToDevice, ix->build_stream));
-      HIPCHK(hipMemcpyAsync(d_tax.p, ctax.data(), nc * 4, hipMemcpyHostToDevice, ix->build_stream));
+      if (!rc) rc = copy_in(&ix->staging, ix->build_stream, d_start.p, cstart.data(), nc * 8);
+      if (!rc) rc = copy_in(&ix->staging, ix->build_stream, d_len.p, clen.data(), nc * 4);
+      if (!rc) rc = copy_in(&ix->staging, ix->build_stream, d_tax.p, ctax.data(), nc * 4);
+      if (rc) return rc;
       launch_build(ix->sp, build_view(ix), ix->d_parents, ix->T, d_bases.as<uint8_t>(), d_start.as<uint64_t>(),
                    d_len.as<uint32_t>(), d_tax.as<int32_t>(), nc, ix->build_stream);
       HIPCHK(hipGetLastError());
@@ -515,6 +532,7 @@ int32_t slk_index_finalize(slk_index *ix) {
   if (rc) return rc;
   ix->stage_keys.release();
   ix->stage_taxa.release();
+  ix->staging.release();
   ix->finalized = true;
   return SLK_OK;
 }
@@ -565,6 +583,7 @@ void slk_index_destroy(slk_index *ix) {
   if (ix->d_parents) (void)hipFree(ix->d_parents);
   ix->stage_keys.release();
   ix->stage_taxa.release();
+  ix->staging.release();
   if (ix->build_stream) (void)hipStreamDestroy(ix->build_stream);
   delete ix;
 }
@@ -610,10 +629,7 @@ void slk_stream_destroy(slk_stream *st) {
   if (st->h_thresholds) (void)hipHostFree(st->h_thresholds);
   if (st->d_status) (void)hipFree(st->d_status);
   if (st->h_status) (void)hipHostFree(st->h_status);
-  for (int i = 0; i < 2; i++) {
-    if (st->stage[i]) (void)hipHostFree(st->stage[i]);
-    if (st->stage_ev[i]) (void)hipEventDestroy(st->stage_ev[i]);
-  }
+  st->staging.release();
   for (int i = 0; i < 4; i++) if (st->ev[i]) (void)hipEventDestroy(st->ev[i]);
   if (st->s) (void)hipStreamDestroy(st->s);
   delete st;
