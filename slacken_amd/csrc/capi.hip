@@ -112,7 +112,7 @@ struct slk_stream {
   hipStream_t s = nullptr;
   DevBuf span_keys, span_meta, span_taxon, span_count;  // per-batch scratch (sparse per-read regions)
   DevBuf bases, offsets, mate_bases, mate_offsets;      // staging for the host-pointer entry points
-  DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items, defer, defer_list, handover_list;
+  DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items, defer, defer_list;
   double *d_thresholds = nullptr;
   double *h_thresholds = nullptr;  // pinned
   int32_t *d_status = nullptr;     // device error bits of the fused kernels
@@ -623,7 +623,7 @@ void slk_stream_destroy(slk_stream *st) {
   (void)hipStreamSynchronize(st->s);
   DevBuf *bufs[] = {&st->span_keys, &st->span_meta, &st->span_taxon, &st->span_count, &st->bases, &st->offsets,
                     &st->mate_bases, &st->mate_offsets, &st->out_taxon, &st->out_cls, &st->out_nd, &st->out_tk,
-                    &st->out_nh, &st->out_offsets, &st->out_items, &st->defer, &st->defer_list, &st->handover_list};
+                    &st->out_nh, &st->out_offsets, &st->out_items, &st->defer, &st->defer_list};
   for (DevBuf *b : bufs) b->release();
   if (st->d_thresholds) (void)hipFree(st->d_thresholds);
   if (st->h_thresholds) (void)hipHostFree(st->h_thresholds);
@@ -749,7 +749,6 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
     A.span_count = want_hits ? st->span_count.as<int32_t>() : nullptr;
     A.status = st->d_status;
     A.work_list = nullptr; A.work_count = nullptr;
-    bool segments_done = false;
     if (lane_path_ok(ix) && !force_wave()) {  // (window of at most 32 m-mers, taxon ids of at most 22 bits)
       st->last_used_lane = true;
       // hot path: one lane per fragment; long fragments and map overflows are deferred to the wave-per-read kernel
@@ -770,21 +769,9 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
       if (!want_hits && !paired && ix->sp.w == 5 && seg_min > 0) {
         A.seg_min_len = (uint32_t)std::max(seg_min, 1001);
         launch_segments(A, st->s);
-        // ... and so do, in a second pass, the shorter ones (over 1000 bases) in which the wave kernel finds a character
-        // outside ACGTU: it would scan them with a single lane
-        HIPCHK(st->handover_list.ensure((R + 1) * sizeof(uint64_t)));
-        HIPCHK(hipMemsetAsync(st->handover_list.p, 0, sizeof(uint64_t), st->s));
-        A.handover_count = (unsigned long long *)st->handover_list.p;
-        A.handover_list = st->handover_list.as<uint64_t>() + 1;
-        launch_fused(MODE_CLASSIFY, A, st->s);
-        FusedArgs B = A;
-        B.work_list = A.handover_list; B.work_count = A.handover_count; B.seg_min_len = 1001;
-        B.handover_list = nullptr; B.handover_count = nullptr;
-        launch_segments(B, st->s);
-        segments_done = true;
       }
     }
-    if (!segments_done) launch_fused(want_hits ? MODE_HITS : MODE_CLASSIFY, A, st->s);
+    launch_fused(want_hits ? MODE_HITS : MODE_CLASSIFY, A, st->s);
     HIPCHK(hipEventRecord(st->ev[1], st->s));
     HIPCHK(hipEventRecord(st->ev[2], st->s));
   } else {

@@ -111,9 +111,6 @@ struct FusedArgs {
   int32_t *status;       // device error bits: 1 = taxon map overflow
   const uint64_t *work_list;             // if set, the fused kernel processes only the fragments work_list[0 .. *work_count)
   const unsigned long long *work_count;  // (device) -- the fragments the lane kernel deferred, compacted by launch_compact_flags
-  uint64_t *handover_list;               // work-list pass of the wave kernel, classification only: unpaired fragments over 1000
-  unsigned long long *handover_count;    // bases that hold a character outside ACGTU are not scanned by one lane (PH_SLOW) but
-                                         // appended here, for a second pass of the segment kernel
   uint32_t seg_min_len;                  // work-list passes: unpaired fragments of at least this many bases belong to the
                                          // lane-per-segment kernel (launch_segments), the others to the wave kernel; 0 = none
 };

@@ -19,9 +19,9 @@
 //          distinct taxon.  Reference: TaxonCounts.toMap/totalKmers (S/slacken/TaxonCounts.scala:70-87),
 //          LowestCommonAncestor.apply/resolveTree (S/slacken/LowestCommonAncestor.scala:49-146), Classifier.classify
 //          (Classifier.scala:439-454).
-// Control flow per fragment: a producer state machine (START -> FAST rounds | SLOW sequential scan -> NEXT mate) fills the
-// LDS span buffer; ONE flush site probes and folds whatever is buffered; repeat until the fragment is exhausted.
-// Mates containing a non-ACGTU character take the sequential single-lane scan (same state machine as kernels.hip).
+// Control flow per fragment: a producer state machine (START -> FAST rounds over the mate, or over its runs of valid
+// characters one after the other (RUNS) when it holds others -> NEXT mate) fills the LDS span buffer; ONE flush site probes and
+// folds whatever is buffered; repeat until the fragment is exhausted.
 #include "engine.h"
 
 #include <cstdlib>
@@ -33,12 +33,6 @@ constexpr int SPAN_CAP = 128;  // buffered spans per wave before a flush
 constexpr int MAP_CAP = 128;   // taxon map slots per wave (power of two)
 constexpr int32_t MAP_EMPTY = -1;  // AMBIGUOUS_SPAN is never inserted, so -1 is free
 
-struct SeqState {  // the sequential scanner's registers, parked in LDS while the wave flushes
-  uint64_t fwd, rc, minv, cur_val, last_key;
-  uint32_t i, run_len, nvalid;
-  int32_t run_class, head, minage, cur_run, total, first, have_last;
-};
-
 struct __attribute__((aligned(16))) WaveLds {
   uint32_t fwd_ring[32];         // 2-bit bases, MSB first inside each dword, ring of 512 bases (two 256-base blocks)
   uint32_t rc_ring[32];          // complement of base p at ring position 511 - p
@@ -48,8 +42,6 @@ struct __attribute__((aligned(16))) WaveLds {
   int32_t result[64];
   int32_t map_key[MAP_CAP];
   int32_t map_cnt[MAP_CAP];
-  uint64_t seq_ring[64];         // window ring of the sequential (slow-path) scanner, w <= 64
-  SeqState seq;
 };
 
 // ---- wave helpers ------------------------------------------------------------------------------------------------
@@ -255,65 +247,6 @@ __device__ __forceinline__ int char_code2(uint8_t c) {  // 0..3 nucleotide, 5 an
   }
 }
 
-// One lane walks a mate character by character until it ends or the span buffer is nearly full; state lives in L->seq.
-// Returns the new buffer fill, with bit 16 set once the mate is exhausted.
-__device__ __forceinline__ int seq_scan(WaveLds *L, ScanParams P, const uint8_t *seq, uint32_t n, int nbuf) {
-  SeqState S = L->seq;
-  const int k = P.k, m = P.m, w = P.w;
-  auto emit = [&](uint64_t key, int32_t kmers, int32_t flag) {
-    bool seqlike = flag == 1;
-    bool distinct = seqlike && (S.first || !(S.have_last && key == S.last_key));  // Supermers.spans :84-90
-    if (seqlike) { S.last_key = key; S.have_last = 1; }
-    S.first = 0;
-    S.total += kmers;
-    put_span(L, nbuf, seqlike ? key : 0, kmers, flag, distinct);
-    nbuf++;
-  };
-  while (S.i <= n && nbuf < SPAN_CAP - 2) {
-    int t = 5, cls = -1;
-    if (S.i < n) { t = char_code2(seq[S.i]); cls = (t < 4) ? 1 : 0; }
-    if (S.run_len > 0 && cls != S.run_class) {
-      if (S.run_class == 1 && S.nvalid >= (uint32_t)k) emit(S.cur_val, S.cur_run, 1);
-      else if (S.run_len >= (uint32_t)k) emit(0, (int32_t)S.run_len - (k - 1), 2);  // Supermers.scala:116-119
-      S.run_len = 0;
-    }
-    if (S.i == n) { S.i++; break; }
-    if (S.run_len == 0) {
-      S.run_class = cls; S.nvalid = 0; S.fwd = 0; S.rc = 0; S.head = w - 1; S.minage = 0; S.minv = ~0ULL; S.cur_run = 0;
-    }
-    S.run_len++;
-    if (t < 4) {
-      S.nvalid++;
-      S.fwd = (S.fwd << 2) | ((uint64_t)t << P.sh);
-      S.rc = ((S.rc >> 2) | ((uint64_t)(3 - t) << 62)) & P.keep;
-      if (S.nvalid >= (uint32_t)m) {
-        uint64_t canon = (P.canonical && S.rc < S.fwd) ? S.rc : S.fwd;
-        uint64_t key = (canon ^ P.xmask) & P.smask;
-        S.head = (S.head + 1 == w) ? 0 : S.head + 1;
-        L->seq_ring[S.head] = key;
-        if (key <= S.minv) { S.minv = key; S.minage = 0; }
-        else if (++S.minage >= w) {
-          int slot = (S.head + 1 == w) ? 0 : S.head + 1;
-          S.minv = ~0ULL;
-          for (int a = w - 1; a >= 0; a--) {
-            uint64_t v = L->seq_ring[slot];
-            if (v <= S.minv) { S.minv = v; S.minage = a; }
-            slot = (slot + 1 == w) ? 0 : slot + 1;
-          }
-        }
-        if (S.nvalid >= (uint32_t)k) {
-          if (S.cur_run == 0) { S.cur_val = S.minv; S.cur_run = 1; }
-          else if (S.minv == S.cur_val) S.cur_run++;
-          else { emit(S.cur_val, S.cur_run, 1); S.cur_val = S.minv; S.cur_run = 1; }
-        }
-      }
-    }
-    S.i++;
-  }
-  L->seq = S;
-  return nbuf | ((S.i > n) ? 0x10000 : 0);
-}
-
 // LowestCommonAncestor.apply :49-78 (wave-uniform arguments and control flow)
 __device__ int32_t lca_uniform(const int32_t *parents, int32_t ntax, int32_t a, int32_t b) {
   if (a == 0 || b == 0) return b == 0 ? a : b;
@@ -383,7 +316,7 @@ __device__ __forceinline__ void resolve_map(WaveLds *L, const FusedArgs &A, uint
   }
 }
 
-enum { PH_START = 0, PH_FAST = 1, PH_SLOW = 2, PH_NEXT = 3 };
+enum { PH_START = 0, PH_FAST = 1, PH_RUNS = 2, PH_NEXT = 3 };
 
 // SLK_WPS: waves per SIMD the register allocator must leave room for (k blocks of 256 threads per CU <=> k waves/SIMD)
 #ifndef SLK_WPS
@@ -426,11 +359,13 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
       L->map_cnt[lane] = 0; L->map_cnt[lane + 64] = 0;
     }
     int mate = 0, phase = PH_START;
-    bool done = false, handed_over = false;
+    bool done = false;
     const uint8_t *seq = nullptr;
     uint32_t n = 0;
-    // fast-path state
-    uint32_t i0 = 0, nwin = 0, staged = 0, blk = 0;
+    // fast-path state: the stretch of valid characters being scanned is [.., fast_n) -- the whole mate, or one of its runs
+    uint32_t i0 = 0, nwin = 0, staged = 0, blk = 0, fast_n = 0;
+    bool runs_mode = false;   // the mate holds characters outside ACGTU: it is taken run by run (PH_RUNS)
+    uint32_t rpos = 0;        // ... and this is where the next run starts
     uint64_t carry_val = 0;
     int carry_run = 0;
     bool seg_first = true;
@@ -446,21 +381,16 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
           bool bad = false;
           uint32_t nblk = (n + 255) / 256;
           for (uint32_t b = nblk; b-- > 0;) bad |= stage_block(L, seq, n, b, lane);
-          if (__ballot(bad) != 0 && MODE == MODE_CLASSIFY && A.handover_list && !A.mate_bases && n > 1000) {
-            // a long fragment with ambiguous characters: the segment kernel scans it with 64 lanes, this path with one
-            if (lane == 0) A.handover_list[atomicAdd(A.handover_count, 1ULL)] = r;
-            handed_over = true;
-            done = true;
-            break;
-          } else if (__ballot(bad) != 0) {
-            if (lane == 0) {
-              SeqState S{};
-              S.first = first; S.have_last = have_last; S.last_key = last_key;
-              L->seq = S;
-            }
-            wave_sync();
-            phase = PH_SLOW;
+          if (__ballot(bad) != 0) {
+            // Supermers.splitByAmbiguity :150-178: the mate is a sequence of runs of valid and of other characters; a valid run
+            // of >= k characters is scanned like a whole clean mate, another run of >= k characters is one ambiguous span
+            runs_mode = true;
+            rpos = 0;
+            staged = min(nblk, 2u) * 256; blk = staged / 256;
+            phase = PH_RUNS;
           } else if (n >= (uint32_t)P.k) {
+            runs_mode = false;
+            fast_n = n;
             nwin = n - P.k + 1;
             total += (int32_t)nwin;  // the super-mers of a run partition its k-mer windows
             i0 = 0; staged = min(nblk, 2u) * 256; blk = staged / 256;
@@ -475,14 +405,14 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
               put_span(L, nbuf, carry_val, carry_run, 1, seg_first ? (first || !have_last || carry_val != last_key) : true);
             nbuf += 1;
             first = false; have_last = true; last_key = carry_val;
-            phase = PH_NEXT;
+            phase = runs_mode ? PH_RUNS : PH_NEXT;
             continue;
           }
           uint32_t need = min(n, i0 + 64 + P.m - 1);
           while (staged < need) { stage_block(L, seq, n, blk, lane); blk++; staged += 256; }
           wave_sync();
           uint32_t q = i0 + lane;
-          uint64_t key = (q + P.m <= n) ? key_at(L, P, q) : ~0ULL;
+          uint64_t key = (q + P.m <= fast_n) ? key_at(L, P, q) : ~0ULL;
           // minimum over lanes [l, l+w): doubling, then one overlapping step (PosRankWindow's observable result)
           uint64_t cur = key;
           int covered = 1;
@@ -518,20 +448,46 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
           nbuf += emitted;
           carry_val = readlane64(res, lastl);
           carry_run = nw - lastl;
-        } else if (phase == PH_SLOW) {
-          int nb = nbuf;
-          if (lane == 0) nb = seq_scan(L, P, seq, n, nbuf);
-          nb = __builtin_amdgcn_readfirstlane(nb);
-          nbuf = nb & 0xFFFF;
-          wave_sync();
-          if (nb & 0x10000) {
-            first = __builtin_amdgcn_readfirstlane(L->seq.first) != 0;
-            have_last = __builtin_amdgcn_readfirstlane(L->seq.have_last) != 0;
-            last_key = bcast64(L->seq.last_key);
-            total += __builtin_amdgcn_readfirstlane(L->seq.total);
-            phase = PH_NEXT;
-          } else {
-            break;  // buffer nearly full: flush, then resume
+        } else if (phase == PH_RUNS) {
+          if (rpos >= n) { phase = PH_NEXT; continue; }
+          // the run that starts at rpos: its class and its end (512 characters per step, 8 per lane)
+          const uint32_t a = rpos;
+          const bool valid_run = char_code2(seq[a]) < 4;
+          uint32_t b = n;
+          for (uint32_t p = a; p < n; p += 512) {
+            const uint32_t q = p + 8 * lane;
+            uint64_t chunk = 0;
+            if (q < n) __builtin_memcpy(&chunk, seq + q, 8);  // (readable: 16 bytes of padding follow the last read)
+            int firstdiff = 8;
+#pragma unroll
+            for (int j = 7; j >= 0; j--) {
+              const bool v = char_code2((uint8_t)(chunk >> (8 * j))) < 4;
+              if (q + j < n && v != valid_run) firstdiff = j;
+            }
+            const uint64_t D = __ballot(firstdiff < 8);
+            if (D != 0) {
+              const int fl = __builtin_ctzll(D);
+              b = p + 8 * fl + (uint32_t)__builtin_amdgcn_readlane(firstdiff, fl);
+              break;
+            }
+          }
+          rpos = b;
+          const uint32_t len = b - a;
+          if (valid_run) {
+            if (len >= (uint32_t)P.k) {
+              fast_n = b;
+              nwin = b - P.k + 1;            // (window starts are absolute positions in the mate)
+              total += (int32_t)(len - P.k + 1);
+              i0 = a;
+              if (a / 256 + 2 < blk || a / 256 >= blk) { blk = a / 256; staged = blk * 256; }  // not in the ring: stage from a's block
+              carry_val = 0; carry_run = 0; seg_first = true;
+              phase = PH_FAST;
+            }
+          } else if (len >= (uint32_t)P.k) {
+            if (lane == 0) put_span(L, nbuf, 0, (int32_t)len - (P.k - 1), 2, false);  // Supermers.scala:116-119
+            nbuf += 1;
+            total += (int32_t)len - (P.k - 1);
+            first = false;
           }
         } else {  // PH_NEXT
           if (mate == 0 && A.mate_bases) {
@@ -594,7 +550,6 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
       if (done) break;
     }
 
-    if (handed_over) { wave_sync(); continue; }
     if (MODE != MODE_CLASSIFY) {
       if (lane == 0) A.span_count[r] = n_out;
     }
