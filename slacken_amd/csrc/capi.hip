@@ -763,9 +763,9 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
       A.work_list = st->defer_list.as<uint64_t>() + 1;
       A.work_count = (const unsigned long long *)st->defer_list.p;
       // of the deferred fragments, the long unpaired ones go to the lane-per-segment kernel (classification only, w = 5)
-      // (4000: below that, too few of the 64 lanes have a segment to scan; read per call, so that tests can move it)
+      // (5000: below that, too few of the 64 lanes have a segment of a useful length; read per call, so that tests can move it)
       const char *seg_env = getenv("SLK_SEG_MIN_LEN");
-      const int seg_min = seg_env ? atoi(seg_env) : 4000;  // 0: wave kernel only
+      const int seg_min = seg_env ? atoi(seg_env) : 5000;  // 0: wave kernel only
       if (!want_hits && !paired && ix->sp.w == 5 && seg_min > 0) {
         A.seg_min_len = (uint32_t)std::max(seg_min, 1001);
         launch_segments(A, st->s);

@@ -24,7 +24,7 @@ SEEDS = sorted(set(range(N_SEEDS)) | {295})
 @pytest.mark.parametrize("seed", SEEDS)
 def test_differential(orc, seed, monkeypatch):
     import slacken_amd
-    monkeypatch.setenv("SLK_SEG_MIN_LEN", "1001" if seed % 2 else "4000")   # (long fragments: segment kernel / wave kernel)
+    monkeypatch.setenv("SLK_SEG_MIN_LEN", "1001" if seed % 2 else "5000")   # (long fragments: segment kernel / wave kernel)
     rng = np.random.default_rng(9000 + seed)
     m = int(rng.integers(8, 33))
     wmax = 32 if seed % 4 else 16

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def segments_from_1001_bases(monkeypatch):
-    # the engine's default hands fragments of 4000 bases and more to the segment kernel; here everything over 1000 goes there,
+    # the engine's default hands fragments of 5000 bases and more to the segment kernel; here everything over 1000 goes there,
     # which makes the segments short (64 windows) and the borders many
     monkeypatch.setenv("SLK_SEG_MIN_LEN", "1001")
 
@@ -133,19 +133,19 @@ def test_very_long_read(orc, world):
     check(orc, world, reads)
 
 
-def test_fragments_with_ambiguous_characters_are_handed_over(orc, world, monkeypatch):
-    """Default threshold: fragments of 1001..3999 bases stay on the wave kernel, unless it finds a character outside ACGTU in
-    them -- those come back to the segment kernel in a second pass instead of being scanned by a single lane."""
-    monkeypatch.setenv("SLK_SEG_MIN_LEN", "4000")
+def test_default_threshold_splits_the_work_between_the_two_kernels(orc, world, monkeypatch):
+    """Default threshold (5000 bases): shorter long fragments, clean or with characters outside ACGTU (which the wave kernel takes
+    run by run), stay on the wave kernel, longer ones go to the segment kernel, short ones to the lane kernel -- one batch."""
+    monkeypatch.delenv("SLK_SEG_MIN_LEN")
     rng = np.random.default_rng(12)
     reads = []
     for _ in range(150):
-        r = long_read(world["lib"], rng, int(rng.integers(1001, 4000)))
+        r = long_read(world["lib"], rng, int(rng.integers(1001, 5000)))
         if rng.random() < 0.5:
-            r = np.where(r == ord("N"), ord("A"), r).astype(np.uint8)    # a clean one: the wave kernel's own
+            r = np.where(r == ord("N"), ord("A"), r).astype(np.uint8)    # a clean one
         reads.append(r)
     reads += synth.make_reads(world["lib"], 200, rng, vary_length=True)
-    reads += [long_read(world["lib"], rng, int(rng.integers(4000, 9000))) for _ in range(20)]
+    reads += [long_read(world["lib"], rng, int(rng.integers(5000, 12000))) for _ in range(20)]
     bases, offsets = synth.pack(reads)
     got = world["st"].classify_batch(bases, offsets, thresholds=(0.0, 0.2), with_hits=False, with_num_hits=True)
     want = orc.classify_batch(world["p"], world["oix"], world["parents"], bases, offsets, None, None, min_hit_groups=2,
