@@ -152,3 +152,31 @@ def test_default_threshold_splits_the_work_between_the_two_kernels(orc, world, m
                               thresholds=(0.0, 0.2))
     for key in ("total_kmers", "num_hits", "num_distinct", "taxon", "classified"):
         assert np.array_equal(got[key], want[key]), key
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_hit_lists_of_long_reads_with_ambiguous_runs(orc, world, paired):
+    """Hit lists of long fragments come from the wave kernel, which takes a mate holding characters outside ACGTU run by run
+    (valid runs on the 64-lane path, other runs of >= k characters as one ambiguous span each): per-read results and the
+    un-merged hit lists against the oracle, single and paired."""
+    rng = np.random.default_rng(40 + paired)
+    reads = [long_read(world["lib"], rng, int(rng.integers(1001, 9000))) for _ in range(80)]
+    reads += [np.full(2000, ord("N"), np.uint8), np.concatenate([np.full(40, ord("N"), np.uint8), world["lib"].genomes[0][:1500]])]
+    mates = None
+    if paired:
+        mates = [long_read(world["lib"], rng, int(rng.integers(200, 3000))) for _ in reads]
+    bases, offsets = synth.pack(reads)
+    mb = mo = None
+    if paired:
+        mb, mo = synth.pack(mates)
+    got = world["st"].classify_batch(bases, offsets, mb, mo, thresholds=(0.0, 0.15), min_hit_groups=2)
+    want = orc.classify_batch(world["p"], world["oix"], world["parents"], bases, offsets, mb, mo, min_hit_groups=2,
+                              thresholds=(0.0, 0.15))
+    for key in ("total_kmers", "num_hits", "num_distinct", "taxon", "classified"):
+        assert np.array_equal(got[key], want[key]), key
+    ho = got["hit_offsets"].astype(np.int64)
+    for i in range(len(reads)):
+        _, hits = orc.classify_read(world["p"], world["oix"], world["parents"], reads[i].tobytes(),
+                                    None if mates is None else mates[i].tobytes(), 2, 0.0)
+        g = got["hits"][ho[i]:ho[i + 1]]
+        assert [(int(t), int(c)) for t, c in zip(g["taxon"], g["count"])] == hits, i
