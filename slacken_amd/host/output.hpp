@@ -192,7 +192,7 @@ struct ClassifiedBatch {
   size_t footprint() const { return hits_capacity * sizeof(slk_hit) / 8 + spans.capacity() * sizeof(slk_span); }
 };
 inline std::shared_ptr<ClassifiedBatch> new_classified_batch() {
-  static auto *pool = new Recycler<ClassifiedBatch>(64, (size_t)256 << 20);
+  static auto *pool = new Recycler<ClassifiedBatch>(32, (size_t)256 << 20);
   return std::shared_ptr<ClassifiedBatch>(pool->acquire(), [](ClassifiedBatch *b) { pool->release(b); });
 }
 
