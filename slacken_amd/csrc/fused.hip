@@ -11,7 +11,7 @@
 //          Reference: KeyValueIndex.getSpans (S/slacken/KeyValueIndex.scala:163-173) = Supermers.splitFragment/spans
 //          (S/slacken/Supermers.scala:49-125) over MinSplitter.splitEncode (S/kmers/minimizer/MinSplitter.scala:98-172),
 //          ShiftScanner.allMatches (ShiftScanner.scala:90-159), RandomXOR/SpacedSeed (MinimizerPriorities.scala:144-321).
-//   probe  8 lanes read one 64-byte bucket (8 x 8 B, one HBM line per probe), 8 probes per wave instruction, four
+//   probe  4 lanes read one 64-byte bucket (4 x 16 B, one HBM line per probe), 16 probes per wave instruction, all four
 //          instructions' loads in flight before the first compare.  Reference: the left join + spanToHit
 //          (S/slacken/Classifier.scala:84-88, KeyValueIndex.scala:176-185).
 //   LCA    a fragment whose hits name ONE taxon (the common case) is resolved without touching the tree; otherwise the
@@ -169,7 +169,9 @@ __device__ __forceinline__ int32_t map_get(const WaveLds *L, int32_t taxon) {
   return 0;
 }
 
-// Look up the (<= 64) buffered spans [s0, s0+cnt) and return this lane's taxon (lane l <-> span s0+l).
+// Look up the (<= 64) buffered spans [s0, s0+cnt) and return this lane's taxon (lane l <-> span s0+l).  The access shape of
+// lane.hip's probe_batch: FOUR lanes read one 64-byte bucket (4 x 16 B = one HBM line), sixteen probes per wave instruction,
+// all four instructions in flight before the first compare.
 __device__ __forceinline__ int32_t probe_chunk(WaveLds *L, const TableView &T, int s0, int cnt, int lane, int32_t meta) {
   const uint64_t NO_TAG = ~0ULL;  // a real tag has at most 64 - taxon_bits significant bits
   uint64_t key = (lane < cnt) ? L->span_key[s0 + lane] : 0;
@@ -182,49 +184,52 @@ __device__ __forceinline__ int32_t probe_chunk(WaveLds *L, const TableView &T, i
   ((ulonglong2 *)L->stash)[lane] = st;
   L->result[lane] = 0;
   wave_sync();
-  const int g = lane >> 3, c = lane & 7;
+  const int g = lane >> 2, c = lane & 3;                           // 16 groups of 4 lanes
   const uint64_t tmask = (1ULL << T.taxon_bits) - 1;
-  const char *cellbase = (const char *)T.cells + c * 8;
-  // displacement 0: all eight steps' loads (64 HBM lines per wave) in flight before the first compare
-  uint32_t more = 0;  // bit s: my group's span s*8+g overflowed its home bucket and is still unresolved
+  const char *cellbase = (const char *)T.cells + c * 16;
+  uint32_t more = 0;  // bit s: my group's span s*16+g overflowed its home bucket and is still unresolved
   {
-    uint64_t cell[8];
+    ulonglong2 cell[4];
 #pragma unroll
-    for (int s = 0; s < 8; s++) {
-      ulonglong2 e = ((const ulonglong2 *)L->stash)[s * 8 + g];
-      cell[s] = 0;
-      if (e.y != NO_TAG) cell[s] = *(const uint64_t *)(cellbase + e.x);
+    for (int s = 0; s < 4; s++) {
+      ulonglong2 e = ((const ulonglong2 *)L->stash)[s * 16 + g];
+      cell[s] = make_ulonglong2(0, 0);
+      if (e.y != NO_TAG) cell[s] = *(const ulonglong2 *)(cellbase + e.x);
     }
 #pragma unroll
-    for (int s = 0; s < 8; s++) {
-      uint64_t want = L->stash[2 * (s * 8 + g) + 1];
-      bool act = want != NO_TAG;
-      bool empty = cell[s] == 0;
-      bool match = !empty && (cell[s] >> T.taxon_bits) == want;
-      if (match) L->result[s * 8 + g] = (int32_t)(cell[s] & tmask);
+    for (int s = 0; s < 4; s++) {
+      const uint64_t want = L->stash[2 * (s * 16 + g) + 1];
+      const bool act = want != NO_TAG;
+      const bool e0 = cell[s].x == 0, e1 = cell[s].y == 0;
+      const bool m0 = act && !e0 && (cell[s].x >> T.taxon_bits) == want;
+      const bool m1 = act && !e1 && (cell[s].y >> T.taxon_bits) == want;
+      if (m0 || m1) L->result[s * 16 + g] = (int32_t)((m0 ? cell[s].x : cell[s].y) & tmask);
       // a group is resolved once one of its lanes matched or saw an empty cell (cells are never freed)
-      uint64_t B = __ballot(match || empty || !act);
-      if (((B - 0x0101010101010101ULL) & ~B & 0x8080808080808080ULL) != 0) {  // some group's byte is zero (rare)
-        if (((B >> (g * 8)) & 0xFF) == 0) more |= 1u << s;
+      const uint64_t B = __ballot(m0 || m1 || e0 || e1 || !act);
+      const uint64_t nz = (B | (B >> 1) | (B >> 2) | (B >> 3)) & 0x1111111111111111ULL;
+      if (nz != 0x1111111111111111ULL) {  // some group saw a full bucket without its key (rare)
+        if (((B >> (g * 4)) & 0xF) == 0) more |= 1u << s;
       }
     }
   }
   if (__ballot(more != 0) != 0) {  // rare: bucket-level linear probing
     for (int d = 1; d <= T.max_disp && __ballot(more != 0) != 0; d++) {
-      for (int s = 0; s < 8; s++) {
-        bool act = (more >> s) & 1;
-        uint64_t cl = 0, want = 0;
+      for (int s = 0; s < 4; s++) {
+        const bool act = (more >> s) & 1;
+        ulonglong2 cl = make_ulonglong2(0, 0);
+        uint64_t want = 0;
         if (act) {
-          ulonglong2 e = ((const ulonglong2 *)L->stash)[s * 8 + g];
+          ulonglong2 e = ((const ulonglong2 *)L->stash)[s * 16 + g];
           want = e.y + (uint64_t)d;
           uint64_t off = (e.x + ((uint64_t)d << 6)) & ((T.bucket_mask << 6) | 63);
-          cl = *(const uint64_t *)(cellbase + off);
+          cl = *(const ulonglong2 *)(cellbase + off);
         }
-        bool empty = cl == 0;
-        bool match = act && !empty && (cl >> T.taxon_bits) == want;
-        if (match) L->result[s * 8 + g] = (int32_t)(cl & tmask);
-        uint64_t B = __ballot(match || empty);
-        if (act && ((B >> (g * 8)) & 0xFF) != 0) more &= ~(1u << s);
+        const bool e0 = cl.x == 0, e1 = cl.y == 0;
+        const bool m0 = act && !e0 && (cl.x >> T.taxon_bits) == want;
+        const bool m1 = act && !e1 && (cl.y >> T.taxon_bits) == want;
+        if (m0 || m1) L->result[s * 16 + g] = (int32_t)((m0 ? cl.x : cl.y) & tmask);
+        const uint64_t B = __ballot(m0 || m1 || e0 || e1);
+        if (act && ((B >> (g * 4)) & 0xF) != 0) more &= ~(1u << s);
       }
     }
   }
