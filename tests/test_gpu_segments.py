@@ -92,7 +92,7 @@ def check(orc, world, reads, thresholds=(0.0, 0.1, 0.5), min_hit_groups=2):
     return got
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SLK_SEG_SEEDS", 4))))   # (SLK_SEG_SEEDS: soak runs)
 def test_long_reads_with_cut_spans(orc, world, seed):
     rng = np.random.default_rng(500 + seed)
     # up to 4200 bases: segments of 64 windows, a border every 64 bases; longer reads: longer segments
