@@ -167,6 +167,9 @@ int32_t slk_spans_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, con
  *   out_hit_offsets[R+1], out_hits[hits_capacity] (both nullable): un-merged TaxonHits in ordinal order incl.
  *     the -1 / -2 entries.  A read with out_hit_offsets[r+1] == out_hit_offsets[r] produced no span: the reference
  *     emits NO row for it (grouping is over span rows, Classifier.scala:92) -- the host must drop it.
+ *     out_hit_offsets without out_hits: the number of spans per read only (offsets[r+1] - offsets[r]); the lists are then
+ *     neither built nor copied, and the call takes the kernels that do not keep span order (the fastest route).
+ * The caller's buffers may be any host memory: the copies go through pinned staging buffers of the stream.
  * Sample-id regex, titles, duplicate-title merging and text formatting stay on the host. */
 int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, const uint64_t *offsets,
                            const uint8_t *mate_bases, const uint64_t *mate_offsets, uint64_t R,
