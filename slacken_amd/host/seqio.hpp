@@ -494,8 +494,13 @@ class AsyncRecordStream {
   }
 
  public:
+  static bool regular_file(const std::string &file) {  // (a pipe -- /dev/stdin, <(zcat x) -- can neither be mapped nor peeked into)
+    struct stat sb;
+    return stat(file.c_str(), &sb) == 0 && S_ISREG(sb.st_mode);
+  }
+
   explicit AsyncRecordStream(const std::string &file) {
-    if (is_compressed(file)) {
+    if (!regular_file(file) || is_compressed(file)) {
       th_.emplace_back([this, file] { run_serial(file); });
       return;
     }

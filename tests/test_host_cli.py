@@ -293,3 +293,18 @@ def test_segment_parallel_parser_on_adversarial_text(tmp_path, seed):
         assert parse(gz, 5, 1) == want
         for chunk, threads in ((1, 3), (2, 2), (3, 4), (7, 1), (64, 5), (1 << 20, 2)):
             assert parse(p, chunk, threads) == want, (ext, chunk, threads)
+
+
+def test_input_from_a_pipe(tmp_path):
+    """A named pipe (or /dev/stdin, or a shell's <(...)) can neither be mapped nor peeked into: it takes the streaming reader,
+    with the format still decided by the name (FileInputs.forFile)."""
+    fifo = tmp_path / "reads.fq"
+    os.mkfifo(fifo)
+    text = FASTQ * 50
+    import threading
+    w = threading.Thread(target=lambda: open(fifo, "w").write(text))
+    w.start()
+    out = run("parse", fifo)
+    w.join()
+    got = [tuple(l.split("\t")) for l in out.rstrip("\n").split("\n")]
+    assert got == hostmodel.parse_fastq(text)
