@@ -217,7 +217,7 @@ def main():
     fused = float(stage_ms[1]) < 0.05 and float(stage_ms[2]) < 0.05  # one fused launch: [fused, 0, ~0]
     dom_ms = float(stage_ms[0]) if fused else float(stage_ms[1])
     dom_name = ("slk::lane_kernel<true> (scan+probe+LCA fused, lane per read; followed by the near-empty deferral "
-                "launches: compact_flags, segment_kernel, fused_kernel<1>)") if fused else "slk::probe_kernel"
+                "launches of segment_kernel and fused_kernel<1>)") if fused else "slk::probe_kernel"
     achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9
     path_achieved = bytes_per_launch / (float(stage_ms.sum()) * 1e-3) / 1e9
 

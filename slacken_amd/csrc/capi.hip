@@ -751,17 +751,13 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
     A.work_list = nullptr; A.work_count = nullptr;
     if (lane_path_ok(ix) && !force_wave()) {  // (window of at most 32 m-mers, taxon ids of at most 22 bits)
       st->last_used_lane = true;
-      // hot path: one lane per fragment; long fragments and map overflows are deferred to the wave-per-read kernel
-      HIPCHK(st->defer.ensure((R + 64) * sizeof(int32_t)));
-      HIPCHK(hipMemsetAsync(st->defer.p, 0, (R + 64) * sizeof(int32_t), st->s));
-      launch_lane(A, st->defer.as<int32_t>(), 1000, st->s);  // queue entries carry 10-bit k-mer counts
-      // the deferred fragments, compacted: [0] = their number, [1..] = their indices
+      // hot path: one lane per fragment; long fragments and map overflows are deferred to the wave-per-read kernel: the lane
+      // kernel appends them to the work list itself ([0] = their number, [1..] = their indices, in no particular order)
       HIPCHK(st->defer_list.ensure((R + 1) * sizeof(uint64_t)));
       HIPCHK(hipMemsetAsync(st->defer_list.p, 0, sizeof(uint64_t), st->s));
-      launch_compact_flags(st->defer.as<int32_t>(), R, st->defer_list.as<uint64_t>() + 1,
-                           (unsigned long long *)st->defer_list.p, st->s);
       A.work_list = st->defer_list.as<uint64_t>() + 1;
       A.work_count = (const unsigned long long *)st->defer_list.p;
+      launch_lane(A, nullptr, 1000, st->s);  // queue entries carry 10-bit k-mer counts
       // of the deferred fragments, the long unpaired ones go to the lane-per-segment kernel (classification only, w = 5)
       // (5000: below that, too few of the 64 lanes have a segment of a useful length; read per call, so that tests can move it)
       const char *seg_env = getenv("SLK_SEG_MIN_LEN");

@@ -110,7 +110,7 @@ struct FusedArgs {
   int32_t *span_count;   // MODE_SPANS / MODE_HITS output
   int32_t *status;       // device error bits: 1 = taxon map overflow
   const uint64_t *work_list;             // if set, the fused kernel processes only the fragments work_list[0 .. *work_count)
-  const unsigned long long *work_count;  // (device) -- the fragments the lane kernel deferred, compacted by launch_compact_flags
+  const unsigned long long *work_count;  // (device) -- the fragments the lane kernel deferred (it appends them itself)
   uint32_t seg_min_len;                  // work-list passes: unpaired fragments of at least this many bases belong to the
                                          // lane-per-segment kernel (launch_segments), the others to the wave kernel; 0 = none
 };
@@ -139,7 +139,6 @@ enum { MODE_SPANS = 0, MODE_CLASSIFY = 1, MODE_HITS = 2 };
 void launch_fused(int mode, const FusedArgs &A, hipStream_t s);
 // list[0 .. *count) = the indices r < R with flags[r] != 0 (in no particular order); *count must be zero beforehand
 void launch_segments(const FusedArgs &A, hipStream_t s);
-void launch_compact_flags(const int32_t *flags, uint64_t R, uint64_t *list, unsigned long long *count, hipStream_t s);
 // lane-per-fragment classify kernel (lane.hip); fragments it cannot take are flagged in defer[] for launch_fused
 void launch_lane(const FusedArgs &A, int32_t *defer, uint32_t max_len, hipStream_t s);
 

@@ -343,9 +343,9 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
   const int w = P.w;
   const uint32_t STEP = 64 - (w - 1);  // k-mer windows resolved per round
   const uint64_t nwaves = (uint64_t)gridDim.x * FW;
-  // Work list: every fragment, or (work_list) the fragments the lane kernel deferred, one per wave iteration.  (They used to
-  // be found 64 flags at a time by ballot, each wave working through its 64 one after the other: with most fragments
-  // deferred -- a batch of long reads -- that left most of the chip idle.)
+  // Work list: every fragment, or (work_list) the fragments the lane kernel deferred -- it appends them to the list itself --
+  // one per wave iteration.  (They used to be found 64 flags at a time by ballot, each wave working through its 64 one after
+  // the other: with most fragments deferred -- a batch of long reads -- that left most of the chip idle.)
   const uint64_t nunits = A.work_list ? (uint64_t)*A.work_count : A.R;
   for (uint64_t unit = (uint64_t)blockIdx.x * FW + wib; unit < nunits; unit += nwaves) {
    {
@@ -865,37 +865,6 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
 
 void launch_segments(const FusedArgs &A, hipStream_t s) {  // work-list pass; A.seg_min_len set, unpaired, window width 5
   hipLaunchKernelGGL(segment_kernel, dim3(256 * 8), dim3(FW * 64), 0, s, A);
-}
-
-__global__ void __launch_bounds__(256) compact_flags_kernel(const int32_t *__restrict__ flags, uint64_t R, uint64_t *__restrict__ list,
-                                                            unsigned long long *__restrict__ count) {
-  const int lane = threadIdx.x & 63;
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
-  // two passes over this wave's chunks, so that the list cursor is bumped once per wave and not once per chunk with a flag
-  // (2e5 flagged fragments of 4e6 made the single cursor the cost of this kernel: 0.73 ms)
-  unsigned long long mine = 0;
-  for (uint64_t base = i - lane; base < R; base += step) {  // wave-uniform trip count
-    const uint64_t r = base + lane;
-    mine += (unsigned long long)__popcll(__ballot(r < R && flags[r] != 0));
-  }
-  if (mine == 0) return;  // (wave-uniform)
-  unsigned long long at = 0;
-  if (lane == 0) at = atomicAdd(count, mine);
-  at = ((unsigned long long)(uint32_t)__shfl((int)(at >> 32), 0) << 32) | (uint32_t)__shfl((int)at, 0);
-  for (uint64_t base = i - lane; base < R; base += step) {
-    const uint64_t r = base + lane;
-    const bool f = r < R && flags[r] != 0;
-    const uint64_t m = __ballot(f);
-    if (f) list[at + lanes_below(m)] = r;
-    at += (unsigned long long)__popcll(m);
-  }
-}
-
-void launch_compact_flags(const int32_t *flags, uint64_t R, uint64_t *list, unsigned long long *count, hipStream_t s) {
-  if (R == 0) return;
-  uint64_t blocks = std::min<uint64_t>((R + 255) / 256, 256 * 8);
-  hipLaunchKernelGGL(compact_flags_kernel, dim3((unsigned)blocks), dim3(256), 0, s, flags, R, list, count);
 }
 
 void launch_fused(int mode, const FusedArgs &A, hipStream_t s) {

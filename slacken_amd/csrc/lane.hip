@@ -539,10 +539,23 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     lane_wave_sync();
 
     // ---- per-read classification (one lane per read) ------------------------------------------------------------------
+    const uint32_t oflags = have ? L->o_flags[lane] : 0u;
+    const bool dfr = have && (too_long || (oflags & 0x80000000u));  // re-done by the wave-per-read / segment kernels
+    if (MODE == LANE_LOCAL) {
+      // straight into the work list of those kernels ([count] at A.work_count, indices at A.work_list; the order of the
+      // list does not matter): one atomic per wave that defers anything, none otherwise
+      const uint64_t DM = __ballot(dfr);
+      if (DM != 0) {
+        unsigned long long at = 0;
+        if (lane == 0) at = atomicAdd(const_cast<unsigned long long *>(A.work_count), (unsigned long long)__popcll(DM));
+        at = lane_readlane64(at, 0);
+        if (dfr) const_cast<uint64_t *>(A.work_list)[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(DM >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)DM, 0))] = r;
+      }
+    } else if (dfr) {
+      defer[r] = 1;  // sharded modes: the caller routes these fragments
+    }
     if (have) {
-      const uint32_t oflags = L->o_flags[lane];
-      if (too_long || (oflags & 0x80000000u)) {
-        defer[r] = 1;  // re-done by the wave-per-read kernel
+      if (dfr) {
       } else if (MODE != LANE_EMIT) {
         OwnerMap M{L, lane};
         const int32_t nd = (int32_t)oflags;
