@@ -273,3 +273,29 @@ def test_cli_long_reads_all_routes_agree(tmp_path, orc):
     out2 = tmp_path / "long_reports"
     classify("-i", loc, "-o", out2, "-c", "0.1", "--nodetailed", fq)
     assert open(f"{out2}_c0.1/all_kreport.txt").read() == open(f"{out}_c0.1/all_kreport.txt").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [dict(SLK_CLASSIFY_THREADS="1", SLK_PARSE_THREADS="1"),
+                                 dict(SLK_CLASSIFY_THREADS="6", SLK_PARSE_THREADS="8", SLK_IO_CHUNK="4096", SLK_HOST_THREADS="3"),
+                                 dict(SLK_CLASSIFY_THREADS="3", SLK_IO_CHUNK="777", SLK_GZIP_IMPL="zlib", SLK_GZIP_LEVEL="1")],
+                         ids=["serial", "many-small-batches", "tiny-segments-zlib"])
+def test_cli_output_does_not_depend_on_the_host_pipeline_shape(tmp_path, env):
+    """Segment size of the parallel parser, number of parsing / classifying / formatting threads, the gzip implementation: the
+    per-read lines (in input order) and the report are the same as with the defaults."""
+    g, loc, tax, reads = make_library(tmp_path, convert=False)
+    rng = np.random.default_rng(5)
+    fq = tmp_path / "r.fq"
+    with open(fq, "w") as f:
+        for i in range(6000):
+            t, s = reads[rng.integers(0, len(reads))]
+            s = s[:int(rng.integers(40, len(s) + 1))]
+            f.write(f"@{t}.{i}\n{s}\n+\n{'I' * len(s)}\n")
+    ref_out = tmp_path / "ref"
+    classify("-i", loc, "-o", ref_out, "-c", "0.1", fq)
+    out = tmp_path / "alt"
+    r = subprocess.run([CLI, "classify", "-i", loc, "-o", str(out), "-c", "0.1", str(fq)], capture_output=True, text=True,
+                       env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stderr
+    assert read_out(f"{out}_c0.1") == read_out(f"{ref_out}_c0.1")
+    assert open(f"{out}_c0.1/all_kreport.txt").read() == open(f"{ref_out}_c0.1/all_kreport.txt").read()
