@@ -23,14 +23,16 @@ def main():
     G, L = 64, 1 << 22
     acgt = np.frombuffer(b"ACGT", np.uint8)
     bases = acgt[rng.integers(0, 4, G * L, dtype=np.uint8)]
-    ix = slacken_amd.Index(expected_records=G * L // 2, max_taxon=len(parents) - 1)
+    kms = [int(x) for x in os.environ.get("KMS", "35,31,7").split(",")]   # k, m, spaces of the splitter
+    ix = slacken_amd.Index(k=kms[0], m=kms[1], spaces=kms[2], expected_records=G * L // 2, max_taxon=len(parents) - 1)
     ix.set_taxonomy(parents)
     ix.add_sequences(bases, np.arange(G + 1, dtype=np.uint64) * np.uint64(L), rng.choice(taxa[len(taxa) // 2:], G).astype(np.int32))
     ix.finalize()
     st = ix.stream()
     d_all = torch.from_numpy(bases).cuda()
     out = dict(seg_min_len=os.environ.get("SLK_SEG_MIN_LEN", "default"))
-    for L_read in (1500, 3000, 5000, 10_000, 30_000, 100_000):
+    lengths = [int(x) for x in os.environ.get("LENGTHS", "1500,3000,5000,10000,30000,100000").split(",")]
+    for L_read in lengths:
         R = max(64, 1_000_000_000 // L_read)
         for with_n in (False, True):
             starts = torch.from_numpy(rng.integers(0, G * L - L_read, R)).cuda()
