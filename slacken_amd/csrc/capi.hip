@@ -112,7 +112,7 @@ struct slk_stream {
   hipStream_t s = nullptr;
   DevBuf span_keys, span_meta, span_taxon, span_count;  // per-batch scratch (sparse per-read regions)
   DevBuf bases, offsets, mate_bases, mate_offsets;      // staging for the host-pointer entry points
-  DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items, defer, defer_list;
+  DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items, defer_list;
   double *d_thresholds = nullptr;
   double *h_thresholds = nullptr;  // pinned
   int32_t *d_status = nullptr;     // device error bits of the fused kernels
@@ -623,7 +623,7 @@ void slk_stream_destroy(slk_stream *st) {
   (void)hipStreamSynchronize(st->s);
   DevBuf *bufs[] = {&st->span_keys, &st->span_meta, &st->span_taxon, &st->span_count, &st->bases, &st->offsets,
                     &st->mate_bases, &st->mate_offsets, &st->out_taxon, &st->out_cls, &st->out_nd, &st->out_tk,
-                    &st->out_nh, &st->out_offsets, &st->out_items, &st->defer, &st->defer_list};
+                    &st->out_nh, &st->out_offsets, &st->out_items, &st->defer_list};
   for (DevBuf *b : bufs) b->release();
   if (st->d_thresholds) (void)hipFree(st->d_thresholds);
   if (st->h_thresholds) (void)hipHostFree(st->h_thresholds);
