@@ -1,23 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- classify throughput of the MI355X engine on BASELINE.json's headline configuration.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: if the process was not started by torch.distributed.run (no WORLD_SIZE in the environment) it starts the N ranks
+itself -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same args>`
+as a CHILD process, before anything in this process has touched the GPU -- and exits with the child's code.  Started by
+torch.distributed.run (the driver's way) it is one rank of the job.  A WORLD_SIZE that differs from --gpus is an error.
 
 Workload (configs[1] of BASELINE.json; synthetic because standard-224 is an S3 download):
   * "standard-224-scale" library: --records (default 1.0e10) unique (minimizer, taxon) records, k=35 m=31 s=7:
-    the minimizers of G synthetic genomes (found with the engine's own scan kernel and merged by LCA) padded with
-    uniformly random 48-significant-bit keys; taxonomy 8 ranks x 8192 nodes relabelled onto ids < 3 080 008.
+    the minimizers of G synthetic genomes (--genomes x --genome-len; default 8192 x 1 Mbp, one per leaf taxon, as SURVEY
+    8d specifies), found and LCA-merged by the engine's own library builder straight into the table
+    (slk_index_add_sequences_device), padded with uniformly random 48-significant-bit keys; taxonomy 8 ranks x 8192 nodes
+    relabelled onto ids < 3 080 008.
   * reads: --reads (default 1.0e7) single-end 150 bp per GPU, 80 % drawn from the genomes (random strand, 1 %
     substitutions), 20 % uniform random, 0.5 % with one N, 0.05 % with a 40-N run.  Resident in HBM before timing.
   * a step = one pass of scan -> probe -> classify over the whole read batch (slk_classify_batch_device).
 Multi-GPU: table replicated, reads sharded (each rank its own batch), no data-path collective => "weak" scaling.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the table probe); `cpu_baseline` times the CPU
-restatement under oracle/ (OpenMP, all host cores) on a bounded sample -- a reported baseline, not the target.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused lane kernel, bound by its table probes);
+`cpu_baseline` times the CPU restatement under oracle/ (OpenMP, all host cores) on a bounded sample -- a reported
+baseline, not the target.
+
+--dry-run: no GPU, no engine: every rank times a trivial numpy step and goes through the same rendezvous (gloo), barrier,
+max-over-ranks and reporting code, so that the N-rank plumbing can be tested on a CPU box.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,15 +41,46 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-GATHER_CEILING_GLPS = 48.5
+# random 64-byte requests/s this part sustains against a 128 GiB table (tools/gather_bench2.hip, profiles/r02_gather_experiments.txt)
+GATHER_CEILING_GLPS = 48.4
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 K, M, SPACES = 35, 31, 7
 READ_LEN = 150
 TAX_EXTENT = 3080008  # README.md:374 of the reference (NCBI taxonomy array extent)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def kernel_source_hash():
+    """sha256 over the engine's kernel sources: a counter-derived figure on file is only quoted for the code it was taken from."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "slacken_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n):
+    """Parent of an N-rank run: nothing here has touched (or will touch) the GPU; the ranks are children."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log("starting", n, "ranks:", " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def build_taxonomy(seed=2240):
@@ -50,20 +95,19 @@ def build_taxonomy(seed=2240):
     return parents, taxa, leaves
 
 
-def genome_records(slacken_amd, genomes, genome_taxa, parents, device):
-    """(key, LCA taxon) records of the genomes, built on the device by the config-5 builder (slk_index_add_sequences:
-    minimizers of every genome, duplicates across genomes merged by LCA -- KeyValueIndex.makeRecords, KeyValueIndex.scala:85-93)
-    and exported sorted by key."""
-    lens = np.array([len(g) for g in genomes], np.uint64)
-    offsets = np.zeros(len(genomes) + 1, np.uint64)
-    np.cumsum(lens, out=offsets[1:])
-    tmp = slacken_amd.Index(k=K, m=M, spaces=SPACES, expected_records=int(offsets[-1]) // 2 + 1024, max_taxon=TAX_EXTENT - 1,
-                            device=device)
-    tmp.set_taxonomy(parents)
-    tmp.add_sequences(np.concatenate(genomes), offsets, genome_taxa.astype(np.int32))
-    keys, tax = tmp.export()
-    tmp.close()
-    return keys, tax
+def make_genomes_device(torch, n_genomes, genome_len, seed, device):
+    """uint8 tensor [n_genomes * genome_len + 64] of uniform ACGT on the GPU (the pad keeps the 16 readable bytes the
+    _device entry points ask for)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    total = n_genomes * genome_len
+    out = torch.full((total + 64,), ord("A"), dtype=torch.uint8, device=device)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    CH = 1 << 28
+    for s in range(0, total, CH):
+        n = min(CH, total - s)
+        out[s:s + n] = acgt[torch.randint(0, 4, (n,), generator=g, device=device)]
+    return out
 
 
 def make_reads_device(torch, genome_cat, genome_len, n_genomes, n_reads, seed, device):
@@ -104,6 +148,40 @@ def make_reads_device(torch, genome_cat, genome_len, n_genomes, n_reads, seed, d
     return flat, offsets
 
 
+def dry_run(args, rank, world):
+    """The N-rank plumbing without a GPU: gloo rendezvous, barrier-bracketed timed loop, max over ranks, one line."""
+    from slacken_amd import dist as sdist
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    n_reads = int(args.reads)
+    x = np.arange(1 << 16, dtype=np.uint64)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        x = x * np.uint64(3) + np.uint64(1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = x * np.uint64(3) + np.uint64(1)
+    barrier()
+    elapsed = sdist.max_over_ranks(time.perf_counter() - t0, dist, None)
+    counts = sdist.allreduce_counts(np.array([n_reads], np.int64), dist, None)
+    if rank == 0:
+        print(json.dumps({"metric": "classify_throughput_150bp_standard224scale", "value": None, "unit": "M reads/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "dry run: no GPU work, rank plumbing only",
+                                     "reads_all_ranks_per_step": int(counts[0])}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,16 +189,25 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--records", type=float, default=1.0e10, help="library records (standard-224-scale)")
     ap.add_argument("--reads", type=float, default=1.0e7, help="150 bp reads per GPU per step")
-    ap.add_argument("--genomes", type=int, default=2048)
-    ap.add_argument("--genome-len", type=int, default=16384)
+    ap.add_argument("--genomes", type=int, default=8192)
+    ap.add_argument("--genome-len", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="rank plumbing only (gloo, no GPU)")
     args = ap.parse_args()
 
-    import torch
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))  # (no GPU call has been made in this process)
     from slacken_amd import dist as sdist
     rank, world, local_rank = sdist.env_rank_world()
     if world != args.gpus:
-        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}")
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}; start it as `python bench.py --gpus N` or "
+                         f"under torch.distributed.run with --nproc-per-node equal to --gpus")
+    if args.dry_run:
+        return dry_run(args, rank, world)
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -136,22 +223,27 @@ def main():
     parents, taxa, leaves = build_taxonomy()
     rng = np.random.default_rng(224)
     G = min(args.genomes, len(leaves))
-    genome_taxa = rng.choice(leaves, size=G, replace=False)
-    acgt = np.frombuffer(b"ACGT", np.uint8)
-    genomes = [acgt[rng.integers(0, 4, args.genome_len)] for _ in range(G)]
-    gkeys, gtax = genome_records(slacken_amd, genomes, genome_taxa, parents, local_rank)
-    log(f"rank {rank}: taxonomy {len(taxa) + 1} nodes, {G} genomes -> {len(gkeys)} records ({time.time() - t0:.1f}s)")
+    genome_taxa = rng.choice(leaves, size=G, replace=False).astype(np.int32)
+    genome_cat = make_genomes_device(torch, G, args.genome_len, 224 + 1, device)
+    g_offsets = np.arange(0, (G + 1) * args.genome_len, args.genome_len, dtype=np.uint64)
+    torch.cuda.synchronize()
+    log(f"rank {rank}: taxonomy {len(taxa) + 1} nodes, {G} genomes x {args.genome_len} bp on the device ({time.time() - t0:.1f}s)")
 
-    # ---- HBM-resident table: genome records + random padding generated on the device
-    ix = slacken_amd.Index(k=K, m=M, spaces=SPACES, expected_records=max(n_records, len(gkeys)),
+    # ---- HBM-resident table: the genomes' minimizers (LCA-merged by the engine's library builder) + random padding
+    # distinct minimizers of the genomes: about 2/(w+1) per k-mer window on random sequence (w = 5)
+    expect_genome = int(G * args.genome_len * 0.36) + 1024
+    ix = slacken_amd.Index(k=K, m=M, spaces=SPACES, expected_records=max(n_records, expect_genome),
                            max_taxon=TAX_EXTENT - 1, device=local_rank)
-    ix.append(gkeys, gtax)
+    ix.set_taxonomy(parents)
+    ix.add_sequences_device(genome_cat.data_ptr(), g_offsets, genome_taxa)
+    n_genome_records = int(ix.info().records)
+    log(f"rank {rank}: {n_genome_records} genome records ({time.time() - t0:.1f}s)")
     smask = ((2**62 - 1) & ~0x0CCCCCCC) << 2  # SpacedSeed mask for m=31, s=7 (48 significant bits), left-aligned
     smask_i64 = smask - (1 << 64) if smask >= (1 << 63) else smask
     d_taxa = torch.from_numpy(taxa).to(device)
     gen = torch.Generator(device=device)
     gen.manual_seed(224 + 7)
-    pad, CH = max(0, n_records - len(gkeys)), 1 << 27
+    pad, CH = max(0, n_records - n_genome_records), 1 << 27
     for s in range(0, pad, CH):
         n = min(CH, pad - s)
         hi = torch.randint(0, 2**32, (n,), generator=gen, device=device, dtype=torch.int64)
@@ -162,7 +254,6 @@ def main():
         torch.cuda.synchronize()
         ix.append_device(keys.data_ptr(), tx.data_ptr(), n)
         del keys, tx
-    ix.set_taxonomy(parents)
     ix.finalize()
     info = ix.info()
     torch.cuda.empty_cache()
@@ -171,7 +262,6 @@ def main():
         f"{info.max_displacement}, {info.duplicate_keys} duplicate pad keys dropped) ({time.time() - t0:.1f}s)")
 
     # ---- reads resident in HBM
-    genome_cat = torch.from_numpy(np.concatenate(genomes)).to(device)
     d_bases, d_offsets = make_reads_device(torch, genome_cat, args.genome_len, G, n_reads, 150 + rank, device)
     total_bases = n_reads * READ_LEN
     d_taxon = torch.zeros(n_reads, dtype=torch.int32, device=device)
@@ -197,15 +287,20 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    stage_ms = np.zeros(3)
+    # Dominant kernel: HIP events recorded on the ENGINE's stream (torch sees it as an external stream) bracket every timed
+    # step's launches -- no host synchronisation inside the timed region; read back after it.  A step's bracket holds the
+    # lane kernel and the near-empty deferral launches behind it (segment_kernel, fused_kernel<1>: a few microseconds).
+    ext = torch.cuda.ExternalStream(st.hip_stream, device=device)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t_start = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        ev[i][0].record(ext)
         step()
-        # HIP events on the engine's own stream bracket each stage kernel (read after the timed region)
+        ev[i][1].record(ext)
     barrier()
     elapsed = time.perf_counter() - t_start
-    # per-stage device time: re-read the events of the LAST timed step (every step launches the same three kernels)
-    stage_ms = np.array(st.last_stage_ms())
+    step_dev_ms = np.array([a.elapsed_time(b) for a, b in ev]) if args.steps else np.zeros(1)
+    stage_ms = np.array(st.last_stage_ms())  # the engine's own events of the LAST timed step: [fused, 0, ~0] on the hot path
     elapsed = sdist.max_over_ranks(elapsed, dist, device)
     ms_per_step = elapsed / args.steps * 1e3
     reads_per_s = world * n_reads / (elapsed / args.steps)
@@ -215,18 +310,24 @@ def main():
     classified = float(d_cls.float().mean().item())
     bytes_per_launch = total_bases + 64 * probes + 8 * n_reads
     fused = float(stage_ms[1]) < 0.05 and float(stage_ms[2]) < 0.05  # one fused launch: [fused, 0, ~0]
-    dom_ms = float(stage_ms[0]) if fused else float(stage_ms[1])
+    # hot path: mean device time of a step's launches over the K timed steps; staged path (other splitters): the probe kernel
+    dom_ms = float(step_dev_ms.mean()) if fused else float(stage_ms[1])
     dom_name = ("slk::lane_kernel<true> (scan+probe+LCA fused, lane per read; followed by the near-empty deferral "
                 "launches of segment_kernel and fused_kernel<1>)") if fused else "slk::probe_kernel"
     achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9
     path_achieved = bytes_per_launch / (float(stage_ms.sum()) * 1e-3) / 1e9
 
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath):  # FETCH_SIZE + WRITE_SIZE of the dominant kernel, rocprofv3 --pmc passes of this same command
-        tj = json.load(open(tpath))
-        if tj.get("reads_per_launch") == n_reads and tj.get("records") == int(args.records):
-            traffic = tj["hbm_bytes_per_launch"]
+    # HBM traffic from the PMC counters is collected by separate rocprofv3 --pmc passes of this command
+    # (tools/profile.sh) and kept on file with the hash of the kernel sources it was measured on: quoted only on a match.
+    traffic, traffic_note = None, "no counter file for this build"
+    if os.path.exists(TRAFFIC_FILE):
+        tj = json.load(open(TRAFFIC_FILE))
+        same = (tj.get("reads_per_launch") == n_reads and tj.get("records") == int(args.records)
+                and tj.get("genomes") == [G, args.genome_len])
+        if same and tj.get("kernel_source_hash") == kernel_source_hash():
+            traffic, traffic_note = tj["hbm_bytes_per_launch"], "profiles/r02_traffic.json (same kernel sources, same workload)"
+        else:
+            traffic_note = "profiles/r02_traffic.json is for other kernel sources or another workload: not quoted"
 
     out = {
         "metric": "classify_throughput_150bp_standard224scale",
@@ -245,10 +346,12 @@ def main():
             "workload": "standard-224-scale synthetic library (k=35,m=31,s=7), synthetic 150 bp single-end reads, "
                         "full table resident in HBM (BASELINE.json configs[1])",
             "records": int(info.records), "table_GiB": round(info.table_bytes / 2**30, 1),
+            "genomes": G, "genome_len": args.genome_len, "genome_records": n_genome_records,
             "reads_per_gpu_per_step": n_reads, "read_len": READ_LEN, "parallelism": f"read-sharded x{world}, table replicated",
             "probes_per_read": round(probes / n_reads, 3), "classified_fraction": round(classified, 4),
             "deferred_to_wave_kernel": st.last_deferred(),
-            "stage_ms": ({"fused": round(dom_ms, 3)} if fused else
+            "stage_ms": ({"fused_last_step": round(float(stage_ms[0]), 3), "step_device_ms_min": round(float(step_dev_ms.min()), 3),
+                          "step_device_ms_max": round(float(step_dev_ms.max()), 3)} if fused else
                          {"scan": round(float(stage_ms[0]), 3), "probe": round(float(stage_ms[1]), 3),
                           "classify": round(float(stage_ms[2]), 3)}),
             "path_GBps_all_kernels": round(path_achieved, 1),
@@ -256,42 +359,56 @@ def main():
         },
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "traffic_source": traffic_note,
                      "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": round(dom_ms, 3),
-                     # the part's measured rate of random 64-byte line reads on a 128 GiB table (tools/gather_bench.hip,
-                     # profiles/r01_gather_microbench.txt): what a hash-table probe can reach, as opposed to the streaming peak
+                     # the part's measured rate of random 64-byte requests on a 128 GiB table (tools/gather_bench2.hip,
+                     # profiles/r02_gather_experiments.txt): what a hash-table probe can reach, as opposed to the streaming peak
                      "random_line_ceiling_Glines_per_s": GATHER_CEILING_GLPS,
                      "probe_lines_per_s_G": round(probes / (dom_ms * 1e-3) / 1e9, 2),
                      "frac_of_random_line_ceiling": round(probes / (dom_ms * 1e-3) / 1e9 / GATHER_CEILING_GLPS, 3)},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, gkeys, gtax, parents, d_bases, n_reads, rng)
+        out["cpu_baseline"] = cpu_baseline(torch, slacken_amd, args, parents, genome_cat, genome_taxa, G, device)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, gkeys, gtax, parents, d_bases, n_reads, rng):
-    """The CPU restatement (oracle/, OpenMP over reads) on a bounded sample of the same reads (sized for roughly 12 s),
-    against the genome records plus random padding up to 2^24 records (hits come from the genome records; the padding
-    keeps the hash table far larger than the CPU caches, as the full library would)."""
+def cpu_baseline(torch, slacken_amd, args, parents, genome_cat, genome_taxa, G, device):
+    """The CPU restatement (oracle/, OpenMP over reads) on a bounded sample of the same workload (sized for roughly 12 s):
+    reads of the same generator drawn from the first 64 genomes, against those genomes' records plus random padding up to
+    2^24 records (hits come from the genome records; the padding keeps the hash table far larger than the CPU caches, as
+    the full library would) -- a CPU table of the full 1.0e10 records would take longer to build than the whole bench run."""
     ncpu = len(os.sched_getaffinity(0))
     os.environ.setdefault("OMP_NUM_THREADS", str(ncpu))
     from oracle import oracle
+    Gc = min(G, 64)
+    L = args.genome_len
+    tmp = slacken_amd.Index(k=K, m=M, spaces=SPACES, expected_records=int(Gc * L * 0.5) + 1024, max_taxon=TAX_EXTENT - 1,
+                            device=device.index)
+    tmp.set_taxonomy(parents)
+    tmp.add_sequences_device(genome_cat.data_ptr(), np.arange(0, (Gc + 1) * L, L, dtype=np.uint64), genome_taxa[:Gc])
+    gkeys, gtax = tmp.export()
+    tmp.close()
     p = oracle.params(k=K, m=M, spaces=SPACES)
+    rng = np.random.default_rng(99)
     pad = max(0, (1 << 24) - len(gkeys))
     pkeys = (rng.integers(0, 2**63, pad, dtype=np.uint64) * np.uint64(2)) & np.uint64(p.space[0])
     ptax = np.full(pad, 1, np.int32)
     oix = oracle.Index(1, np.concatenate([gkeys, pkeys.view(np.int64)]), np.concatenate([gtax, ptax]))
-    probe_n = min(n_reads, 200000)
-    bases = d_bases[:probe_n * READ_LEN].cpu().numpy()
+    n_sample = 2_000_000
+    d_bases, _ = make_reads_device(torch, genome_cat, L, Gc, n_sample, 151, device)
+    h_bases = d_bases[:n_sample * READ_LEN].cpu().numpy()
+    del d_bases
+    probe_n = 200000
     offsets = np.arange(0, (probe_n + 1) * READ_LEN, READ_LEN, dtype=np.uint64)
     t = time.perf_counter()
-    res = oracle.classify_batch(p, oix, parents, bases, offsets)  # also warms the table
+    res = oracle.classify_batch(p, oix, parents, h_bases[:probe_n * READ_LEN], offsets)  # also warms the table
     rate = probe_n / (time.perf_counter() - t)
-    S = int(min(n_reads, max(probe_n, rate * 12.0)))
-    bases = d_bases[:S * READ_LEN].cpu().numpy()
+    S = int(min(n_sample, max(probe_n, rate * 12.0)))
+    bases = h_bases[:S * READ_LEN]
     offsets = np.arange(0, (S + 1) * READ_LEN, READ_LEN, dtype=np.uint64)
     passes, dt = 0, 0.0
     while dt < 10.0 and passes < 8:  # about 10-30 s of wall time on the host cores
@@ -299,11 +416,11 @@ def cpu_baseline(args, gkeys, gtax, parents, d_bases, n_reads, rng):
         res = oracle.classify_batch(p, oix, parents, bases, offsets)
         dt += time.perf_counter() - t
         passes += 1
-    S *= passes
-    return {"value": round(S / dt / 1e6, 4), "unit": "M reads/s", "cores": int(res["threads"]), "kind": "port",
-            "sample": f"{passes} pass(es) over the first {S // passes} of the step's reads, CPU restatement (oracle/, OpenMP, {res['threads']} threads on "
-                      f"{ncpu} usable CPUs) vs {len(gkeys)} genome records + random padding to 2^24 records in a DRAM "
-                      f"hash table; {dt:.1f} s; the reference's own Spark path cannot run here (no JVM)"}
+    return {"value": round(S * passes / dt / 1e6, 4), "unit": "M reads/s", "cores": int(res["threads"]), "kind": "port",
+            "sample": f"{passes} pass(es) over {S} reads of the step's generator drawn from the first {Gc} genomes, CPU restatement "
+                      f"(oracle/, OpenMP, {res['threads']} threads on {ncpu} usable CPUs) vs their {len(gkeys)} records + random "
+                      f"padding to 2^24 records in a DRAM hash table; {dt:.1f} s; the reference's own Spark path cannot run "
+                      f"here (no JVM)"}
 
 
 if __name__ == "__main__":

@@ -130,6 +130,10 @@ int32_t slk_index_set_taxonomy(slk_index *ix, const int32_t *parents, int32_t T)
  * whose keys do not occur in the sequences; the result does not depend on the order or batching of the calls. */
 int32_t slk_index_add_sequences(slk_index *ix, const uint8_t *bases, const uint64_t *offsets, const int32_t *taxa,
                                 uint64_t n_sequences);
+/* The same with the bases already resident on the index's GPU (d_bases: device pointer, readable 16 bytes past
+ * offsets[n_sequences]; offsets and taxa: host arrays).  The sequences are scanned where they lie. */
+int32_t slk_index_add_sequences_device(slk_index *ix, const uint8_t *d_bases, const uint64_t *offsets, const int32_t *taxa,
+                                       uint64_t n_sequences);
 int32_t slk_index_finalize(slk_index *ix);
 /* The table's records as (key, taxon) arrays -- what KeyValueIndex.writeRecords would persist (KeyValueIndex.scala:125-139).
  * The order is unspecified (a set).  *n_records receives the number of records; if it exceeds capacity only the first
@@ -176,6 +180,20 @@ int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, 
                            int32_t min_hit_groups, const double *thresholds, int32_t C, int32_t *out_taxon,
                            uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers,
                            uint64_t *out_hit_offsets, slk_hit *out_hits, uint64_t hits_capacity);
+
+/* ---- kernel-3-only entry: Classifier.classify (object, S/slacken/Classifier.scala:439-454) on hit lists the caller holds
+ * (host pointers; synchronous): TaxonCounts.toMap/totalKmers + resolveTree + the minHitGroups test for R lists of un-merged
+ * hits in ordinal order.  This is what the host uses to reproduce the reference's regrouping by TITLE
+ * (groupBy("seqTitle") + collect_list, Classifier.scala:92; sorted by ordinal :136): fragments that share a title are one
+ * read there, so the host concatenates their hit lists, sorts them stably by ordinal and classifies the merged list here.
+ *   hits[hit_offsets[r] .. hit_offsets[r+1])   list r; taxon AMBIGUOUS / MATE_PAIR_BORDER entries as slk_classify_batch
+ *                                              returns them
+ *   distinct[i] (nullable)                     OrdinalSpan.distinct of hit i (slk_span.distinct of the same ordinal);
+ *                                              NULL = no hit counts as distinct
+ *   out_num_distinct[R], out_total_kmers[R]    nullable */
+int32_t slk_classify_hits(slk_index *ix, slk_stream *st, uint64_t R, const uint64_t *hit_offsets, const slk_hit *hits,
+                          const uint8_t *distinct, int32_t min_hit_groups, const double *thresholds, int32_t C,
+                          int32_t *out_taxon, uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers);
 
 /* Same computation with every pointer (bases, offsets, mates, thresholds excepted: host) resident on the index's
  * GPU; asynchronous on st.  d_out_num_hits[R] (nullable) receives the span count per read (0 => no row);

@@ -44,9 +44,9 @@ HIT_DTYPE = np.dtype([("taxon", "<i4"), ("count", "<i4")])
 # every symbol include/slacken_amd.h declares
 EXPORTS = ["slk_device_count", "slk_last_error", "slk_version", "slk_index_create", "slk_index_append",
            "slk_index_append_device", "slk_index_set_taxonomy", "slk_index_finalize", "slk_index_get_info",
-           "slk_index_lookup", "slk_index_add_sequences", "slk_index_export", "slk_index_destroy", "slk_stream_create", "slk_stream_synchronize",
+           "slk_index_lookup", "slk_index_add_sequences", "slk_index_add_sequences_device", "slk_index_export", "slk_index_destroy", "slk_stream_create", "slk_stream_synchronize",
            "slk_stream_hip_stream", "slk_stream_destroy", "slk_spans_batch", "slk_classify_batch",
-           "slk_classify_batch_device", "slk_stream_last_stage_ms", "slk_scan_device", "slk_lookup_device",
+           "slk_classify_batch_device", "slk_classify_hits", "slk_stream_last_stage_ms", "slk_scan_device", "slk_lookup_device",
            "slk_shard_of", "slk_classify_hits_device", "slk_shard_emit_device", "slk_shard_scatter_device",
            "slk_shard_apply_device", "slk_stream_last_deferred"]
 
@@ -81,6 +81,7 @@ def lib():
     L.slk_index_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
     L.slk_index_lookup.argtypes = [vp, i64p, C.c_uint64, i32p]
     L.slk_index_add_sequences.argtypes = [vp, u8p, u64p, i32p, C.c_uint64]
+    L.slk_index_add_sequences_device.argtypes = [vp, u8p, u64p, i32p, C.c_uint64]
     L.slk_index_export.argtypes = [vp, i64p, i32p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.slk_index_destroy.argtypes = [vp]
     L.slk_index_destroy.restype = None
@@ -95,6 +96,8 @@ def lib():
                                      C.c_int32, i32p, u8p, i32p, i32p, u64p, vp, C.c_uint64]
     L.slk_classify_batch_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_uint64, C.c_uint64,
                                             C.c_int32, C.POINTER(C.c_double), C.c_int32, i32p, u8p, i32p, i32p, i32p, i32p]
+    L.slk_classify_hits.argtypes = [vp, vp, C.c_uint64, u64p, vp, u8p, C.c_int32, C.POINTER(C.c_double), C.c_int32, i32p, u8p,
+                                    i32p, i32p]
     L.slk_stream_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.slk_scan_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, u64p, i32p, i32p]
     L.slk_lookup_device.argtypes = [vp, vp, i64p, C.c_uint64, i32p]
@@ -169,6 +172,12 @@ class Index:
         bases, offsets, taxa = _np(bases, np.uint8), _np(offsets, np.uint64), _np(taxa, np.int32)
         assert offsets.size == taxa.size + 1
         _check(lib().slk_index_add_sequences(self.h, _ptr(bases), _ptr(offsets), _ptr(taxa), taxa.size))
+
+    def add_sequences_device(self, d_bases_ptr, offsets, taxa):
+        """add_sequences with the bases resident on the index's GPU (raw device address, 16 readable bytes past the end)."""
+        offsets, taxa = _np(offsets, np.uint64), _np(taxa, np.int32)
+        assert offsets.size == taxa.size + 1
+        _check(lib().slk_index_add_sequences_device(self.h, d_bases_ptr, _ptr(offsets), _ptr(taxa), taxa.size))
 
     def export(self):
         """(keys, taxa) of every record in the table, sorted by key."""
@@ -273,6 +282,21 @@ class Stream:
         elif with_num_hits:
             out["num_hits"] = np.diff(hit_off.astype(np.int64)).astype(np.int32)
         return out
+
+    def classify_hits(self, hit_offsets, hits, distinct=None, min_hit_groups=2, thresholds=(0.0,)):
+        """Classifier.classify on caller-assembled hit lists (HIT_DTYPE array + offsets); distinct: uint8 per hit or None."""
+        hit_offsets = _np(hit_offsets, np.uint64)
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        if distinct is not None:
+            distinct = _np(distinct, np.uint8)
+        R = hit_offsets.size - 1
+        Cn = len(thresholds)
+        thr = (C.c_double * Cn)(*thresholds)
+        taxon, cls = np.zeros((Cn, R), np.int32), np.zeros((Cn, R), np.uint8)
+        nd, tk = np.zeros(R, np.int32), np.zeros(R, np.int32)
+        _check(lib().slk_classify_hits(self.index.h, self.h, R, _ptr(hit_offsets), _ptr(hits), _ptr(distinct), min_hit_groups,
+                                       thr, Cn, _ptr(taxon), _ptr(cls), _ptr(nd), _ptr(tk)))
+        return dict(taxon=taxon, classified=cls, num_distinct=nd, total_kmers=tk)
 
     def classify_batch_device(self, d_bases, d_offsets, R, total_bases, d_out_taxon, d_out_classified,
                               d_out_num_distinct=None, d_out_total_kmers=None, d_out_num_hits=None, d_out_num_probes=None,

@@ -436,8 +436,9 @@ int32_t slk_index_set_taxonomy(slk_index *ix, const int32_t *parents, int32_t T)
   return SLK_OK;
 }
 
-int32_t slk_index_add_sequences(slk_index *ix, const uint8_t *bases, const uint64_t *offsets, const int32_t *taxa,
-                                uint64_t S) {
+// bases_on_device: `bases` is resident on the index's GPU (readable 16 bytes past offsets[S]) and is scanned where it lies
+static int32_t add_sequences(slk_index *ix, const uint8_t *bases, const uint64_t *offsets, const int32_t *taxa, uint64_t S,
+                             bool bases_on_device) {
   if (!ix || (S && (!bases || !offsets || !taxa))) return fail(SLK_E_INVALID, "null argument");
   if (ix->finalized) return fail(SLK_E_STATE, "index is finalized");
   if (ix->W > 1) return fail(SLK_E_UNSUPPORTED, "library construction supports minimizers of up to 32 nt (one id column)");
@@ -445,7 +446,7 @@ int32_t slk_index_add_sequences(slk_index *ix, const uint8_t *bases, const uint6
   if (ix->sp.w > BUILD_MAX_W) return fail(SLK_E_UNSUPPORTED, "library construction supports windows of up to %d m-mers (k - m + 1 = %d)", BUILD_MAX_W, ix->sp.w);
   int32_t rc = set_device(ix);
   if (rc) return rc;
-  const int32_t max_t = (1 << ix->taxon_bits) - 1;
+  const int32_t max_t = (int32_t)((1LL << ix->taxon_bits) - 1);
   const uint32_t k = (uint32_t)ix->sp.k, CW = BUILD_CHUNK_WINDOWS;
   for (uint64_t i = 0; i < S; i++) {
     if (offsets[i + 1] < offsets[i]) return fail(SLK_E_INVALID, "offsets must be non-decreasing (sequence %llu)", (unsigned long long)i);
@@ -477,17 +478,22 @@ int32_t slk_index_add_sequences(slk_index *ix, const uint8_t *bases, const uint6
     }
     if (!cstart.empty()) {
       uint64_t nc = cstart.size();
-      HIPCHK(d_bases.ensure(gbytes + 16));
       HIPCHK(d_start.ensure(nc * 8));
       HIPCHK(d_len.ensure(nc * 4));
       HIPCHK(d_tax.ensure(nc * 4));
-      rc = copy_in(&ix->staging, ix->build_stream, d_bases.p, bases + g0, gbytes);
-      HIPCHK(hipMemsetAsync((uint8_t *)d_bases.p + gbytes, 0, 16, ix->build_stream));
-      if (!rc) rc = copy_in(&ix->staging, ix->build_stream, d_start.p, cstart.data(), nc * 8);
+      const uint8_t *src = bases + g0;
+      if (!bases_on_device) {
+        HIPCHK(d_bases.ensure(gbytes + 16));
+        rc = copy_in(&ix->staging, ix->build_stream, d_bases.p, bases + g0, gbytes);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync((uint8_t *)d_bases.p + gbytes, 0, 16, ix->build_stream));
+        src = d_bases.as<uint8_t>();
+      }
+      rc = copy_in(&ix->staging, ix->build_stream, d_start.p, cstart.data(), nc * 8);
       if (!rc) rc = copy_in(&ix->staging, ix->build_stream, d_len.p, clen.data(), nc * 4);
       if (!rc) rc = copy_in(&ix->staging, ix->build_stream, d_tax.p, ctax.data(), nc * 4);
       if (rc) return rc;
-      launch_build(ix->sp, build_view(ix), ix->d_parents, ix->T, d_bases.as<uint8_t>(), d_start.as<uint64_t>(),
+      launch_build(ix->sp, build_view(ix), ix->d_parents, ix->T, src, d_start.as<uint64_t>(),
                    d_len.as<uint32_t>(), d_tax.as<int32_t>(), nc, ix->build_stream);
       HIPCHK(hipGetLastError());
       HIPCHK(hipStreamSynchronize(ix->build_stream));
@@ -496,6 +502,16 @@ int32_t slk_index_add_sequences(slk_index *ix, const uint8_t *bases, const uint6
   }
   d_bases.release(); d_start.release(); d_len.release(); d_tax.release();
   return read_build_counters(ix);
+}
+
+int32_t slk_index_add_sequences(slk_index *ix, const uint8_t *bases, const uint64_t *offsets, const int32_t *taxa,
+                                uint64_t S) {
+  return add_sequences(ix, bases, offsets, taxa, S, false);
+}
+
+int32_t slk_index_add_sequences_device(slk_index *ix, const uint8_t *d_bases, const uint64_t *offsets, const int32_t *taxa,
+                                       uint64_t S) {
+  return add_sequences(ix, d_bases, offsets, taxa, S, true);
 }
 
 int32_t slk_index_export(const slk_index *ix, int64_t *keys, int32_t *taxa, uint64_t capacity, uint64_t *n_records) {
@@ -951,6 +967,68 @@ int32_t slk_classify_hits_device(slk_index *ix, slk_stream *st, const uint64_t *
                   min_hit_groups, st->d_thresholds, C, d_out_taxon, d_out_classified, d_out_num_distinct,
                   d_out_total_kmers, d_out_num_hits, nullptr, st->s);
   HIPCHK(hipGetLastError());
+  return SLK_OK;
+}
+
+// Classifier.classify (object, Classifier.scala:439-454) for hit lists the caller assembled itself: the host merges the
+// hits of fragments that share a title (groupBy("seqTitle"), Classifier.scala:92, then sorted by ordinal :136) and has the
+// merged lists classified here.  Host pointers; synchronous.
+int32_t slk_classify_hits(slk_index *ix, slk_stream *st, uint64_t R, const uint64_t *hit_offsets, const slk_hit *hits,
+                          const uint8_t *distinct, int32_t min_hit_groups, const double *thresholds, int32_t C,
+                          int32_t *out_taxon, uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers) {
+  int32_t rc = check_ready(ix, st, true);
+  if (rc) return rc;
+  if (C < 1 || C > MAX_THRESHOLDS || !thresholds) return fail(SLK_E_INVALID, "need 1..%d thresholds", MAX_THRESHOLDS);
+  if (!hit_offsets || (R && (!out_taxon || !out_classified))) return fail(SLK_E_INVALID, "null argument");
+  for (uint64_t r = 0; r < R; r++)
+    if (hit_offsets[r + 1] < hit_offsets[r] || hit_offsets[r + 1] - hit_offsets[r] > 0x7fffffffULL)
+      return fail(SLK_E_INVALID, "hit_offsets must be non-decreasing (read %llu)", (unsigned long long)r);
+  const uint64_t n = R ? hit_offsets[R] - hit_offsets[0] : 0;
+  if (n && !hits) return fail(SLK_E_INVALID, "null argument");
+  rc = set_device(ix);
+  if (rc) return rc;
+  if (R == 0) return SLK_OK;
+  // the staged classify kernel's input: one slot per hit (fragment r's slots start at offsets[r]), meta = kmers|flag|distinct
+  const uint64_t h0 = hit_offsets[0];
+  std::vector<uint64_t> offs(R + 1);
+  std::vector<int32_t> meta(n + 1), taxon(n + 1), count(R);
+  for (uint64_t r = 0; r <= R; r++) offs[r] = hit_offsets[r] - h0;
+  for (uint64_t r = 0; r < R; r++) count[r] = (int32_t)(offs[r + 1] - offs[r]);
+  for (uint64_t i = 0; i < n; i++) {
+    const slk_hit &h = hits[h0 + i];
+    const int32_t flag = h.taxon == SLK_TAXON_AMBIGUOUS ? SLK_FLAG_AMBIGUOUS : h.taxon == SLK_TAXON_MATE_PAIR_BORDER ? SLK_FLAG_MATE_PAIR_BORDER : SLK_FLAG_SEQUENCE;
+    if (h.taxon < SLK_TAXON_MATE_PAIR_BORDER) return fail(SLK_E_INVALID, "hit %llu: taxon %d", (unsigned long long)i, h.taxon);
+    meta[i] = pack_meta(h.count, flag, (flag == SLK_FLAG_SEQUENCE && distinct && distinct[h0 + i]) ? 1 : 0);
+    taxon[i] = h.taxon;
+  }
+  HIPCHK(st->offsets.ensure((R + 1) * 8));
+  HIPCHK(st->span_meta.ensure((n + 1) * 4));
+  HIPCHK(st->span_taxon.ensure((n + 1) * 4));
+  HIPCHK(st->span_count.ensure((R + 1) * 4));
+  HIPCHK(st->span_keys.ensure((n + 1) * 8));
+  HIPCHK(st->out_taxon.ensure((size_t)C * R * 4));
+  HIPCHK(st->out_cls.ensure((size_t)C * R));
+  HIPCHK(st->out_nd.ensure(R * 4));
+  HIPCHK(st->out_tk.ensure(R * 4));
+  rc = copy_in(st, st->offsets.p, offs.data(), (R + 1) * 8);
+  if (!rc) rc = copy_in(st, st->span_meta.p, meta.data(), (n + 1) * 4);
+  if (!rc) rc = copy_in(st, st->span_taxon.p, taxon.data(), (n + 1) * 4);
+  if (!rc) rc = copy_in(st, st->span_count.p, count.data(), R * 4);
+  if (rc) return rc;
+  memcpy(st->h_thresholds, thresholds, C * sizeof(double));
+  HIPCHK(hipMemcpyAsync(st->d_thresholds, st->h_thresholds, C * sizeof(double), hipMemcpyHostToDevice, st->s));
+  st->last.valid = false;
+  launch_classify(ix->d_parents, ix->T, st->offsets.as<uint64_t>(), nullptr, R, st->span_meta.as<int32_t>(),
+                  st->span_taxon.as<int32_t>(), st->span_count.as<int32_t>(), st->span_keys.as<uint64_t>(), min_hit_groups,
+                  st->d_thresholds, C, st->out_taxon.as<int32_t>(), st->out_cls.as<uint8_t>(), st->out_nd.as<int32_t>(),
+                  st->out_tk.as<int32_t>(), nullptr, nullptr, st->s);
+  HIPCHK(hipGetLastError());
+  rc = copy_out(st, out_taxon, st->out_taxon.p, (size_t)C * R * 4);
+  if (!rc) rc = copy_out(st, out_classified, st->out_cls.p, (size_t)C * R);
+  if (!rc && out_num_distinct) rc = copy_out(st, out_num_distinct, st->out_nd.p, R * 4);
+  if (!rc && out_total_kmers) rc = copy_out(st, out_total_kmers, st->out_tk.p, R * 4);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(st->s));
   return SLK_OK;
 }
 

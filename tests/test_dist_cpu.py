@@ -50,3 +50,39 @@ def test_shard_ranges_partition():
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
             assert max(hi - lo for lo, hi in r) - min(hi - lo for lo, hi in r) <= 1
+
+
+def _bench(*args, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], capture_output=True, text=True, env=e, timeout=300)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, [json.loads(ln) for ln in lines]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun around it) must itself start two ranks and print ONE line with n_gpus = 2
+    (dry mode: gloo, no GPU work; the launch, rendezvous, barrier, max-over-ranks and reporting code are the real ones)."""
+    p, lines = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--reads", "1000", "--dry-run")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    assert lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 3 and lines[0]["dry_run"] is True
+    assert lines[0]["config"]["reads_all_ranks_per_step"] == 2000   # summed over both ranks
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """Under a launcher whose WORLD_SIZE differs from --gpus the bench exits non-zero instead of reporting a 1-rank number as N."""
+    p, lines = _bench("--gpus", "4", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and not lines
+    assert "WORLD_SIZE=1 but --gpus 4" in p.stderr
+
+
+def test_bench_single_rank_dry_line():
+    p, lines = _bench("--dry-run", "--steps", "2")
+    assert p.returncode == 0 and len(lines) == 1 and lines[0]["n_gpus"] == 1
