@@ -95,6 +95,8 @@ def lib():
         L.orc_classify_read.argtypes = [C.POINTER(Params), C.c_void_p, i32p, C.c_int32, C.c_char_p, C.c_int,
                                         C.c_char_p, C.c_int, C.c_int, C.c_double, C.POINTER(ReadResult),
                                         C.POINTER(Hit), C.c_int]
+        L.orc_classify_hits.argtypes = [i32p, C.c_int32, C.POINTER(Hit), u8p, C.c_int, C.c_int, C.c_double,
+                                        C.POINTER(ReadResult)]
         L.orc_length_string.argtypes = [C.POINTER(Hit), C.c_int, C.c_int, C.c_char_p, C.c_int]
         L.orc_pairs_in_order_string.argtypes = [C.POINTER(Hit), C.c_int, C.c_char_p, C.c_int]
         L.orc_classify_batch.argtypes = [C.POINTER(Params), C.c_void_p, i32p, C.c_int32, u8p, u64p, u8p, u64p,
@@ -270,6 +272,20 @@ def classify_read(p, index, parents, seq1, seq2=None, min_hit_groups=2, confiden
     r = dict(taxon=res.taxon, classified=bool(res.classified), num_distinct=res.num_distinct,
              total_kmers=res.total_kmers, num_hits=res.num_hits)
     return r, [(hits[i].taxon, hits[i].count) for i in range(n)]
+
+
+def classify_hits(parents, hits, distinct, min_hit_groups=2, confidence=0.0):
+    """Classifier.classify (Classifier.scala:439-454) on a given hit list [(taxon, count)...] in ordinal order with the
+    spans' distinct flags -- e.g. the list merged from the fragments that share a title (Classifier.scala:92,136)."""
+    parents = np.ascontiguousarray(parents, np.int32)
+    arr = (Hit * max(1, len(hits)))(*[Hit(t, c) for t, c in hits])
+    d = np.ascontiguousarray(list(distinct) + [0], np.uint8)
+    res = ReadResult()
+    rc = lib().orc_classify_hits(_p(parents, C.c_int32), len(parents), arr, _p(d, C.c_uint8), len(hits), min_hit_groups,
+                                 float(confidence), C.byref(res))
+    assert rc == 0
+    return dict(taxon=res.taxon, classified=bool(res.classified), num_distinct=res.num_distinct,
+                total_kmers=res.total_kmers, num_hits=res.num_hits)
 
 
 def length_string(hits, k):

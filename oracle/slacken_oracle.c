@@ -711,24 +711,43 @@ int orc_classify_read(const orc_params *p, const orc_index *ix, const int32_t *p
   return ns;
 }
 
-/* TaxonCounts.lengthString :114-121 */
+/* TaxonCounts.lengthString :114-121, on the fromHits-merged (taxa, counts) as the reference computes it.  A single fragment
+   has at most one border; a row merged from several fragments that share a title (Classifier.scala:92) can have several, and
+   adjacent ones (equal ordinals) collapse into ONE merged entry before indexOf / take / drop are applied. */
 int orc_length_string(const orc_hit *hits, int n, int k, char *out, int cap) {
-  /* taxa.indexOf(MATE_PAIR_BORDER) on the merged list == first border hit; sums are unaffected by merging */
+  int32_t *mt = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+  long *mc = (long *)malloc(sizeof(long) * (size_t)(n > 0 ? n : 1));
+  int nm = 0;
+  for (int i = 0; i < n; i++) { /* fromHits :31-48 */
+    if (nm > 0 && mt[nm - 1] == hits[i].taxon) mc[nm - 1] += hits[i].count;
+    else { mt[nm] = hits[i].taxon; mc[nm] = hits[i].count; nm++; }
+  }
   int border = -1;
-  for (int i = 0; i < n; i++) if (hits[i].taxon == ORC_MATE_PAIR_BORDER) { border = i; break; }
+  for (int i = 0; i < nm; i++) if (mt[i] == ORC_MATE_PAIR_BORDER) { border = i; break; } /* taxa.indexOf */
   long a = 0, b = 0;
   int r;
   if (border == -1) {
-    for (int i = 0; i < n; i++) a += hits[i].count;
+    for (int i = 0; i < nm; i++) a += mc[i];                       /* counts.sum */
     r = snprintf(out, cap, "%ld", a + (k - 1));
   } else {
-    /* merged list: adjacent border hits would merge into ONE entry; drop(border + 1) then keeps only later entries.
-       A fragment has exactly one border, so take/drop around it are plain prefix/suffix sums. */
-    for (int i = 0; i < border; i++) a += hits[i].count;
-    for (int i = border + 1; i < n; i++) b += hits[i].count;
+    for (int i = 0; i < border; i++) a += mc[i];                   /* counts.take(border).sum */
+    for (int i = border + 1; i < nm; i++) b += mc[i];              /* counts.drop(border + 1).sum */
     r = snprintf(out, cap, "%ld|%ld", a + (k - 1), b + (k - 1));
   }
+  free(mt); free(mc);
   return (r < 0 || r >= cap) ? -5 : r;
+}
+
+/* Classifier.classify (object, :439-454) on a caller-assembled hit list: what classifyHits does with the hits that
+   groupBy("seqTitle") collected (:92) once they are sorted by ordinal (:136). */
+int orc_classify_hits(const int32_t *parents, int32_t T, const orc_hit *hits, const uint8_t *distinct, int n,
+                      int min_hit_groups, double confidence, orc_read_result *res) {
+  int32_t *mt = (int32_t *)malloc(sizeof(int32_t) * (size_t)(2 * n + 2));
+  int32_t *mc = (int32_t *)malloc(sizeof(int32_t) * (size_t)(2 * n + 2));
+  if (!mt || !mc) { free(mt); free(mc); return -1; }
+  classify_hits(parents, T, hits, distinct, n, min_hit_groups, confidence, mt, mc, res);
+  free(mt); free(mc);
+  return 0;
 }
 
 /* TaxonCounts.pairsInOrderString :94-110 over fromHits-merged pairs */

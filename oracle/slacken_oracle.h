@@ -137,6 +137,10 @@ int orc_classify_read(const orc_params *p, const orc_index *ix, const int32_t *p
 /* Kraken-style strings: TaxonCounts.lengthString :114-121 and pairsInOrderString :94-110 from
  * un-merged ordinal-ordered hits. Return the string length (excluding NUL) or <0 if cap is too small. */
 int orc_length_string(const orc_hit *hits, int n, int k, char *out, int cap);
+/* Classifier.classify (object, Classifier.scala:439-454) on a given list of hits in ordinal order (distinct[i] =
+ * OrdinalSpan.distinct of hit i): used for rows merged from fragments that share a title (Classifier.scala:92,136). */
+int orc_classify_hits(const int32_t *parents, int32_t T, const orc_hit *hits, const uint8_t *distinct, int n,
+                      int min_hit_groups, double confidence, orc_read_result *res);
 int orc_pairs_in_order_string(const orc_hit *hits, int n, char *out, int cap);
 
 /* Batch form with the same argument meaning as slk_classify_batch (include/slacken_amd.h).

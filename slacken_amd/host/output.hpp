@@ -21,6 +21,7 @@
 #include "../../include/slacken_amd.h"
 #include "seqio.hpp"
 #include "taxonomy.hpp"
+#include "titles.hpp"
 
 namespace slk_host {
 
@@ -51,6 +52,25 @@ inline void append_length_string(std::string &s, const slk_hit *h, size_t n, int
   append_int(s, a + (k - 1));
   if (border == n) return;
   for (size_t i = border + 1; i < n; i++) b += h[i].count;
+  s.push_back('|');
+  append_int(s, b + (k - 1));
+}
+// The same on the fromHits-merged (taxa, counts), literally: needed for a row merged from several fragments that share a title
+// (Classifier.scala:92), which can hold several borders -- adjacent ones (equal ordinals) collapse into one merged entry
+// before indexOf / take / drop apply.  For a single fragment (at most one border) both forms agree.
+inline void append_length_string_merged(std::string &s, const slk_hit *h, size_t n, int k) {
+  std::vector<std::pair<int32_t, long>> m;
+  for (size_t i = 0; i < n; i++) {
+    if (!m.empty() && m.back().first == h[i].taxon) m.back().second += h[i].count;
+    else m.emplace_back(h[i].taxon, h[i].count);
+  }
+  size_t border = m.size();
+  for (size_t i = 0; i < m.size(); i++) if (m[i].first == SLK_TAXON_MATE_PAIR_BORDER) { border = i; break; }
+  long a = 0, b = 0;
+  for (size_t i = 0; i < border; i++) a += m[i].second;
+  append_int(s, a + (k - 1));
+  if (border == m.size()) return;
+  for (size_t i = border + 1; i < m.size(); i++) b += m[i].second;
   s.push_back('|');
   append_int(s, b + (k - 1));
 }
@@ -208,6 +228,7 @@ class OutputSink {
   struct SliceOut {
     std::map<Key, std::string> gz;
     std::map<Key, std::map<Taxon, long>> counts;
+    std::vector<uint64_t> repeated;  // hashes of titles that had been seen before (titles.hpp)
   };
   const OutputOptions o_;
   const Taxonomy &tax_;
@@ -217,7 +238,11 @@ class OutputSink {
   std::deque<std::future<SliceOut>> pending_;
   std::map<Key, FILE *> files_;
   std::map<Key, std::map<Taxon, long>> counts_;
+  mutable ConcurrentTitleSet titles_;  // every title that produced a row
+  RepeatedTitles repeated_;
+  bool drained_ = false;
 
+ public:
   // Per-read output: group 1 of the first match, else "other" (Classifier.classifyHits, Classifier.scala:138-142).
   // Reports only (--nodetailed): the reference takes the SQL route, ifnull(regexp_extract(title, re, 1), "other")
   // (SQLClassifier, Classifier.scala:297-300) -- and regexp_extract yields "" rather than null without a match, so there the
@@ -228,7 +253,23 @@ class OutputSink {
     if (std::regex_search(title.data(), title.data() + title.size(), m, re_) && m.size() > 1) return m[1].str();
     return o_.detailed ? "other" : "";
   }
+  // ClassifiedRead.outputLine, Classifier.scala:41-44
+  static void append_output_line(std::string &s, bool classified, std::string_view title, int32_t taxon, const slk_hit *h, size_t n,
+                                 int k, bool merged_row) {
+    s.push_back(classified ? 'C' : 'U');
+    s.push_back('\t');
+    s.append(title);
+    s.push_back('\t');
+    append_int(s, taxon);
+    s.push_back('\t');
+    if (merged_row) append_length_string_merged(s, h, n, k);
+    else append_length_string(s, h, n, k);
+    s.push_back('\t');
+    append_pairs_in_order(s, h, n);
+    s.push_back('\n');
+  }
 
+ private:
   SliceOut do_slice(std::shared_ptr<const ClassifiedBatch> b, size_t i0, size_t i1) const {
     SliceOut out;
     std::map<Key, std::string> text;
@@ -237,6 +278,8 @@ class OutputSink {
       const size_t h0 = b->hit_offs[i], h1 = b->hit_offs[i + 1];
       if (h1 == h0) continue;  // no span => no row at all (grouping is over span rows, Classifier.scala:92)
       std::string_view title = b->frags->title(i);
+      const uint64_t th = title_hash(title);
+      if (titles_.insert(th)) out.repeated.push_back(th);
       std::string sample = sample_of(title);
       for (int c = 0; c < b->C; c++) {
         const bool classified = b->classified[(size_t)c * n + i] != 0;
@@ -245,17 +288,7 @@ class OutputSink {
         Key key(c, sample);
         out.counts[key][t] += 1;
         if (!o_.detailed) continue;
-        std::string &s = text[key];  // ClassifiedRead.outputLine, Classifier.scala:41-44
-        s.push_back(classified ? 'C' : 'U');
-        s.push_back('\t');
-        s.append(title);
-        s.push_back('\t');
-        append_int(s, t);
-        s.push_back('\t');
-        append_length_string(s, &b->hits[h0], h1 - h0, o_.k);
-        s.push_back('\t');
-        append_pairs_in_order(s, &b->hits[h0], h1 - h0);
-        s.push_back('\n');
+        append_output_line(text[key], classified, title, t, &b->hits[h0], h1 - h0, o_.k, false);
       }
     }
     for (auto &kv : text) out.gz[kv.first] = gzip_member(kv.second);
@@ -277,6 +310,7 @@ class OutputSink {
       auto &dst = counts_[kv.first];
       for (auto &tc : kv.second) dst[tc.first] += tc.second;
     }
+    repeated_.add(so.repeated);
   }
 
  public:
@@ -303,10 +337,72 @@ class OutputSink {
     while (pending_.size() > 8 * pool_.size()) { commit(pending_.front().get()); pending_.pop_front(); }
   }
 
-  void finish() {  // Classifier.reportOutputLocation :419-420 + KrakenReport
+  // All rows of the first pass are on disk and counted once this returns.
+  void drain() {
     while (!pending_.empty()) { commit(pending_.front().get()); pending_.pop_front(); }
     for (auto &kv : files_) if (kv.second) { fclose(kv.second); kv.second = nullptr; }
+    drained_ = true;
+  }
+  RepeatedTitles &repeated() { return repeated_; }
+  const OutputOptions &options() const { return o_; }
+
+  // ---- corrections for titles that occur more than once (slacken_cli.cpp: resolve_repeated_titles); after drain() ----
+  void adjust_count(int c, const std::string &sample, Taxon t, long delta) {
+    auto &m = counts_[Key(c, sample)];
+    if ((m[t] += delta) == 0) m.erase(t);
+  }
+  // Drops the per-read lines whose title is in `titles` from the part files and appends `extra` (text per (threshold, sample)).
+  void replace_rows(const std::function<bool(std::string_view)> &in_titles, const std::map<std::pair<int, std::string>, std::string> &extra) {
+    if (!o_.detailed) return;
+    std::map<Key, bool> todo;
+    for (auto &kv : files_) todo[kv.first] = true;
+    for (auto &kv : extra) todo[kv.first] = true;
+    for (auto &kt : todo) {
+      const Key &key = kt.first;
+      const std::string dir = locations_[key.first] + "/sample=" + key.second;
+      const std::string path = dir + "/part-00000.txt.gz", tmp = path + ".tmp";
+      std::filesystem::create_directories(dir);
+      FILE *out = fopen(tmp.c_str(), "wb");
+      if (!out) throw std::runtime_error("cannot write under " + dir);
+      std::string text;
+      auto flush = [&](bool all) {
+        if (text.empty() || (!all && text.size() < ((size_t)8 << 20))) return;
+        std::string gz = gzip_member(text);
+        if (fwrite(gz.data(), 1, gz.size(), out) != gz.size()) throw std::runtime_error("write failed");
+        text.clear();
+      };
+      if (std::filesystem::exists(path)) {
+        gzFile in = gzopen(path.c_str(), "rb");
+        if (!in) throw std::runtime_error("cannot read " + path);
+        gzbuffer(in, 1 << 20);
+        std::string line;
+        std::vector<char> buf(1 << 16);
+        bool open_line = false;
+        while (gzgets(in, buf.data(), (int)buf.size())) {
+          const size_t len = strlen(buf.data());
+          if (!open_line) line.clear();
+          line.append(buf.data(), len);
+          open_line = len == 0 || buf[len - 1] != '\n';
+          if (open_line) continue;
+          const size_t t0 = line.find('\t'), t1 = t0 == std::string::npos ? t0 : line.find('\t', t0 + 1);
+          if (t1 != std::string::npos && in_titles(std::string_view(line).substr(t0 + 1, t1 - t0 - 1))) continue;
+          text.append(line);
+          flush(false);
+        }
+        gzclose(in);
+      }
+      auto ex = extra.find(key);
+      if (ex != extra.end()) text.append(ex->second);
+      flush(true);
+      fclose(out);
+      std::filesystem::rename(tmp, path);
+    }
+  }
+
+  void finish() {  // Classifier.reportOutputLocation :419-420 + KrakenReport
+    if (!drained_) drain();
     for (auto &kv : counts_) {
+      if (kv.second.empty()) continue;
       std::vector<std::pair<Taxon, long>> counts(kv.second.begin(), kv.second.end());
       std::ofstream rep(locations_[kv.first.first] + "/" + kv.first.second + "_kreport.txt");
       KrakenReport(tax_, counts).print(rep);

@@ -15,6 +15,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include "titles.hpp"
 
 #include <condition_variable>
 #include <cstring>
@@ -567,6 +568,16 @@ class FragmentSource {
   std::unique_ptr<AsyncRecordStream> s1_, s2_;
   bool joined_ = false;  // the rest of the mate file has been loaded into mates_ (its order differs from the first file's)
   std::unordered_map<std::string, std::string> mates_;
+  // Paired input is an inner join on the header in the reference (InputReader.scala:104-119): a header that occurs twice in
+  // one of the files multiplies.  The walk below pairs every header once; headers seen twice on one side are reported to
+  // rep_ and regrouped afterwards (titles.hpp).
+  RepeatedTitles *rep_;
+  PairTitleTracker seen_;
+  void note(std::string_view title, unsigned sides) {
+    if (!rep_) return;
+    const uint64_t h = title_hash(title);
+    if (seen_.seen(h, sides)) rep_->add(h);
+  }
 
   bool open_next() {
     if (next_file_ >= files_.size()) return false;
@@ -575,11 +586,13 @@ class FragmentSource {
     next_file_ += paired_ ? 2 : 1;
     joined_ = false;
     mates_.clear();
+    seen_ = PairTitleTracker();
     return true;
   }
 
  public:
-  FragmentSource(std::vector<std::string> files, bool paired) : files_(std::move(files)), paired_(paired) {}
+  FragmentSource(std::vector<std::string> files, bool paired, RepeatedTitles *rep = nullptr)
+      : files_(std::move(files)), paired_(paired), rep_(rep) {}
 
   // Appends up to max_fragments (and about max_bases) to b; false when every file is exhausted and nothing was added.
   // Records move a run at a time (one copy of the bases of the run, not one per record).
@@ -613,6 +626,7 @@ class FragmentSource {
           size_t ok = 0;
           while (ok < n && remove_suffix(c1->title(i1 + ok), "/1") == remove_suffix(c2->title(i2 + ok), "/2")) ok++;
           if (ok) {
+            if (rep_) for (size_t r = 0; r < ok; r++) note(remove_suffix(c1->title(i1 + r), "/1"), 3);
             bp->append(*c1, i1, ok, "/1");
             bp->append_mates(*c2, i2, ok);
             s1_->advance(ok);
@@ -622,13 +636,17 @@ class FragmentSource {
           if (ok == n) continue;
         }
         std::string_view h2, m;
-        while (s2_->next(h2, m)) mates_.emplace(std::string(remove_suffix(h2, "/2")), std::string(m));
+        while (s2_->next(h2, m)) {
+          note(remove_suffix(h2, "/2"), 2);
+          mates_.emplace(std::string(remove_suffix(h2, "/2")), std::string(m));
+        }
         joined_ = true;
         continue;
       }
       std::string_view h, sq;
       s1_->next(h, sq);
       h = remove_suffix(h, "/1");
+      note(h, 1);
       auto it = mates_.find(std::string(h));
       if (it == mates_.end()) continue;  // inner join: no mate, no fragment
       std::string_view m(it->second);
@@ -671,9 +689,9 @@ class BatchPrefetcher {
   }
 
  public:
-  BatchPrefetcher(std::vector<std::string> files, bool paired, size_t max_fragments = (size_t)1 << 17,
+  BatchPrefetcher(std::vector<std::string> files, bool paired, RepeatedTitles *rep = nullptr, size_t max_fragments = (size_t)1 << 17,
                   size_t max_bases = (size_t)512 << 20, size_t depth = 2)
-      : src_(std::move(files), paired), max_fragments_(max_fragments), max_bases_(max_bases), depth_(depth), th_([this] { run(); }) {}
+      : src_(std::move(files), paired, rep), max_fragments_(max_fragments), max_bases_(max_bases), depth_(depth), th_([this] { run(); }) {}
   ~BatchPrefetcher() {
     { std::lock_guard<std::mutex> lk(mu_); stop_ = true; cv_.notify_all(); }
     th_.join();

@@ -16,6 +16,7 @@
 #include <filesystem>
 #include <iostream>
 #include <unordered_map>
+#include <algorithm>
 
 #include "../../include/slacken_amd.h"
 #include "output.hpp"
@@ -226,6 +227,7 @@ struct ClassifyOpts {
   bool paired = false, with_unclassified = true, detailed = true;
   std::vector<double> thresholds;
   std::vector<std::string> files;
+  std::vector<int> devices{0};  // --devices: the GPUs that share the reads (table replicated on each)
   // classify2 (Slacken.scala:199-260)
   std::string library, rank = "species";
   int min_count = -1, min_distinct = -1, reads = -1;
@@ -247,6 +249,23 @@ static ClassifyOpts parse_classify_opts(int argc, char **argv, bool two_step) {
     else if (a == "--nodetailed") o.detailed = false;
     else if (a == "-c" || a == "--confidence") { while (i + 1 < argc && (isdigit(argv[i + 1][0]) || argv[i + 1][0] == '.')) o.thresholds.push_back(std::stod(argv[++i])); }
     else if (a == "--sample-regex") o.sample_regex = next();
+    else if (a == "--devices") {
+      std::string v = next();
+      o.devices.clear();
+      if (v == "all") {
+        for (int d = 0; d < slk_device_count(); d++) o.devices.push_back(d);
+        if (o.devices.empty()) die("--devices all: no GPU visible");
+      } else {
+        size_t p0 = 0;
+        while (p0 <= v.size()) {
+          size_t p1 = v.find(',', p0);
+          if (p1 == std::string::npos) p1 = v.size();
+          if (p1 == p0 || !isdigit((unsigned char)v[p0])) die("--devices wants `all` or a comma-separated list of device numbers");
+          o.devices.push_back(std::stoi(v.substr(p0, p1 - p0)));
+          p0 = p1 + 1;
+        }
+      }
+    }
     else if (two_step && (a == "-l" || a == "--library")) o.library = next();
     else if (two_step && a == "--rank") o.rank = next();
     else if (two_step && (a == "-C" || a == "--min-count")) o.min_count = std::stoi(next());
@@ -272,21 +291,61 @@ static ClassifyOpts parse_classify_opts(int argc, char **argv, bool two_step) {
 }
 
 // ---- the device-side index as the host sees it ----
+// The table is REPLICATED on every device of --devices and the reads are shared out between them batch by batch (SURVEY 8e;
+// the reference's counterpart is the fan-out of the span rows over the partitions, KeyValueIndex.scala:169-172): there is
+// no exchange between devices, only the host-side merge of the per-taxon counts that the report is made of.  The same
+// device may be listed more than once (two tables on it): that is how the multi-device path is tested on a one-GPU box.
 struct DeviceIndex {
-  slk_index *ix = nullptr;
-  slk_stream *st = nullptr;
+  std::vector<slk_index *> ixs;   // one per device of the list
+  slk_index *ix = nullptr;        // = ixs[0]
+  slk_stream *st = nullptr;       // a stream on ixs[0]
+  std::vector<int> devices{0};
   ~DeviceIndex() { reset(); }
-  void reset() { if (st) slk_stream_destroy(st); if (ix) slk_index_destroy(ix); st = nullptr; ix = nullptr; }
+  void reset() {
+    if (st) slk_stream_destroy(st);
+    for (slk_index *i : ixs) slk_index_destroy(i);
+    ixs.clear(); st = nullptr; ix = nullptr;
+  }
+  template <class F> void on_each(F f) {  // f(index) on every replica, side by side
+    if (ixs.size() == 1) { f(ixs[0]); return; }
+    std::vector<std::thread> th;
+    std::vector<std::string> err(ixs.size());
+    for (size_t i = 0; i < ixs.size(); i++)
+      th.emplace_back([&, i] { if (f(ixs[i]) != SLK_OK) err[i] = slk_last_error(); });  // (slk_last_error is per thread)
+    for (auto &t : th) t.join();
+    for (auto &e : err) if (!e.empty()) die(e);
+  }
   void create(const IndexParams &ip, const Taxonomy &tax, uint64_t expected_records, int32_t max_taxon) {
     slk_params sp{ip.k, ip.m, ip.spaces, ip.canonical ? 1 : 0, ip.xorMask, (ip.m + 31) / 32, 0};
     slk_table_config cfg{expected_records, max_taxon, 0.0f};
-    SLK_CALL(slk_index_create(&sp, &cfg, 0, &ix));
     std::vector<int32_t> parents(tax.parents.begin(), tax.parents.end());
     if (max_taxon + 1 > (int32_t)parents.size()) parents.resize(max_taxon + 1, 0);
-    SLK_CALL(slk_index_set_taxonomy(ix, parents.data(), (int32_t)parents.size()));
+    for (int d : devices) {
+      slk_index *one = nullptr;
+      SLK_CALL(slk_index_create(&sp, &cfg, d, &one));
+      ixs.push_back(one);
+      SLK_CALL(slk_index_set_taxonomy(one, parents.data(), (int32_t)parents.size()));
+    }
+    ix = ixs[0];
   }
+  void append(const int64_t *keys, const int32_t *taxa, uint64_t n) {
+    if (ixs.size() == 1) { SLK_CALL(slk_index_append(ix, keys, taxa, n)); return; }
+    on_each([&](slk_index *i) { return slk_index_append(i, keys, taxa, n); });
+  }
+  int32_t add_sequences(const uint8_t *bases, const uint64_t *offsets, const int32_t *taxa, uint64_t n) {
+    // (every replica builds the same records: the result does not depend on insertion order)
+    std::vector<int32_t> rc(ixs.size(), SLK_OK);
+    std::vector<std::string> err(ixs.size());
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < ixs.size(); i++)
+      th.emplace_back([&, i] { rc[i] = slk_index_add_sequences(ixs[i], bases, offsets, taxa, n); if (rc[i]) err[i] = slk_last_error(); });
+    for (auto &t : th) t.join();
+    for (size_t i = 0; i < ixs.size(); i++) if (rc[i] != SLK_OK) { last_error = err[i]; return rc[i]; }
+    return SLK_OK;
+  }
+  std::string last_error;
   void finalize() {
-    SLK_CALL(slk_index_finalize(ix));
+    for (slk_index *i : ixs) SLK_CALL(slk_index_finalize(i));
     SLK_CALL(slk_stream_create(ix, &st));
   }
 };
@@ -295,7 +354,7 @@ struct DeviceIndex {
 // handed to f (shared ownership: output formatting keeps them alive on its own threads).
 template <class F>
 static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &files, bool paired, int min_hits,
-                            const std::vector<double> &thresholds, bool want_spans, bool want_hits, F f) {
+                            const std::vector<double> &thresholds, bool want_spans, bool want_hits, F f, RepeatedTitles *rep = nullptr) {
   // Several input files (or pairs) are read side by side, each on its own threads -- a gzip stream inflates on one core -- and
   // their batches are taken in turn: the order of the output is deterministic, though interleaved between files at batch
   // granularity (the reference's output order is whatever Spark's partitions give).
@@ -309,7 +368,7 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
     if (next_src >= nsrc) return nullptr;
     std::vector<std::string> fs(files.begin() + next_src * unit, files.begin() + (next_src + 1) * unit);
     next_src++;
-    return std::make_unique<BatchPrefetcher>(fs, paired);
+    return std::make_unique<BatchPrefetcher>(fs, paired, rep);
   };
   while (active.size() < conc) { auto r = open_next(); if (!r) break; active.push_back(std::move(r)); }
   size_t turn = 0;
@@ -328,10 +387,14 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
   // HIP stream): one worker's copies overlap another's kernels.  Batches are taken and handed to f in input order.
   const int C = (int)thresholds.size();
   const char *wenv = getenv("SLK_CLASSIFY_THREADS");
-  const size_t n_workers = std::max<size_t>(1, std::min<size_t>(8, wenv ? (size_t)atol(wenv) : 2));
+  // (SLK_CLASSIFY_THREADS: threads per device; with several devices worker i drives device i mod N, each on its own table)
+  const size_t per_dev = std::max<size_t>(1, std::min<size_t>(8, wenv ? (size_t)atol(wenv) : 2));
+  const size_t n_workers = per_dev * dev.ixs.size();
   std::vector<slk_stream *> streams(n_workers, nullptr);
+  std::vector<slk_index *> stream_ix(n_workers, nullptr);
+  for (size_t i = 0; i < n_workers; i++) stream_ix[i] = dev.ixs[i % dev.ixs.size()];
   streams[0] = dev.st;
-  for (size_t i = 1; i < n_workers; i++) SLK_CALL(slk_stream_create(dev.ix, &streams[i]));
+  for (size_t i = 1; i < n_workers; i++) SLK_CALL(slk_stream_create(stream_ix[i], &streams[i]));
   std::atomic<size_t> total{0}, n_batches{0};
   const bool timing = getenv("SLK_HOST_TIMING") != nullptr;  // where the wall clock of the workers goes, by stage
   std::mutex mu_in, mu_out, mu_stat;
@@ -341,7 +404,7 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
   std::exception_ptr failure;
   std::atomic<bool> failed{false};
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  auto work = [&](slk_stream *st) {
+  auto work = [&](slk_index *wix, slk_stream *st) {
     std::vector<int32_t> nd, tk;
     double w_input = 0, w_device = 0, w_hand_over = 0;
     try {
@@ -372,12 +435,12 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
         if (want_hits) b->reserve_hits(cap);
         const uint8_t *mb = fb.paired ? fb.mate_bases.data() : nullptr;
         const uint64_t *mo = fb.paired ? fb.mate_offs.data() : nullptr;
-        SLK_CALL(slk_classify_batch(dev.ix, st, fb.bases.data(), fb.offs.data(), mb, mo, n, min_hits, thresholds.data(), C,
+        SLK_CALL(slk_classify_batch(wix, st, fb.bases.data(), fb.offs.data(), mb, mo, n, min_hits, thresholds.data(), C,
                                     b->taxon.data(), b->classified.data(), nd.data(), tk.data(), b->hit_offs.data(), want_hits ? b->hits.get() : nullptr, cap));
         if (want_spans) {
           b->span_offs.resize(n + 1);
           b->spans.resize(cap);
-          SLK_CALL(slk_spans_batch(dev.ix, st, fb.bases.data(), fb.offs.data(), mb, mo, n, b->span_offs.data(), b->spans.data(), cap));
+          SLK_CALL(slk_spans_batch(wix, st, fb.bases.data(), fb.offs.data(), mb, mo, n, b->span_offs.data(), b->spans.data(), cap));
         }
         double t2 = now();
         w_device += t2 - t1;
@@ -401,13 +464,13 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
     t_input += w_input; t_device += w_device; t_hand_over += w_hand_over;
   };
   std::vector<std::thread> workers;
-  for (size_t i = 1; i < n_workers; i++) workers.emplace_back(work, streams[i]);
-  work(streams[0]);
+  for (size_t i = 1; i < n_workers; i++) workers.emplace_back(work, stream_ix[i], streams[i]);
+  work(stream_ix[0], streams[0]);
   for (auto &t : workers) t.join();
   for (size_t i = 1; i < n_workers; i++) slk_stream_destroy(streams[i]);
   if (failure) std::rethrow_exception(failure);
   if (timing)
-    std::cerr << "host timing: " << n_batches << " batches on " << n_workers << " classify thread(s); summed over them: waiting for input "
+    std::cerr << "host timing: " << n_batches << " batches on " << n_workers << " classify thread(s) over " << dev.ixs.size() << " device table(s); summed over them: waiting for input "
               << t_input << " s, upload+kernels+download " << t_device << " s, waiting for their turn and handing over to the output threads "
               << t_hand_over << " s" << std::endl;
   std::cerr << total << " fragments" << std::endl;
@@ -421,6 +484,202 @@ static size_t host_threads() {
   return std::min<size_t>(32, std::max<unsigned>(2, hc) - 1);
 }
 
+// ---- titles that occur more than once ----
+// The reference regroups the hits of ALL fragments by title (groupBy("seqTitle") + collect_list, Classifier.scala:92; the
+// same in SQLClassifier :281-290) and sorts each group by ordinal (:136, a stable sort): fragments that share a title are
+// ONE read -- one row, one classification of the merged hit list.  Its paired reader is an inner join on the header
+// (InputReader.scala:104-119), so a header that repeats inside a file of a pair multiplies before that grouping.
+// The first pass streams the input once and treats every fragment on its own -- exact for every title that occurs once.
+// The titles whose hash was seen twice (OutputSink, FragmentSource) are settled here: their records are read again, joined
+// as the reference joins them, classified with hit lists, merged per title, classified again from the merged list
+// (slk_classify_hits), and their rows and counts of the first pass are replaced.  The order of equal ordinals in a merged
+// list is not defined by the reference (collect_list after a shuffle); here it is input order.
+struct RepeatFragment { std::string title, seq, mate; };
+struct RepeatResult {
+  std::vector<slk_hit> hits;
+  std::vector<uint8_t> distinct;
+  std::vector<int32_t> taxon;        // per threshold
+  std::vector<uint8_t> classified;   // per threshold
+};
+
+static std::vector<RepeatResult> classify_fragments(DeviceIndex &dev, const std::vector<RepeatFragment> &frags, const std::vector<size_t> &pick,
+                                                    bool paired, int min_hits, const std::vector<double> &thresholds, bool want_distinct) {
+  const int C = (int)thresholds.size();
+  std::vector<RepeatResult> out(pick.size());
+  size_t i0 = 0;
+  while (i0 < pick.size()) {
+    FragmentBatch fb;
+    fb.paired = paired;
+    size_t i1 = i0;
+    while (i1 < pick.size() && i1 - i0 < ((size_t)1 << 16) && fb.bases.size() + fb.mate_bases.size() < ((size_t)256 << 20)) {
+      const RepeatFragment &f = frags[pick[i1]];
+      std::string_view m(f.mate);
+      fb.add(f.title, f.seq, paired ? &m : nullptr);
+      i1++;
+    }
+    const size_t n = i1 - i0, cap = fb.bases.size() + fb.mate_bases.size() + n + 1;
+    std::vector<int32_t> taxon((size_t)C * n), nd(n), tk(n);
+    std::vector<uint8_t> cls((size_t)C * n);
+    std::vector<uint64_t> hit_offs(n + 1), span_offs(n + 1);
+    std::vector<slk_hit> hits(cap);
+    std::vector<slk_span> spans(want_distinct ? cap : 0);
+    const uint8_t *mb = paired ? fb.mate_bases.data() : nullptr;
+    const uint64_t *mo = paired ? fb.mate_offs.data() : nullptr;
+    SLK_CALL(slk_classify_batch(dev.ix, dev.st, fb.bases.data(), fb.offs.data(), mb, mo, n, min_hits, thresholds.data(), C, taxon.data(),
+                                cls.data(), nd.data(), tk.data(), hit_offs.data(), hits.data(), cap));
+    if (want_distinct) SLK_CALL(slk_spans_batch(dev.ix, dev.st, fb.bases.data(), fb.offs.data(), mb, mo, n, span_offs.data(), spans.data(), cap));
+    for (size_t i = 0; i < n; i++) {
+      RepeatResult &r = out[i0 + i];
+      r.hits.assign(hits.begin() + hit_offs[i], hits.begin() + hit_offs[i + 1]);
+      if (want_distinct) {
+        if (span_offs[i + 1] - span_offs[i] != hit_offs[i + 1] - hit_offs[i]) die("internal: span and hit lists differ in length");
+        for (size_t j = span_offs[i]; j < span_offs[i + 1]; j++) r.distinct.push_back(spans[j].distinct);
+      }
+      for (int c = 0; c < C; c++) { r.taxon.push_back(taxon[(size_t)c * n + i]); r.classified.push_back(cls[(size_t)c * n + i]); }
+    }
+    i0 = i1;
+  }
+  return out;
+}
+
+static void resolve_repeated_titles(DeviceIndex &dev, const IndexParams &ip, const ClassifyOpts &o, OutputSink &sink) {
+  Timer t("Regroup repeated titles");
+  const FlatHashSet<0> D = sink.repeated().to_set();
+  const size_t unit = o.paired ? 2 : 1;
+  std::vector<RepeatFragment> joined;   // the fragments of the reference's reader for these titles
+  std::vector<RepeatFragment> first;    // paired: the fragments the first pass made of them (its rows are what gets replaced)
+  std::string_view h, sq;
+  for (size_t u = 0; u + unit <= o.files.size(); u += unit) {
+    if (!o.paired) {
+      AsyncRecordStream rs(o.files[u]);
+      while (rs.next(h, sq)) if (D.contains(title_hash(h))) joined.push_back({std::string(h), std::string(sq), std::string()});
+      continue;
+    }
+    // PairedInputReader.getFragments: every record of file 1 with every record of file 2 of the same header
+    std::vector<std::string> order;
+    std::unordered_map<std::string, std::pair<std::vector<std::string>, std::vector<std::string>>> lists;
+    {
+      AsyncRecordStream r1(o.files[u]);
+      while (r1.next(h, sq)) {
+        h = remove_suffix(h, "/1");
+        if (!D.contains(title_hash(h))) continue;
+        auto it = lists.try_emplace(std::string(h)).first;
+        if (it->second.first.empty()) order.push_back(it->first);
+        it->second.first.emplace_back(sq);
+      }
+      AsyncRecordStream r2(o.files[u + 1]);
+      while (r2.next(h, sq)) {
+        h = remove_suffix(h, "/2");
+        if (!D.contains(title_hash(h))) continue;
+        auto it = lists.find(std::string(h));
+        if (it != lists.end()) it->second.second.emplace_back(sq);
+      }
+    }
+    for (const std::string &title : order) {
+      auto &l = lists[title];
+      for (const std::string &s1 : l.first) for (const std::string &s2 : l.second) joined.push_back({title, s1, s2});
+    }
+    FragmentSource src({o.files[u], o.files[u + 1]}, true);
+    for (;;) {
+      FragmentBatchPtr bp;
+      if (!src.fill(bp, (size_t)1 << 17, (size_t)512 << 20)) break;
+      for (size_t i = 0; i < bp->size(); i++)
+        if (D.contains(title_hash(bp->title(i)))) first.push_back({std::string(bp->title(i)), std::string(bp->seq(i)), std::string(bp->mate(i))});
+    }
+  }
+  // titles (compared as strings) with more than one fragment
+  std::unordered_map<std::string_view, std::vector<size_t>> groups;
+  std::vector<std::string_view> group_order;
+  for (size_t i = 0; i < joined.size(); i++) {
+    auto &g = groups[joined[i].title];
+    if (g.empty()) group_order.push_back(joined[i].title);
+    g.push_back(i);
+  }
+  std::vector<size_t> pick;
+  std::vector<std::string_view> merged_titles;
+  for (std::string_view title : group_order) {
+    const auto &g = groups[title];
+    if (g.size() < 2) continue;   // (a hash collision, or a header that repeats on one side of a pair without a partner)
+    merged_titles.push_back(title);
+    pick.insert(pick.end(), g.begin(), g.end());
+  }
+  if (merged_titles.empty()) return;
+  std::cerr << merged_titles.size() << " read titles occur more than once (" << pick.size() << " fragments): their hits are regrouped by title" << std::endl;
+  const int C = (int)o.thresholds.size();
+  std::vector<RepeatResult> res = classify_fragments(dev, joined, pick, o.paired, o.min_hits, o.thresholds, true);
+  // what the first pass counted (and wrote) for these titles
+  auto uncount = [&](const std::string &title, const RepeatResult &r) {
+    if (r.hits.empty()) return;  // no span, no row
+    const std::string sample = sink.sample_of(title);
+    for (int c = 0; c < C; c++)
+      if (r.classified[c] || o.with_unclassified) sink.adjust_count(c, sample, r.taxon[c], -1);
+  };
+  if (!o.paired) {
+    for (size_t i = 0; i < pick.size(); i++) uncount(joined[pick[i]].title, res[i]);
+  } else {
+    std::vector<size_t> pick1;
+    for (size_t i = 0; i < first.size(); i++) {
+      auto it = groups.find(first[i].title);
+      if (it != groups.end() && it->second.size() >= 2) pick1.push_back(i);
+    }
+    std::vector<RepeatResult> res1 = classify_fragments(dev, first, pick1, true, o.min_hits, o.thresholds, false);
+    for (size_t i = 0; i < pick1.size(); i++) uncount(first[pick1[i]].title, res1[i]);
+  }
+  // merged hit lists: concatenation in input order, stable sort by ordinal (Classifier.scala:136)
+  std::vector<uint64_t> moffs(1, 0);
+  std::vector<slk_hit> mhits;
+  std::vector<uint8_t> mdistinct;
+  {
+    size_t at = 0;
+    struct Ref { uint32_t ordinal; uint32_t member; };
+    std::vector<Ref> refs;
+    for (std::string_view title : merged_titles) {
+      const size_t gn = groups[title].size();
+      refs.clear();
+      for (size_t m = 0; m < gn; m++)
+        for (size_t j = 0; j < res[at + m].hits.size(); j++) refs.push_back({(uint32_t)j, (uint32_t)m});
+      std::stable_sort(refs.begin(), refs.end(), [](const Ref &a, const Ref &b) { return a.ordinal < b.ordinal; });
+      for (const Ref &r : refs) {
+        mhits.push_back(res[at + r.member].hits[r.ordinal]);
+        mdistinct.push_back(res[at + r.member].distinct[r.ordinal]);
+      }
+      moffs.push_back(mhits.size());
+      at += gn;
+    }
+  }
+  const size_t R = merged_titles.size();
+  std::vector<int32_t> mtaxon((size_t)C * R);
+  std::vector<uint8_t> mcls((size_t)C * R);
+  for (size_t r0 = 0; r0 < R;) {   // (bounded calls: a merged list per title, a few million hits per call)
+    size_t r1 = r0 + 1;
+    while (r1 < R && r1 - r0 < ((size_t)1 << 18) && moffs[r1 + 1] - moffs[r0] < ((size_t)1 << 23)) r1++;
+    const size_t n = r1 - r0;
+    std::vector<int32_t> tx((size_t)C * n);
+    std::vector<uint8_t> cl((size_t)C * n);
+    SLK_CALL(slk_classify_hits(dev.ix, dev.st, n, moffs.data() + r0, mhits.data(), mdistinct.data(), o.min_hits, o.thresholds.data(), C,
+                               tx.data(), cl.data(), nullptr, nullptr));
+    for (int c = 0; c < C; c++)
+      for (size_t i = 0; i < n; i++) { mtaxon[(size_t)c * R + r0 + i] = tx[(size_t)c * n + i]; mcls[(size_t)c * R + r0 + i] = cl[(size_t)c * n + i]; }
+    r0 = r1;
+  }
+  std::map<std::pair<int, std::string>, std::string> extra;
+  for (size_t r = 0; r < R; r++) {
+    const size_t n = moffs[r + 1] - moffs[r];
+    if (n == 0) continue;   // none of the fragments had a span: no row
+    const std::string sample = sink.sample_of(merged_titles[r]);
+    for (int c = 0; c < C; c++) {
+      const bool classified = mcls[(size_t)c * R + r] != 0;
+      if (!classified && !o.with_unclassified) continue;
+      const int32_t tx = mtaxon[(size_t)c * R + r];
+      sink.adjust_count(c, sample, tx, +1);
+      if (o.detailed) OutputSink::append_output_line(extra[{c, sample}], classified, merged_titles[r], tx, mhits.data() + moffs[r], n, ip.k, true);
+    }
+  }
+  std::unordered_map<std::string_view, bool> drop;
+  for (std::string_view title : merged_titles) drop[title] = true;
+  sink.replace_rows([&](std::string_view title) { return drop.count(title) != 0; }, extra);
+}
+
 // Classifier.classifyHitsAndWrite / writePerSampleOutput (Classifier.scala:156-227): per-read lines and Kraken reports
 static void classify_and_write(DeviceIndex &dev, const IndexParams &ip, const Taxonomy &tax, const ClassifyOpts &o) {
   OutputOptions oo;
@@ -429,7 +688,9 @@ static void classify_and_write(DeviceIndex &dev, const IndexParams &ip, const Ta
   Timer t("Classify reads");
   OutputSink sink(oo, tax, host_threads());
   classify_stream(dev, o.files, o.paired, o.min_hits, o.thresholds, false, o.detailed,   // (hit lists only feed the per-read lines)
-                  [&](std::shared_ptr<const ClassifiedBatch> b) { sink.submit(std::move(b)); });
+                  [&](std::shared_ptr<const ClassifiedBatch> b) { sink.submit(std::move(b)); }, &sink.repeated());
+  sink.drain();
+  if (!sink.repeated().empty()) resolve_repeated_titles(dev, ip, o, sink);
   sink.finish();
 }
 
@@ -456,7 +717,7 @@ static void load_index(const std::string &location, IndexParams &ip, Taxonomy &t
     auto drain_one = [&]() {
       FileRecords fr = pending.front().get();
       pending.pop_front();
-      SLK_CALL(slk_index_append(dev.ix, fr.keys.data(), fr.taxa.data(), fr.taxa.size()));
+      dev.append(fr.keys.data(), fr.taxa.data(), fr.taxa.size());
     };
     for (auto &file : parquet_list_files(location)) {
       pending.push_back(pool.submit([file, W]() {
@@ -477,7 +738,7 @@ static void load_index(const std::string &location, IndexParams &ip, Taxonomy &t
     if (rec.max_taxon == 0)  // an older file without the recorded maximum: one pass over the taxon column
       rec.for_each_chunk(false, [&](const int64_t *, const int32_t *taxa, uint64_t c) { for (uint64_t i = 0; i < c; i++) max_taxon = std::max(max_taxon, taxa[i]); });
     dev.create(ip, tax, rec.n, max_taxon);
-    rec.for_each_chunk(true, [&](const int64_t *keys, const int32_t *taxa, uint64_t c) { SLK_CALL(slk_index_append(dev.ix, keys, taxa, c)); });
+    rec.for_each_chunk(true, [&](const int64_t *keys, const int32_t *taxa, uint64_t c) { dev.append(keys, taxa, c); });
   }
   dev.finalize();
   std::cerr << "index: " << n_records << " records, k=" << ip.k << " m=" << ip.m << " spaces=" << ip.spaces << std::endl;
@@ -488,6 +749,7 @@ static int cmd_classify(int argc, char **argv) {
   IndexParams ip;
   Taxonomy tax;
   DeviceIndex dev;
+  dev.devices = o.devices;
   load_index(o.index, ip, tax, dev);
   classify_and_write(dev, ip, tax, o);
   return 0;
@@ -512,6 +774,7 @@ static int cmd_classify2(int argc, char **argv) {
   int32_t max_taxon;
   {
     DeviceIndex base;
+    base.devices = o.devices;
     load_index(o.index, ip, tax, base);
     slk_index_info info;
     SLK_CALL(slk_index_get_info(base.ix, &info));
@@ -595,11 +858,12 @@ static int cmd_classify2(int argc, char **argv) {
   const int w = ip.k - ip.m + 1;
   uint64_t expected = (uint64_t)((double)bases.size() * std::min(1.0, 2.5 / (w + 1))) + 1024;
   DeviceIndex dyn;
+  dyn.devices = o.devices;
   for (int attempt = 0;; attempt++) {
     dyn.create(ip, tax, expected, max_taxon);
-    int32_t rc = slk_index_add_sequences(dyn.ix, bases.data(), offsets.data(), taxa.data(), taxa.size());
+    int32_t rc = dyn.add_sequences(bases.data(), offsets.data(), taxa.data(), taxa.size());
     if (rc == SLK_OK) break;
-    if (rc != SLK_E_CAPACITY || attempt == 1) die(std::string("slk_index_add_sequences: ") + slk_last_error());
+    if (rc != SLK_E_CAPACITY || attempt == 1) die("slk_index_add_sequences: " + dyn.last_error);
     dyn.reset();  // low-complexity sequence: retry with one record per base
     expected = bases.size() + 1024;
   }
@@ -624,6 +888,7 @@ static const char *HELP =
     "      --sample-regex RE  group 1 of the first match in the read id names the sample\n"
     "      --[no]unclassified keep (default) or drop unclassified reads\n"
     "      --[no]detailed     per-read output (default) or reports only\n"
+    "      --devices LIST     GPUs that share the reads, `all` or e.g. 0,1,2,3 (default 0); the library is replicated on each\n"
     "  FILES                  FASTA / FASTQ, plain, .gz or .bz2; @list.txt names a file of file names\n"
     "options of classify2 (Slacken.scala:199-260): --library DIR (DIR/library/**/*.fna, DIR/seqid2taxid.map), --rank RANK (species),\n"
     "  -R, --reads N (100) | -C, --min-count N | -D, --min-distinct N, --init-confidence X (0.15)\n"

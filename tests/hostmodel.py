@@ -127,3 +127,39 @@ def with_descendants(tax, taxa):
         out.add(t)
         stack.extend(tax.children[t])
     return out
+
+
+# ---- regrouping by title: Classifier.spansToGroupedHits (S/slacken/Classifier.scala:77-96) + classifyHits (:124-147) ----
+def merge_by_title(fragments):
+    """fragments: [(title, hits, distinct)] in input order, hits = [(taxon, count)...] in ordinal order (a fragment without
+    spans has no span rows and takes no part).  The reference groups the span rows of ALL fragments by title string
+    (groupBy("seqTitle").agg(collect_list(hit)), :92) and sorts each group's hits by ordinal with a stable sort
+    (java.util.Arrays.sort on objects, :136).  The order of equal ordinals is whatever collect_list delivered -- not
+    defined by Spark; this host fixes it to input order.  Returns [(title, merged hits, merged distinct)] in order of first
+    appearance."""
+    groups, order = {}, []
+    for title, hits, distinct in fragments:
+        if not hits:
+            continue
+        if title not in groups:
+            groups[title] = []
+            order.append(title)
+        groups[title].append((hits, distinct))
+    out = []
+    for title in order:
+        rows = [(ordinal, seq, h, d) for seq, (hits, distinct) in enumerate(groups[title])
+                for ordinal, (h, d) in enumerate(zip(hits, distinct))]
+        rows.sort(key=lambda r: r[0])   # stable: equal ordinals keep fragment order
+        out.append((title, [r[2] for r in rows], [r[3] for r in rows]))
+    return out
+
+
+def paired_join(records1, records2):
+    """PairedInputReader.getFragments (S/kmers/input/InputReader.scala:104-119): inner join of the two files' records on the
+    header with /1 and /2 removed -- every record of file 1 with EVERY record of file 2 that has the same header.
+    records: [(header, seq)].  Returns [(header, seq1, seq2)], file-1 order then file-2 order (Spark's order is undefined)."""
+    strip = lambda h, suf: h[:-len(suf)] if h.endswith(suf) else h
+    by2 = {}
+    for h, s in records2:
+        by2.setdefault(strip(h, "/2"), []).append(s)
+    return [(strip(h, "/1"), s, m) for h, s in records1 for m in by2.get(strip(h, "/1"), [])]

@@ -349,3 +349,43 @@ def test_c_example_runs(tmp_path):
     assert out[1].startswith("read 0: taxon 2 classified 1")      # the shared stretch: the genus (LCA of both species)
     assert out[2].startswith("read 1: taxon 3 classified 1")      # species 3's own sequence
     assert out[3].startswith("read 2: taxon 0 classified 0")
+
+
+def test_classify_hits_entry(orc, world):
+    """slk_classify_hits (kernel 3 alone: Classifier.classify, Classifier.scala:439-454) on caller-assembled hit lists vs the
+    oracle: lists of the kind the host builds when it regroups fragments by title -- several borders, ambiguous spans,
+    NONE hits, taxa in any order, an empty list."""
+    import slacken_amd
+    rng = np.random.default_rng(92)
+    parents = world["parents"]
+    defined = np.array(taxgen.defined_taxa(parents), np.int32)
+    lists, flags = [], []
+    for r in range(400):
+        n = int(rng.integers(0, 90)) if r else 0
+        pool = rng.choice(defined, size=int(rng.integers(1, 9)))
+        hits, dis = [], []
+        for _ in range(n):
+            u = rng.random()
+            if u < 0.05:
+                hits.append((-2, -34)); dis.append(0)
+            elif u < 0.10:
+                hits.append((-1, int(rng.integers(1, 40)))); dis.append(0)
+            elif u < 0.35:
+                hits.append((0, int(rng.integers(1, 6)))); dis.append(int(rng.random() < 0.7))
+            else:
+                hits.append((int(rng.choice(pool)), int(rng.integers(1, 6)))); dis.append(int(rng.random() < 0.7))
+        lists.append(hits)
+        flags.append(dis)
+    offs = np.cumsum([0] + [len(h) for h in lists]).astype(np.uint64)
+    flat = np.array([h for hs in lists for h in hs] or [(0, 0)], slacken_amd.capi.HIT_DTYPE)[:int(offs[-1])]
+    dflat = np.array([d for ds in flags for d in ds], np.uint8)
+    thr = (0.0, 0.15, 0.5, 1.0)
+    for mhg in (1, 2, 5):
+        got = world["st"].classify_hits(offs, flat, dflat, min_hit_groups=mhg, thresholds=thr)
+        for c, t in enumerate(thr):
+            for r, (hits, dis) in enumerate(zip(lists, flags)):
+                want = orc.classify_hits(parents, hits, dis, mhg, t)
+                assert (int(got["taxon"][c, r]), bool(got["classified"][c, r])) == (want["taxon"], want["classified"]), (mhg, t, r)
+                assert int(got["num_distinct"][r]) == want["num_distinct"] and int(got["total_kmers"][r]) == want["total_kmers"]
+    none = world["st"].classify_hits(offs, flat, None)   # no distinct flags: nothing counts as a hit group
+    assert not none["classified"].any() and not none["num_distinct"].any()

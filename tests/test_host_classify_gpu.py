@@ -299,3 +299,143 @@ def test_cli_output_does_not_depend_on_the_host_pipeline_shape(tmp_path, env):
     assert r.returncode == 0, r.stderr
     assert read_out(f"{out}_c0.1") == read_out(f"{ref_out}_c0.1")
     assert open(f"{out}_c0.1/all_kreport.txt").read() == open(f"{ref_out}_c0.1/all_kreport.txt").read()
+
+
+# ---- titles that occur more than once: Classifier.scala:92 (groupBy seqTitle), :136 (sort by ordinal); the paired reader's
+# inner join on the header, InputReader.scala:104-119.  Expected rows come from the restatement in hostmodel.py
+# (merge_by_title, paired_join) over the oracle's per-fragment hit lists and its Classifier.classify on the merged list.
+# The reference holds no fixture for this: parity unpinned (restatement vs engine).
+def _oracle_env():
+    from oracle import oracle
+    g = json.load(open(os.path.join(GOLD, "golden_classify.json")))
+    lib = np.load(os.path.join(GOLD, "library.npz"))
+    p = oracle.params(k=g["k"], m=g["m"], spaces=g["spaces"])
+    return oracle, g, p, oracle.Index(1, lib["keys"], lib["taxa"]), lib["parents"]
+
+
+def _expected_rows(fragments, thresholds=(0.0,), min_hit_groups=2):
+    """fragments: [(title, seq1, seq2 or None)] in input order -> {threshold: [output lines]} in order of first appearance."""
+    oracle, g, p, oix, parents = _oracle_env()
+    per = []
+    for title, s1, s2 in fragments:
+        _, hits = oracle.classify_read(p, oix, parents, s1, s2)
+        sp = oracle.spans(p, s1, s2)
+        per.append((title, hits, [int(x["distinct"]) for x in sp]))
+        assert len(sp) == len(hits)
+    out = {}
+    for thr in thresholds:
+        rows = []
+        for title, hits, distinct in hostmodel.merge_by_title(per):
+            r = oracle.classify_hits(parents, hits, distinct, min_hit_groups, thr)
+            rows.append(oracle.output_line(r["classified"], title, r["taxon"], hits, g["k"]))
+        out[thr] = rows
+    return out
+
+
+def _report_of(tax, lines):
+    counts = {}
+    for l in lines:
+        t = int(l.split("\t")[2])
+        counts[t] = counts.get(t, 0) + 1
+    return hostmodel.kraken_report(tax, sorted(counts.items()))[0]
+
+
+@pytest.mark.gpu
+def test_cli_repeated_titles_unpaired(tmp_path):
+    """Both mate files given WITHOUT -p: every id occurs twice (the realistic way to get repeated titles).  The reference makes
+    one row per id from the hits of both fragments; so must the CLI, in the lines, in the reports and with --nodetailed."""
+    g, loc, tax, reads = make_library(tmp_path)
+    f1, f2 = tmp_path / "s_1.fq", tmp_path / "s_2.fa"
+    ids = list(range(0, 240, 2))
+    with open(f1, "w") as a:
+        for i in ids:
+            a.write(f"@{reads[i][0]} first\n{reads[i][1]}\n+\n{'I' * len(reads[i][1])}\n")
+        a.write(f"@{reads[300][0]}\n{reads[300][1]}\n+\n{'I' * len(reads[300][1])}\n")       # occurs once
+        a.write(f"@{reads[0][0]}\n{reads[301][1]}\n+\n{'I' * len(reads[301][1])}\n")         # a third fragment of id 0
+        a.write(f"@short\nACGT\n+\nIIII\n")                                                  # no span: no row
+    with open(f2, "w") as b:
+        for i in reversed(ids):
+            b.write(f">{reads[i][0]} second\n{reads[i + 1][1]}\n")
+        b.write(">short\nACGTACGT\n")                                                        # still no span
+    frags = [(reads[i][0], reads[i][1], None) for i in ids] + [(reads[300][0], reads[300][1], None), (reads[0][0], reads[301][1], None),
+                                                             ("short", "ACGT", None)]
+    frags += [(reads[i][0], reads[i + 1][1], None) for i in reversed(ids)] + [("short", "ACGTACGT", None)]
+    want = _expected_rows(frags, thresholds=(0.0, 0.5))
+    out = tmp_path / "rep"
+    r = classify("-i", loc, "-o", out, "-c", "0.0", "0.5", f1, f2)
+    assert "occur more than once" in r.stderr
+    for thr, suffix in ((0.0, "0.0"), (0.5, "0.5")):
+        lines = read_out(f"{out}_c{suffix}")
+        assert sorted(lines) == sorted(want[thr])          # (row order is not part of the contract: Spark's partition order)
+        assert len(lines) == len(ids) + 1
+        rep = open(f"{out}_c{suffix}/all_kreport.txt").read().rstrip("\n").split("\n")
+        assert rep == _report_of(tax, want[thr])
+    out2 = tmp_path / "rep_nd"
+    classify("-i", loc, "-o", out2, "-c", "0.0", "0.5", "--nodetailed", f1, f2)
+    for suffix in ("0.0", "0.5"):
+        assert open(f"{out2}_c{suffix}/all_kreport.txt").read() == open(f"{out}_c{suffix}/all_kreport.txt").read()
+    out3 = tmp_path / "rep_nu"
+    classify("-i", loc, "-o", out3, "--nounclassified", f1, f2)
+    assert sorted(read_out(f"{out3}_c0.0")) == sorted(l for l in want[0.0] if l.startswith("C"))
+    # a merged row differs from its fragments' own rows: the regrouping is not a no-op on this input
+    solo = _expected_rows(frags[:3])[0.0]
+    assert not set(solo) <= set(want[0.0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shuffled", [False, True], ids=["lockstep", "shuffled"])
+def test_cli_repeated_headers_paired(tmp_path, shuffled):
+    """A header that repeats inside a file of a pair: the reference's join pairs every record of file 1 with every record of
+    file 2 of that header (2 x 2, 2 x 1, 1 x 2 below), and the title grouping then merges the products into one row."""
+    g, loc, tax, reads = make_library(tmp_path)
+    t = [r[0] for r in reads]
+    s = [r[1] for r in reads]
+    rec1 = [(t[0], s[0]), (t[2], s[2]), (t[4], s[4]), (t[2], s[6]), (t[8], s[8]), (t[10], s[10]), (t[8], s[12]), (t[14], s[14])]
+    rec2 = [(t[0], s[1]), (t[2], s[3]), (t[4], s[5]), (t[2], s[7]), (t[8], s[9]), (t[10], s[11]), (t[10], s[13]), (t[14], s[15])]
+    if shuffled:
+        rec2 = rec2[::-1]
+    f1, f2 = tmp_path / "r_1.fq", tmp_path / "r_2.fq"
+    with open(f1, "w") as a:
+        for h, q in rec1:
+            a.write(f"@{h}/1\n{q}\n+\n{'I' * len(q)}\n")
+    with open(f2, "w") as b:
+        for h, q in rec2:
+            b.write(f"@{h}/2\n{q}\n+\n{'I' * len(q)}\n")
+    frags = hostmodel.paired_join([(h + "/1", q) for h, q in rec1], [(h + "/2", q) for h, q in rec2])
+    assert len(frags) == 3 + 4 + 2 + 2
+    want = _expected_rows(frags)[0.0]
+    out = tmp_path / "rp"
+    classify("-i", loc, "-o", out, "-p", f1, f2)
+    lines = read_out(f"{out}_c0.0")
+    assert sorted(lines) == sorted(want) and len(lines) == 6
+    assert open(f"{out}_c0.0/all_kreport.txt").read().rstrip("\n").split("\n") == _report_of(tax, want)
+    out2 = tmp_path / "rp_nd"
+    classify("-i", loc, "-o", out2, "-p", "--nodetailed", f1, f2)
+    assert open(f"{out2}_c0.0/all_kreport.txt").read() == open(f"{out}_c0.0/all_kreport.txt").read()
+
+
+@pytest.mark.gpu
+def test_cli_devices_share_the_reads(tmp_path):
+    """--devices: the table is replicated and the reads are shared out batch by batch.  The output does not depend on
+    the device list -- byte for byte.  (On a one-GPU box the same device is listed twice: two tables, two sets of streams.)"""
+    g, loc, tax, reads = make_library(tmp_path)
+    fq = tmp_path / "reads.fq"
+    with open(fq, "w") as f:
+        for rep in range(40):     # enough batches for every worker to get some
+            for t, s in reads:
+                f.write(f"@{t}.{rep}\n{s}\n+\n{'I' * len(s)}\n")
+    env = dict(os.environ, SLK_IO_CHUNK=str(1 << 18))   # small segments => many batches
+    outs = []
+    for name, devs in (("one", "0"), ("two", "0,0")):
+        out = tmp_path / name
+        r = subprocess.run([CLI, "classify", "-i", loc, "-o", str(out), "-c", "0.0", "0.15", "--devices", devs, str(fq)],
+                           capture_output=True, text=True, env=dict(env, SLK_HOST_TIMING="1"))
+        assert r.returncode == 0, r.stderr
+        assert f"over {len(devs.split(','))} device table(s)" in r.stderr
+        outs.append(out)
+    for suffix in ("0.00", "0.15"):
+        a, b = (gzip.open(f"{o}_c{suffix}/sample=all/part-00000.txt.gz", "rb").read() for o in outs)
+        assert a == b and a.count(b"\n") >= 40 * 500
+        assert open(f"{outs[0]}_c{suffix}/all_kreport.txt").read() == open(f"{outs[1]}_c{suffix}/all_kreport.txt").read()
+    bad = subprocess.run([CLI, "classify", "-i", loc, "-o", str(tmp_path / "x"), "--devices", "0,99", str(fq)], capture_output=True, text=True)
+    assert bad.returncode != 0 and "out of range" in bad.stderr

@@ -1,0 +1,68 @@
+"""Regrouping by title (Classifier.scala:92,136) and the paired reader's join (InputReader.scala:104-119): the restatement in
+hostmodel.py and the oracle's Classifier.classify on merged hit lists, on CPU.  The engine's side of it is tested through the
+CLI in test_host_classify_gpu.py.  The reference holds no fixture for repeated titles: parity unpinned."""
+import json
+import os
+
+import numpy as np
+
+import hostmodel
+from oracle import oracle
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_merge_is_a_stable_sort_by_ordinal():
+    a = [(5, 3), (0, 2), (5, 1)]
+    b = [(7, 4), (-2, -34), (7, 2), (9, 9)]
+    (title, hits, distinct), = hostmodel.merge_by_title([("x", a, [1, 0, 1]), ("x", b, [1, 0, 0, 1])])
+    assert title == "x"
+    assert hits == [(5, 3), (7, 4), (0, 2), (-2, -34), (5, 1), (7, 2), (9, 9)]
+    assert distinct == [1, 1, 0, 0, 1, 0, 1]
+    # fragments without spans take no part; order of first appearance
+    rows = hostmodel.merge_by_title([("b", [], []), ("a", a, [1, 1, 1]), ("b", b, [0] * 4), ("c", [], [])])
+    assert [r[0] for r in rows] == ["a", "b"] and rows[1][1] == b
+
+
+def test_paired_join_multiplies_repeated_headers():
+    r1 = [("x/1", "A"), ("y/1", "C"), ("x/1", "G"), ("z/1", "T")]
+    r2 = [("y/2", "c"), ("x/2", "a"), ("x/2", "g"), ("w/2", "t")]
+    assert hostmodel.paired_join(r1, r2) == [("x", "A", "a"), ("x", "A", "g"), ("y", "C", "c"), ("x", "G", "a"), ("x", "G", "g")]
+
+
+def test_length_string_is_taken_from_the_merged_counts():
+    """TaxonCounts.lengthString (TaxonCounts.scala:114-121) works on the fromHits-merged arrays: two fragments' borders have
+    the same ordinal only if their first mates have equally many spans -- then they are adjacent and collapse."""
+    k = 35
+    one = [(5, 3), (-2, -34), (7, 4)]
+    assert oracle.length_string(one, k) == "37|38"
+    adjacent = [(5, 3), (5, 2), (-2, -34), (-2, -34), (7, 4), (7, 1)]
+    assert oracle.length_string(adjacent, k) == "39|39"            # the collapsed border entry is skipped as a whole
+    apart = [(5, 3), (-2, -34), (7, 4), (-2, -34), (8, 1)]
+    assert oracle.length_string(apart, k) == "37|5"                # the second border's count is part of drop(border + 1).sum
+    assert oracle.pairs_in_order_string(adjacent) == "5:5 |:| 7:5"
+
+
+def test_classify_hits_equals_classify_read_on_a_single_fragment():
+    g = json.load(open(os.path.join(GOLD, "golden_classify.json")))
+    lib = np.load(os.path.join(GOLD, "library.npz"))
+    p = oracle.params(k=g["k"], m=g["m"], spaces=g["spaces"])
+    oix = oracle.Index(1, lib["keys"], lib["taxa"])
+    reads = [line.rstrip("\n").split("\t") for line in open(os.path.join(GOLD, "reads.tsv"))][:60]
+    for thr in (0.0, 0.5):
+        for (t1, s1), (t2, s2) in zip(reads[::2], reads[1::2]):
+            res, hits = oracle.classify_read(p, oix, lib["parents"], s1, s2, confidence=thr)
+            distinct = [x["distinct"] for x in oracle.spans(p, s1, s2)]
+            again = oracle.classify_hits(lib["parents"], hits, distinct, 2, thr)
+            assert again == res
+    # merging two fragments: counts add up, distinct hits add up
+    (_, s1), (_, s2) = reads[0], reads[1]
+    r1, h1 = oracle.classify_read(p, oix, lib["parents"], s1)
+    r2, h2 = oracle.classify_read(p, oix, lib["parents"], s2)
+    d1 = [x["distinct"] for x in oracle.spans(p, s1)]
+    d2 = [x["distinct"] for x in oracle.spans(p, s2)]
+    (_, hits, distinct), = hostmodel.merge_by_title([("t", h1, d1), ("t", h2, d2)])
+    m = oracle.classify_hits(lib["parents"], hits, distinct)
+    assert m["total_kmers"] == r1["total_kmers"] + r2["total_kmers"]
+    assert m["num_distinct"] == r1["num_distinct"] + r2["num_distinct"]
+    assert m["num_hits"] == len(h1) + len(h2)
