@@ -96,12 +96,11 @@ def build_taxonomy(seed=2240):
 
 
 def make_genomes_device(torch, n_genomes, genome_len, seed, device):
-    """uint8 tensor [n_genomes * genome_len + 64] of uniform ACGT on the GPU (the pad keeps the 16 readable bytes the
-    _device entry points ask for)."""
+    """uint8 tensor [n_genomes * genome_len] of uniform ACGT on the GPU."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     total = n_genomes * genome_len
-    out = torch.full((total + 64,), ord("A"), dtype=torch.uint8, device=device)
+    out = torch.empty((total,), dtype=torch.uint8, device=device)
     acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
     CH = 1 << 28
     for s in range(0, total, CH):
@@ -118,8 +117,8 @@ def make_reads_device(torch, genome_cat, genome_len, n_genomes, n_reads, seed, d
     for a, b in zip(b"ACGTN", b"TGCAN"):
         comp[a] = b
     acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
-    flat = torch.full((n_reads * READ_LEN + 64,), ord("A"), dtype=torch.uint8, device=device)  # 16+ readable pad bytes
-    out = flat[:n_reads * READ_LEN].view(n_reads, READ_LEN)
+    flat = torch.empty((n_reads * READ_LEN,), dtype=torch.uint8, device=device)  # exactly offsets[R] bytes: no padding needed
+    out = flat.view(n_reads, READ_LEN)
     ar = torch.arange(READ_LEN, device=device)
     CH = 1 << 20
     for s in range(0, n_reads, CH):
@@ -299,6 +298,7 @@ def main():
         ev[i][1].record(ext)
     barrier()
     elapsed = time.perf_counter() - t_start
+    st.synchronize()   # (the engine's own check of the queued calls: raises if a device-side error was flagged)
     step_dev_ms = np.array([a.elapsed_time(b) for a, b in ev]) if args.steps else np.zeros(1)
     stage_ms = np.array(st.last_stage_ms())  # the engine's own events of the LAST timed step: [fused, 0, ~0] on the hot path
     elapsed = sdist.max_over_ranks(elapsed, dist, device)

@@ -17,6 +17,8 @@
  *   - plain pointers and sizes only.  "host" entry points take host pointers and do their own H2D/D2H; "_device"
  *     entry points take pointers to memory already resident on the index's GPU and are asynchronous on the
  *     slk_stream (call slk_stream_synchronize before reading results);
+ *   - a buffer of bases is exactly offsets[R] (mate_offsets[R]) bytes: nothing past it is read, no padding is needed
+ *     (the kernels stream 16-byte blocks and assemble a buffer's last block from byte loads);
  *   - an slk_index is immutable after slk_index_finalize() and may be shared by many threads; an slk_stream holds
  *     one HIP stream plus the scratch of ONE in-flight batch: use one per calling thread.
  *   - minimizers of up to 128 nt (id_longs = ceil(m/32) <= 4 key words per record, row-major) are supported by
@@ -130,8 +132,8 @@ int32_t slk_index_set_taxonomy(slk_index *ix, const int32_t *parents, int32_t T)
  * whose keys do not occur in the sequences; the result does not depend on the order or batching of the calls. */
 int32_t slk_index_add_sequences(slk_index *ix, const uint8_t *bases, const uint64_t *offsets, const int32_t *taxa,
                                 uint64_t n_sequences);
-/* The same with the bases already resident on the index's GPU (d_bases: device pointer, readable 16 bytes past
- * offsets[n_sequences]; offsets and taxa: host arrays).  The sequences are scanned where they lie. */
+/* The same with the bases already resident on the index's GPU (d_bases: device pointer to offsets[n_sequences] bytes;
+ * offsets and taxa: host arrays).  The sequences are scanned where they lie. */
 int32_t slk_index_add_sequences_device(slk_index *ix, const uint8_t *d_bases, const uint64_t *offsets, const int32_t *taxa,
                                        uint64_t n_sequences);
 int32_t slk_index_finalize(slk_index *ix);
@@ -239,7 +241,7 @@ uint32_t slk_shard_of(int64_t key, uint32_t n_shards);
  *                           as slk_classify_batch_device.
  * d_defer[R] (zeroed by slk_shard_emit_device) is set to 1 for fragments this path does not take (longer than 1000 bases,
  * or more than 12 distinct taxa): classify those with the staged calls above.  SLK_E_UNSUPPORTED if the index's splitter
- * is outside the fused kernel's range (window wider than 16 m-mers or taxon ids beyond 22 bits): use the staged calls. */
+ * is outside the fused kernel's range (window wider than 32 m-mers or taxon ids beyond 22 bits): use the staged calls. */
 int32_t slk_shard_emit_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
                               const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
                               uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys, uint64_t *d_send_slots,

@@ -93,7 +93,7 @@ __device__ __forceinline__ int code_of(uint32_t c) {  // BitRepresentation.charT
 }
 
 __global__ void __launch_bounds__(BW * 64) build_kernel(ScanParams P, TableBuild T, const int32_t *__restrict__ parents,
-                                                        int32_t ntax, const uint8_t *__restrict__ bases,
+                                                        int32_t ntax, const uint8_t *__restrict__ bases, uint64_t total_bases,
                                                         const uint64_t *__restrict__ chunk_start,
                                                         const uint32_t *__restrict__ chunk_len,
                                                         const int32_t *__restrict__ chunk_taxon, uint64_t nchunks) {
@@ -130,9 +130,9 @@ __global__ void __launch_bounds__(BW * 64) build_kernel(ScanParams P, TableBuild
   };
 
   for (uint32_t step = 0; step < maxlen; step++) {
-    if ((step & 15) == 0) {  // 16 bytes per lane every 16 steps (bases[] is padded by 16 bytes)
+    if ((step & 15) == 0) {  // 16 bytes per lane every 16 steps (the buffer's last block: byte loads, engine.h)
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (step < len) __builtin_memcpy(&v, bases + start + step, 16);
+      if (step < len) v = load_block16(bases + start + step, clamp_room(total_bases - start - step));
       lo = ((uint64_t)v.y << 32) | v.x;
       hi = ((uint64_t)v.w << 32) | v.z;
     }
@@ -237,14 +237,14 @@ __global__ void __launch_bounds__(256) export_kernel(TableView T, uint64_t ncell
 }  // namespace
 
 void launch_build(const ScanParams &P, const TableBuild &T, const int32_t *parents, int32_t ntax, const uint8_t *bases,
-                  const uint64_t *chunk_start, const uint32_t *chunk_len, const int32_t *chunk_taxon, uint64_t nchunks,
+                  uint64_t total_bases, const uint64_t *chunk_start, const uint32_t *chunk_len, const int32_t *chunk_taxon, uint64_t nchunks,
                   hipStream_t s) {
   if (nchunks == 0) return;
   const unsigned block = BW * 64;
   size_t lds = (size_t)block * P.w * 8;
   uint64_t blocks = (nchunks + block - 1) / block;
-  hipLaunchKernelGGL(build_kernel, dim3((unsigned)blocks), dim3(block), lds, s, P, T, parents, ntax, bases, chunk_start,
-                     chunk_len, chunk_taxon, nchunks);
+  hipLaunchKernelGGL(build_kernel, dim3((unsigned)blocks), dim3(block), lds, s, P, T, parents, ntax, bases, total_bases,
+                     chunk_start, chunk_len, chunk_taxon, nchunks);
 }
 
 void launch_export(const TableView &T, uint64_t nbuckets, int64_t *keys, int32_t *taxa, uint64_t capacity,

@@ -38,7 +38,6 @@ static int32_t fail(int32_t code, const char *fmt, ...) {
     }                                                                                                  \
   } while (0)
 
-#define MAX_THRESHOLDS 16
 
 struct DevBuf {
   void *p = nullptr;
@@ -113,23 +112,25 @@ struct slk_stream {
   DevBuf span_keys, span_meta, span_taxon, span_count;  // per-batch scratch (sparse per-read regions)
   DevBuf bases, offsets, mate_bases, mate_offsets;      // staging for the host-pointer entry points
   DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items, defer_list;
-  double *d_thresholds = nullptr;
-  double *h_thresholds = nullptr;  // pinned
   int32_t *d_status = nullptr;     // device error bits of the fused kernels
   int32_t *h_status = nullptr;     // pinned copy, refreshed after every classify launch
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   Staging staging;
   bool timed = false;
   bool last_used_lane = false;  // the last classify call ran the lane kernel (defer_list[0] is its deferral count)
-  struct LastCall {  // the arguments of the classify call in flight, for the unbounded re-run (check_status)
+  // The arguments of every classify call queued since the stream was last synchronised, for the unbounded re-run
+  // (check_status): a taxon-map overflow is only seen at the next synchronisation, and by then several calls may have gone by.
+  struct LastCall {
     bool valid = false, want_hits = false;
+    Thresholds thr{};
     const uint8_t *bases = nullptr, *mate_bases = nullptr;
     const uint64_t *offsets = nullptr, *mate_offsets = nullptr;
     uint64_t R = 0, total = 0, mate_total = 0;
     int32_t min_hit_groups = 0, C = 0;
     int32_t *out_taxon = nullptr, *out_nd = nullptr, *out_tk = nullptr, *out_nh = nullptr, *out_np = nullptr;
     uint8_t *out_cls = nullptr;
-  } last;
+  };
+  std::vector<LastCall> queued;
 };
 
 static int32_t check_status(slk_stream *st);
@@ -436,7 +437,7 @@ int32_t slk_index_set_taxonomy(slk_index *ix, const int32_t *parents, int32_t T)
   return SLK_OK;
 }
 
-// bases_on_device: `bases` is resident on the index's GPU (readable 16 bytes past offsets[S]) and is scanned where it lies
+// bases_on_device: `bases` is resident on the index's GPU and is scanned where it lies
 static int32_t add_sequences(slk_index *ix, const uint8_t *bases, const uint64_t *offsets, const int32_t *taxa, uint64_t S,
                              bool bases_on_device) {
   if (!ix || (S && (!bases || !offsets || !taxa))) return fail(SLK_E_INVALID, "null argument");
@@ -483,17 +484,16 @@ static int32_t add_sequences(slk_index *ix, const uint8_t *bases, const uint64_t
       HIPCHK(d_tax.ensure(nc * 4));
       const uint8_t *src = bases + g0;
       if (!bases_on_device) {
-        HIPCHK(d_bases.ensure(gbytes + 16));
+        HIPCHK(d_bases.ensure(gbytes));
         rc = copy_in(&ix->staging, ix->build_stream, d_bases.p, bases + g0, gbytes);
         if (rc) return rc;
-        HIPCHK(hipMemsetAsync((uint8_t *)d_bases.p + gbytes, 0, 16, ix->build_stream));
         src = d_bases.as<uint8_t>();
       }
       rc = copy_in(&ix->staging, ix->build_stream, d_start.p, cstart.data(), nc * 8);
       if (!rc) rc = copy_in(&ix->staging, ix->build_stream, d_len.p, clen.data(), nc * 4);
       if (!rc) rc = copy_in(&ix->staging, ix->build_stream, d_tax.p, ctax.data(), nc * 4);
       if (rc) return rc;
-      launch_build(ix->sp, build_view(ix), ix->d_parents, ix->T, src, d_start.as<uint64_t>(),
+      launch_build(ix->sp, build_view(ix), ix->d_parents, ix->T, src, gbytes, d_start.as<uint64_t>(),
                    d_len.as<uint32_t>(), d_tax.as<int32_t>(), nc, ix->build_stream);
       HIPCHK(hipGetLastError());
       HIPCHK(hipStreamSynchronize(ix->build_stream));
@@ -613,8 +613,6 @@ int32_t slk_stream_create(slk_index *ix, slk_stream **out) {
   st->ix = ix;
   st->device = ix->device;
   HIPCHK(hipStreamCreate(&st->s));
-  HIPCHK(hipMalloc((void **)&st->d_thresholds, MAX_THRESHOLDS * sizeof(double)));
-  HIPCHK(hipHostMalloc((void **)&st->h_thresholds, MAX_THRESHOLDS * sizeof(double), hipHostMallocDefault));
   for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&st->ev[i]));
   HIPCHK(hipMalloc((void **)&st->d_status, sizeof(int32_t)));
   HIPCHK(hipMemset(st->d_status, 0, sizeof(int32_t)));
@@ -641,8 +639,6 @@ void slk_stream_destroy(slk_stream *st) {
                     &st->mate_bases, &st->mate_offsets, &st->out_taxon, &st->out_cls, &st->out_nd, &st->out_tk,
                     &st->out_nh, &st->out_offsets, &st->out_items, &st->defer_list};
   for (DevBuf *b : bufs) b->release();
-  if (st->d_thresholds) (void)hipFree(st->d_thresholds);
-  if (st->h_thresholds) (void)hipHostFree(st->h_thresholds);
   if (st->d_status) (void)hipFree(st->d_status);
   if (st->h_status) (void)hipHostFree(st->h_status);
   st->staging.release();
@@ -691,9 +687,8 @@ static uint64_t span_slots(uint64_t total_bases, uint64_t total_mate_bases, uint
 // distinct taxa than that (long reads across conserved regions can) raises status bit 1; the batch is then classified again
 // by the staged kernels, whose per-fragment map lives in HBM scratch and is unbounded -- the same three kernels that serve
 // windows wider than 32 m-mers.  Slower (HBM intermediates), rare, and bit-identical for every other fragment.
-static int32_t run_unbounded(slk_stream *st) {
+static int32_t run_unbounded(slk_stream *st, const slk_stream::LastCall &L) {
   slk_index *ix = st->ix;
-  const slk_stream::LastCall &L = st->last;
   const bool paired = L.mate_bases != nullptr;
   int32_t rc = ensure_scratch(st, span_slots(L.total, L.mate_total, L.R, paired), L.R);
   if (rc) return rc;
@@ -703,7 +698,7 @@ static int32_t run_unbounded(slk_stream *st) {
                st->span_count.as<int32_t>(), st->span_taxon.as<int32_t>(), st->s);
   launch_classify(ix->d_parents, ix->T, L.offsets, L.mate_offsets, L.R, st->span_meta.as<int32_t>(),
                   st->span_taxon.as<int32_t>(), st->span_count.as<int32_t>(), st->span_keys.as<uint64_t>(),
-                  L.min_hit_groups, st->d_thresholds, L.C, L.out_taxon, L.out_cls, L.out_nd, L.out_tk, L.out_nh, L.out_np, st->s);
+                  L.min_hit_groups, L.thr, L.C, L.out_taxon, L.out_cls, L.out_nd, L.out_tk, L.out_nh, L.out_np, st->s);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st->s));
   return SLK_OK;
@@ -711,12 +706,21 @@ static int32_t run_unbounded(slk_stream *st) {
 
 static int32_t check_status(slk_stream *st) {  // call after the stream has been synchronised
   int32_t v = *st->h_status;
+  std::vector<slk_stream::LastCall> queued;
+  queued.swap(st->queued);
   if (v != 0) {
     *st->h_status = 0;
     HIPCHK(hipMemsetAsync(st->d_status, 0, sizeof(int32_t), st->s));
-    if (v == 1 && st->last.valid) {
-      st->last.valid = false;
-      return run_unbounded(st);
+    if (v == 1 && !queued.empty()) {
+      // Some queued batch held a fragment with more distinct taxa than the LDS maps take.  The status word does not say
+      // which, so every batch queued since the last synchronisation is classified again by the unbounded kernels, in
+      // order (callers that reuse their output buffers from call to call end up with the last call's results, as before).
+      for (const slk_stream::LastCall &L : queued) {
+        if (!L.valid) return fail(SLK_E_CAPACITY, "a fragment hit more than %d distinct taxa; the per-read taxon map overflowed", 128);
+        int32_t rc = run_unbounded(st, L);
+        if (rc) return rc;
+      }
+      return SLK_OK;
     }
     if (v & 2) return fail(SLK_E_CAPACITY, "a send list of slk_shard_emit_device overflowed its capacity_per_sublist");
     if (v & 1) return fail(SLK_E_CAPACITY, "a fragment hit more than %d distinct taxa; the per-read taxon map overflowed", 128);
@@ -741,12 +745,18 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
     rc = ensure_scratch(st, span_slots(total_bases, total_mate_bases, R, paired), R);
     if (rc) return rc;
   }
-  memcpy(st->h_thresholds, thresholds, C * sizeof(double));
-  HIPCHK(hipMemcpyAsync(st->d_thresholds, st->h_thresholds, C * sizeof(double), hipMemcpyHostToDevice, st->s));
+  Thresholds thr{};
+  memcpy(thr.v, thresholds, C * sizeof(double));
   HIPCHK(hipEventRecord(st->ev[0], st->s));
   {
-    slk_stream::LastCall &L = st->last;
-    L.valid = fused; L.want_hits = want_hits;
+    if (st->queued.size() >= 4096) {  // (a caller that never synchronises: settle what is queued before taking more)
+      HIPCHK(hipStreamSynchronize(st->s));
+      rc = check_status(st);
+      if (rc) return rc;
+    }
+    st->queued.emplace_back();
+    slk_stream::LastCall &L = st->queued.back();
+    L.valid = fused; L.want_hits = want_hits; L.thr = thr;
     L.bases = d_bases; L.offsets = d_offsets; L.mate_bases = d_mate_bases; L.mate_offsets = d_mate_offsets;
     L.R = R; L.total = total_bases; L.mate_total = total_mate_bases; L.min_hit_groups = min_hit_groups; L.C = C;
     L.out_taxon = d_out_taxon; L.out_cls = d_out_classified; L.out_nd = d_out_num_distinct; L.out_tk = d_out_total_kmers;
@@ -756,7 +766,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
     FusedArgs A{};
     A.P = ix->sp; A.T = ix->view(); A.parents = ix->d_parents; A.ntax = ix->T;
     A.bases = d_bases; A.offsets = d_offsets; A.mate_bases = d_mate_bases; A.mate_offsets = d_mate_offsets; A.R = R;
-    A.min_hit_groups = min_hit_groups; A.thresholds = st->d_thresholds; A.C = C;
+    A.min_hit_groups = min_hit_groups; A.thr = thr; A.C = C;
     A.out_taxon = d_out_taxon; A.out_classified = d_out_classified;
     A.out_nd = d_out_num_distinct; A.out_tk = d_out_total_kmers; A.out_nh = d_out_num_hits; A.out_np = d_out_num_probes;
     A.span_keys = nullptr;
@@ -804,7 +814,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
     // the key slots are dead after the probe: the per-read taxon->count map reuses them
     launch_classify(ix->d_parents, ix->T, d_offsets, d_mate_offsets, R, st->span_meta.as<int32_t>(),
                     st->span_taxon.as<int32_t>(), st->span_count.as<int32_t>(), st->span_keys.as<uint64_t>(),
-                    min_hit_groups, st->d_thresholds, C, d_out_taxon, d_out_classified, d_out_num_distinct,
+                    min_hit_groups, thr, C, d_out_taxon, d_out_classified, d_out_num_distinct,
                     d_out_total_kmers, d_out_num_hits, d_out_num_probes, st->s);
   }
   HIPCHK(hipEventRecord(st->ev[3], st->s));
@@ -896,7 +906,7 @@ int32_t slk_shard_emit_device(slk_index *ix, slk_stream *st, const uint8_t *d_ba
   ShardIO S{};
   S.n_shards = (int32_t)n_shards; S.n_sub = (int32_t)n_sublists; S.cap = capacity_per_sublist; S.send_keys = d_send_keys; S.send_slots = d_send_slots;
   S.send_counts = (unsigned long long *)d_send_counts;
-  st->last.valid = false;
+  st->queued.emplace_back();  // (not re-runnable: an overflow of this call is reported as an error)
   launch_lane_sharded(LANE_EMIT, A, S, d_defer, 1000, st->s);
   HIPCHK(hipMemcpyAsync(st->h_status, st->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st->s));
   HIPCHK(hipGetLastError());
@@ -930,18 +940,18 @@ int32_t slk_shard_apply_device(slk_index *ix, slk_stream *st, const uint8_t *d_b
     return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
   rc = set_device(ix);
   if (rc) return rc;
-  memcpy(st->h_thresholds, thresholds, C * sizeof(double));
-  HIPCHK(hipMemcpyAsync(st->d_thresholds, st->h_thresholds, C * sizeof(double), hipMemcpyHostToDevice, st->s));
+  Thresholds thr{};
+  memcpy(thr.v, thresholds, C * sizeof(double));
   FusedArgs A{};
   A.P = ix->sp; A.parents = ix->d_parents; A.ntax = ix->T;
   A.bases = d_bases; A.offsets = d_offsets; A.mate_bases = d_mate_bases; A.mate_offsets = d_mate_offsets; A.R = R;
-  A.min_hit_groups = min_hit_groups; A.thresholds = st->d_thresholds; A.C = C;
+  A.min_hit_groups = min_hit_groups; A.thr = thr; A.C = C;
   A.out_taxon = d_out_taxon; A.out_classified = d_out_classified;
   A.out_nd = d_out_num_distinct; A.out_tk = d_out_total_kmers; A.out_nh = d_out_num_hits;
   A.status = st->d_status;
   ShardIO S{};
   S.taxa = d_taxa_by_slot;
-  st->last.valid = false;
+  st->queued.emplace_back();
   launch_lane_sharded(LANE_APPLY, A, S, d_defer, 1000, st->s);
   HIPCHK(hipGetLastError());
   return SLK_OK;
@@ -961,10 +971,10 @@ int32_t slk_classify_hits_device(slk_index *ix, slk_stream *st, const uint64_t *
     return fail(SLK_E_INVALID, "null argument");
   rc = set_device(ix);
   if (rc) return rc;
-  memcpy(st->h_thresholds, thresholds, C * sizeof(double));
-  HIPCHK(hipMemcpyAsync(st->d_thresholds, st->h_thresholds, C * sizeof(double), hipMemcpyHostToDevice, st->s));
+  Thresholds thr{};
+  memcpy(thr.v, thresholds, C * sizeof(double));
   launch_classify(ix->d_parents, ix->T, d_offsets, d_mate_offsets, R, d_span_meta, d_span_taxon, d_span_count, d_scratch,
-                  min_hit_groups, st->d_thresholds, C, d_out_taxon, d_out_classified, d_out_num_distinct,
+                  min_hit_groups, thr, C, d_out_taxon, d_out_classified, d_out_num_distinct,
                   d_out_total_kmers, d_out_num_hits, nullptr, st->s);
   HIPCHK(hipGetLastError());
   return SLK_OK;
@@ -1015,12 +1025,11 @@ int32_t slk_classify_hits(slk_index *ix, slk_stream *st, uint64_t R, const uint6
   if (!rc) rc = copy_in(st, st->span_taxon.p, taxon.data(), (n + 1) * 4);
   if (!rc) rc = copy_in(st, st->span_count.p, count.data(), R * 4);
   if (rc) return rc;
-  memcpy(st->h_thresholds, thresholds, C * sizeof(double));
-  HIPCHK(hipMemcpyAsync(st->d_thresholds, st->h_thresholds, C * sizeof(double), hipMemcpyHostToDevice, st->s));
-  st->last.valid = false;
+  Thresholds thr{};
+  memcpy(thr.v, thresholds, C * sizeof(double));
   launch_classify(ix->d_parents, ix->T, st->offsets.as<uint64_t>(), nullptr, R, st->span_meta.as<int32_t>(),
                   st->span_taxon.as<int32_t>(), st->span_count.as<int32_t>(), st->span_keys.as<uint64_t>(), min_hit_groups,
-                  st->d_thresholds, C, st->out_taxon.as<int32_t>(), st->out_cls.as<uint8_t>(), st->out_nd.as<int32_t>(),
+                  thr, C, st->out_taxon.as<int32_t>(), st->out_cls.as<uint8_t>(), st->out_nd.as<int32_t>(),
                   st->out_tk.as<int32_t>(), nullptr, nullptr, st->s);
   HIPCHK(hipGetLastError());
   rc = copy_out(st, out_taxon, st->out_taxon.p, (size_t)C * R * 4);
@@ -1063,13 +1072,13 @@ static int32_t upload_reads(slk_stream *st, const uint8_t *bases, const uint64_t
   }
   *total = offsets[R];
   *mate_total = mate_offsets ? mate_offsets[R] : 0;
-  HIPCHK(st->bases.ensure(*total + 16));
+  HIPCHK(st->bases.ensure(*total));
   HIPCHK(st->offsets.ensure((R + 1) * 8));
   int32_t rc = copy_in(st, st->bases.p, bases, *total);
   if (!rc) rc = copy_in(st, st->offsets.p, offsets, (R + 1) * 8);
   if (rc) return rc;
   if (mate_offsets) {
-    HIPCHK(st->mate_bases.ensure(*mate_total + 16));
+    HIPCHK(st->mate_bases.ensure(*mate_total));
     HIPCHK(st->mate_offsets.ensure((R + 1) * 8));
     rc = copy_in(st, st->mate_bases.p, mate_bases, *mate_total);
     if (!rc) rc = copy_in(st, st->mate_offsets.p, mate_offsets, (R + 1) * 8);

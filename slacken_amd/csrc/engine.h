@@ -77,6 +77,24 @@ __device__ inline uint64_t span_region(const uint64_t *offsets, const uint64_t *
   return offsets[r] + (mate_offsets ? mate_offsets[r] + r : 0);
 }
 
+// 16 bytes of a read stream at `src`.  The kernels consume sequences in 16-byte blocks; a block may reach past the end of its
+// sequence (into the next one -- harmless, those bytes are never used), but it must not reach past the end of the caller's
+// BUFFER: `room` = bytes between src and the end of the buffer.  Only the last block of a buffer takes the byte loads.
+__device__ __forceinline__ uint4 load_block16(const uint8_t *src, uint32_t room) {
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (room >= 16u) {
+    __builtin_memcpy(&v, src, 16);
+  } else {
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t j = 0; j < 15; j++)
+      if (j < room) w[j >> 2] |= (uint32_t)src[j] << (8 * (j & 3));
+    v = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t clamp_room(uint64_t bytes) { return bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)bytes; }
+
 // build-time view of the table (table_insert_kernel)
 struct TableBuild {
   uint64_t *cells;
@@ -86,6 +104,11 @@ struct TableBuild {
   int32_t *max_disp;           // device: running maximum displacement
   unsigned long long *n_inserted, *n_duplicate, *n_overflow;
 };
+
+// Confidence thresholds travel BY VALUE in the kernel arguments: several classify calls may be queued on a stream, each with
+// its own list, and none of them shares a staging buffer with another.
+constexpr int MAX_THRESHOLDS = 16;
+struct Thresholds { double v[MAX_THRESHOLDS]; };
 
 // arguments of the fused wave-per-read kernels (fused.hip)
 struct FusedArgs {
@@ -99,7 +122,7 @@ struct FusedArgs {
   const uint64_t *mate_offsets;
   uint64_t R;
   int32_t min_hit_groups;
-  const double *thresholds;
+  Thresholds thr;
   int32_t C;
   int32_t *out_taxon;
   uint8_t *out_classified;
@@ -148,7 +171,7 @@ void launch_table_insert(const TableBuild &t, const int64_t *keys, const int32_t
 constexpr uint32_t BUILD_CHUNK_WINDOWS = 512;
 constexpr int BUILD_MAX_W = 28;
 void launch_build(const ScanParams &P, const TableBuild &T, const int32_t *parents, int32_t ntax, const uint8_t *bases,
-                  const uint64_t *chunk_start, const uint32_t *chunk_len, const int32_t *chunk_taxon, uint64_t nchunks,
+                  uint64_t total_bases, const uint64_t *chunk_start, const uint32_t *chunk_len, const int32_t *chunk_taxon, uint64_t nchunks,
                   hipStream_t s);
 void launch_export(const TableView &T, uint64_t nbuckets, int64_t *keys, int32_t *taxa, uint64_t capacity,
                    unsigned long long *counter, hipStream_t s);
@@ -161,7 +184,7 @@ void launch_probe(const TableView &T, const uint64_t *offsets, const uint64_t *m
                   hipStream_t s);
 void launch_classify(const int32_t *parents, int32_t T, const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R,
                      const int32_t *span_meta, const int32_t *span_taxon, const int32_t *span_count,
-                     uint64_t *map_scratch, int32_t min_hit_groups, const double *d_thresholds, int32_t C,
+                     uint64_t *map_scratch, int32_t min_hit_groups, const Thresholds &thr, int32_t C,
                      int32_t *out_taxon, uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers,
                      int32_t *out_num_hits, int32_t *out_num_probes, hipStream_t s);
 void launch_gather_spans(const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, const uint64_t *span_keys,

@@ -296,7 +296,7 @@ __device__ __forceinline__ void resolve_map(WaveLds *L, const FusedArgs &A, uint
     }
   }
   for (int32_t c = 0; c < A.C; c++) {
-    double required = ceil(__dmul_rn(A.thresholds[c], (double)total));  // Math.ceil(confidence * totalKmers) :94
+    double required = ceil(__dmul_rn(A.thr.v[c], (double)total));  // Math.ceil(confidence * totalKmers) :94
     int32_t mt = maxTaxon;
     int32_t ms = map_get(L, mt);  // :125
     while (mt != 0 && (double)ms < required) {  // :126-144
@@ -567,10 +567,10 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
       // Every non-NONE hit names t0 (or there is none): resolveTree's first loop yields t0; lifting it changes nothing
       // because NONE is in no clade, so the result is t0 iff its own k-mer count reaches the required score (:125-146).
       bool need_count = false;
-      for (int32_t c = 0; c < A.C; c++) need_count |= A.thresholds[c] > 0.0;
+      for (int32_t c = 0; c < A.C; c++) need_count |= A.thr.v[c] > 0.0;
       int32_t c0 = (need_count && t0 != 0) ? wave_sum(acc_t0) : 0;
       for (int32_t c = 0; c < A.C; c++) {
-        double required = ceil(__dmul_rn(A.thresholds[c], (double)total));
+        double required = ceil(__dmul_rn(A.thr.v[c], (double)total));
         int32_t mt = (t0 != 0 && !((double)c0 < required)) ? t0 : 0;
         bool classified = (mt != 0) && (nd >= A.min_hit_groups);
         if (lane == 0) {
@@ -612,12 +612,13 @@ struct __attribute__((aligned(16))) SegLds {
 };
 enum { SEGF_HAS = 1, SEGF_ENDS_OPEN = 2, SEGF_END_AMB = 4 };
 
-__device__ __forceinline__ uint4 seg_refill(SegLds *G, int lane, const uint8_t *seq, uint32_t p, uint32_t n) {
+// (room: bytes from seq to the end of the caller's buffer -- the buffer's last block is assembled from byte loads)
+__device__ __forceinline__ uint4 seg_refill(SegLds *G, int lane, const uint8_t *seq, uint32_t p, uint32_t n, uint32_t room) {
   uint4 v[SEG_SBLK];
 #pragma unroll
   for (int i = 0; i < SEG_SBLK; i++) {
     v[i] = make_uint4(0, 0, 0, 0);
-    if (p + 16u * i < n) __builtin_memcpy(&v[i], seq + p + 16u * i, 16);
+    if (p + 16u * i < n) v[i] = load_block16(seq + p + 16u * i, room - (p + 16u * i));
   }
 #pragma unroll
   for (int i = 1; i < SEG_SBLK; i++) G->sbuf[(i - 1) * 64 + lane] = v[i];
@@ -635,6 +636,7 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
   const int k = P.k, m = P.m;
   const uint64_t nwaves = (uint64_t)gridDim.x * FW;
   const uint64_t nunits = (uint64_t)*A.work_count;
+  const uint64_t bases_end = A.offsets[A.R];
   const uint32_t VM = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20) | (1u << 21);  // A C G T U, either case
   for (uint64_t unit = (uint64_t)blockIdx.x * FW + wib; unit < nunits; unit += nwaves) {
     const uint64_t r = A.work_list[unit];
@@ -648,6 +650,7 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
     const bool exists = w0 < nwin;
     const uint8_t *seq = A.bases + o + (exists ? w0 : 0);
     const uint32_t n = exists ? (min(nwin, w0 + S) - w0) + (uint32_t)k - 1 : 0;
+    const uint32_t room = clamp_room(bases_end - o - (exists ? w0 : 0));  // bytes from seq to the end of the caller's buffer
     // ---- wave state (as fused_kernel) ----
     int nbuf = 0, n_out = 0;
     int32_t nd = 0, np = 0, t0 = 0;
@@ -661,7 +664,7 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
     uint32_t cur = 0, b1 = 0, b2 = 0, b3 = 0;
     int sb = 1;
     if (!fin) {
-      uint4 v = seg_refill(G, lane, seq, 0, n);
+      uint4 v = seg_refill(G, lane, seq, 0, n, room);
       cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
     }
     int run_class = 0;
@@ -740,7 +743,7 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
           if (refill && pos < n) {
             uint4 v;
             if (sb < SEG_SBLK) { v = G->sbuf[(sb - 1) * 64 + lane]; sb++; }
-            else { v = seg_refill(G, lane, seq, pos, n); sb = 1; }
+            else { v = seg_refill(G, lane, seq, pos, n, room); sb = 1; }
             cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
           }
         }
@@ -841,10 +844,10 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
       resolve_map(L, A, r, lane, total, nd);
     } else {
       bool need_count = false;
-      for (int32_t c = 0; c < A.C; c++) need_count |= A.thresholds[c] > 0.0;
+      for (int32_t c = 0; c < A.C; c++) need_count |= A.thr.v[c] > 0.0;
       int32_t c0 = (need_count && t0 != 0) ? wave_sum(acc_t0) : 0;
       for (int32_t c = 0; c < A.C; c++) {
-        double required = ceil(__dmul_rn(A.thresholds[c], (double)total));
+        double required = ceil(__dmul_rn(A.thr.v[c], (double)total));
         int32_t mt = (t0 != 0 && !((double)c0 < required)) ? t0 : 0;
         bool classified = (mt != 0) && (nd >= A.min_hit_groups);
         if (lane == 0) {

@@ -59,6 +59,17 @@ struct __attribute__((aligned(16))) LaneLds {
   uint16_t q_ord[QCAP];           // hit-list output only: the queue entry's ordinal among its fragment's spans
 };
 
+// Timing experiments (probes off, map updates off, everything served from the L2 ...) change what the kernel computes: they
+// exist only in a build with -DSLK_TUNING (make EXTRA=-DSLK_TUNING), where SLK_DEBUG_ABLATE selects them.  The shipped
+// library has no such switch.
+#ifdef SLK_TUNING
+#define SLK_TUNE(...) __VA_ARGS__
+#define SLK_TUNE_ON(bit) ((dbg & (bit)) != 0)
+#else
+#define SLK_TUNE(...)
+#define SLK_TUNE_ON(bit) false
+#endif
+
 #ifndef SLK_PROBE_NT
 #define SLK_PROBE_NT 0
 #endif
@@ -131,7 +142,7 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int q
 #pragma unroll
   for (int s = 0; s < 4; s++) {
     uint32_t bkt = ((const uint4 *)L->stash)[s * 16 + g].x;
-    if (dbg & 4) bkt &= 1023u;                                            // (timing experiment 4: every probe hits the L2)
+    SLK_TUNE(if (dbg & 4) bkt &= 1023u;)                                  // (timing experiment 4: every probe hits the L2)
     // non-temporal: a bucket is touched once; keeping it out of the L2's way leaves the read stream's lines resident
     // between a lane's consecutive 16-byte loads (inactive entries read some bucket: harmless)
     cell[s] = SLK_PROBE_LOAD((const ulonglong2 *)(cellbase + ((uint64_t)bkt << 6)));
@@ -171,7 +182,7 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int q
   lane_wave_sync();
   // step 3: one lane per entry
   const int32_t taxon = (int32_t)((const uint4 *)L->stash)[lane].y;
-  if (!(dbg & 2)) fold_hit(L, in, meta, taxon);
+  if (!SLK_TUNE_ON(2)) fold_hit(L, in, meta, taxon);
   if (HITS && in) {
     // the un-merged hit list (TaxonHit, KeyValueIndex.scala:436-441) in the fragment's span region.  An entry handed back
     // to the queue writes NONE here and its final taxon when a later batch resolves it.
@@ -287,14 +298,16 @@ __device__ __forceinline__ int lane_code(uint32_t c) {
 // requests (PMC: ~1.0e8 of 5.2e8 fabric reads per launch were re-fetched read bytes).  So a refill fetches SBLK sub-blocks
 // back to back (the L1 merges requests to a line that is already on its way), keeps the first in registers and parks the
 // others in the lane's own LDS slots.  Measured per 10 M x 150 bp launch: 16 bytes per refill 9.28 ms, 48: 9.0, 64: 8.8,
-// 80: 8.5 (two refills per 150-base read), 96: 8.6, 112 and more: slower (the LDS they take costs resident waves).  Sub-blocks starting at or beyond the end of the read are not fetched, so nothing
-// beyond the 16 readable bytes after the last read is touched.
-__device__ __forceinline__ uint4 stream_refill(LaneLds *L, int lane, const uint8_t *seq, uint32_t p, uint32_t n) {
+// 80: 8.5 (two refills per 150-base read), 96: 8.6, 112 and more: slower (the LDS they take costs resident waves).  Sub-blocks
+// starting at or beyond the end of the read are not fetched, and the block that holds the last bytes of the caller's buffer
+// is assembled from byte loads (load_block16; `room` = bytes from seq to the end of the buffer): nothing outside the buffer
+// is touched.
+__device__ __forceinline__ uint4 stream_refill(LaneLds *L, int lane, const uint8_t *seq, uint32_t p, uint32_t n, uint32_t room) {
   uint4 v[SBLK];
 #pragma unroll
   for (int i = 0; i < SBLK; i++) {
     v[i] = make_uint4(0, 0, 0, 0);
-    if (p + 16u * i < n) __builtin_memcpy(&v[i], seq + p + 16u * i, 16);
+    if (p + 16u * i < n) v[i] = load_block16(seq + p + 16u * i, room - (p + 16u * i));
   }
 #pragma unroll
   for (int i = 1; i < SBLK; i++) L->sbuf[(i - 1) * 64 + lane] = v[i];
@@ -325,6 +338,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
   LaneLds *L = (LaneLds *)(lds_raw + (size_t)wib * per_wave);
   uint64_t *win = (uint64_t *)((unsigned char *)L + fixed);
   const bool paired = A.mate_bases != nullptr;
+  const uint64_t bases_end = A.offsets[A.R], mates_end = paired ? A.mate_offsets[A.R] : 0;  // (wave-uniform loads)
   const uint64_t ntiles = (A.R + 63) / 64;
   const uint64_t nwaves = (uint64_t)gridDim.x * LW;
 
@@ -334,17 +348,14 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     // ---- fragment descriptor ----
     const uint8_t *seq = A.bases;
     uint32_t n = 0, n2 = 0;
-    const uint8_t *seq2 = nullptr;
+    uint32_t room = 0;  // bytes from the fragment's first base to the end of the caller's buffer
     if (have) {
       uint64_t o = A.offsets[r];
       seq = A.bases + o;
       n = (uint32_t)(A.offsets[r + 1] - o);
-      if (dbg & 8) seq = A.bases + A.offsets[r & 1023];  // (timing experiment 8: the read stream comes from the L2)
-      if (paired) {
-        uint64_t o2 = A.mate_offsets[r];
-        seq2 = A.mate_bases + o2;
-        n2 = (uint32_t)(A.mate_offsets[r + 1] - o2);
-      }
+      room = clamp_room(bases_end - o);
+      SLK_TUNE(if (dbg & 8) { seq = A.bases + A.offsets[r & 1023]; room = clamp_room(bases_end - A.offsets[r & 1023]); })  // (timing experiment 8: the read stream comes from the L2)
+      if (paired) n2 = (uint32_t)(A.mate_offsets[r + 1] - A.mate_offsets[r]);  // (the mate's place is read again when the scan gets there)
     }
     bool too_long = have && ((uint64_t)n + n2 > max_len);
     bool fin = !have || too_long;
@@ -361,7 +372,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     uint32_t cur = 0, b1 = 0, b2 = 0, b3 = 0;  // 16 buffered characters
     int sb = 1;  // next staged sub-block (SBLK: none left, fetch)
     if (!fin && n > 0) {
-      uint4 v = stream_refill(L, lane, seq, 0, n);
+      uint4 v = stream_refill(L, lane, seq, 0, n, room);
       cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
     }
     int run_class = 0;
@@ -456,7 +467,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
           if (pos < n) {
             uint4 v;
             if (sb < SBLK) { v = L->sbuf[(sb - 1) * 64 + lane]; sb++; }
-            else { v = stream_refill(L, lane, seq, pos, n); sb = 1; }
+            else { v = stream_refill(L, lane, seq, pos, n, room); sb = 1; }
             cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
           }
         }
@@ -474,9 +485,10 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
             nhits++;
             first = false;
             mate = 1;
-            seq = seq2; n = n2; pos = 0;
+            const uint64_t o2 = A.mate_offsets[r];
+            seq = A.mate_bases + o2; n = (uint32_t)(A.mate_offsets[r + 1] - o2); room = clamp_room(mates_end - o2); pos = 0;
             if (n > 0) {
-              uint4 v = stream_refill(L, lane, seq, 0, n);
+              uint4 v = stream_refill(L, lane, seq, 0, n, room);
               sb = 1;
               cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
             }
@@ -520,7 +532,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
           int back = 0;
           if (MODE == LANE_EMIT) emit_batch(L, S, A.status, qhead, 64, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1));
           else if (MODE == LANE_APPLY) apply_batch(L, S, qhead, 64, lane);
-          else if (!(dbg & 1)) back = probe_batch<HITS>(L, A.T, qhead, qn, 64, lane, dbg, A.span_meta, A.span_taxon);
+          else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS>(L, A.T, qhead, qn, 64, lane, dbg, A.span_meta, A.span_taxon);
           qhead = (qhead + 64) & (QCAP - 1);
           qn += back - 64;
         }
@@ -532,7 +544,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       int back = 0;
       if (MODE == LANE_EMIT) emit_batch(L, S, A.status, qhead, cnt, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1));
       else if (MODE == LANE_APPLY) apply_batch(L, S, qhead, cnt, lane);
-      else if (!(dbg & 1)) back = probe_batch<HITS>(L, A.T, qhead, qn, cnt, lane, dbg, A.span_meta, A.span_taxon);
+      else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS>(L, A.T, qhead, qn, cnt, lane, dbg, A.span_meta, A.span_taxon);
       qhead = (qhead + cnt) & (QCAP - 1);
       qn += back - cnt;
     }
@@ -566,7 +578,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
           if (kk != 0) { D++; t0 = kk; c0 = M.cnt(s); }
         }
         int32_t maxTaxon = t0;  // D <= 1: the single taxon (or NONE)
-        if (D >= 2 && !(dbg & 16)) {  // resolveTree step 1 (:101-123): LCA of the taxa with the maximal root-path score  (16: timing experiment)
+        if (D >= 2 && !SLK_TUNE_ON(16)) {  // resolveTree step 1 (:101-123): LCA of the taxa with the maximal root-path score  (16: timing experiment)
           // A taxon's score is the k-mer count of the map taxa on its root path.  Instead of walking every root path to
           // the end (distinct taxa x depth parent loads), each taxon walks only to its NEAREST ancestor that is in the map;
           // the score is then the sum along those links, which stay in LDS.  (The probe queue's LDS is idle by now: it
@@ -592,7 +604,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
           }
         }
         for (int32_t c = 0; c < A.C; c++) {
-          double required = ceil(__dmul_rn(A.thresholds[c], (double)total));  // Math.ceil(confidence * totalKmers) :94
+          double required = ceil(__dmul_rn(A.thr.v[c], (double)total));  // Math.ceil(confidence * totalKmers) :94
           int32_t mt = maxTaxon;
           int32_t ms = (D >= 2) ? M.get(mt) : c0;                             // :125
           bool first_candidate = true;
@@ -647,7 +659,11 @@ static void launch_lane_mode(const FusedArgs &A, const ShardIO &S, int32_t *defe
   static const int bpc = getenv("SLK_LANE_BLOCKS_PER_CU") ? atoi(getenv("SLK_LANE_BLOCKS_PER_CU")) : 0;  // (tuning experiment)
   if (bpc > 0 && blocks > (uint64_t)256 * bpc) blocks = (uint64_t)256 * bpc;
   dim3 g((unsigned)blocks), b(LW * 64);
+#ifdef SLK_TUNING
   static const int dbg = getenv("SLK_DEBUG_ABLATE") ? atoi(getenv("SLK_DEBUG_ABLATE")) : 0;  // timing experiments only: 1 = no probes, 2 = no map updates
+#else
+  const int dbg = 0;
+#endif
   static bool occ_printed = false;
   if (getenv("SLK_DEBUG_OCC") && !occ_printed) {  // (tuning aid)
     occ_printed = true;

@@ -76,7 +76,7 @@ class ShardedClassifier:
 
     def classify(self, d_bases, d_offsets, R, total_bases, thresholds=(0.0,), min_hit_groups=2, fast=True, d_mate_bases=None,
                  d_mate_offsets=None, total_mate_bases=0):
-        """d_bases uint8 [total_bases + >=16 pad], d_offsets int64 [R+1] (device tensors); second mates likewise (optional)."""
+        """d_bases uint8 [total_bases], d_offsets int64 [R+1] (device tensors); second mates likewise (optional)."""
         mates = (d_mate_bases, d_mate_offsets, total_mate_bases) if d_mate_bases is not None else None
         if fast:
             out = self._classify_fast(d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups, mates)

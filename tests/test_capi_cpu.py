@@ -68,3 +68,11 @@ def test_header_is_plain_c(tmp_path):
                    'slk_hit h = {0, 0}; (void)p; (void)h; return slk_device_count() < 0; }\n')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)])
+
+
+def test_release_library_has_no_result_changing_switches():
+    """The timing experiments of the hot kernel (probes off, map updates off ...) exist only in a -DSLK_TUNING build: the shipped
+    library does not even hold the name of the environment variable that selects them."""
+    import slacken_amd
+    blob = open(slacken_amd.lib_path(), "rb").read()
+    assert b"SLK_DEBUG_ABLATE" not in blob

@@ -22,28 +22,28 @@ def big():
     dev = torch.device("cuda", 0)
     parents, taxa, leaves = bench.build_taxonomy()
     rng = np.random.default_rng(224)
-    G, GL = 256, 16384
-    genome_taxa = rng.choice(leaves, size=G, replace=False)
-    genomes = [np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, GL)] for _ in range(G)]
-    gkeys, gtax = bench.genome_records(slacken_amd, genomes, genome_taxa, parents, 0)
+    G, GL = 256, 1 << 20    # 2.7e8 genome bases: hit-bearing records spread over the whole table, as in the bench
+    genome_taxa = rng.choice(leaves, size=G, replace=False).astype(np.int32)
+    genome_cat = bench.make_genomes_device(torch, G, GL, 225, dev)
     ix = slacken_amd.Index(expected_records=n_records, max_taxon=bench.TAX_EXTENT - 1)
-    ix.append(gkeys, gtax)
+    ix.set_taxonomy(parents)
+    ix.add_sequences_device(genome_cat.data_ptr(), np.arange(0, (G + 1) * GL, GL, dtype=np.uint64), genome_taxa)
+    n_genome = int(ix.info().records)
     smask = ((2**62 - 1) & ~0x0CCCCCCC) << 2
     smask -= 1 << 64
     d_taxa = torch.from_numpy(taxa).to(dev)
     gen = torch.Generator(device=dev)
     gen.manual_seed(7)
-    for s in range(0, n_records - len(gkeys), 1 << 27):
-        n = min(1 << 27, n_records - len(gkeys) - s)
+    for s in range(0, n_records - n_genome, 1 << 27):
+        n = min(1 << 27, n_records - n_genome - s)
         keys = ((torch.randint(0, 2**32, (n,), generator=gen, device=dev, dtype=torch.int64) << 32) |
                 torch.randint(0, 2**32, (n,), generator=gen, device=dev, dtype=torch.int64)) & smask
         tx = d_taxa[torch.randint(0, len(taxa), (n,), generator=gen, device=dev)]
         torch.cuda.synchronize()
         ix.append_device(keys.data_ptr(), tx.data_ptr(), n)
         del keys, tx
-    ix.set_taxonomy(parents)
     ix.finalize()
-    bases, offsets = bench.make_reads_device(torch, torch.from_numpy(np.concatenate(genomes)).to(dev), GL, G, n_reads, 150, dev)
+    bases, offsets = bench.make_reads_device(torch, genome_cat, GL, G, n_reads, 150, dev)
     return dict(torch=torch, ix=ix, st=ix.stream(), bases=bases, offsets=offsets, R=n_reads, dev=dev,
                 ntax=bench.TAX_EXTENT)
 

@@ -143,9 +143,9 @@ def test_single_rank_paired(orc):
     b1, o1 = synth.pack(r1)
     b2, o2 = synth.pack(r2)
     dev = torch.device("cuda", 0)
-    pad = torch.full((64,), 65, dtype=torch.uint8)
-    d = [torch.cat([torch.from_numpy(b1), pad]).to(dev), torch.from_numpy(o1.astype(np.int64)).to(dev),
-         torch.cat([torch.from_numpy(b2), pad]).to(dev), torch.from_numpy(o2.astype(np.int64)).to(dev)]
+    # (device buffers are exactly offsets[R] bytes: the kernels read nothing past them)
+    d = [torch.from_numpy(b1).to(dev), torch.from_numpy(o1.astype(np.int64)).to(dev),
+         torch.from_numpy(b2).to(dev), torch.from_numpy(o2.astype(np.int64)).to(dev)]
     R = len(r1)
     want = orc.classify_batch(p, orc.Index(1, lib.keys, lib.taxa), parents, b1, o1, b2, o2, thresholds=(0.0, 0.15))
     sc = sharded.ShardedClassifier(ix, 0, 1, None, dev)
