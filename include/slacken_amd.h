@@ -110,6 +110,14 @@ int32_t slk_device_count(void);
 const char *slk_last_error(void);
 const char *slk_version(void);
 
+/* Pinned host memory.  The host entry points accept any host memory; buffers that come from slk_host_alloc (or were
+ * registered with slk_host_register: long-lived caller buffers, e.g. a JVM direct ByteBuffer) are DMA'd from and to
+ * directly, at PCIe rate, instead of being copied through the stream's staging buffers.  A pointer anywhere inside such a
+ * buffer qualifies.  slk_host_free takes the pointer slk_host_alloc returned / slk_host_register was given. */
+int32_t slk_host_alloc(size_t bytes, void **out);
+int32_t slk_host_register(void *ptr, size_t bytes);
+int32_t slk_host_free(void *ptr);
+
 /* ---- index: replaces KeyValueIndex.load / loadRecords (S/slacken/KeyValueIndex.scala:150-159,413-426) ---- */
 int32_t slk_index_create(const slk_params *params, const slk_table_config *cfg, int32_t device, slk_index **out);
 /* Append records (id1: int64 left-aligned minimizer, taxon: int32) -- the rows of the Parquet table, in any order

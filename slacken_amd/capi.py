@@ -42,7 +42,7 @@ SPAN_DTYPE = np.dtype([("key", "<i8"), ("kmers", "<i4"), ("flag", "i1"), ("disti
 HIT_DTYPE = np.dtype([("taxon", "<i4"), ("count", "<i4")])
 
 # every symbol include/slacken_amd.h declares
-EXPORTS = ["slk_device_count", "slk_last_error", "slk_version", "slk_index_create", "slk_index_append",
+EXPORTS = ["slk_device_count", "slk_last_error", "slk_version", "slk_host_alloc", "slk_host_register", "slk_host_free", "slk_index_create", "slk_index_append",
            "slk_index_append_device", "slk_index_set_taxonomy", "slk_index_finalize", "slk_index_get_info",
            "slk_index_lookup", "slk_index_add_sequences", "slk_index_add_sequences_device", "slk_index_export", "slk_index_destroy", "slk_stream_create", "slk_stream_synchronize",
            "slk_stream_hip_stream", "slk_stream_destroy", "slk_spans_batch", "slk_classify_batch",
@@ -73,6 +73,9 @@ def lib():
     L.slk_device_count.restype = C.c_int32
     L.slk_last_error.restype = C.c_char_p
     L.slk_version.restype = C.c_char_p
+    L.slk_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.slk_host_register.argtypes = [vp, C.c_size_t]
+    L.slk_host_free.argtypes = [vp]
     L.slk_index_create.argtypes = [C.POINTER(_Params), C.POINTER(_TableConfig), C.c_int32, C.POINTER(vp)]
     L.slk_index_append.argtypes = [vp, i64p, i32p, C.c_uint64]
     L.slk_index_append_device.argtypes = [vp, i64p, i32p, C.c_uint64]
@@ -130,6 +133,29 @@ def _np(a, dtype):
 
 def _ptr(a):
     return a.ctypes.data if a is not None else None
+
+
+def pinned_array(shape, dtype):
+    """A numpy array in pinned host memory (slk_host_alloc): the host entry points DMA from and to it directly.
+    Keep the array (or a view of it) alive while it is in use; the memory is freed with the array's base object."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    p = C.c_void_p()
+    _check(lib().slk_host_alloc(max(n, 1), C.byref(p)))
+
+    class _Owner:
+        def __init__(self, addr):
+            self.addr = addr
+
+        def __del__(self):
+            try:
+                lib().slk_host_free(self.addr)
+            except Exception:
+                pass
+
+    buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
+    buf._owner = _Owner(p.value)   # freed when the last view goes
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
 @dataclass
@@ -252,16 +278,23 @@ class Stream:
         return out_off, out[:int(out_off[R])]
 
     def classify_batch(self, bases, offsets, mate_bases=None, mate_offsets=None, min_hit_groups=2,
-                       thresholds=(0.0,), with_hits=True, hits_capacity=None, with_num_hits=False):
+                       thresholds=(0.0,), with_hits=True, hits_capacity=None, with_num_hits=False, out=None):
+        """out: optional dict of preallocated result arrays (taxon [C,R] int32, classified [C,R] uint8, num_distinct [R],
+        total_kmers [R]) -- e.g. pinned_array()s, which the library fills by DMA."""
         bases, offsets = _np(bases, np.uint8), _np(offsets, np.uint64)
         R = offsets.size - 1
         if mate_bases is not None:
             mate_bases, mate_offsets = _np(mate_bases, np.uint8), _np(mate_offsets, np.uint64)
         Cn = len(thresholds)
         thr = (C.c_double * Cn)(*thresholds)
-        taxon = np.zeros((Cn, R), np.int32)
-        cls = np.zeros((Cn, R), np.uint8)
-        nd, tk = np.zeros(R, np.int32), np.zeros(R, np.int32)
+        if out is not None:
+            taxon, cls, nd, tk = out["taxon"], out["classified"], out["num_distinct"], out["total_kmers"]
+            assert taxon.shape == (Cn, R) and taxon.dtype == np.int32 and cls.shape == (Cn, R) and cls.dtype == np.uint8
+            assert all(a.flags.c_contiguous for a in (taxon, cls, nd, tk))
+        else:
+            taxon = np.zeros((Cn, R), np.int32)
+            cls = np.zeros((Cn, R), np.uint8)
+            nd, tk = np.zeros(R, np.int32), np.zeros(R, np.int32)
         hit_off = hits = None
         cap = 0
         if with_hits:

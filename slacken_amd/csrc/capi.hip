@@ -10,7 +10,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace slk;
@@ -54,16 +59,122 @@ struct DevBuf {
   template <class T> T *as() const { return (T *)p; }
 };
 
-// Two pinned buffers: every copy between the caller's memory and HBM goes through them (copy_in / copy_out), so the
+// ---- host side of the copies ----------------------------------------------------------------------------------------------
+// A few threads that move bytes between the caller's (pageable) memory and the pinned staging buffers: one thread copies
+// at 10-12 GB/s, PCIe Gen5 x16 takes ~55.  Started on first use; SLK_COPY_THREADS (default 6, 1 = the calling thread only).
+class HostPool {
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(size_t)> *fn_ = nullptr;
+  size_t next_ = 0, n_ = 0, active_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+  std::mutex call_mu_;  // one parallel_for at a time (others wait: the pool is for memory-bound copies)
+
+  void worker() {
+    uint64_t seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&] { return stop_ || (gen_ != seen && fn_); });
+      if (stop_) return;
+      seen = gen_;
+      while (fn_ && next_ < n_) {
+        size_t i = next_++;
+        active_++;
+        const std::function<void(size_t)> *f = fn_;
+        lk.unlock();
+        (*f)(i);
+        lk.lock();
+        active_--;
+      }
+      done_.notify_all();
+    }
+  }
+
+ public:
+  explicit HostPool(size_t n) { for (size_t i = 0; i + 1 < n; i++) th_.emplace_back([this] { worker(); }); }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+  size_t size() const { return th_.size() + 1; }
+  void parallel_for(size_t n, const std::function<void(size_t)> &f) {  // f(0) .. f(n-1), the caller takes part
+    if (n == 0) return;
+    if (th_.empty() || n == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+    std::lock_guard<std::mutex> call(call_mu_);
+    std::unique_lock<std::mutex> lk(mu_);
+    fn_ = &f; next_ = 0; n_ = n; gen_++;
+    cv_.notify_all();
+    while (next_ < n_) {
+      size_t i = next_++;
+      active_++;
+      lk.unlock();
+      f(i);
+      lk.lock();
+      active_--;
+    }
+    done_.wait(lk, [&] { return active_ == 0; });
+    fn_ = nullptr;
+  }
+};
+static HostPool &host_pool() {
+  static HostPool *pool = [] {
+    const char *e = getenv("SLK_COPY_THREADS");
+    long n = e ? atol(e) : 6;
+    unsigned hc = std::thread::hardware_concurrency();
+    if (hc && n > (long)hc) n = hc;
+    return new HostPool((size_t)std::max<long>(1, n));  // (never destroyed: worker threads must not be joined at process exit)
+  }();
+  return *pool;
+}
+static void parallel_memcpy(void *dst, const void *src, size_t n) {
+  const size_t SLICE = (size_t)1 << 20;
+  if (n <= 2 * SLICE) { memcpy(dst, src, n); return; }
+  const size_t parts = std::min(host_pool().size(), (n + SLICE - 1) / SLICE);
+  const size_t per = ((n + parts - 1) / parts + 63) & ~(size_t)63;
+  host_pool().parallel_for(parts, [&](size_t i) {
+    const size_t a = i * per, b = std::min(n, a + per);
+    if (a < b) memcpy((char *)dst + a, (const char *)src + a, b - a);
+  });
+}
+
+// Host memory the library has pinned (slk_host_alloc / slk_host_register): copies from and to it are DMA'd directly.
+struct PinnedRanges {
+  std::mutex mu;
+  std::map<uintptr_t, std::pair<size_t, bool>> ranges;  // start -> (bytes, allocated by us)
+  void add(void *p, size_t n, bool owned) { std::lock_guard<std::mutex> lk(mu); ranges[(uintptr_t)p] = {n, owned}; }
+  bool remove(void *p, bool *owned) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = ranges.find((uintptr_t)p);
+    if (it == ranges.end()) return false;
+    *owned = it->second.second;
+    ranges.erase(it);
+    return true;
+  }
+  bool covers(const void *p, size_t n) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (ranges.empty()) return false;
+    auto it = ranges.upper_bound((uintptr_t)p);
+    if (it == ranges.begin()) return false;
+    --it;
+    return (uintptr_t)p + n <= it->first + it->second.first;
+  }
+};
+static PinnedRanges &pinned() { static PinnedRanges *r = new PinnedRanges(); return *r; }
+
+// Pinned staging buffers: every copy between PAGEABLE caller memory and HBM goes through them (copy_in / copy_out), so the
 // runtime never has to pin the caller's pages for DMA -- that path took tens of ms per call once an application with many
-// threads was mapping and unmapping memory around it.
+// threads was mapping and unmapping memory around it.  Memory from slk_host_alloc / slk_host_register skips them.
+constexpr int N_STAGE = 3;
 struct Staging {
-  void *buf[2] = {nullptr, nullptr};
-  hipEvent_t ev[2] = {nullptr, nullptr};
-  bool busy[2] = {false, false};
+  void *buf[N_STAGE] = {};
+  hipEvent_t ev[N_STAGE] = {};
+  bool busy[N_STAGE] = {};
   int next = 0;
   void release() {
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < N_STAGE; i++) {
       if (buf[i]) (void)hipHostFree(buf[i]);
       if (ev[i]) (void)hipEventDestroy(ev[i]);
       buf[i] = nullptr; ev[i] = nullptr; busy[i] = false;
@@ -116,6 +227,11 @@ struct slk_stream {
   int32_t *h_status = nullptr;     // pinned copy, refreshed after every classify launch
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   Staging staging;
+  // large host-pointer calls: the reads go up on a second stream, sub-batch by sub-batch, while the kernels of the
+  // sub-batches before run on s (slk_classify_batch)
+  hipStream_t cs = nullptr;
+  Staging staging_c;
+  std::vector<hipEvent_t> up_ev;
   bool timed = false;
   bool last_used_lane = false;  // the last classify call ran the lane kernel (defer_list[0] is its deferral count)
   // The arguments of every classify call queued since the stream was last synchronised, for the unbounded re-run
@@ -125,7 +241,7 @@ struct slk_stream {
     Thresholds thr{};
     const uint8_t *bases = nullptr, *mate_bases = nullptr;
     const uint64_t *offsets = nullptr, *mate_offsets = nullptr;
-    uint64_t R = 0, total = 0, mate_total = 0;
+    uint64_t R = 0, total = 0, mate_total = 0, out_stride = 0;
     int32_t min_hit_groups = 0, C = 0;
     int32_t *out_taxon = nullptr, *out_nd = nullptr, *out_tk = nullptr, *out_nh = nullptr, *out_np = nullptr;
     uint8_t *out_cls = nullptr;
@@ -135,27 +251,34 @@ struct slk_stream {
 
 static int32_t check_status(slk_stream *st);
 
-static const size_t STAGE_BYTES = (size_t)4 << 20;
+static const size_t STAGE_BYTES = (size_t)8 << 20;
 
 static int32_t stage_ready(Staging *g) {
   if (g->buf[0]) return SLK_OK;
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < N_STAGE; i++) {
     HIPCHK(hipHostMalloc(&g->buf[i], STAGE_BYTES, hipHostMallocDefault));
     HIPCHK(hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming));
   }
   return SLK_OK;
 }
 
-// caller memory -> HBM, ordered on s.  The caller's buffer is free on return; the last DMA may still be in flight.
+// caller memory -> HBM, ordered on s.  The caller's buffer is free on return unless it is pinned memory of the library
+// (then the DMA reads it directly and is complete when s has been synchronised -- every host entry point does before it
+// returns); the last DMA may still be in flight.
 static int32_t copy_in(Staging *g, hipStream_t s, void *d_dst, const void *h_src, size_t n) {
+  if (n == 0) return SLK_OK;
+  if (pinned().covers(h_src, n)) {
+    HIPCHK(hipMemcpyAsync(d_dst, h_src, n, hipMemcpyHostToDevice, s));
+    return SLK_OK;
+  }
   int32_t rc = stage_ready(g);
   if (rc) return rc;
   for (size_t o = 0; o < n; o += STAGE_BYTES) {
     const size_t len = std::min(STAGE_BYTES, n - o);
     const int b = g->next;
-    g->next ^= 1;
-    if (g->busy[b]) HIPCHK(hipEventSynchronize(g->ev[b]));  // the DMA that last read this buffer
-    memcpy(g->buf[b], (const char *)h_src + o, len);
+    g->next = (g->next + 1) % N_STAGE;
+    if (g->busy[b]) HIPCHK(hipEventSynchronize(g->ev[b]));  // the DMA that last used this buffer
+    parallel_memcpy(g->buf[b], (const char *)h_src + o, len);
     HIPCHK(hipMemcpyAsync((char *)d_dst + o, g->buf[b], len, hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(g->ev[b], s));
     g->busy[b] = true;
@@ -166,26 +289,32 @@ static int32_t copy_in(Staging *g, hipStream_t s, void *d_dst, const void *h_src
 // HBM -> caller memory, after everything queued on s; complete on return.  The DMA of one piece overlaps the copy of the
 // piece before it into the caller's buffer.
 static int32_t copy_out(Staging *g, hipStream_t s, void *h_dst, const void *d_src, size_t n) {
+  if (n == 0) return SLK_OK;
+  if (pinned().covers(h_dst, n)) {
+    HIPCHK(hipMemcpyAsync(h_dst, d_src, n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return SLK_OK;
+  }
   int32_t rc = stage_ready(g);
   if (rc) return rc;
   size_t prev_o = 0, prev_len = 0;
   int prev_b = -1;
   for (size_t o = 0; o < n; o += STAGE_BYTES) {
     const size_t len = std::min(STAGE_BYTES, n - o);
-    const int b = prev_b < 0 ? 0 : prev_b ^ 1;
+    const int b = prev_b < 0 ? 0 : (prev_b + 1) % N_STAGE;
     // (stream order protects the buffer: an earlier copy_in DMA out of it is queued before this write into it)
     HIPCHK(hipMemcpyAsync(g->buf[b], (const char *)d_src + o, len, hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(g->ev[b], s));
     g->busy[b] = true;
     if (prev_b >= 0) {
       HIPCHK(hipEventSynchronize(g->ev[prev_b]));
-      memcpy((char *)h_dst + prev_o, g->buf[prev_b], prev_len);
+      parallel_memcpy((char *)h_dst + prev_o, g->buf[prev_b], prev_len);
     }
     prev_b = b; prev_o = o; prev_len = len;
   }
   if (prev_b >= 0) {
     HIPCHK(hipEventSynchronize(g->ev[prev_b]));
-    memcpy((char *)h_dst + prev_o, g->buf[prev_b], prev_len);
+    parallel_memcpy((char *)h_dst + prev_o, g->buf[prev_b], prev_len);
   }
   return SLK_OK;
 }
@@ -205,6 +334,31 @@ extern "C" {
 
 const char *slk_last_error(void) { return g_err.c_str(); }
 const char *slk_version(void) { return "slacken_amd 0.1 (gfx950)"; }
+
+// Pinned host memory: buffers the host entry points can DMA from and to directly, without the staging copy.
+int32_t slk_host_alloc(size_t bytes, void **out) {
+  if (!out) return fail(SLK_E_INVALID, "null argument");
+  *out = nullptr;
+  void *p = nullptr;
+  HIPCHK(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
+  pinned().add(p, bytes ? bytes : 1, true);
+  *out = p;
+  return SLK_OK;
+}
+int32_t slk_host_register(void *ptr, size_t bytes) {
+  if (!ptr || !bytes) return fail(SLK_E_INVALID, "null argument");
+  HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  pinned().add(ptr, bytes, false);
+  return SLK_OK;
+}
+int32_t slk_host_free(void *ptr) {  // memory of slk_host_alloc is freed, memory of slk_host_register is unpinned
+  if (!ptr) return SLK_OK;
+  bool owned = false;
+  if (!pinned().remove(ptr, &owned)) return fail(SLK_E_INVALID, "not a pointer of slk_host_alloc / slk_host_register");
+  if (owned) HIPCHK(hipHostFree(ptr));
+  else HIPCHK(hipHostUnregister(ptr));
+  return SLK_OK;
+}
 
 int32_t slk_device_count(void) {
   int n = 0;
@@ -642,6 +796,9 @@ void slk_stream_destroy(slk_stream *st) {
   if (st->d_status) (void)hipFree(st->d_status);
   if (st->h_status) (void)hipHostFree(st->h_status);
   st->staging.release();
+  st->staging_c.release();
+  for (hipEvent_t e : st->up_ev) (void)hipEventDestroy(e);
+  if (st->cs) (void)hipStreamDestroy(st->cs);
   for (int i = 0; i < 4; i++) if (st->ev[i]) (void)hipEventDestroy(st->ev[i]);
   if (st->s) (void)hipStreamDestroy(st->s);
   delete st;
@@ -698,7 +855,7 @@ static int32_t run_unbounded(slk_stream *st, const slk_stream::LastCall &L) {
                st->span_count.as<int32_t>(), st->span_taxon.as<int32_t>(), st->s);
   launch_classify(ix->d_parents, ix->T, L.offsets, L.mate_offsets, L.R, st->span_meta.as<int32_t>(),
                   st->span_taxon.as<int32_t>(), st->span_count.as<int32_t>(), st->span_keys.as<uint64_t>(),
-                  L.min_hit_groups, L.thr, L.C, L.out_taxon, L.out_cls, L.out_nd, L.out_tk, L.out_nh, L.out_np, st->s);
+                  L.min_hit_groups, L.thr, L.C, L.out_stride, L.out_taxon, L.out_cls, L.out_nd, L.out_tk, L.out_nh, L.out_np, st->s);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st->s));
   return SLK_OK;
@@ -736,7 +893,8 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
                             uint64_t total_bases, uint64_t total_mate_bases, int32_t min_hit_groups,
                             const double *thresholds, int32_t C, int32_t *d_out_taxon, uint8_t *d_out_classified,
                             int32_t *d_out_num_distinct, int32_t *d_out_total_kmers, int32_t *d_out_num_hits,
-                            int32_t *d_out_num_probes, bool want_hits) {
+                            int32_t *d_out_num_probes, bool want_hits, uint64_t out_stride = 0) {
+  if (out_stride == 0) out_stride = R;
   bool paired = d_mate_bases != nullptr;
   bool fused = use_fused(ix);
   int32_t rc;
@@ -759,6 +917,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
     L.valid = fused; L.want_hits = want_hits; L.thr = thr;
     L.bases = d_bases; L.offsets = d_offsets; L.mate_bases = d_mate_bases; L.mate_offsets = d_mate_offsets;
     L.R = R; L.total = total_bases; L.mate_total = total_mate_bases; L.min_hit_groups = min_hit_groups; L.C = C;
+    L.out_stride = out_stride;
     L.out_taxon = d_out_taxon; L.out_cls = d_out_classified; L.out_nd = d_out_num_distinct; L.out_tk = d_out_total_kmers;
     L.out_nh = d_out_num_hits; L.out_np = d_out_num_probes;
   }
@@ -766,6 +925,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
     FusedArgs A{};
     A.P = ix->sp; A.T = ix->view(); A.parents = ix->d_parents; A.ntax = ix->T;
     A.bases = d_bases; A.offsets = d_offsets; A.mate_bases = d_mate_bases; A.mate_offsets = d_mate_offsets; A.R = R;
+    A.out_stride = out_stride;
     A.min_hit_groups = min_hit_groups; A.thr = thr; A.C = C;
     A.out_taxon = d_out_taxon; A.out_classified = d_out_classified;
     A.out_nd = d_out_num_distinct; A.out_tk = d_out_total_kmers; A.out_nh = d_out_num_hits; A.out_np = d_out_num_probes;
@@ -814,7 +974,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
     // the key slots are dead after the probe: the per-read taxon->count map reuses them
     launch_classify(ix->d_parents, ix->T, d_offsets, d_mate_offsets, R, st->span_meta.as<int32_t>(),
                     st->span_taxon.as<int32_t>(), st->span_count.as<int32_t>(), st->span_keys.as<uint64_t>(),
-                    min_hit_groups, thr, C, d_out_taxon, d_out_classified, d_out_num_distinct,
+                    min_hit_groups, thr, C, out_stride, d_out_taxon, d_out_classified, d_out_num_distinct,
                     d_out_total_kmers, d_out_num_hits, d_out_num_probes, st->s);
   }
   HIPCHK(hipEventRecord(st->ev[3], st->s));
@@ -945,6 +1105,7 @@ int32_t slk_shard_apply_device(slk_index *ix, slk_stream *st, const uint8_t *d_b
   FusedArgs A{};
   A.P = ix->sp; A.parents = ix->d_parents; A.ntax = ix->T;
   A.bases = d_bases; A.offsets = d_offsets; A.mate_bases = d_mate_bases; A.mate_offsets = d_mate_offsets; A.R = R;
+  A.out_stride = R;
   A.min_hit_groups = min_hit_groups; A.thr = thr; A.C = C;
   A.out_taxon = d_out_taxon; A.out_classified = d_out_classified;
   A.out_nd = d_out_num_distinct; A.out_tk = d_out_total_kmers; A.out_nh = d_out_num_hits;
@@ -974,7 +1135,7 @@ int32_t slk_classify_hits_device(slk_index *ix, slk_stream *st, const uint64_t *
   Thresholds thr{};
   memcpy(thr.v, thresholds, C * sizeof(double));
   launch_classify(ix->d_parents, ix->T, d_offsets, d_mate_offsets, R, d_span_meta, d_span_taxon, d_span_count, d_scratch,
-                  min_hit_groups, thr, C, d_out_taxon, d_out_classified, d_out_num_distinct,
+                  min_hit_groups, thr, C, R, d_out_taxon, d_out_classified, d_out_num_distinct,
                   d_out_total_kmers, d_out_num_hits, nullptr, st->s);
   HIPCHK(hipGetLastError());
   return SLK_OK;
@@ -1029,7 +1190,7 @@ int32_t slk_classify_hits(slk_index *ix, slk_stream *st, uint64_t R, const uint6
   memcpy(thr.v, thresholds, C * sizeof(double));
   launch_classify(ix->d_parents, ix->T, st->offsets.as<uint64_t>(), nullptr, R, st->span_meta.as<int32_t>(),
                   st->span_taxon.as<int32_t>(), st->span_count.as<int32_t>(), st->span_keys.as<uint64_t>(), min_hit_groups,
-                  thr, C, st->out_taxon.as<int32_t>(), st->out_cls.as<uint8_t>(), st->out_nd.as<int32_t>(),
+                  thr, C, R, st->out_taxon.as<int32_t>(), st->out_cls.as<uint8_t>(), st->out_nd.as<int32_t>(),
                   st->out_tk.as<int32_t>(), nullptr, nullptr, st->s);
   HIPCHK(hipGetLastError());
   rc = copy_out(st, out_taxon, st->out_taxon.p, (size_t)C * R * 4);
@@ -1061,20 +1222,34 @@ int32_t slk_stream_last_stage_ms(slk_stream *st, float out_ms[3]) {
   return SLK_OK;
 }
 
+static int32_t validate_reads(const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R) {
+  // (4 M reads are 4 M compares per array: split over the copy threads)
+  const uint64_t PART = 1 << 18;
+  const uint64_t parts = (R + PART - 1) / PART;
+  std::vector<uint64_t> bad(parts, ~0ULL);
+  host_pool().parallel_for(parts, [&](size_t pi) {
+    const uint64_t r1 = std::min<uint64_t>(R, (pi + 1) * PART);
+    for (uint64_t r = pi * PART; r < r1; r++) {
+      const bool ok = offsets[r + 1] >= offsets[r] && offsets[r + 1] - offsets[r] <= 0x7fffffffULL &&
+                      (!mate_offsets || (mate_offsets[r + 1] >= mate_offsets[r] && mate_offsets[r + 1] - mate_offsets[r] <= 0x7fffffffULL));
+      if (!ok) { bad[pi] = r; break; }
+    }
+  });
+  for (uint64_t b : bad)
+    if (b != ~0ULL)
+      return fail(SLK_E_INVALID, "offsets (and mate_offsets) must be non-decreasing with reads shorter than 2^31 (read %llu)", (unsigned long long)b);
+  return SLK_OK;
+}
+
 static int32_t upload_reads(slk_stream *st, const uint8_t *bases, const uint64_t *offsets, const uint8_t *mate_bases,
                             const uint64_t *mate_offsets, uint64_t R, uint64_t *total, uint64_t *mate_total) {
-  for (uint64_t r = 0; r < R; r++) {
-    if (offsets[r + 1] < offsets[r] || offsets[r + 1] - offsets[r] > 0x7fffffffULL)
-      return fail(SLK_E_INVALID, "offsets must be non-decreasing with reads shorter than 2^31 (read %llu)",
-                  (unsigned long long)r);
-    if (mate_offsets && (mate_offsets[r + 1] < mate_offsets[r] || mate_offsets[r + 1] - mate_offsets[r] > 0x7fffffffULL))
-      return fail(SLK_E_INVALID, "mate_offsets must be non-decreasing (read %llu)", (unsigned long long)r);
-  }
+  int32_t rc = validate_reads(offsets, mate_offsets, R);
+  if (rc) return rc;
   *total = offsets[R];
   *mate_total = mate_offsets ? mate_offsets[R] : 0;
   HIPCHK(st->bases.ensure(*total));
   HIPCHK(st->offsets.ensure((R + 1) * 8));
-  int32_t rc = copy_in(st, st->bases.p, bases, *total);
+  rc = copy_in(st, st->bases.p, bases, *total);
   if (!rc) rc = copy_in(st, st->offsets.p, offsets, (R + 1) * 8);
   if (rc) return rc;
   if (mate_offsets) {
@@ -1169,23 +1344,70 @@ int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, 
   static const bool call_timing = getenv("SLK_DEBUG_CALL_TIMING") != nullptr;  // tuning aid: wall clock of the phases of a call
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tp[6] = {now(), 0, 0, 0, 0, 0};
-  uint64_t total, mate_total;
-  rc = upload_reads(st, bases, offsets, mate_bases, mate_offsets, R, &total, &mate_total);
-  if (rc) return rc;
-  if (call_timing) { (void)hipStreamSynchronize(st->s); tp[1] = now(); }
-  bool paired = mate_offsets != nullptr;
+  uint64_t total = 0, mate_total = 0;
+  const bool paired = mate_offsets != nullptr;
+  const bool want_hits = out_hit_offsets != nullptr && out_hits != nullptr;
   HIPCHK(st->out_taxon.ensure((size_t)C * R * 4));
   HIPCHK(st->out_cls.ensure((size_t)C * R));
   HIPCHK(st->out_nd.ensure(R * 4));
   HIPCHK(st->out_tk.ensure(R * 4));
   HIPCHK(st->out_nh.ensure(R * 4));
+  // A large call is cut into sub-batches: the reads of sub-batch i+1 go up (on a second stream) while the kernels of
+  // sub-batch i run, so the call costs its upload plus ONE sub-batch of kernel time.  (Calls that want the hit lists
+  // keep the one-piece route: their cost is the download of the lists.)
+  const char *sub_env = getenv("SLK_HOST_SUBBATCH");  // (read per call, so that tests can move it)
+  const uint64_t SUB = sub_env ? (uint64_t)std::max(1L, atol(sub_env)) : (uint64_t)1 << 18;
+  if (!want_hits && use_fused(ix) && R >= 2 * SUB) {
+    rc = validate_reads(offsets, mate_offsets, R);
+    if (rc) return rc;
+    total = offsets[R];
+    mate_total = paired ? mate_offsets[R] : 0;
+    HIPCHK(st->bases.ensure(total));
+    HIPCHK(st->offsets.ensure((R + 1) * 8));
+    if (paired) {
+      HIPCHK(st->mate_bases.ensure(mate_total));
+      HIPCHK(st->mate_offsets.ensure((R + 1) * 8));
+    }
+    if (!st->cs) HIPCHK(hipStreamCreateWithFlags(&st->cs, hipStreamNonBlocking));
+    const uint64_t nsub = (R + SUB - 1) / SUB;
+    while (st->up_ev.size() < nsub) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      st->up_ev.push_back(e);
+    }
+    rc = copy_in(&st->staging_c, st->cs, st->offsets.p, offsets, (R + 1) * 8);
+    if (!rc && paired) rc = copy_in(&st->staging_c, st->cs, st->mate_offsets.p, mate_offsets, (R + 1) * 8);
+    if (rc) return rc;
+    for (uint64_t i = 0; i < nsub; i++) {
+      const uint64_t r0 = i * SUB, r1 = std::min(R, r0 + SUB), n = r1 - r0;
+      rc = copy_in(&st->staging_c, st->cs, st->bases.as<uint8_t>() + offsets[r0], bases + offsets[r0], offsets[r1] - offsets[r0]);
+      if (!rc && paired)
+        rc = copy_in(&st->staging_c, st->cs, st->mate_bases.as<uint8_t>() + mate_offsets[r0], mate_bases + mate_offsets[r0],
+                     mate_offsets[r1] - mate_offsets[r0]);
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(st->up_ev[i], st->cs));
+      HIPCHK(hipStreamWaitEvent(st->s, st->up_ev[i], 0));
+      rc = run_classify(ix, st, st->bases.as<uint8_t>(), st->offsets.as<uint64_t>() + r0, paired ? st->mate_bases.as<uint8_t>() : nullptr,
+                        paired ? st->mate_offsets.as<uint64_t>() + r0 : nullptr, n, offsets[r1] - offsets[r0],
+                        paired ? mate_offsets[r1] - mate_offsets[r0] : 0, min_hit_groups, thresholds, C, st->out_taxon.as<int32_t>() + r0,
+                        st->out_cls.as<uint8_t>() + r0, st->out_nd.as<int32_t>() + r0, st->out_tk.as<int32_t>() + r0,
+                        st->out_nh.as<int32_t>() + r0, nullptr, false, R);
+      if (rc) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(st->cs));  // (the caller's buffers are free from here on)
+    if (call_timing) tp[1] = now();
+  } else {
+    rc = upload_reads(st, bases, offsets, mate_bases, mate_offsets, R, &total, &mate_total);
+    if (rc) return rc;
+    if (call_timing) { (void)hipStreamSynchronize(st->s); tp[1] = now(); }
+    rc = run_classify(ix, st, st->bases.as<uint8_t>(), st->offsets.as<uint64_t>(), paired ? st->mate_bases.as<uint8_t>() : nullptr,
+                      paired ? st->mate_offsets.as<uint64_t>() : nullptr, R, total, mate_total, min_hit_groups, thresholds, C,
+                      st->out_taxon.as<int32_t>(), st->out_cls.as<uint8_t>(), st->out_nd.as<int32_t>(), st->out_tk.as<int32_t>(),
+                      st->out_nh.as<int32_t>(), nullptr, want_hits);
+    if (rc) return rc;
+  }
   const uint64_t *d_off = st->offsets.as<uint64_t>();
   const uint64_t *d_moff = paired ? st->mate_offsets.as<uint64_t>() : nullptr;
-  rc = run_classify(ix, st, st->bases.as<uint8_t>(), d_off, paired ? st->mate_bases.as<uint8_t>() : nullptr, d_moff, R,
-                    total, mate_total, min_hit_groups, thresholds, C, st->out_taxon.as<int32_t>(),
-                    st->out_cls.as<uint8_t>(), st->out_nd.as<int32_t>(), st->out_tk.as<int32_t>(),
-                    st->out_nh.as<int32_t>(), nullptr, out_hit_offsets != nullptr && out_hits != nullptr);
-  if (rc) return rc;
   HIPCHK(hipStreamSynchronize(st->s));
   tp[2] = now();
   rc = check_status(st);  // (re-runs the batch through the unbounded path if a taxon map overflowed)

@@ -121,6 +121,7 @@ struct FusedArgs {
   const uint8_t *mate_bases;
   const uint64_t *mate_offsets;
   uint64_t R;
+  uint64_t out_stride;   // out_taxon / out_classified are [C][out_stride] (= R unless this launch is a sub-batch of a larger call)
   int32_t min_hit_groups;
   Thresholds thr;
   int32_t C;
@@ -184,7 +185,7 @@ void launch_probe(const TableView &T, const uint64_t *offsets, const uint64_t *m
                   hipStream_t s);
 void launch_classify(const int32_t *parents, int32_t T, const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R,
                      const int32_t *span_meta, const int32_t *span_taxon, const int32_t *span_count,
-                     uint64_t *map_scratch, int32_t min_hit_groups, const Thresholds &thr, int32_t C,
+                     uint64_t *map_scratch, int32_t min_hit_groups, const Thresholds &thr, int32_t C, uint64_t out_stride,
                      int32_t *out_taxon, uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers,
                      int32_t *out_num_hits, int32_t *out_num_probes, hipStream_t s);
 void launch_gather_spans(const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, const uint64_t *span_keys,

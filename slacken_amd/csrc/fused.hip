@@ -315,8 +315,8 @@ __device__ __forceinline__ void resolve_map(WaveLds *L, const FusedArgs &A, uint
     }
     bool classified = (mt != 0) && (nd >= A.min_hit_groups);  // Classifier.scala:445
     if (lane == 0) {
-      A.out_taxon[(uint64_t)c * A.R + r] = classified ? mt : 0;
-      A.out_classified[(uint64_t)c * A.R + r] = classified ? 1 : 0;
+      A.out_taxon[(uint64_t)c * A.out_stride + r] = classified ? mt : 0;
+      A.out_classified[(uint64_t)c * A.out_stride + r] = classified ? 1 : 0;
     }
   }
 }
@@ -574,8 +574,8 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
         int32_t mt = (t0 != 0 && !((double)c0 < required)) ? t0 : 0;
         bool classified = (mt != 0) && (nd >= A.min_hit_groups);
         if (lane == 0) {
-          A.out_taxon[(uint64_t)c * A.R + r] = classified ? mt : 0;
-          A.out_classified[(uint64_t)c * A.R + r] = classified ? 1 : 0;
+          A.out_taxon[(uint64_t)c * A.out_stride + r] = classified ? mt : 0;
+          A.out_classified[(uint64_t)c * A.out_stride + r] = classified ? 1 : 0;
         }
       }
     }
@@ -851,8 +851,8 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
         int32_t mt = (t0 != 0 && !((double)c0 < required)) ? t0 : 0;
         bool classified = (mt != 0) && (nd >= A.min_hit_groups);
         if (lane == 0) {
-          A.out_taxon[(uint64_t)c * A.R + r] = classified ? mt : 0;
-          A.out_classified[(uint64_t)c * A.R + r] = classified ? 1 : 0;
+          A.out_taxon[(uint64_t)c * A.out_stride + r] = classified ? mt : 0;
+          A.out_classified[(uint64_t)c * A.out_stride + r] = classified ? 1 : 0;
         }
       }
     }

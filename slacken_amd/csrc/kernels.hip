@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256) classify_kernel(Tax tx, const uint64_t *_
                                                        const int32_t *__restrict__ span_taxon,
                                                        const int32_t *__restrict__ span_count,
                                                        uint64_t *__restrict__ map_scratch, int32_t min_hit_groups,
-                                                       Thresholds thr, int32_t C,
+                                                       Thresholds thr, int32_t C, uint64_t out_stride,
                                                        int32_t *__restrict__ out_taxon, uint8_t *__restrict__ out_classified,
                                                        int32_t *__restrict__ out_num_distinct,
                                                        int32_t *__restrict__ out_total_kmers,
@@ -343,8 +343,8 @@ __global__ void __launch_bounds__(256) classify_kernel(Tax tx, const uint64_t *_
       mt = tx.parent(mt);
     }
     bool classified = (mt != 0) && (nd >= min_hit_groups);   // Classifier.scala:445
-    out_taxon[(uint64_t)c * R + r] = classified ? mt : 0;
-    out_classified[(uint64_t)c * R + r] = classified ? 1 : 0;
+    out_taxon[(uint64_t)c * out_stride + r] = classified ? mt : 0;
+    out_classified[(uint64_t)c * out_stride + r] = classified ? 1 : 0;
   }
   if (out_num_distinct) out_num_distinct[r] = nd;
   if (out_total_kmers) out_total_kmers[r] = total;
@@ -442,14 +442,14 @@ void launch_probe(const TableView &T, const uint64_t *offsets, const uint64_t *m
 }
 void launch_classify(const int32_t *parents, int32_t T, const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R,
                      const int32_t *span_meta, const int32_t *span_taxon, const int32_t *span_count,
-                     uint64_t *map_scratch, int32_t min_hit_groups, const Thresholds &thr, int32_t C,
+                     uint64_t *map_scratch, int32_t min_hit_groups, const Thresholds &thr, int32_t C, uint64_t out_stride,
                      int32_t *out_taxon, uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers,
                      int32_t *out_num_hits, int32_t *out_num_probes, hipStream_t s) {
   if (R == 0) return;
   Tax tx{parents, T};
   uint64_t blocks = (R + 255) / 256;
   hipLaunchKernelGGL(classify_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tx, offsets, mate_offsets, R, span_meta,
-                     span_taxon, span_count, map_scratch, min_hit_groups, thr, C, out_taxon, out_classified,
+                     span_taxon, span_count, map_scratch, min_hit_groups, thr, C, out_stride, out_taxon, out_classified,
                      out_num_distinct, out_total_kmers, out_num_hits, out_num_probes);
 }
 void launch_gather_spans(const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, const uint64_t *span_keys,

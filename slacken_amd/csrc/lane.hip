@@ -633,8 +633,8 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
             mt = lane_parent(A.parents, A.ntax, mt);
           }
           bool classified = (mt != 0) && (nd >= A.min_hit_groups);            // Classifier.scala:445
-          A.out_taxon[(uint64_t)c * A.R + r] = classified ? mt : 0;
-          A.out_classified[(uint64_t)c * A.R + r] = classified ? 1 : 0;
+          A.out_taxon[(uint64_t)c * A.out_stride + r] = classified ? mt : 0;
+          A.out_classified[(uint64_t)c * A.out_stride + r] = classified ? 1 : 0;
         }
         if (A.out_nd) A.out_nd[r] = nd;
         if (A.out_tk) A.out_tk[r] = total;

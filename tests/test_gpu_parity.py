@@ -389,3 +389,48 @@ def test_classify_hits_entry(orc, world):
                 assert int(got["num_distinct"][r]) == want["num_distinct"] and int(got["total_kmers"][r]) == want["total_kmers"]
     none = world["st"].classify_hits(offs, flat, None)   # no distinct flags: nothing counts as a hit group
     assert not none["classified"].any() and not none["num_distinct"].any()
+
+
+def test_host_entry_subbatches_and_pinned_buffers(orc, world):
+    """The host-pointer entry cuts a large call into sub-batches (upload of one overlapping the kernels of the one before) and
+    DMAs straight from and to buffers of slk_host_alloc: neither may change a result.  SLK_HOST_SUBBATCH moves the sub-batch
+    size so that a small batch takes the pipelined route."""
+    import slacken_amd
+    from slacken_amd import capi
+    rng = np.random.default_rng(77)
+    reads = synth.make_reads(world["lib"], 3001, rng, vary_length=True, n_single=0.1, n_run=0.05, short=0.05)
+    mates = synth.make_reads(world["lib"], 3001, rng, vary_length=True, short=0.1)
+    bases, offsets = synth.pack(reads)
+    mb, mo = synth.pack(mates)
+    thr = (0.0, 0.3)
+    keys = ("taxon", "classified", "num_distinct", "total_kmers")
+    for m_b, m_o in ((None, None), (mb, mo)):
+        want = orc.classify_batch(world["p"], world["oix"], world["parents"], bases, offsets, m_b, m_o, thresholds=thr)
+        old = os.environ.get("SLK_HOST_SUBBATCH")
+        try:
+            for sub in ("256", "1000", "1500"):   # 12, 4 and 3 sub-batches (the last ones ragged)
+                os.environ["SLK_HOST_SUBBATCH"] = sub
+                got = world["st"].classify_batch(bases, offsets, m_b, m_o, thresholds=thr, with_hits=False, with_num_hits=True)
+                for k in keys + ("num_hits",):
+                    assert np.array_equal(got[k], want[k]), (sub, k)
+            # pinned input and output buffers, pipelined and in one piece
+            pb = capi.pinned_array(bases.shape, np.uint8); pb[:] = bases
+            po = capi.pinned_array(offsets.shape, np.uint64); po[:] = offsets
+            out = dict(taxon=capi.pinned_array((2, len(reads)), np.int32), classified=capi.pinned_array((2, len(reads)), np.uint8),
+                       num_distinct=capi.pinned_array((len(reads),), np.int32), total_kmers=capi.pinned_array((len(reads),), np.int32))
+            for sub in ("700", "100000"):
+                os.environ["SLK_HOST_SUBBATCH"] = sub
+                for a in out.values():
+                    a[...] = 0
+                world["st"].classify_batch(pb, po, m_b, m_o, thresholds=thr, with_hits=False, out=out)
+                for k in keys:
+                    assert np.array_equal(out[k], want[k]), (sub, k)
+            full = world["st"].classify_batch(pb[3:], offsets[:1], with_hits=True)   # a pointer INSIDE a pinned buffer, no reads
+            assert full["taxon"].shape == (1, 0)
+        finally:
+            if old is None:
+                os.environ.pop("SLK_HOST_SUBBATCH", None)
+            else:
+                os.environ["SLK_HOST_SUBBATCH"] = old
+    lib = slacken_amd.lib()
+    assert lib.slk_host_free(12345) != 0 and b"slk_host_alloc" in lib.slk_last_error()
