@@ -87,6 +87,9 @@ typedef struct {
   uint64_t duplicate_keys;  /* appended records whose key was already present (contract violation; first kept) */
   int32_t taxonomy_size;
   int32_t device;
+  int32_t dense_taxa;       /* > 0: taxon ids beyond 22 bits were renumbered internally at slk_index_finalize (the number of
+                               taxonomy nodes); every taxon that crosses this ABI is still the caller's id */
+  int32_t reserved;
 } slk_index_info;
 
 /* OrdinalSpan (S/slacken/package.scala:61-62) without the title; ordinal = position in the read's span list.
@@ -144,6 +147,10 @@ int32_t slk_index_add_sequences(slk_index *ix, const uint8_t *bases, const uint6
  * offsets and taxa: host arrays).  The sequences are scanned where they lie. */
 int32_t slk_index_add_sequences_device(slk_index *ix, const uint8_t *d_bases, const uint64_t *offsets, const int32_t *taxa,
                                        uint64_t n_sequences);
+/* Ends the build.  If the taxon ids need more than 22 bits (slk_table_config.max_taxon >= 2^22), the taxonomy has been set
+ * and every record's taxon is one of its nodes, the table is renumbered here to dense internal ids (one pass over the
+ * cells) so that the fast kernels apply; ids crossing the ABI are unaffected.  Set the taxonomy BEFORE finalizing to get
+ * this; it cannot be replaced afterwards on such an index. */
 int32_t slk_index_finalize(slk_index *ix);
 /* The table's records as (key, taxon) arrays -- what KeyValueIndex.writeRecords would persist (KeyValueIndex.scala:125-139).
  * The order is unspecified (a set).  *n_records receives the number of records; if it exceeds capacity only the first
@@ -249,7 +256,9 @@ uint32_t slk_shard_of(int64_t key, uint32_t n_shards);
  *                           as slk_classify_batch_device.
  * d_defer[R] (zeroed by slk_shard_emit_device) is set to 1 for fragments this path does not take (longer than 1000 bases,
  * or more than 12 distinct taxa): classify those with the staged calls above.  SLK_E_UNSUPPORTED if the index's splitter
- * is outside the fused kernel's range (window wider than 32 m-mers or taxon ids beyond 22 bits): use the staged calls. */
+ * is outside the fused kernel's range (window wider than 32 m-mers, or taxon ids beyond 22 bits that slk_index_finalize could
+ * not renumber): use the staged calls.  d_taxa_by_slot is filled by slk_shard_scatter_device only (it holds the engine's
+ * internal ids). */
 int32_t slk_shard_emit_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
                               const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
                               uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys, uint64_t *d_send_slots,

@@ -35,7 +35,7 @@ class IndexInfo(C.Structure):
     _fields_ = [("records", C.c_uint64), ("buckets", C.c_uint64), ("table_bytes", C.c_uint64),
                 ("bucket_bits", C.c_int32), ("taxon_bits", C.c_int32), ("disp_bits", C.c_int32),
                 ("max_displacement", C.c_int32), ("duplicate_keys", C.c_uint64), ("taxonomy_size", C.c_int32),
-                ("device", C.c_int32)]
+                ("device", C.c_int32), ("dense_taxa", C.c_int32), ("reserved", C.c_int32)]
 
 
 SPAN_DTYPE = np.dtype([("key", "<i8"), ("kmers", "<i4"), ("flag", "i1"), ("distinct", "u1"), ("pad", "<u2")])

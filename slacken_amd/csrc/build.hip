@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256) export_kernel(TableView T, uint64_t ncell
     unsigned long long slot = first + before;
     if (slot < capacity) {
       keys[slot] = (int64_t)fmix64_inverse(h);
-      taxa[slot] = (int32_t)(cell & tmask);
+      taxa[slot] = ext_taxon(T, (int32_t)(cell & tmask));
     }
   }
 }

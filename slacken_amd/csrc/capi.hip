@@ -191,8 +191,12 @@ struct slk_index {
   int32_t bucket_bits = 0, taxon_bits = 0, disp_bits = 0;
   int32_t *d_max_disp = nullptr;
   unsigned long long *d_counters = nullptr;  // inserted, duplicate, overflow
-  int32_t *d_parents = nullptr;
+  int32_t *d_parents = nullptr;   // the taxonomy as given (ids of the caller)
   int32_t T = 0;
+  std::vector<int32_t> h_parents;  // host copy, for the dense renumbering at finalize
+  // dense taxon ids (engine.h: TableView.to_orig): set up by slk_index_finalize when the caller's ids need more than 22 bits
+  int32_t *d_parents_dense = nullptr, *d_to_orig = nullptr, *d_to_dense = nullptr;
+  int32_t D = 0;                   // nodes of the taxonomy = largest dense id (0: ids are stored as given)
   bool finalized = false;
   int32_t max_disp = 0;
   uint64_t records = 0, dups = 0;
@@ -212,7 +216,17 @@ struct slk_index {
     v.taxon_bits = taxon_bits;
     v.disp_bits = disp_bits;
     v.max_disp = max_disp;
+    v.to_orig = d_to_orig;
     return v;
+  }
+  // what the fused kernels walk: the parents array in the ids the cells hold
+  const int32_t *kernel_parents() const { return D ? d_parents_dense : d_parents; }
+  int32_t kernel_ntax() const { return D ? D + 1 : T; }
+  int internal_taxon_bits() const {
+    if (!D) return taxon_bits;
+    int b = 1;
+    while ((1LL << b) <= (long long)D) b++;
+    return b;
   }
 };
 
@@ -584,10 +598,12 @@ int32_t slk_index_set_taxonomy(slk_index *ix, const int32_t *parents, int32_t T)
       for (int32_t y : path) state[y] = 2;
     }
   }
+  if (ix->D) return fail(SLK_E_STATE, "this finalized index stores dense taxon ids derived from its taxonomy: the taxonomy cannot be replaced");
   if (ix->d_parents) { HIPCHK(hipFree(ix->d_parents)); ix->d_parents = nullptr; }
   HIPCHK(hipMalloc((void **)&ix->d_parents, (size_t)T * sizeof(int32_t)));
   HIPCHK(hipMemcpy(ix->d_parents, parents, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice));
   ix->T = T;
+  ix->h_parents.assign(parents, parents + T);
   return SLK_OK;
 }
 
@@ -694,6 +710,49 @@ int32_t slk_index_export(const slk_index *ix, int64_t *keys, int32_t *taxa, uint
   return SLK_OK;
 }
 
+// Dense taxon ids.  The lane-per-fragment kernel keeps a fragment's taxon -> count map as one LDS word per entry
+// (taxon << 10 | count): taxon ids of up to 22 bits.  NCBI's ids pass 2^22 = 4 194 304 within a few releases, but the NODES of
+// the taxonomy are far fewer than the id range; so when the caller's ids do not fit, the cells are rewritten once, here, to hold
+// the rank of their taxon among the taxonomy's nodes (in increasing id order, ROOT = 1 stays 1), the fused kernels walk a
+// parents array in those ranks, and ids are translated back where taxa leave the engine (engine.h: ext_taxon).  Needs the
+// taxonomy to be set before finalize and every record's taxon to be one of its nodes; otherwise the ids stay as given and
+// fragments take the wave-per-fragment kernel, as before.
+static int32_t make_dense_taxa(slk_index *ix) {
+  if (ix->W > 1 || ix->taxon_bits <= 22 || ix->h_parents.empty() || ix->D) return SLK_OK;
+  const int32_t T = ix->T;
+  std::vector<int32_t> to_dense((size_t)T, 0), to_orig(1, 0);
+  for (int32_t t = 1; t < T; t++)
+    if (t == 1 || ix->h_parents[t] != 0) { to_dense[t] = (int32_t)to_orig.size(); to_orig.push_back(t); }
+  const int32_t D = (int32_t)to_orig.size() - 1;
+  if (D < 1 || D >= (1 << 22)) return SLK_OK;
+  std::vector<int32_t> pd((size_t)D + 1, 0);
+  for (int32_t d = 1; d <= D; d++) pd[d] = to_dense[ix->h_parents[to_orig[d]]];  // (parent of ROOT is NONE = 0)
+  int32_t *d_td = nullptr, *d_to = nullptr, *d_pd = nullptr;
+  unsigned long long *d_bad = nullptr, bad = 0;
+  HIPCHK(hipMalloc((void **)&d_td, (size_t)T * 4));
+  HIPCHK(hipMalloc((void **)&d_bad, 8));
+  HIPCHK(hipMemcpy(d_td, to_dense.data(), (size_t)T * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(d_bad, 0, 8));
+  launch_remap_cells(ix->cells, ix->nbuckets * 8, ix->taxon_bits, d_td, T, d_bad, false, ix->build_stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ix->build_stream));
+  HIPCHK(hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost));
+  if (bad != 0) {  // records whose taxon is not a node of this taxonomy: keep the ids as they are
+    (void)hipFree(d_td); (void)hipFree(d_bad);
+    return SLK_OK;
+  }
+  launch_remap_cells(ix->cells, ix->nbuckets * 8, ix->taxon_bits, d_td, T, d_bad, true, ix->build_stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ix->build_stream));
+  (void)hipFree(d_bad);
+  HIPCHK(hipMalloc((void **)&d_to, ((size_t)D + 1) * 4));
+  HIPCHK(hipMalloc((void **)&d_pd, ((size_t)D + 1) * 4));
+  HIPCHK(hipMemcpy(d_to, to_orig.data(), ((size_t)D + 1) * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_pd, pd.data(), ((size_t)D + 1) * 4, hipMemcpyHostToDevice));
+  ix->d_to_dense = d_td; ix->d_to_orig = d_to; ix->d_parents_dense = d_pd; ix->D = D;
+  return SLK_OK;
+}
+
 int32_t slk_index_finalize(slk_index *ix) {
   if (!ix) return fail(SLK_E_INVALID, "null argument");
   int32_t rc = set_device(ix);
@@ -703,6 +762,10 @@ int32_t slk_index_finalize(slk_index *ix) {
   ix->stage_keys.release();
   ix->stage_taxa.release();
   ix->staging.release();
+  if (!ix->finalized) {
+    rc = make_dense_taxa(ix);
+    if (rc) return rc;
+  }
   ix->finalized = true;
   return SLK_OK;
 }
@@ -720,6 +783,7 @@ int32_t slk_index_get_info(const slk_index *ix, slk_index_info *out) {
   out->duplicate_keys = ix->dups;
   out->taxonomy_size = ix->T;
   out->device = ix->device;
+  out->dense_taxa = ix->D;
   return SLK_OK;
 }
 
@@ -751,6 +815,9 @@ void slk_index_destroy(slk_index *ix) {
   if (ix->d_max_disp) (void)hipFree(ix->d_max_disp);
   if (ix->d_counters) (void)hipFree(ix->d_counters);
   if (ix->d_parents) (void)hipFree(ix->d_parents);
+  if (ix->d_parents_dense) (void)hipFree(ix->d_parents_dense);
+  if (ix->d_to_orig) (void)hipFree(ix->d_to_orig);
+  if (ix->d_to_dense) (void)hipFree(ix->d_to_dense);
   ix->stage_keys.release();
   ix->stage_taxa.release();
   ix->staging.release();
@@ -886,7 +953,7 @@ static int32_t check_status(slk_stream *st) {  // call after the stream has been
   return SLK_OK;
 }
 
-static bool lane_path_ok(const slk_index *ix) { return use_fused(ix) && ix->sp.w <= 32 && ix->taxon_bits <= 22; }
+static bool lane_path_ok(const slk_index *ix) { return use_fused(ix) && ix->sp.w <= 32 && ix->internal_taxon_bits() <= 22; }
 
 static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
                             const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
@@ -923,7 +990,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
   }
   if (fused) {
     FusedArgs A{};
-    A.P = ix->sp; A.T = ix->view(); A.parents = ix->d_parents; A.ntax = ix->T;
+    A.P = ix->sp; A.T = ix->view(); A.parents = ix->kernel_parents(); A.ntax = ix->kernel_ntax();
     A.bases = d_bases; A.offsets = d_offsets; A.mate_bases = d_mate_bases; A.mate_offsets = d_mate_offsets; A.R = R;
     A.out_stride = out_stride;
     A.min_hit_groups = min_hit_groups; A.thr = thr; A.C = C;
@@ -1080,7 +1147,7 @@ int32_t slk_shard_scatter_device(slk_index *ix, slk_stream *st, const uint64_t *
   if (n && (!d_slots || !d_taxa || !d_taxa_by_slot)) return fail(SLK_E_INVALID, "null argument");
   rc = set_device(ix);
   if (rc) return rc;
-  launch_scatter_taxa(d_slots, d_taxa, n, d_taxa_by_slot, st->s);
+  launch_scatter_taxa(d_slots, d_taxa, n, d_taxa_by_slot, ix->d_to_dense, ix->T, st->s);
   HIPCHK(hipGetLastError());
   return SLK_OK;
 }
@@ -1103,7 +1170,7 @@ int32_t slk_shard_apply_device(slk_index *ix, slk_stream *st, const uint8_t *d_b
   Thresholds thr{};
   memcpy(thr.v, thresholds, C * sizeof(double));
   FusedArgs A{};
-  A.P = ix->sp; A.parents = ix->d_parents; A.ntax = ix->T;
+  A.P = ix->sp; A.T = ix->view(); A.parents = ix->kernel_parents(); A.ntax = ix->kernel_ntax();   // (A.T: for to_orig only)
   A.bases = d_bases; A.offsets = d_offsets; A.mate_bases = d_mate_bases; A.mate_offsets = d_mate_offsets; A.R = R;
   A.out_stride = R;
   A.min_hit_groups = min_hit_groups; A.thr = thr; A.C = C;

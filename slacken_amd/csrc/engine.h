@@ -54,7 +54,12 @@ struct TableView {
   int32_t taxon_bits;
   int32_t disp_bits;
   int32_t max_disp;   // largest displacement in use
+  // Dense taxon ids (slk_index_finalize): when the caller's ids need more than 22 bits, the cells hold the rank of the taxon
+  // among the taxonomy's nodes instead (the lane kernel packs taxon << 10 | count into one LDS word), the kernels walk a
+  // parents array in those ranks, and ids are translated back wherever a taxon leaves the engine.  nullptr: ids as given.
+  const int32_t *to_orig;
 };
+__device__ __forceinline__ int32_t ext_taxon(const TableView &T, int32_t t) { return (T.to_orig != nullptr && t > 0) ? T.to_orig[t] : t; }
 
 __host__ __device__ inline uint64_t fmix64(uint64_t x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
@@ -157,7 +162,12 @@ enum { LANE_LOCAL = 0, LANE_EMIT = 1, LANE_APPLY = 2 };
 void launch_lane_sharded(int mode, const FusedArgs &A, const ShardIO &S, int32_t *defer, uint32_t max_len, hipStream_t s);
 // cooperative point lookups (4 lanes x 16 B per bucket) and the scatter of returned taxa to their slots (shard.hip)
 void launch_lookup_coop(const TableView &t, const int64_t *keys, uint64_t n, int32_t *out, hipStream_t s);
-void launch_scatter_taxa(const uint64_t *slots, const int32_t *taxa, uint64_t n, int32_t *taxa_by_slot, hipStream_t s);
+// (to_dense, if set: the owners' answers carry the caller's ids, the apply kernel wants the cells' dense ones)
+void launch_scatter_taxa(const uint64_t *slots, const int32_t *taxa, uint64_t n, int32_t *taxa_by_slot, const int32_t *to_dense,
+                         int32_t n_to_dense, hipStream_t s);
+// cells' taxon field -> to_dense[taxon]; *undefined counts the cells whose taxon has no dense id; apply = false: count only
+void launch_remap_cells(uint64_t *cells, uint64_t ncells, int32_t taxon_bits, const int32_t *to_dense, int32_t n_to_dense,
+                        unsigned long long *undefined, bool apply, hipStream_t s);
 
 enum { MODE_SPANS = 0, MODE_CLASSIFY = 1, MODE_HITS = 2 };
 void launch_fused(int mode, const FusedArgs &A, hipStream_t s);

@@ -315,7 +315,7 @@ __device__ __forceinline__ void resolve_map(WaveLds *L, const FusedArgs &A, uint
     }
     bool classified = (mt != 0) && (nd >= A.min_hit_groups);  // Classifier.scala:445
     if (lane == 0) {
-      A.out_taxon[(uint64_t)c * A.out_stride + r] = classified ? mt : 0;
+      A.out_taxon[(uint64_t)c * A.out_stride + r] = classified ? ext_taxon(A.T, mt) : 0;
       A.out_classified[(uint64_t)c * A.out_stride + r] = classified ? 1 : 0;
     }
   }
@@ -545,7 +545,7 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
           }
           if (MODE == MODE_HITS && in) {
             A.span_meta[base + n_out + lane] = meta;
-            A.span_taxon[base + n_out + lane] = taxon;
+            A.span_taxon[base + n_out + lane] = ext_taxon(A.T, taxon);
           }
         }
         n_out += cnt;
@@ -574,7 +574,7 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
         int32_t mt = (t0 != 0 && !((double)c0 < required)) ? t0 : 0;
         bool classified = (mt != 0) && (nd >= A.min_hit_groups);
         if (lane == 0) {
-          A.out_taxon[(uint64_t)c * A.out_stride + r] = classified ? mt : 0;
+          A.out_taxon[(uint64_t)c * A.out_stride + r] = classified ? ext_taxon(A.T, mt) : 0;
           A.out_classified[(uint64_t)c * A.out_stride + r] = classified ? 1 : 0;
         }
       }
@@ -851,7 +851,7 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
         int32_t mt = (t0 != 0 && !((double)c0 < required)) ? t0 : 0;
         bool classified = (mt != 0) && (nd >= A.min_hit_groups);
         if (lane == 0) {
-          A.out_taxon[(uint64_t)c * A.out_stride + r] = classified ? mt : 0;
+          A.out_taxon[(uint64_t)c * A.out_stride + r] = classified ? ext_taxon(A.T, mt) : 0;
           A.out_classified[(uint64_t)c * A.out_stride + r] = classified ? 1 : 0;
         }
       }

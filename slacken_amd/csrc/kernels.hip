@@ -14,6 +14,8 @@
 //                    (S/slacken/LowestCommonAncestor.scala:49-146), Taxonomy.hasAncestor (S/slacken/Taxonomy.scala:236-244).
 #include "engine.h"
 
+#include <algorithm>
+
 namespace slk {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -99,7 +101,7 @@ __global__ void __launch_bounds__(256) table_lookup_kernel(TableView t, const in
                                                            int32_t *__restrict__ out) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) out[i] = table_lookup(t, (uint64_t)keys[i]);
+  for (; i < n; i += stride) out[i] = ext_taxon(t, table_lookup(t, (uint64_t)keys[i]));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -247,7 +249,7 @@ __global__ void __launch_bounds__(256) probe_kernel(TableView T, const uint64_t 
       // spanToHit (KeyValueIndex.scala:176-185): flag wins over any record; unmatched -> NONE
       if (flag == 2) taxon = -1;
       else if (flag == 3) taxon = -2;
-      else taxon = table_lookup(T, span_keys[base + j]);
+      else taxon = ext_taxon(T, table_lookup(T, span_keys[base + j]));
       span_taxon[base + j] = taxon;
     }
   }
@@ -407,6 +409,33 @@ __global__ void __launch_bounds__(256) gather_hits_kernel(const uint64_t *__rest
 }
 
 // ---- launchers (called from capi.hip) ----
+// slk_index_finalize, dense taxon ids: the taxon field of every cell becomes to_dense[taxon] (cells whose taxon has no dense
+// id -- not a node of the taxonomy -- are counted; the caller first counts, and rewrites only if there are none)
+__global__ void __launch_bounds__(256) remap_cells_kernel(uint64_t *__restrict__ cells, uint64_t ncells, int32_t taxon_bits,
+                                                          const int32_t *__restrict__ to_dense, int32_t n_to_dense,
+                                                          unsigned long long *__restrict__ undefined, bool apply) {
+  const uint64_t tmask = (1ULL << taxon_bits) - 1;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  int bad = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncells; i += step) {
+    const uint64_t c = cells[i];
+    if (c == 0) continue;
+    const uint64_t t = c & tmask;
+    const int32_t d = t < (uint64_t)n_to_dense ? to_dense[t] : 0;
+    if (d == 0) bad++;
+    else if (apply) cells[i] = (c & ~tmask) | (uint64_t)(uint32_t)d;
+  }
+  for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(undefined, (unsigned long long)bad);
+}
+void launch_remap_cells(uint64_t *cells, uint64_t ncells, int32_t taxon_bits, const int32_t *to_dense, int32_t n_to_dense,
+                        unsigned long long *undefined, bool apply, hipStream_t s) {
+  if (ncells == 0) return;
+  uint64_t blocks = std::min<uint64_t>((ncells + 255) / 256, 256 * 64);
+  hipLaunchKernelGGL(remap_cells_kernel, dim3((unsigned)blocks), dim3(256), 0, s, cells, ncells, taxon_bits, to_dense, n_to_dense,
+                     undefined, apply);
+}
+
 void launch_table_insert(const TableBuild &t, const int64_t *keys, const int32_t *taxa, uint64_t n, hipStream_t s) {
   uint64_t blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;

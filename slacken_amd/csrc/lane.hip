@@ -187,7 +187,7 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int q
     // the un-merged hit list (TaxonHit, KeyValueIndex.scala:436-441) in the fragment's span region.  An entry handed back
     // to the queue writes NONE here and its final taxon when a later batch resolves it.
     const uint64_t at = L->rb[meta & 63] + ord;
-    hit_taxon[at] = taxon;
+    hit_taxon[at] = ext_taxon(T, taxon);
     hit_meta[at] = pack_meta((int32_t)((meta >> 7) & 0x3FF), 1, (meta >> 6) & 1);
   }
   lane_wave_sync();
@@ -633,7 +633,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
             mt = lane_parent(A.parents, A.ntax, mt);
           }
           bool classified = (mt != 0) && (nd >= A.min_hit_groups);            // Classifier.scala:445
-          A.out_taxon[(uint64_t)c * A.out_stride + r] = classified ? mt : 0;
+          A.out_taxon[(uint64_t)c * A.out_stride + r] = classified ? ext_taxon(A.T, mt) : 0;
           A.out_classified[(uint64_t)c * A.out_stride + r] = classified ? 1 : 0;
         }
         if (A.out_nd) A.out_nd[r] = nd;

@@ -83,16 +83,21 @@ __global__ void __launch_bounds__(SW * 64) lookup_coop_kernel(TableView T, const
         if (has_empty) break;
       }
     }
-    if (in) out[i] = taxon;
+    if (in) out[i] = ext_taxon(T, taxon);
     wsync();
   }
 }
 
 __global__ void __launch_bounds__(256) scatter_taxa_kernel(const uint64_t *__restrict__ slots, const int32_t *__restrict__ taxa,
-                                                           uint64_t n, int32_t *__restrict__ by_slot) {
+                                                           uint64_t n, int32_t *__restrict__ by_slot,
+                                                           const int32_t *__restrict__ to_dense, int32_t n_to_dense) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += step) by_slot[slots[i]] = taxa[i];
+  for (; i < n; i += step) {
+    int32_t t = taxa[i];
+    if (to_dense != nullptr && t > 0) t = t < n_to_dense ? to_dense[t] : 0;  // (a taxon outside the taxonomy cannot be in this rank's table either)
+    by_slot[slots[i]] = t;
+  }
 }
 
 }  // namespace
@@ -102,10 +107,11 @@ void launch_lookup_coop(const TableView &t, const int64_t *keys, uint64_t n, int
   uint64_t blocks = std::min<uint64_t>((n + SW * 64 - 1) / (SW * 64), 256 * 16);
   hipLaunchKernelGGL(lookup_coop_kernel, dim3((unsigned)blocks), dim3(SW * 64), 0, s, t, keys, n, out);
 }
-void launch_scatter_taxa(const uint64_t *slots, const int32_t *taxa, uint64_t n, int32_t *taxa_by_slot, hipStream_t s) {
+void launch_scatter_taxa(const uint64_t *slots, const int32_t *taxa, uint64_t n, int32_t *taxa_by_slot, const int32_t *to_dense,
+                         int32_t n_to_dense, hipStream_t s) {
   if (n == 0) return;
   uint64_t blocks = std::min<uint64_t>((n + 255) / 256, 256 * 32);
-  hipLaunchKernelGGL(scatter_taxa_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slots, taxa, n, taxa_by_slot);
+  hipLaunchKernelGGL(scatter_taxa_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slots, taxa, n, taxa_by_slot, to_dense, n_to_dense);
 }
 
 }  // namespace slk

@@ -305,8 +305,12 @@ def test_streams_on_threads_share_one_index(orc, world):
     assert not errors, errors
 
 
-def test_taxon_ids_beyond_22_bits(orc):
-    """The lane kernel packs (taxon << 10 | count) into one LDS word: taxon ids of 2^22 and more must take the wave kernel."""
+@pytest.mark.parametrize("taxonomy_first", [False, True], ids=["ids-as-given", "dense-ids"])
+def test_taxon_ids_beyond_22_bits(orc, taxonomy_first):
+    """The lane kernel packs (taxon << 10 | count) into one LDS word.  With the taxonomy set before slk_index_finalize the table
+    is renumbered to dense internal ids and the lane kernel serves ids of 2^22 and more at full speed (nothing deferred);
+    without it (taxonomy set after the records were finalized) the ids stay as given and the wave kernel takes every fragment.
+    Either way every taxon that crosses the ABI -- calls, hit lists, lookups, exported records -- is the caller's id."""
     import slacken_amd
     rng = np.random.default_rng(2222)
     small = taxgen.taxonomy(8 * 16, rng)
@@ -326,15 +330,34 @@ def test_taxon_ids_beyond_22_bits(orc):
         tx.append(np.full(len(kk), t, np.int32))
     keys, idx = np.unique(np.concatenate(keys), return_index=True)
     tx = np.concatenate(tx)[idx]
+    # give some minimizers an inner node (an LCA, as a real library has): reads then hit several taxa of a lineage
+    inner = np.array([t for t in np.nonzero(parents)[0] if t > (1 << 22) and (parents == t).any()], np.int32)
+    tx[::7] = inner[np.arange(len(tx[::7])) % len(inner)]
     ix = slacken_amd.Index(expected_records=len(keys), max_taxon=len(parents) - 1)
     assert ix.info().taxon_bits > 22
     ix.append(keys, tx)
-    ix.set_taxonomy(parents)
-    ix.finalize()
+    if taxonomy_first:
+        ix.set_taxonomy(parents)
+        ix.finalize()
+        assert ix.info().dense_taxa == len(taxgen.defined_taxa(parents))
+        with pytest.raises(slacken_amd.SlackenError):
+            ix.set_taxonomy(parents)          # the dense ids derive from it
+    else:
+        ix.finalize()
+        ix.set_taxonomy(parents)
+        assert ix.info().dense_taxa == 0
     reads = synth.make_reads(L, 800, rng)
     world = dict(p=p, st=ix.stream(), oix=orc.Index(1, keys, tx), parents=parents)
     got = check_classify(orc, world, reads, thresholds=(0.0, 0.2))
     assert (got["taxon"][0] > (1 << 22)).any()
+    assert world["st"].last_deferred() == 0 if taxonomy_first else True
+    bases, offsets = synth.pack(reads)
+    world["st"].classify_batch(bases, offsets, with_hits=False)
+    assert (world["st"].last_deferred() == 0) == taxonomy_first     # dense ids: the lane kernel kept every fragment
+    assert np.array_equal(ix.lookup(keys), tx)
+    ek, et = ix.export()
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(ek, keys[order]) and np.array_equal(et, tx[order])
 
 
 def test_c_example_runs(tmp_path):

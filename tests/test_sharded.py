@@ -44,7 +44,7 @@ def _rank(rank, world, port, payload, outdir, fast):
     lo, hi = (rank * R) // world, ((rank + 1) * R) // world
     dev = torch.device("cuda", 0)
     b0, b1 = int(offsets[lo]), int(offsets[hi])
-    d_bases = torch.cat([torch.from_numpy(bases[b0:b1]), torch.full((64,), 65, dtype=torch.uint8)]).to(dev)
+    d_bases = torch.from_numpy(bases[b0:b1]).to(dev)
     d_off = torch.from_numpy((offsets[lo:hi + 1] - offsets[lo]).astype(np.int64)).to(dev)
     sc = sharded.ShardedClassifier(ix, rank, world, dist, dev, exchange_on_cpu=True)
     out = sc.classify(d_bases, d_off, hi - lo, b1 - b0, thresholds=(0.0, 0.2), fast=fast)
@@ -89,13 +89,17 @@ def test_two_ranks_half_table_each(orc, tmp_path, fast):
 
 
 @pytest.mark.gpu
-def test_single_rank_fast_route_with_deferrals(orc):
+@pytest.mark.parametrize("big_ids", [False, True], ids=["ids<2^22", "dense-ids"])
+def test_single_rank_fast_route_with_deferrals(orc, big_ids):
     """world = 1: no exchange, but the same emit -> lookup -> scatter -> apply pipeline, incl. fragments the fused kernel
-    hands back (longer than 1000 bases; more than 12 distinct taxa) and empty / vanishing fragments."""
+    hands back (longer than 1000 bases; more than 12 distinct taxa) and empty / vanishing fragments.  With taxon ids beyond
+    22 bits the table holds dense internal ids: the owners' answers (caller's ids) are translated by the scatter."""
     import synth
     import taxgen
     rng = np.random.default_rng(43)
     parents = taxgen.taxonomy(8 * 64, rng)
+    if big_ids:
+        parents, _ = taxgen.sparse_relabel(parents, 5_000_000, rng)
     taxa = np.array(taxgen.defined_taxa(parents))
     p = orc.params()
     reads = synth.make_reads(synth.Library(orc, p, parents, n_genomes=4, genome_len=8000), 500, rng, vary_length=True)
@@ -107,9 +111,10 @@ def test_single_rank_fast_route_with_deferrals(orc):
     ix.append(keys, tx)
     ix.set_taxonomy(parents)
     ix.finalize()
+    assert (ix.info().dense_taxa > 0) == big_ids
     bases, offsets = synth.pack(reads)
     dev = torch.device("cuda", 0)
-    d_bases = torch.cat([torch.from_numpy(bases), torch.full((64,), 65, dtype=torch.uint8)]).to(dev)
+    d_bases = torch.from_numpy(bases).to(dev)
     d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
     sc = sharded.ShardedClassifier(ix, 0, 1, None, dev)
     R = len(reads)
