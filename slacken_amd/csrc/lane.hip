@@ -342,9 +342,13 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
   const uint64_t ntiles = (A.R + 63) / 64;
   const uint64_t nwaves = (uint64_t)gridDim.x * LW;
 
+  // The 64 lanes of a wave run in lockstep, so a tile lasts as long as its longest fragment: when the batch mixes lengths the
+  // tiles take the fragments in a length-bucketed order (launch_tile_order) instead of input order.
+  const bool reorder = MODE == LANE_LOCAL && A.tile_order_on != nullptr && *A.tile_order_on != 0;
   for (uint64_t tile = (uint64_t)blockIdx.x * LW + wib; tile < ntiles; tile += nwaves) {
-    const uint64_t r = tile * 64 + lane;
-    const bool have = r < A.R;
+    const uint64_t slot_in_batch = tile * 64 + lane;
+    const bool have = slot_in_batch < A.R;
+    const uint64_t r = (have && reorder) ? (uint64_t)A.tile_order[slot_in_batch] : slot_in_batch;
     // ---- fragment descriptor ----
     const uint8_t *seq = A.bases;
     uint32_t n = 0, n2 = 0;
@@ -645,6 +649,49 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     }
     lane_wave_sync();
   }
+}
+
+// ---- length-bucketed tile order --------------------------------------------------------------------------------------------
+constexpr int ORDER_WIN = 16384;   // fragments per window: one workgroup sorts one window by length class (64 classes)
+constexpr int ORDER_THREADS = 256;
+__global__ void __launch_bounds__(ORDER_THREADS) tile_order_kernel(const uint64_t *__restrict__ offsets,
+                                                                   const uint64_t *__restrict__ mate_offsets, uint64_t R,
+                                                                   uint32_t max_len, uint32_t *__restrict__ order,
+                                                                   uint32_t *__restrict__ mixed) {
+  __shared__ uint8_t cls[ORDER_WIN];
+  __shared__ uint32_t hist[64], cursor[64];
+  const uint64_t base = (uint64_t)blockIdx.x * ORDER_WIN;
+  const uint32_t n = (uint32_t)min((uint64_t)ORDER_WIN, R - base);
+  if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+  __syncthreads();
+  // class 0 = the longest the lane kernel takes ... class 62 = the shortest; class 63 = fragments it hands on (too long):
+  // long fragments first, so that a window's last tiles are its cheapest
+  const uint32_t width = max_len / 62 + 1;
+  for (uint32_t i = threadIdx.x; i < n; i += ORDER_THREADS) {
+    const uint64_t r = base + i;
+    uint64_t len = offsets[r + 1] - offsets[r];
+    if (mate_offsets) len += mate_offsets[r + 1] - mate_offsets[r];
+    const uint32_t c = len > max_len ? 63u : 62u - (uint32_t)len / width;
+    cls[i] = (uint8_t)c;
+    atomicAdd(&hist[c], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t at = 0, used = 0;
+    for (int c = 0; c < 64; c++) { cursor[c] = at; at += hist[c]; used += hist[c] != 0; }
+    if (used > 1) atomicOr(mixed, 1u);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += ORDER_THREADS) {
+    const uint32_t pos = atomicAdd(&cursor[cls[i]], 1u);
+    order[base + pos] = (uint32_t)(base + i);
+  }
+}
+void launch_tile_order(const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, uint32_t max_len, uint32_t *order,
+                       uint32_t *mixed, hipStream_t s) {
+  if (R == 0) return;
+  const uint64_t blocks = (R + ORDER_WIN - 1) / ORDER_WIN;
+  hipLaunchKernelGGL(tile_order_kernel, dim3((unsigned)blocks), dim3(ORDER_THREADS), 0, s, offsets, mate_offsets, R, max_len, order, mixed);
 }
 
 template <int MODE, bool HITS>
