@@ -236,7 +236,7 @@ struct slk_stream {
   hipStream_t s = nullptr;
   DevBuf span_keys, span_meta, span_taxon, span_count;  // per-batch scratch (sparse per-read regions)
   DevBuf bases, offsets, mate_bases, mate_offsets;      // staging for the host-pointer entry points
-  DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items, defer_list, tile_order;
+  DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items, defer_list;
   int32_t *d_status = nullptr;     // device error bits of the fused kernels
   int32_t *h_status = nullptr;     // pinned copy, refreshed after every classify launch
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -858,7 +858,7 @@ void slk_stream_destroy(slk_stream *st) {
   (void)hipStreamSynchronize(st->s);
   DevBuf *bufs[] = {&st->span_keys, &st->span_meta, &st->span_taxon, &st->span_count, &st->bases, &st->offsets,
                     &st->mate_bases, &st->mate_offsets, &st->out_taxon, &st->out_cls, &st->out_nd, &st->out_tk,
-                    &st->out_nh, &st->out_offsets, &st->out_items, &st->defer_list, &st->tile_order};
+                    &st->out_nh, &st->out_offsets, &st->out_items, &st->defer_list};
   for (DevBuf *b : bufs) b->release();
   if (st->d_status) (void)hipFree(st->d_status);
   if (st->h_status) (void)hipHostFree(st->h_status);
@@ -1010,16 +1010,6 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
       HIPCHK(hipMemsetAsync(st->defer_list.p, 0, sizeof(uint64_t), st->s));
       A.work_list = st->defer_list.as<uint64_t>() + 1;
       A.work_count = (const unsigned long long *)st->defer_list.p;
-      // length-bucketed tile order (only used by the kernel if the batch turns out to mix lengths); SLK_TILE_ORDER=0: A/B switch
-      static const bool order_on = !(getenv("SLK_TILE_ORDER") && getenv("SLK_TILE_ORDER")[0] == '0');
-      if (order_on && R >= 4096 && R < 0xFFFFFFFFull) {
-        HIPCHK(st->tile_order.ensure((R + 1) * sizeof(uint32_t)));
-        uint32_t *flag = st->tile_order.as<uint32_t>() + R;   // [R] = "the batch mixes lengths"
-        HIPCHK(hipMemsetAsync(flag, 0, sizeof(uint32_t), st->s));
-        launch_tile_order(d_offsets, d_mate_offsets, R, 1000, st->tile_order.as<uint32_t>(), flag, st->s);
-        A.tile_order = st->tile_order.as<uint32_t>();
-        A.tile_order_on = flag;
-      }
       launch_lane(A, nullptr, 1000, st->s);  // queue entries carry 10-bit k-mer counts
       // of the deferred fragments, the long unpaired ones go to the lane-per-segment kernel (classification only, w = 5)
       // (5000: below that, too few of the 64 lanes have a segment of a useful length; read per call, so that tests can move it)

@@ -140,9 +140,6 @@ struct FusedArgs {
   int32_t *status;       // device error bits: 1 = taxon map overflow
   const uint64_t *work_list;             // if set, the fused kernel processes only the fragments work_list[0 .. *work_count)
   const unsigned long long *work_count;  // (device) -- the fragments the lane kernel deferred (it appends them itself)
-  // lane kernel, LANE_LOCAL: the fragments in the order the tiles take them (launch_tile_order), used when *tile_order_on != 0
-  const uint32_t *tile_order;
-  const uint32_t *tile_order_on;
   uint32_t seg_min_len;                  // work-list passes: unpaired fragments of at least this many bases belong to the
                                          // lane-per-segment kernel (launch_segments), the others to the wave kernel; 0 = none
 };
@@ -178,11 +175,6 @@ void launch_fused(int mode, const FusedArgs &A, hipStream_t s);
 void launch_segments(const FusedArgs &A, hipStream_t s);
 // lane-per-fragment classify kernel (lane.hip); fragments it cannot take are flagged in defer[] for launch_fused
 void launch_lane(const FusedArgs &A, int32_t *defer, uint32_t max_len, hipStream_t s);
-// Length-bucketed tile order for the lane kernel: order[R] = the fragment indices, permuted inside windows of 16 384 so that
-// the 64 fragments of a tile have (nearly) the same number of bases; *mixed is set to 1 if any window holds fragments of
-// different length classes (left alone otherwise: the kernel then takes the fragments in input order).  *mixed must be 0.
-void launch_tile_order(const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, uint32_t max_len, uint32_t *order,
-                       uint32_t *mixed, hipStream_t s);
 
 // launchers (kernels.hip)
 void launch_table_insert(const TableBuild &t, const int64_t *keys, const int32_t *taxa, uint64_t n, hipStream_t s);

@@ -342,13 +342,42 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
   const uint64_t ntiles = (A.R + 63) / 64;
   const uint64_t nwaves = (uint64_t)gridDim.x * LW;
 
-  // The 64 lanes of a wave run in lockstep, so a tile lasts as long as its longest fragment: when the batch mixes lengths the
-  // tiles take the fragments in a length-bucketed order (launch_tile_order) instead of input order.
-  const bool reorder = MODE == LANE_LOCAL && A.tile_order_on != nullptr && *A.tile_order_on != 0;
-  for (uint64_t tile = (uint64_t)blockIdx.x * LW + wib; tile < ntiles; tile += nwaves) {
-    const uint64_t slot_in_batch = tile * 64 + lane;
-    const bool have = slot_in_batch < A.R;
-    const uint64_t r = (have && reorder) ? (uint64_t)A.tile_order[slot_in_batch] : slot_in_batch;
+  // The 64 lanes of a wave run in lockstep, so a tile lasts as long as its longest fragment.  A block's waves therefore share
+  // out the block's LW * 64 consecutive fragments by LENGTH (a counting sort over 64 length classes in LDS, longest first):
+  // with LW = 4, lengths uniform in 50..250 fill tiles of 200-250, 150-200, ... bases instead of four tiles that each wait
+  // for a 250-base fragment.  Everything a lane touches stays inside the block's own fragments (same lines, same CU).
+  __shared__ uint32_t ord_cnt[64];
+  __shared__ uint16_t ord_perm[LW * 64];
+  for (uint64_t tile0 = (uint64_t)blockIdx.x * LW; tile0 < ntiles; tile0 += nwaves) {
+    const uint64_t tile = tile0 + wib;
+    uint64_t r;
+    {
+      const uint32_t t = threadIdx.x;
+      const uint64_t i = tile0 * 64 + t;
+      uint64_t len = 0;
+      if (i < A.R) {
+        len = A.offsets[i + 1] - A.offsets[i];
+        if (paired) len += A.mate_offsets[i + 1] - A.mate_offsets[i];
+      }
+      // class 0 = the longest the kernel takes ... 61 = the shortest; 62 = handed on (too long: no steps); 63 = beyond the batch
+      const uint32_t cls = i >= A.R ? 63u : len > max_len ? 62u : 61u - (uint32_t)(len * 62 / ((uint64_t)max_len + 1));
+      if (t < 64) ord_cnt[t] = 0;
+      __syncthreads();
+      atomicAdd(&ord_cnt[cls], 1u);
+      __syncthreads();
+      if (wib == 0) {  // exclusive prefix over the 64 classes
+        const uint32_t c = ord_cnt[lane];
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += up; }
+        ord_cnt[lane] = incl - c;
+      }
+      __syncthreads();
+      ord_perm[atomicAdd(&ord_cnt[cls], 1u)] = (uint16_t)t;
+      __syncthreads();
+      r = tile0 * 64 + ord_perm[t];
+    }
+    const bool have = r < A.R;
     // ---- fragment descriptor ----
     const uint8_t *seq = A.bases;
     uint32_t n = 0, n2 = 0;
@@ -649,49 +678,6 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     }
     lane_wave_sync();
   }
-}
-
-// ---- length-bucketed tile order --------------------------------------------------------------------------------------------
-constexpr int ORDER_WIN = 16384;   // fragments per window: one workgroup sorts one window by length class (64 classes)
-constexpr int ORDER_THREADS = 256;
-__global__ void __launch_bounds__(ORDER_THREADS) tile_order_kernel(const uint64_t *__restrict__ offsets,
-                                                                   const uint64_t *__restrict__ mate_offsets, uint64_t R,
-                                                                   uint32_t max_len, uint32_t *__restrict__ order,
-                                                                   uint32_t *__restrict__ mixed) {
-  __shared__ uint8_t cls[ORDER_WIN];
-  __shared__ uint32_t hist[64], cursor[64];
-  const uint64_t base = (uint64_t)blockIdx.x * ORDER_WIN;
-  const uint32_t n = (uint32_t)min((uint64_t)ORDER_WIN, R - base);
-  if (threadIdx.x < 64) hist[threadIdx.x] = 0;
-  __syncthreads();
-  // class 0 = the longest the lane kernel takes ... class 62 = the shortest; class 63 = fragments it hands on (too long):
-  // long fragments first, so that a window's last tiles are its cheapest
-  const uint32_t width = max_len / 62 + 1;
-  for (uint32_t i = threadIdx.x; i < n; i += ORDER_THREADS) {
-    const uint64_t r = base + i;
-    uint64_t len = offsets[r + 1] - offsets[r];
-    if (mate_offsets) len += mate_offsets[r + 1] - mate_offsets[r];
-    const uint32_t c = len > max_len ? 63u : 62u - (uint32_t)len / width;
-    cls[i] = (uint8_t)c;
-    atomicAdd(&hist[c], 1u);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t at = 0, used = 0;
-    for (int c = 0; c < 64; c++) { cursor[c] = at; at += hist[c]; used += hist[c] != 0; }
-    if (used > 1) atomicOr(mixed, 1u);
-  }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n; i += ORDER_THREADS) {
-    const uint32_t pos = atomicAdd(&cursor[cls[i]], 1u);
-    order[base + pos] = (uint32_t)(base + i);
-  }
-}
-void launch_tile_order(const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, uint32_t max_len, uint32_t *order,
-                       uint32_t *mixed, hipStream_t s) {
-  if (R == 0) return;
-  const uint64_t blocks = (R + ORDER_WIN - 1) / ORDER_WIN;
-  hipLaunchKernelGGL(tile_order_kernel, dim3((unsigned)blocks), dim3(ORDER_THREADS), 0, s, offsets, mate_offsets, R, max_len, order, mixed);
 }
 
 template <int MODE, bool HITS>
