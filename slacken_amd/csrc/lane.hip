@@ -342,41 +342,13 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
   const uint64_t ntiles = (A.R + 63) / 64;
   const uint64_t nwaves = (uint64_t)gridDim.x * LW;
 
-  // The 64 lanes of a wave run in lockstep, so a tile lasts as long as its longest fragment.  A block's waves therefore share
-  // out the block's LW * 64 consecutive fragments by LENGTH (a counting sort over 64 length classes in LDS, longest first):
-  // with LW = 4, lengths uniform in 50..250 fill tiles of 200-250, 150-200, ... bases instead of four tiles that each wait
-  // for a 250-base fragment.  Everything a lane touches stays inside the block's own fragments (same lines, same CU).
-  __shared__ uint32_t ord_cnt[64];
-  __shared__ uint16_t ord_perm[LW * 64];
-  for (uint64_t tile0 = (uint64_t)blockIdx.x * LW; tile0 < ntiles; tile0 += nwaves) {
-    const uint64_t tile = tile0 + wib;
-    uint64_t r;
-    {
-      const uint32_t t = threadIdx.x;
-      const uint64_t i = tile0 * 64 + t;
-      uint64_t len = 0;
-      if (i < A.R) {
-        len = A.offsets[i + 1] - A.offsets[i];
-        if (paired) len += A.mate_offsets[i + 1] - A.mate_offsets[i];
-      }
-      // class 0 = the longest the kernel takes ... 61 = the shortest; 62 = handed on (too long: no steps); 63 = beyond the batch
-      const uint32_t cls = i >= A.R ? 63u : len > max_len ? 62u : 61u - (uint32_t)(len * 62 / ((uint64_t)max_len + 1));
-      if (t < 64) ord_cnt[t] = 0;
-      __syncthreads();
-      atomicAdd(&ord_cnt[cls], 1u);
-      __syncthreads();
-      if (wib == 0) {  // exclusive prefix over the 64 classes
-        const uint32_t c = ord_cnt[lane];
-        uint32_t incl = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += up; }
-        ord_cnt[lane] = incl - c;
-      }
-      __syncthreads();
-      ord_perm[atomicAdd(&ord_cnt[cls], 1u)] = (uint16_t)t;
-      __syncthreads();
-      r = tile0 * 64 + ord_perm[t];
-    }
+  // (The 64 lanes of a wave run in lockstep, so a tile lasts as long as its longest fragment.  Two ways of handing the tiles
+  // fragments of similar length were measured in round 2 and dropped, profiles/r02_mixed_lengths.json: sorting a block's 256
+  // fragments over its four waves gains nothing, because a block's LDS and wave slots are held until its longest wave ends;
+  // a length-bucketed order inside windows of 16 384 fragments gains 4 % on lengths uniform in 50..250 -- where a globally
+  // sorted input gains 20 % -- because every lane then pays scattered loads of its offsets and scattered stores of its results.)
+  for (uint64_t tile = (uint64_t)blockIdx.x * LW + wib; tile < ntiles; tile += nwaves) {
+    const uint64_t r = tile * 64 + lane;
     const bool have = r < A.R;
     // ---- fragment descriptor ----
     const uint8_t *seq = A.bases;
