@@ -1111,15 +1111,20 @@ uint32_t slk_shard_of(int64_t key, uint32_t n_shards) {
 }
 
 
+// rows of the batch log (engine.h: ShardIO.batch_base) a batch needs: tile t starts at row floor(span_region(64 t) / 64) + t
+uint64_t slk_shard_batch_rows(uint64_t total_bases, uint64_t total_mate_bases, uint64_t R, int32_t paired) {
+  return (span_slots(total_bases, total_mate_bases, R, paired != 0) >> 6) + (R + 63) / 64 + 2;
+}
+
 int32_t slk_shard_emit_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
                               const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
-                              uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys, uint64_t *d_send_slots,
-                              uint64_t capacity_per_sublist, uint64_t *d_send_counts, int32_t *d_defer) {
+                              uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys,
+                              uint64_t capacity_per_sublist, uint64_t *d_send_counts, uint32_t *d_batch_base, int32_t *d_defer) {
   int32_t rc = check_ready(ix, st, false);
   if (rc) return rc;
   if (!lane_path_ok(ix)) return fail(SLK_E_UNSUPPORTED, "splitter outside the fused kernel's range: use the staged calls");
   if (n_sublists < 1 || n_sublists > 4096 || (n_sublists & (n_sublists - 1))) return fail(SLK_E_INVALID, "n_sublists must be a power of two <= 4096");
-  if (n_shards < 1 || n_shards > 64 || !d_send_counts || !d_defer || (R && (!d_bases || !d_offsets || !d_send_keys || !d_send_slots)))
+  if (n_shards < 1 || n_shards > 64 || !d_send_counts || !d_defer || (R && (!d_bases || !d_offsets || !d_send_keys || !d_batch_base)))
     return fail(SLK_E_INVALID, "bad argument");
   if ((d_mate_bases == nullptr) != (d_mate_offsets == nullptr))
     return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
@@ -1131,8 +1136,8 @@ int32_t slk_shard_emit_device(slk_index *ix, slk_stream *st, const uint8_t *d_ba
   A.P = ix->sp; A.bases = d_bases; A.offsets = d_offsets; A.mate_bases = d_mate_bases; A.mate_offsets = d_mate_offsets; A.R = R;
   A.status = st->d_status;
   ShardIO S{};
-  S.n_shards = (int32_t)n_shards; S.n_sub = (int32_t)n_sublists; S.cap = capacity_per_sublist; S.send_keys = d_send_keys; S.send_slots = d_send_slots;
-  S.send_counts = (unsigned long long *)d_send_counts;
+  S.n_shards = (int32_t)n_shards; S.n_sub = (int32_t)n_sublists; S.cap = capacity_per_sublist; S.send_keys = d_send_keys;
+  S.send_counts = (unsigned long long *)d_send_counts; S.batch_base = d_batch_base;
   st->queued.emplace_back();  // (not re-runnable: an overflow of this call is reported as an error)
   launch_lane_sharded(LANE_EMIT, A, S, d_defer, 1000, st->s);
   HIPCHK(hipMemcpyAsync(st->h_status, st->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st->s));
@@ -1140,28 +1145,35 @@ int32_t slk_shard_emit_device(slk_index *ix, slk_stream *st, const uint8_t *d_ba
   return SLK_OK;
 }
 
-int32_t slk_shard_scatter_device(slk_index *ix, slk_stream *st, const uint64_t *d_slots, const int32_t *d_taxa, uint64_t n,
-                                 int32_t *d_taxa_by_slot) {
+int32_t slk_shard_compact_device(slk_index *ix, slk_stream *st, const int64_t *d_send_keys, uint32_t n_shards, uint32_t n_sublists,
+                                 uint64_t capacity_per_sublist, const uint64_t *d_send_counts, int64_t *d_out_keys,
+                                 uint64_t *d_list_offsets, uint64_t *d_owner_counts) {
   int32_t rc = check_ready(ix, st, false);
   if (rc) return rc;
-  if (n && (!d_slots || !d_taxa || !d_taxa_by_slot)) return fail(SLK_E_INVALID, "null argument");
+  if (n_sublists < 1 || n_sublists > 4096 || n_shards < 1 || n_shards > 64 || !d_send_keys || !d_send_counts || !d_out_keys ||
+      !d_list_offsets || !d_owner_counts)
+    return fail(SLK_E_INVALID, "bad argument");
   rc = set_device(ix);
   if (rc) return rc;
-  launch_scatter_taxa(d_slots, d_taxa, n, d_taxa_by_slot, ix->d_to_dense, ix->T, st->s);
+  launch_compact_lists(d_send_keys, (const unsigned long long *)d_send_counts, n_shards, n_sublists, capacity_per_sublist, d_out_keys,
+                       d_list_offsets, d_owner_counts, st->s);
   HIPCHK(hipGetLastError());
   return SLK_OK;
 }
 
 int32_t slk_shard_apply_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
                                const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
-                               const int32_t *d_taxa_by_slot, int32_t min_hit_groups, const double *thresholds, int32_t C,
+                               uint32_t n_shards, uint32_t n_sublists, const int32_t *d_taxa, const uint64_t *d_list_offsets,
+                               const uint32_t *d_batch_base, int32_t min_hit_groups, const double *thresholds, int32_t C,
                                int32_t *d_out_taxon, uint8_t *d_out_classified, int32_t *d_out_num_distinct,
                                int32_t *d_out_total_kmers, int32_t *d_out_num_hits, int32_t *d_defer) {
   int32_t rc = check_ready(ix, st, true);
   if (rc) return rc;
   if (!lane_path_ok(ix)) return fail(SLK_E_UNSUPPORTED, "splitter outside the fused kernel's range: use the staged calls");
   if (C < 1 || C > MAX_THRESHOLDS || !thresholds) return fail(SLK_E_INVALID, "need 1..%d thresholds", MAX_THRESHOLDS);
-  if (!d_defer || (R && (!d_bases || !d_offsets || !d_taxa_by_slot || !d_out_taxon || !d_out_classified)))
+  if (n_sublists < 1 || n_sublists > 4096 || (n_sublists & (n_sublists - 1)) || n_shards < 1 || n_shards > 64)
+    return fail(SLK_E_INVALID, "bad n_shards / n_sublists");
+  if (!d_defer || (R && (!d_bases || !d_offsets || !d_taxa || !d_list_offsets || !d_batch_base || !d_out_taxon || !d_out_classified)))
     return fail(SLK_E_INVALID, "null argument");
   if ((d_mate_bases == nullptr) != (d_mate_offsets == nullptr))
     return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
@@ -1178,7 +1190,9 @@ int32_t slk_shard_apply_device(slk_index *ix, slk_stream *st, const uint8_t *d_b
   A.out_nd = d_out_num_distinct; A.out_tk = d_out_total_kmers; A.out_nh = d_out_num_hits;
   A.status = st->d_status;
   ShardIO S{};
-  S.taxa = d_taxa_by_slot;
+  S.n_shards = (int32_t)n_shards; S.n_sub = (int32_t)n_sublists;
+  S.batch_base = const_cast<uint32_t *>(d_batch_base); S.list_off = d_list_offsets; S.taxa = d_taxa;
+  S.to_dense = ix->d_to_dense; S.n_to_dense = ix->T;
   st->queued.emplace_back();
   launch_lane_sharded(LANE_APPLY, A, S, d_defer, 1000, st->s);
   HIPCHK(hipGetLastError());

@@ -146,25 +146,29 @@ struct FusedArgs {
 
 // Table-sharded classification (BASELINE configs[3]): the lane kernel runs twice per batch.  LANE_EMIT scans the
 // fragments and, instead of probing, appends every minimizer to the send list of the rank that owns it
-// (fmix64(key) mod n_shards) together with the slot its taxon must come back to; LANE_APPLY scans again and takes each
-// probe's taxon from those slots (filled from the owners' answers) instead of from the local table.
+// (fmix64(key) mod n_shards), logging per probe batch where each owner's group of keys went; LANE_APPLY scans again, forms
+// the same batches, and takes each probe's taxon from the owners' answers at the logged list positions.
 struct ShardIO {
   int32_t n_shards;
-  int32_t n_sub;                     // sub-lists per shard (power of two): waves append to sub-list (wave id mod n_sub), so that
+  int32_t n_sub;                     // sub-lists per shard (power of two): waves append to sub-list (tile index mod n_sub), so that
                                      // the cursor atomics spread over n_sub addresses per shard instead of serialising on one
   uint64_t cap;                      // capacity of each sub-list
-  int64_t *send_keys;                // [n_shards][n_sub][cap]
-  uint64_t *send_slots;              // [n_shards][n_sub][cap]: span_region(r) + ordinal of the probe within fragment r
-  unsigned long long *send_counts;   // [n_shards][n_sub] cursors; a cursor beyond cap raises status bit 2
-  const int32_t *taxa;               // LANE_APPLY: taxon per slot
+  int64_t *send_keys;                // LANE_EMIT: [n_shards][n_sub][cap]
+  unsigned long long *send_counts;   // LANE_EMIT: [n_shards][n_sub] cursors; a cursor beyond cap raises status bit 2
+  uint32_t *batch_base;              // [rows][n_shards]: where a probe batch's keys for an owner start in its sub-list
+  const uint64_t *list_off;          // LANE_APPLY: [n_shards * n_sub + 1] start of every sub-list in the compacted order
+  const int32_t *taxa;               // LANE_APPLY: the owners' answers, in the compacted order of the keys
+  const int32_t *to_dense;           // LANE_APPLY: caller's id -> the table's dense id (nullptr: ids as given)
+  int32_t n_to_dense;
 };
 enum { LANE_LOCAL = 0, LANE_EMIT = 1, LANE_APPLY = 2 };
 void launch_lane_sharded(int mode, const FusedArgs &A, const ShardIO &S, int32_t *defer, uint32_t max_len, hipStream_t s);
 // cooperative point lookups (4 lanes x 16 B per bucket) and the scatter of returned taxa to their slots (shard.hip)
 void launch_lookup_coop(const TableView &t, const int64_t *keys, uint64_t n, int32_t *out, hipStream_t s);
-// (to_dense, if set: the owners' answers carry the caller's ids, the apply kernel wants the cells' dense ones)
-void launch_scatter_taxa(const uint64_t *slots, const int32_t *taxa, uint64_t n, int32_t *taxa_by_slot, const int32_t *to_dense,
-                         int32_t n_to_dense, hipStream_t s);
+// The send lists as one contiguous array in (owner, sub-list) order: list_off[n_lists + 1] = exclusive prefix of the list
+// lengths, owner_counts[n_shards] = keys per owner (the all-to-all's split sizes), out_keys = the lists back to back.
+void launch_compact_lists(const int64_t *send_keys, const unsigned long long *send_counts, uint32_t n_shards, uint32_t n_sub,
+                          uint64_t cap, int64_t *out_keys, uint64_t *list_off, uint64_t *owner_counts, hipStream_t s);
 // cells' taxon field -> to_dense[taxon]; *undefined counts the cells whose taxon has no dense id; apply = false: count only
 void launch_remap_cells(uint64_t *cells, uint64_t ncells, int32_t taxon_bits, const int32_t *to_dense, int32_t n_to_dense,
                         unsigned long long *undefined, bool apply, hipStream_t s);

@@ -195,22 +195,27 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int q
 }
 
 // ---- table-sharded mode (engine.h: ShardIO) ------------------------------------------------------------------------------
-// The queue entries of these two modes carry the probe's ordinal within its fragment; with the fragment's span region (kept
-// per lane in the LDS words the local mode uses as probe stash) that names the slot through which the owner's answer returns.
+// Both modes run the same scan, so they form the same probe batches in the same order.  LANE_EMIT appends a batch's keys to
+// the send lists of their owners (one cursor bump per owner per batch) and logs where each owner's group went
+// (batch_base[row][owner]); LANE_APPLY finds the same keys in its queue again, recomputes owner and rank inside the group,
+// and reads the taxon the owner returned for that list position.  Nothing but 8-byte keys, 4-byte taxa and the 4-byte log
+// entries touches HBM: no per-probe slot addresses, no scatter of the answers.
 __device__ __forceinline__ uint64_t lane_readlane64(uint64_t v, int src) {
   uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src);
   return ((uint64_t)hi << 32) | lo;
 }
+__device__ __forceinline__ uint32_t shard_owner(uint64_t key, uint32_t ns) {  // == slk_shard_of
+  const uint64_t h = fmix64(key);
+  return (ns & (ns - 1)) == 0 ? (uint32_t)(h & (ns - 1)) : (uint32_t)(h % ns);
+}
 // LANE_EMIT: append the batch's minimizers to their owners' send lists (one atomic per owner per batch)
-__device__ __forceinline__ void emit_batch(LaneLds *L, const ShardIO &S, int32_t *status, int qhead, int cnt, int lane, uint32_t sub) {
+__device__ __forceinline__ void emit_batch(LaneLds *L, const ShardIO &S, int32_t *status, int qhead, int cnt, int lane, uint32_t sub,
+                                           uint64_t row) {
   const bool in = lane < cnt;
   const int qi = (qhead + lane) & (QCAP - 1);
   const uint64_t key = L->q_key[qi];
-  const uint32_t meta = L->q_meta[qi];
-  const uint64_t slot = L->stash[meta & 63] + ((meta >> 7) & 0x3FF);
-  const uint64_t h = fmix64(key);
   const uint32_t ns = (uint32_t)S.n_shards;
-  const uint32_t g = (ns & (ns - 1)) == 0 ? (uint32_t)(h & (ns - 1)) : (uint32_t)(h % ns);  // == slk_shard_of
+  const uint32_t g = shard_owner(key, ns);
   for (uint32_t sh = 0; sh < ns; sh++) {
     const bool mine = in && g == sh;
     const uint64_t m = __ballot(mine);
@@ -218,27 +223,36 @@ __device__ __forceinline__ void emit_batch(LaneLds *L, const ShardIO &S, int32_t
     const int leader = __ffsll((long long)m) - 1;
     unsigned long long base = 0;
     const uint64_t list = (uint64_t)sh * (uint32_t)S.n_sub + sub;
-    if (lane == leader) base = atomicAdd(&S.send_counts[list], (unsigned long long)__popcll(m));
+    if (lane == leader) {
+      base = atomicAdd(&S.send_counts[list], (unsigned long long)__popcll(m));
+      S.batch_base[row * ns + sh] = (uint32_t)base;
+    }
     base = lane_readlane64(base, leader);
     if (mine) {
       const uint64_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-      if (pos < S.cap) {
-        S.send_keys[list * S.cap + pos] = (int64_t)key;
-        S.send_slots[list * S.cap + pos] = slot;
-      } else {
-        atomicOr(status, 2);
-      }
+      if (pos < S.cap) S.send_keys[list * S.cap + pos] = (int64_t)key;
+      else atomicOr(status, 2);
     }
   }
   lane_wave_sync();
 }
-// LANE_APPLY: the batch's taxa come from the slots the owners' answers were scattered to
-__device__ __forceinline__ void apply_batch(LaneLds *L, const ShardIO &S, int qhead, int cnt, int lane) {
+// LANE_APPLY: the batch's taxa come from the owners' answers, which arrive list by list in the order the keys were sent
+__device__ __forceinline__ void apply_batch(LaneLds *L, const ShardIO &S, int qhead, int cnt, int lane, uint32_t sub, uint64_t row) {
   const bool in = lane < cnt;
   const int qi = (qhead + lane) & (QCAP - 1);
+  const uint64_t key = L->q_key[qi];
   const uint32_t meta = L->q_meta[qi];
-  const uint64_t slot = L->stash[meta & 63] + ((meta >> 17) & 0x3FF);
-  const int32_t taxon = in ? S.taxa[slot] : 0;
+  const uint32_t ns = (uint32_t)S.n_shards;
+  const uint32_t g = shard_owner(key, ns);
+  int32_t taxon = 0;
+  for (uint32_t sh = 0; sh < ns; sh++) {
+    const bool mine = in && g == sh;
+    const uint64_t m = __ballot(mine);
+    if (m == 0) continue;
+    const uint64_t at = S.list_off[(uint64_t)sh * (uint32_t)S.n_sub + sub] + S.batch_base[row * ns + sh];   // (wave-uniform loads)
+    if (mine) taxon = S.taxa[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))];
+  }
+  if (S.to_dense != nullptr && taxon > 0) taxon = taxon < S.n_to_dense ? S.to_dense[taxon] : 0;  // (owners answer in the caller's ids)
   fold_hit(L, in, meta, taxon);
   lane_wave_sync();
 }
@@ -364,7 +378,10 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     }
     bool too_long = have && ((uint64_t)n + n2 > max_len);
     bool fin = !have || too_long;
-    if (MODE != LANE_LOCAL) L->stash[lane] = have ? span_region(A.offsets, A.mate_offsets, r) : 0;  // (read after a wave sync)
+    // sharded modes: the tile's first row in the batch log.  A tile's probes number at most its bases, and tile t starts at
+    // row floor(span_region(first fragment of t) / 64) + t: rows of different tiles never overlap (capi.hip: shard_batch_rows)
+    uint64_t row = 0;
+    if (MODE != LANE_LOCAL) row = (span_region(A.offsets, A.mate_offsets, tile * 64) >> 6) + tile;
     const uint64_t rbase = (HITS && have) ? span_region(A.offsets, A.mate_offsets, r) : 0;
     if (HITS) L->rb[lane] = rbase;
     // ---- per-lane LDS state ----
@@ -525,9 +542,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
           int slot = (qhead + qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(E >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)E, 0))) & (QCAP - 1);
           L->q_key[slot] = ekey;
           if (HITS) L->q_ord[slot] = (uint16_t)ord0;
-          if (MODE == LANE_EMIT) L->q_meta[slot] = (uint32_t)lane | ((uint32_t)(np - 1) << 7);
-          else L->q_meta[slot] = (uint32_t)lane | (distinct ? 64u : 0u) | ((uint32_t)ekmers << 7) |
-                                 (MODE == LANE_APPLY ? (uint32_t)(np - 1) << 17 : 0u);
+          L->q_meta[slot] = (uint32_t)lane | (distinct ? 64u : 0u) | ((uint32_t)ekmers << 7);
         }
         qn += __popcll(E);
         // (a loop, not an if: a batch can hand entries back -- bucket overflows re-queued with a larger displacement -- and
@@ -535,8 +550,8 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
         while (qn >= 64) {
           lane_wave_sync();
           int back = 0;
-          if (MODE == LANE_EMIT) emit_batch(L, S, A.status, qhead, 64, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1));
-          else if (MODE == LANE_APPLY) apply_batch(L, S, qhead, 64, lane);
+          if (MODE == LANE_EMIT) emit_batch(L, S, A.status, qhead, 64, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++);
+          else if (MODE == LANE_APPLY) apply_batch(L, S, qhead, 64, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++);
           else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS>(L, A.T, qhead, qn, 64, lane, dbg, A.span_meta, A.span_taxon);
           qhead = (qhead + 64) & (QCAP - 1);
           qn += back - 64;
@@ -547,8 +562,8 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       lane_wave_sync();
       const int cnt = min(qn, 64);
       int back = 0;
-      if (MODE == LANE_EMIT) emit_batch(L, S, A.status, qhead, cnt, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1));
-      else if (MODE == LANE_APPLY) apply_batch(L, S, qhead, cnt, lane);
+      if (MODE == LANE_EMIT) emit_batch(L, S, A.status, qhead, cnt, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++);
+      else if (MODE == LANE_APPLY) apply_batch(L, S, qhead, cnt, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++);
       else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS>(L, A.T, qhead, qn, cnt, lane, dbg, A.span_meta, A.span_taxon);
       qhead = (qhead + cnt) & (QCAP - 1);
       qn += back - cnt;

@@ -88,16 +88,41 @@ __global__ void __launch_bounds__(SW * 64) lookup_coop_kernel(TableView T, const
   }
 }
 
-__global__ void __launch_bounds__(256) scatter_taxa_kernel(const uint64_t *__restrict__ slots, const int32_t *__restrict__ taxa,
-                                                           uint64_t n, int32_t *__restrict__ by_slot,
-                                                           const int32_t *__restrict__ to_dense, int32_t n_to_dense) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += step) {
-    int32_t t = taxa[i];
-    if (to_dense != nullptr && t > 0) t = t < n_to_dense ? to_dense[t] : 0;  // (a taxon outside the taxonomy cannot be in this rank's table either)
-    by_slot[slots[i]] = t;
+// exclusive prefix of the sub-list lengths (clamped to the capacity: an overflow has been flagged by the emit kernel)
+__global__ void __launch_bounds__(256) list_prefix_kernel(const unsigned long long *__restrict__ counts, uint32_t n_shards, uint32_t n_sub,
+                                                          uint64_t cap, uint64_t *__restrict__ list_off, uint64_t *__restrict__ owner_counts) {
+  __shared__ uint64_t part[256];
+  const uint32_t n = n_shards * n_sub, t = threadIdx.x;
+  const uint32_t per = (n + 255) / 256;
+  const uint32_t a = min(n, t * per), b = min(n, a + per);
+  uint64_t sum = 0;
+  for (uint32_t i = a; i < b; i++) sum += min((uint64_t)counts[i], cap);
+  part[t] = sum;
+  __syncthreads();
+  if (t == 0) {
+    uint64_t run = 0;
+    for (int i = 0; i < 256; i++) { uint64_t v = part[i]; part[i] = run; run += v; }
+    list_off[n] = run;
   }
+  __syncthreads();
+  uint64_t run = part[t];
+  for (uint32_t i = a; i < b; i++) { list_off[i] = run; run += min((uint64_t)counts[i], cap); }
+  __syncthreads();
+  __threadfence_block();
+  if (t < n_shards) {  // (n_shards <= 64)
+    uint64_t c = 0;
+    for (uint32_t i = t * n_sub; i < (t + 1) * n_sub; i++) c += min((uint64_t)counts[i], cap);
+    owner_counts[t] = c;
+  }
+}
+// one block column per sub-list: its keys move to their place in the contiguous array
+__global__ void __launch_bounds__(256) list_copy_kernel(const int64_t *__restrict__ send_keys, const unsigned long long *__restrict__ counts,
+                                                        uint64_t cap, const uint64_t *__restrict__ list_off, int64_t *__restrict__ out) {
+  const uint64_t list = blockIdx.y;
+  const uint64_t n = min((uint64_t)counts[list], cap);
+  const int64_t *src = send_keys + list * cap;
+  int64_t *dst = out + list_off[list];
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
 }  // namespace
@@ -107,11 +132,12 @@ void launch_lookup_coop(const TableView &t, const int64_t *keys, uint64_t n, int
   uint64_t blocks = std::min<uint64_t>((n + SW * 64 - 1) / (SW * 64), 256 * 16);
   hipLaunchKernelGGL(lookup_coop_kernel, dim3((unsigned)blocks), dim3(SW * 64), 0, s, t, keys, n, out);
 }
-void launch_scatter_taxa(const uint64_t *slots, const int32_t *taxa, uint64_t n, int32_t *taxa_by_slot, const int32_t *to_dense,
-                         int32_t n_to_dense, hipStream_t s) {
-  if (n == 0) return;
-  uint64_t blocks = std::min<uint64_t>((n + 255) / 256, 256 * 32);
-  hipLaunchKernelGGL(scatter_taxa_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slots, taxa, n, taxa_by_slot, to_dense, n_to_dense);
+void launch_compact_lists(const int64_t *send_keys, const unsigned long long *send_counts, uint32_t n_shards, uint32_t n_sub,
+                          uint64_t cap, int64_t *out_keys, uint64_t *list_off, uint64_t *owner_counts, hipStream_t s) {
+  hipLaunchKernelGGL(list_prefix_kernel, dim3(1), dim3(256), 0, s, send_counts, n_shards, n_sub, cap, list_off, owner_counts);
+  const uint32_t n_lists = n_shards * n_sub;
+  // (about 8 blocks per list at the usual 2048 lists: the lists are a few MB each)
+  hipLaunchKernelGGL(list_copy_kernel, dim3(8, n_lists), dim3(256), 0, s, send_keys, send_counts, cap, list_off, out_keys);
 }
 
 }  // namespace slk

@@ -6,9 +6,10 @@ join (S/slacken/Classifier.scala:84) for the one case where data must move; with
 mode (no collective at all).
 
 Host plumbing only: torch for device buffers and the collectives, the engine for all compute.  Two routes:
-  fast    slk_shard_emit_device -> all-to-all -> slk_lookup_device -> all-to-all -> slk_shard_scatter_device ->
-          slk_shard_apply_device: the fused lane-per-fragment kernel runs on both sides of the exchange, no span arrays;
-          takes fragments of up to 1000 bases with at most 12 distinct taxa;
+  fast    slk_shard_emit_device -> slk_shard_compact_device -> all-to-all -> slk_lookup_device -> all-to-all ->
+          slk_shard_apply_device: the fused lane-per-fragment kernel runs on both sides of the exchange, nothing but 8-byte keys
+          and 4-byte taxa moves; takes fragments of up to 1000 bases with at most 12 distinct taxa; classify_many keeps two
+          batches in flight so that the exchange of one overlaps the scans of its neighbours;
   staged  slk_scan_device / slk_lookup_device / slk_classify_hits_device with the exchange lists built by torch ops: takes
           everything, and the fragments the fast route hands back (`defer`)."""
 import numpy as np
@@ -92,71 +93,159 @@ class ShardedClassifier:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return bool(int(t.item()))
 
-    def _classify_fast(self, d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups, mates=None):
+    # ---- the fast route, in stages that are interleaved between batches (classify_many) -------------------------------------
+    # All torch work of a batch is issued on the ENGINE's stream (wrapped as a torch ExternalStream): torch kernels,
+    # collectives and engine kernels of one batch are ordered by that stream itself, whatever stream the caller works on.
+    # Two batches on two engine streams overlap where the hardware has room: emit and apply are bound by instruction issue,
+    # the owners' lookup by HBM requests, the exchange by the links.
+    def _stream(self, which=0):
+        if not hasattr(self, "_streams"):
+            self._streams = [self.st, self.ix.stream()]
+            self._ext = [self.torch.cuda.ExternalStream(s.hip_stream, device=self.device) for s in self._streams]
+        return self._streams[which], self._ext[which]
+
+    def _fast_emit(self, which, d_bases, d_offsets, R, total_bases, mates, cap_scale=1):
+        """stage 1 (asynchronous): scan + send lists + their compaction.  Returns the batch's state, or None if this index's
+        splitter only has the staged route."""
         import slacken_amd
         from slacken_amd import capi
         torch, dev, W = self.torch, self.device, self.world
-        # about 0.26 probes per base on random sequence, spread evenly by the hash over W owners and by the wave index over
-        # SUB sub-lists per owner (each fed by at least 64 waves, so that the spread holds): 0.6 / (W * SUB) per base leaves 2x
-        # headroom; a list that overflows all the same makes the engine say so, and the batch is emitted again with twice the room
+        st, ext = self._stream(which)
         mb, mo, mtotal = mates if mates is not None else (None, None, 0)
         mkw = dict(d_mate_bases=mb.data_ptr(), d_mate_offsets=mo.data_ptr()) if mates is not None else {}
+        # about 0.26 probes per base on random sequence, spread evenly by the hash over W owners and by the tile index over SUB
+        # sub-lists per owner (each fed by at least 64 tiles, so that the spread holds): 0.6 / (W * SUB) per base leaves 2x
+        # headroom; a list that overflows all the same makes the engine say so, and the batch is emitted again with more room
         tiles = (R + 63) // 64
         SUB = 1
         while SUB < 256 and SUB * 2 * 64 <= tiles:
             SUB *= 2
-        cap = int((total_bases + mtotal) * 0.6 / (W * SUB)) + (1 << 12)
-        defer = torch.empty(max(R, 1), dtype=torch.int32, device=dev)
-        unsupported = False
-        while True:
+        cap = (int((total_bases + mtotal) * 0.6 / (W * SUB)) + (1 << 12)) * cap_scale
+        rows = int(capi.lib().slk_shard_batch_rows(total_bases, mtotal, R, 1 if mates is not None else 0))
+        ext.wait_stream(torch.cuda.current_stream())    # the caller's tensors were produced on ITS stream
+        with torch.cuda.stream(ext):
+            defer = torch.empty(max(R, 1), dtype=torch.int32, device=dev)
+            batch_base = torch.empty(rows * W, dtype=torch.int32, device=dev)
             send_keys = torch.empty(W * SUB * cap, dtype=torch.int64, device=dev)
-            send_slots = torch.empty(W * SUB * cap, dtype=torch.int64, device=dev)
-            counts = torch.zeros(W * SUB, dtype=torch.int64, device=dev)
+            counts = torch.empty(W * SUB, dtype=torch.int64, device=dev)
             try:
-                self.st.shard_emit_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, W, SUB, send_keys.data_ptr(),
-                                          send_slots.data_ptr(), cap, counts.data_ptr(), defer.data_ptr(), **mkw)
-                self.st.synchronize()
-                break
+                st.shard_emit_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, W, SUB, send_keys.data_ptr(), cap, counts.data_ptr(),
+                                     batch_base.data_ptr(), defer.data_ptr(), **mkw)
             except slacken_amd.SlackenError as e:
-                if e.code == capi.E_CAPACITY:
-                    del send_keys, send_slots
-                    cap *= 2
-                    continue
-                if e.code != capi.E_UNSUPPORTED:   # (unsupported: this splitter only has the staged route)
+                if e.code != capi.E_UNSUPPORTED:
                     raise
-                unsupported = True
-                break
-        if self._any_rank(unsupported):
-            return None
-        sub_counts = [int(v) for v in counts.tolist()]          # [owner][sub-list], owner-major: concatenation order
-        send_counts = [sum(sub_counts[g * SUB:(g + 1) * SUB]) for g in range(W)]
-        keys = torch.cat([send_keys[i * cap:i * cap + n] for i, n in enumerate(sub_counts)])
-        slots = torch.cat([send_slots[i * cap:i * cap + n] for i, n in enumerate(sub_counts)])
-        del send_keys, send_slots
-        recv_keys, recv_counts = self._all_to_all(keys, send_counts)
-        found = torch.zeros(max(recv_keys.numel(), 1), dtype=torch.int32, device=dev)
-        if recv_keys.numel():
-            recv_keys = recv_keys.contiguous()
-            self.st.lookup_device(recv_keys.data_ptr(), recv_keys.numel(), found.data_ptr())
-            self.st.synchronize()
-        back, _ = self._all_to_all(found[:recv_keys.numel()].contiguous(), recv_counts)
-        by_slot = torch.empty(total_bases + mtotal + R + 1, dtype=torch.int32, device=dev)
-        back = back.contiguous()
-        self.st.shard_scatter_device(slots.data_ptr(), back.data_ptr(), back.numel(), by_slot.data_ptr())
+                return None
+            out_keys = torch.empty_like(send_keys)   # (room for every list at its capacity; the used prefix is what is sent)
+            list_off = torch.empty(W * SUB + 1, dtype=torch.int64, device=dev)
+            owner_counts = torch.empty(W, dtype=torch.int64, device=dev)
+            st.shard_compact_device(send_keys.data_ptr(), W, SUB, cap, counts.data_ptr(), out_keys.data_ptr(), list_off.data_ptr(),
+                                    owner_counts.data_ptr())
+            h_counts = torch.empty(W, dtype=torch.int64, pin_memory=True)
+            h_counts.copy_(owner_counts, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(ext)
+        return dict(st=st, ext=ext, R=R, SUB=SUB, defer=defer, batch_base=batch_base, send_keys=send_keys, counts=counts,
+                    out_keys=out_keys, list_off=list_off, h_counts=h_counts, ready=ready, mkw=mkw, d_bases=d_bases,
+                    d_offsets=d_offsets, mates=mates)
+
+    def _fast_ready(self, b):
+        """the batch's only host wait: W numbers (the exchange's split sizes) and the engine's status word.  False: a send list
+        overflowed its capacity."""
+        import slacken_amd
+        from slacken_amd import capi
+        b["ready"].synchronize()
+        try:
+            b["st"].synchronize()
+        except slacken_amd.SlackenError as e:
+            if e.code == capi.E_CAPACITY:
+                return False
+            raise
+        return True
+
+    def _fast_exchange(self, b):
+        """stage 2 (asynchronous but for the collectives' own host side): keys to their owners, lookup, taxa back"""
+        torch = self.torch
+        send_counts = [int(v) for v in b["h_counts"].tolist()]
+        n_send = sum(send_counts)
+        with torch.cuda.stream(b["ext"]):
+            recv_keys, recv_counts = self._all_to_all(b["out_keys"][:n_send], send_counts)
+            found = torch.empty(max(recv_keys.numel(), 1), dtype=torch.int32, device=self.device)
+            if recv_keys.numel():
+                recv_keys = recv_keys.contiguous()
+                b["st"].lookup_device(recv_keys.data_ptr(), recv_keys.numel(), found.data_ptr())
+            back, _ = self._all_to_all(found[:recv_keys.numel()], recv_counts)
+            b["taxa"] = back.contiguous() if back.numel() else torch.zeros(1, dtype=torch.int32, device=self.device)
+        b["exchanged"] = n_send
+        b["recv_keys"] = recv_keys          # (kept alive until the lookup has run)
+        del b["send_keys"], b["out_keys"]
+
+    def _fast_apply(self, b, thresholds, min_hit_groups):
+        """stage 3 (asynchronous): the second scan.  The result tensors are valid once the batch's stream has been synchronised."""
+        torch, dev, R, W = self.torch, self.device, b["R"], self.world
         C = len(thresholds)
-        out = dict(taxon=torch.zeros(C * max(R, 1), dtype=torch.int32, device=dev),
-                   classified=torch.zeros(C * max(R, 1), dtype=torch.uint8, device=dev),
-                   num_distinct=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
-                   total_kmers=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
-                   num_hits=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
-                   exchanged_keys=int(keys.numel()))
-        self.st.shard_apply_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, by_slot.data_ptr(), out["taxon"].data_ptr(),
-                                   out["classified"].data_ptr(), defer.data_ptr(), out["num_distinct"].data_ptr(),
-                                   out["total_kmers"].data_ptr(), out["num_hits"].data_ptr(), min_hit_groups=min_hit_groups,
-                                   thresholds=thresholds, **mkw)
-        self.st.synchronize()
-        # fragments the fused kernel does not take: a compacted batch through the staged route (all ranks, also with none)
-        idx = torch.nonzero(defer[:R]).flatten() if R else torch.zeros(0, dtype=torch.int64, device=dev)
+        with torch.cuda.stream(b["ext"]):
+            out = dict(taxon=torch.zeros(C * max(R, 1), dtype=torch.int32, device=dev),
+                       classified=torch.zeros(C * max(R, 1), dtype=torch.uint8, device=dev),
+                       num_distinct=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
+                       total_kmers=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
+                       num_hits=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
+                       exchanged_keys=b["exchanged"])
+            b["st"].shard_apply_device(b["d_bases"].data_ptr(), b["d_offsets"].data_ptr(), R, W, b["SUB"], b["taxa"].data_ptr(),
+                                       b["list_off"].data_ptr(), b["batch_base"].data_ptr(), out["taxon"].data_ptr(),
+                                       out["classified"].data_ptr(), b["defer"].data_ptr(), out["num_distinct"].data_ptr(),
+                                       out["total_kmers"].data_ptr(), out["num_hits"].data_ptr(), min_hit_groups=min_hit_groups,
+                                       thresholds=thresholds, **b["mkw"])
+            for k in ("taxa", "batch_base", "list_off", "counts", "recv_keys"):   # (their memory goes back to this stream's pool:
+                b.pop(k, None)                                                     #  whatever reuses it is ordered after the apply)
+        return out
+
+    def _emit_until_it_fits(self, which, batch):
+        """emit (again with longer lists while any rank's overflowed); None if the fast route does not apply"""
+        d_bases, d_offsets, R, total_bases, mates = batch
+        scale = 1
+        while True:
+            b = self._fast_emit(which, d_bases, d_offsets, R, total_bases, mates, scale)
+            if self._any_rank(b is None):
+                return None
+            if not self._any_rank(not self._fast_ready(b)):
+                return b
+            scale *= 2
+
+    def _classify_fast(self, d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups, mates=None):
+        outs = self.classify_many([(d_bases, d_offsets, R, total_bases, mates)], thresholds, min_hit_groups)
+        return None if outs is None else outs[0]
+
+    def classify_many(self, batches, thresholds=(0.0,), min_hit_groups=2):
+        """The fast route over several batches [(d_bases, d_offsets, R, total_bases, mates or None)], two in flight: batch i+1 is
+        scanned (emit) while batch i's keys are exchanged and looked up and batch i-1's answers are applied.  Every rank must
+        pass the same number of batches.  Returns the list of result dicts, or None if the splitter only has the staged route."""
+        states, outs = [], []
+
+        def finish(i):   # exchange + apply of batch i (issued asynchronously on its stream)
+            self._fast_exchange(states[i])
+            outs.append(self._fast_apply(states[i], thresholds, min_hit_groups))
+
+        for i, batch in enumerate(batches):
+            b = self._emit_until_it_fits(i % 2, batch)    # (its host wait comes while batch i-1's exchange is still to be issued)
+            if b is None:
+                return None
+            states.append(b)
+            if i >= 1:
+                finish(i - 1)
+        if states:
+            finish(len(states) - 1)
+        for i, (b, batch) in enumerate(zip(states, batches)):
+            b["st"].synchronize()
+            d_bases, d_offsets, R, total_bases, mates = batch
+            outs[i] = self._finish_deferred(outs[i], b, d_bases, d_offsets, R, thresholds, min_hit_groups, mates)
+        return outs
+
+    def _finish_deferred(self, out, b, d_bases, d_offsets, R, thresholds, min_hit_groups, mates):
+        """fragments the fused kernel does not take: a compacted batch through the staged route (all ranks, also with none)"""
+        torch, dev = self.torch, self.device
+        C = len(thresholds)
+        mb, mo, mtotal = mates if mates is not None else (None, None, 0)
+        idx = torch.nonzero(b["defer"][:R]).flatten() if R else torch.zeros(0, dtype=torch.int64, device=dev)
         out["deferred"] = int(idx.numel())
         if self._any_rank(idx.numel() > 0):
             def compact(bases, offsets):
@@ -166,12 +255,9 @@ class ShardedClassifier:
                 sub_total = int(sub_off[-1].item()) if idx.numel() else 0
                 src = torch.repeat_interleave(offsets[idx], lens) + (torch.arange(sub_total, device=dev) -
                                                                      torch.repeat_interleave(sub_off[:-1], lens))
-                return torch.cat([bases[src], torch.zeros(64, dtype=torch.uint8, device=dev)]), sub_off, sub_total
+                return (bases[src] if sub_total else torch.zeros(1, dtype=torch.uint8, device=dev)), sub_off, sub_total
             sub_bases, sub_off, sub_total = compact(d_bases, d_offsets)
-            sub_mates = None
-            if mates is not None:
-                smb, smo, smt = compact(mb, mo)
-                sub_mates = (smb, smo, smt)
+            sub_mates = compact(mb, mo) if mates is not None else None
             sub = self._classify_staged(sub_bases, sub_off, int(idx.numel()), sub_total, thresholds, min_hit_groups, sub_mates)
             n = int(idx.numel())
             if n:
@@ -192,6 +278,7 @@ class ShardedClassifier:
         meta = torch.empty(slots, dtype=torch.int32, device=dev)
         count = torch.zeros(max(R, 1), dtype=torch.int32, device=dev)
         taxon = torch.zeros(slots, dtype=torch.int32, device=dev)
+        torch.cuda.current_stream().synchronize()    # (the engine's stream is not torch's: order the two explicitly)
         self.st.scan_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, keys.data_ptr(), meta.data_ptr(), count.data_ptr(), **mkw)
         self.st.synchronize()
         cnt = count[:R].long()
@@ -209,6 +296,7 @@ class ShardedClassifier:
         found = torch.zeros(max(recv_keys.numel(), 1), dtype=torch.int32, device=dev)
         if recv_keys.numel():
             recv_keys = recv_keys.contiguous()
+            torch.cuda.current_stream().synchronize()
             self.st.lookup_device(recv_keys.data_ptr(), recv_keys.numel(), found.data_ptr())
             self.st.synchronize()
         back, _ = self._all_to_all(found[:recv_keys.numel()].contiguous(), recv_counts)
@@ -223,6 +311,7 @@ class ShardedClassifier:
                    num_hits=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
                    exchanged_keys=int(k.numel()))
         scratch = keys  # the key slots are dead after the exchange
+        torch.cuda.current_stream().synchronize()
         self.st.classify_hits_device(d_offsets.data_ptr(), R, meta.data_ptr(), taxon.data_ptr(), count.data_ptr(),
                                      scratch.data_ptr(), out["taxon"].data_ptr(), out["classified"].data_ptr(),
                                      out["num_distinct"].data_ptr(), out["total_kmers"].data_ptr(),

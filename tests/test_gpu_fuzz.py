@@ -86,7 +86,7 @@ def test_differential(orc, seed, monkeypatch):
 
 @pytest.mark.parametrize("seed", range(max(6, N_SEEDS // 4)))
 def test_sharded_routes_differential(orc, seed):
-    """The table-sharded pipeline (world = 1: emit -> lookup -> scatter -> apply, with deferrals through the staged route)
+    """The table-sharded pipeline (world = 1: emit -> compact -> lookup -> apply, with deferrals through the staged route)
     over random splitters and read shapes, single and paired, against the oracle."""
     import torch
     import slacken_amd

@@ -91,9 +91,9 @@ def test_two_ranks_half_table_each(orc, tmp_path, fast):
 @pytest.mark.gpu
 @pytest.mark.parametrize("big_ids", [False, True], ids=["ids<2^22", "dense-ids"])
 def test_single_rank_fast_route_with_deferrals(orc, big_ids):
-    """world = 1: no exchange, but the same emit -> lookup -> scatter -> apply pipeline, incl. fragments the fused kernel
+    """world = 1: no exchange, but the same emit -> compact -> lookup -> apply pipeline, incl. fragments the fused kernel
     hands back (longer than 1000 bases; more than 12 distinct taxa) and empty / vanishing fragments.  With taxon ids beyond
-    22 bits the table holds dense internal ids: the owners' answers (caller's ids) are translated by the scatter."""
+    22 bits the table holds dense internal ids: the owners' answers (caller's ids) are translated by the apply kernel."""
     import synth
     import taxgen
     rng = np.random.default_rng(43)

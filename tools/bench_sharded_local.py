@@ -18,7 +18,7 @@ R = int(os.environ.get('R', 2_000_000))
 starts = rng.integers(0, G * L - 150, R)
 d_all = torch.from_numpy(bases).cuda()
 idx = torch.from_numpy(starts).cuda()[:, None] + torch.arange(150, device="cuda")[None, :]
-d_b = torch.cat([d_all[idx.reshape(-1)], torch.zeros(64, dtype=torch.uint8, device="cuda")])
+d_b = d_all[idx.reshape(-1)]
 d_o = torch.arange(0, (R + 1) * 150, 150, dtype=torch.int64, device="cuda")
 sc = ShardedClassifier(ix, 0, 1, None, torch.device("cuda", 0))
 for fast in (False, True):
@@ -27,6 +27,15 @@ for fast in (False, True):
         out = sc.classify(d_b, d_o, R, R * 150, fast=fast)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print("sharded world=1", "fast" if fast else "staged", round(dt * 1e3, 1), "ms", round(R / dt / 1e6, 1), "M reads/s", out.get("deferred"))
+# several batches, two in flight (classify_many): what a run over many batches costs per batch
+NB = int(os.environ.get("NB", 6))
+batches = [(d_b, d_o, R, R * 150, None)] * NB
+for _ in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    outs = sc.classify_many(batches)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print("sharded world=1 fast, pipelined over", NB, "batches:", round(dt / NB * 1e3, 1), "ms per batch", round(NB * R / dt / 1e6, 1), "M reads/s")
+assert all(bool((o["taxon"] == out["taxon"]).all()) for o in outs)
 st = ix.stream()
 d_t = torch.zeros(R, dtype=torch.int32, device="cuda"); d_c = torch.zeros(R, dtype=torch.uint8, device="cuda")
 for _ in range(3):

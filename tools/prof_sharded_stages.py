@@ -17,7 +17,7 @@ R = 10_000_000
 d_all = torch.from_numpy(bases).cuda()
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 stt = torch.randint(0, G * L - 150, (R,), generator=g, device="cuda")
-d_b = torch.cat([d_all[(stt[:, None] + torch.arange(150, device="cuda")[None, :]).reshape(-1)], torch.zeros(64, dtype=torch.uint8, device="cuda")])
+d_b = d_all[(stt[:, None] + torch.arange(150, device="cuda")[None, :]).reshape(-1)]
 d_o = torch.arange(0, (R + 1) * 150, 150, dtype=torch.int64, device="cuda")
 st = ix.stream()
 W = 1; total = R * 150
@@ -26,20 +26,20 @@ cap = int(total * 0.6 / (W * SUB)) + (1 << 12)
 def T(name, f):
     torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(); st.synchronize(); torch.cuda.synchronize()
     print(f"{name:10s} {(time.perf_counter()-t0)*1e3:8.2f} ms"); return r
+from slacken_amd import capi
+rows = int(capi.lib().slk_shard_batch_rows(total, 0, R, 0))
 for it in range(2):
     print("iter", it)
     send_keys = T("alloc", lambda: torch.empty(W * SUB * cap, dtype=torch.int64, device="cuda"))
-    send_slots = torch.empty(W * SUB * cap, dtype=torch.int64, device="cuda")
     counts = torch.zeros(W * SUB, dtype=torch.int64, device="cuda")
+    batch_base = torch.empty(rows * W, dtype=torch.int32, device="cuda")
     defer = torch.empty(R, dtype=torch.int32, device="cuda")
-    T("emit", lambda: st.shard_emit_device(d_b.data_ptr(), d_o.data_ptr(), R, W, SUB, send_keys.data_ptr(), send_slots.data_ptr(), cap, counts.data_ptr(), defer.data_ptr()))
-    sc = counts.tolist(); n = int(sum(sc)); print("keys", n)
-    keys = T("cat", lambda: torch.cat([send_keys[i * cap:i * cap + c] for i, c in enumerate(sc)]))
-    slots = torch.cat([send_slots[i * cap:i * cap + c] for i, c in enumerate(sc)])
-    found = T("zeros", lambda: torch.zeros(n, dtype=torch.int32, device="cuda"))
-    T("lookup", lambda: st.lookup_device(keys.data_ptr(), n, found.data_ptr()))
-    by_slot = torch.empty(total + R + 1, dtype=torch.int32, device="cuda")
-    T("scatter", lambda: st.shard_scatter_device(slots.data_ptr(), found.data_ptr(), n, by_slot.data_ptr()))
+    T("emit", lambda: st.shard_emit_device(d_b.data_ptr(), d_o.data_ptr(), R, W, SUB, send_keys.data_ptr(), cap, counts.data_ptr(), batch_base.data_ptr(), defer.data_ptr()))
+    out_keys = torch.empty_like(send_keys); list_off = torch.empty(W * SUB + 1, dtype=torch.int64, device="cuda"); oc = torch.empty(W, dtype=torch.int64, device="cuda")
+    T("compact", lambda: st.shard_compact_device(send_keys.data_ptr(), W, SUB, cap, counts.data_ptr(), out_keys.data_ptr(), list_off.data_ptr(), oc.data_ptr()))
+    n = int(oc.sum().item()); print("keys", n)
+    found = T("empty", lambda: torch.empty(n, dtype=torch.int32, device="cuda"))
+    T("lookup", lambda: st.lookup_device(out_keys.data_ptr(), n, found.data_ptr()))
     out_t = torch.zeros(R, dtype=torch.int32, device="cuda"); out_c = torch.zeros(R, dtype=torch.uint8, device="cuda")
-    T("apply", lambda: st.shard_apply_device(d_b.data_ptr(), d_o.data_ptr(), R, by_slot.data_ptr(), out_t.data_ptr(), out_c.data_ptr(), defer.data_ptr()))
+    T("apply", lambda: st.shard_apply_device(d_b.data_ptr(), d_o.data_ptr(), R, W, SUB, found.data_ptr(), list_off.data_ptr(), batch_base.data_ptr(), out_t.data_ptr(), out_c.data_ptr(), defer.data_ptr()))
     T("nonzero", lambda: torch.nonzero(defer))
