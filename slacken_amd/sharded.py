@@ -98,9 +98,11 @@ class ShardedClassifier:
     # collectives and engine kernels of one batch are ordered by that stream itself, whatever stream the caller works on.
     # Two batches on two engine streams overlap where the hardware has room: emit and apply are bound by instruction issue,
     # the owners' lookup by HBM requests, the exchange by the links.
+    N_STREAMS = int(__import__("os").environ.get("SLK_SHARD_STREAMS", "2"))   # batches in flight (classify_many)
+
     def _stream(self, which=0):
         if not hasattr(self, "_streams"):
-            self._streams = [self.st, self.ix.stream()]
+            self._streams = [self.st] + [self.ix.stream() for _ in range(self.N_STREAMS - 1)]
             self._ext = [self.torch.cuda.ExternalStream(s.hip_stream, device=self.device) for s in self._streams]
         return self._streams[which], self._ext[which]
 
@@ -199,41 +201,34 @@ class ShardedClassifier:
                 b.pop(k, None)                                                     #  whatever reuses it is ordered after the apply)
         return out
 
-    def _emit_until_it_fits(self, which, batch):
-        """emit (again with longer lists while any rank's overflowed); None if the fast route does not apply"""
-        d_bases, d_offsets, R, total_bases, mates = batch
-        scale = 1
-        while True:
-            b = self._fast_emit(which, d_bases, d_offsets, R, total_bases, mates, scale)
-            if self._any_rank(b is None):
-                return None
-            if not self._any_rank(not self._fast_ready(b)):
-                return b
-            scale *= 2
-
     def _classify_fast(self, d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups, mates=None):
         outs = self.classify_many([(d_bases, d_offsets, R, total_bases, mates)], thresholds, min_hit_groups)
         return None if outs is None else outs[0]
 
     def classify_many(self, batches, thresholds=(0.0,), min_hit_groups=2):
-        """The fast route over several batches [(d_bases, d_offsets, R, total_bases, mates or None)], two in flight: batch i+1 is
-        scanned (emit) while batch i's keys are exchanged and looked up and batch i-1's answers are applied.  Every rank must
-        pass the same number of batches.  Returns the list of result dicts, or None if the splitter only has the staged route."""
+        """The fast route over several batches [(d_bases, d_offsets, R, total_bases, mates or None)], two in flight on two engine
+        streams: while batch i is scanned (emit), batch i-1's keys are exchanged and looked up and its answers applied.  Every rank
+        must pass the same number of batches.  Returns the list of result dicts, or None if the splitter only has the staged route."""
         states, outs = [], []
 
-        def finish(i):   # exchange + apply of batch i (issued asynchronously on its stream)
-            self._fast_exchange(states[i])
-            outs.append(self._fast_apply(states[i], thresholds, min_hit_groups))
+        def settle(j):   # batch j: its one host wait, then exchange + lookup + apply issued on its stream
+            b, scale = states[j], 1
+            while self._any_rank(not self._fast_ready(b)):      # (rare: a send list overflowed somewhere -- every rank emits again)
+                scale *= 2
+                d_bases, d_offsets, R, total_bases, mates = batches[j]
+                b = states[j] = self._fast_emit(j % self.N_STREAMS, d_bases, d_offsets, R, total_bases, mates, scale)
+            self._fast_exchange(b)
+            outs.append(self._fast_apply(b, thresholds, min_hit_groups))
 
-        for i, batch in enumerate(batches):
-            b = self._emit_until_it_fits(i % 2, batch)    # (its host wait comes while batch i-1's exchange is still to be issued)
-            if b is None:
+        for i, (d_bases, d_offsets, R, total_bases, mates) in enumerate(batches):
+            b = self._fast_emit(i % self.N_STREAMS, d_bases, d_offsets, R, total_bases, mates)    # asynchronous
+            if i == 0 and self._any_rank(b is None):
                 return None
             states.append(b)
-            if i >= 1:
-                finish(i - 1)
-        if states:
-            finish(len(states) - 1)
+            if i >= self.N_STREAMS - 1:
+                settle(i - (self.N_STREAMS - 1))     # (the emits of the batches after it are running meanwhile on the other streams)
+        for j in range(max(0, len(states) - (self.N_STREAMS - 1)), len(states)):
+            settle(j)
         for i, (b, batch) in enumerate(zip(states, batches)):
             b["st"].synchronize()
             d_bases, d_offsets, R, total_bases, mates = batch
