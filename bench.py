@@ -192,6 +192,9 @@ def main():
     ap.add_argument("--genome-len", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing only (gloo, no GPU)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N ranks that all use GPU 0 (gloo for the rendezvous): rehearses the N-rank GPU path on a one-GPU box; "
+                         "not a measurement")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -209,12 +212,17 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")     # (RCCL refuses two ranks on one GPU)
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     import slacken_amd
     n_records, n_reads = int(args.records), int(args.reads)
@@ -301,7 +309,7 @@ def main():
     st.synchronize()   # (the engine's own check of the queued calls: raises if a device-side error was flagged)
     step_dev_ms = np.array([a.elapsed_time(b) for a, b in ev]) if args.steps else np.zeros(1)
     stage_ms = np.array(st.last_stage_ms())  # the engine's own events of the LAST timed step: [fused, 0, ~0] on the hot path
-    elapsed = sdist.max_over_ranks(elapsed, dist, device)
+    elapsed = sdist.max_over_ranks(elapsed, dist, None if args.rehearse_on_one_gpu else device)
     ms_per_step = elapsed / args.steps * 1e3
     reads_per_s = world * n_reads / (elapsed / args.steps)
 
@@ -342,6 +350,7 @@ def main():
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
+        **({"rehearsal": "all ranks on GPU 0: not a measurement"} if args.rehearse_on_one_gpu else {}),
         "config": {
             "workload": "standard-224-scale synthetic library (k=35,m=31,s=7), synthetic 150 bp single-end reads, "
                         "full table resident in HBM (BASELINE.json configs[1])",

@@ -125,3 +125,25 @@ def test_poly_a_known_answer(big):
     out = run(big, bases, big["offsets"][:R + 1], R)
     assert bool((out["nh"] == 1).all()) and bool((out["tk"] == 116).all()) and bool((out["np_"] == 1).all())
     assert bool((out["taxon"] == out["taxon"][0]).all())
+
+
+def test_bench_two_ranks_rehearsal():
+    """`python bench.py --gpus 2` end to end on the GPU: the parent starts two ranks itself, each builds its table, classifies its
+    own batch, and rank 0 prints ONE line with n_gpus = 2 and the sum of both ranks' reads.  (Both ranks share GPU 0 here --
+    an 8-GPU node is the driver's -- so the rendezvous is gloo and the figure is not a measurement.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--records", "2e8",
+                        "--reads", "1e6", "--genomes", "64", "--genome-len", "262144", "--rehearse-on-one-gpu"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "cpu_baseline" not in line
+    assert line["config"]["reads_per_gpu_per_step"] == 1_000_000
+    assert abs(line["value"] - 2 * 1.0 / (line["ms_per_step"] * 1e-3)) < 0.01 * line["value"]     # whole-job reads / max-rank time
+    assert 0.0 < line["roofline"]["frac"] < 1.0
