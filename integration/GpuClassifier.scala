@@ -26,6 +26,11 @@ object Native {
                             mateOffsets: Array[Long], r: Int, minHitGroups: Int, thresholds: Array[Double], outTaxon: Array[Int],
                             outClassified: Array[Byte], outNumDistinct: Array[Int], outTotalKmers: Array[Int],
                             outHitOffsets: Array[Long], outHits: ByteBuffer, hitsCapacity: Long): Unit
+  /** slk_classify_hits: Classifier.classify (object, Classifier.scala:439-454) on hit lists the caller merged itself */
+  @native def classifyHits(h: Long, s: Long, r: Int, hitOffsets: Array[Long], hits: ByteBuffer, distinct: Array[Byte],
+                           minHitGroups: Int, thresholds: Array[Double], outTaxon: Array[Int], outClassified: Array[Byte]): Unit
+  /** slk_host_alloc as a direct buffer (NewDirectByteBuffer): the library DMAs from and to it without a staging copy */
+  @native def allocPinned(bytes: Long): ByteBuffer
 }
 
 /** One table per executor JVM: the records are loaded once (replacing the per-query Parquet scan + join of
@@ -56,7 +61,13 @@ object GpuIndexHolder {
 final class GpuClassifier(index: KeyValueIndex, handle: => Long)(implicit spark: SparkSession) {
   import spark.implicits._
 
-  /** Drop-in for Classifier.classify (Classifier.scala:114-121) with per-read output. */
+  /** Drop-in for Classifier.classify (Classifier.scala:114-121) with per-read output.
+   * Titles: the reference groups the span rows of ALL fragments by title (Classifier.scala:92), so fragments that share a title are
+   * one read.  This method classifies fragments individually, which is the same thing for every title that occurs once.  For inputs
+   * where titles repeat, follow it with the reference's own grouping: `rows.groupByKey(_.title)`, leave groups of one alone, and for
+   * the others concatenate the fragments' hits, sort them stably by ordinal (Classifier.scala:136) and classify the merged list with
+   * Native.classifyHits (the per-hit `distinct` flags come from a getSpans-style call, slk_spans_batch) -- what the stand-alone
+   * host does in slacken_cli.cpp: resolve_repeated_titles.  Batch buffers should come from Native.allocPinned and be reused. */
   def classify(subjects: Dataset[InputFragment], cpar: ClassifyParams, threshold: Double): Dataset[ClassifiedRead] = {
     val k = index.params.k
     val sre = cpar.sampleRegex.map(_.r)

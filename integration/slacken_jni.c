@@ -110,3 +110,37 @@ JNIEXPORT void JNICALL Java_com_jnpersson_slacken_gpu_Native_classifyBatch(
   (*e)->ReleaseLongArrayElements(e, offsets, o, JNI_ABORT);
   if (rc != SLK_OK) throw_state(e);
 }
+
+/* slk_classify_hits: hit lists merged by the caller (fragments that share a title, Classifier.scala:92,136) */
+JNIEXPORT void JNICALL Java_com_jnpersson_slacken_gpu_Native_classifyHits(JNIEnv *e, jclass c, jlong h, jlong s, jint r, jlongArray hitOffsets,
+                                                                          jobject hits, jbyteArray distinct, jint minHitGroups,
+                                                                          jdoubleArray thresholds, jintArray outTaxon, jbyteArray outClassified) {
+  (void)c;
+  jsize C = (*e)->GetArrayLength(e, thresholds);
+  jlong *ho = (*e)->GetPrimitiveArrayCritical(e, hitOffsets, NULL);
+  jbyte *di = distinct ? (*e)->GetPrimitiveArrayCritical(e, distinct, NULL) : NULL;
+  jdouble *thr = (*e)->GetPrimitiveArrayCritical(e, thresholds, NULL);
+  jint *tx = (*e)->GetPrimitiveArrayCritical(e, outTaxon, NULL);
+  jbyte *cl = (*e)->GetPrimitiveArrayCritical(e, outClassified, NULL);
+  int32_t rc = slk_classify_hits((slk_index *)(intptr_t)h, (slk_stream *)(intptr_t)s, (uint64_t)r, (const uint64_t *)ho,
+                                 (const slk_hit *)(*e)->GetDirectBufferAddress(e, hits), (const uint8_t *)di, minHitGroups, thr, (int32_t)C,
+                                 (int32_t *)tx, (uint8_t *)cl, NULL, NULL);
+  (*e)->ReleasePrimitiveArrayCritical(e, outClassified, cl, 0);
+  (*e)->ReleasePrimitiveArrayCritical(e, outTaxon, tx, 0);
+  (*e)->ReleasePrimitiveArrayCritical(e, thresholds, thr, JNI_ABORT);
+  if (di) (*e)->ReleasePrimitiveArrayCritical(e, distinct, di, JNI_ABORT);
+  (*e)->ReleasePrimitiveArrayCritical(e, hitOffsets, ho, JNI_ABORT);
+  if (rc != SLK_OK) (*e)->ThrowNew(e, (*e)->FindClass(e, "java/lang/IllegalStateException"), slk_last_error());
+}
+
+/* slk_host_alloc as a direct ByteBuffer: batch buffers the library DMAs from and to without a staging copy (reuse them; free with
+ * slk_host_free(GetDirectBufferAddress(buffer)) when the executor shuts down) */
+JNIEXPORT jobject JNICALL Java_com_jnpersson_slacken_gpu_Native_allocPinned(JNIEnv *e, jclass c, jlong bytes) {
+  (void)c;
+  void *p = NULL;
+  if (slk_host_alloc((size_t)bytes, &p) != SLK_OK) {
+    (*e)->ThrowNew(e, (*e)->FindClass(e, "java/lang/OutOfMemoryError"), slk_last_error());
+    return NULL;
+  }
+  return (*e)->NewDirectByteBuffer(e, p, bytes);
+}
