@@ -236,7 +236,7 @@ struct slk_stream {
   hipStream_t s = nullptr;
   DevBuf span_keys, span_meta, span_taxon, span_count;  // per-batch scratch (sparse per-read regions)
   DevBuf bases, offsets, mate_bases, mate_offsets;      // staging for the host-pointer entry points
-  DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items, defer_list;
+  DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items, defer_list, handled;
   int32_t *d_status = nullptr;     // device error bits of the fused kernels
   int32_t *h_status = nullptr;     // pinned copy, refreshed after every classify launch
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -858,7 +858,7 @@ void slk_stream_destroy(slk_stream *st) {
   (void)hipStreamSynchronize(st->s);
   DevBuf *bufs[] = {&st->span_keys, &st->span_meta, &st->span_taxon, &st->span_count, &st->bases, &st->offsets,
                     &st->mate_bases, &st->mate_offsets, &st->out_taxon, &st->out_cls, &st->out_nd, &st->out_tk,
-                    &st->out_nh, &st->out_offsets, &st->out_items, &st->defer_list};
+                    &st->out_nh, &st->out_offsets, &st->out_items, &st->defer_list, &st->handled};
   for (DevBuf *b : bufs) b->release();
   if (st->d_status) (void)hipFree(st->d_status);
   if (st->h_status) (void)hipHostFree(st->h_status);
@@ -1010,7 +1010,18 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
       HIPCHK(hipMemsetAsync(st->defer_list.p, 0, sizeof(uint64_t), st->s));
       A.work_list = st->defer_list.as<uint64_t>() + 1;
       A.work_count = (const unsigned long long *)st->defer_list.p;
-      launch_lane(A, nullptr, 1000, st->s);  // queue entries carry 10-bit k-mer counts
+      launch_lane(A, nullptr, 1000, st->s);  // (the one-word map entries carry 10-bit k-mer counts)
+      // of the fragments it handed on, those of up to 4999 bases take the lane kernel's long variant (32-bit counts);
+      // SLK_LANE_LONG_MAX moves the limit (at most 8191: queue entries carry 13-bit k-mer counts), 0 turns the pass off
+      const char *long_env = getenv("SLK_LANE_LONG_MAX");
+      const int long_max = std::min(long_env ? atoi(long_env) : 4999, 8191);
+      if (long_max > 1000) {
+        HIPCHK(st->handled.ensure(R + 1));
+        HIPCHK(hipMemsetAsync(st->handled.p, 0, R + 1, st->s));
+        A.handled = st->handled.as<uint8_t>();
+        A.lane_short_max = 1000;
+        launch_lane_long(A, (uint32_t)long_max, st->s);
+      }
       // of the deferred fragments, the long unpaired ones go to the lane-per-segment kernel (classification only, w = 5)
       // (5000: below that, too few of the 64 lanes have a segment of a useful length; read per call, so that tests can move it)
       const char *seg_env = getenv("SLK_SEG_MIN_LEN");

@@ -140,6 +140,8 @@ struct FusedArgs {
   int32_t *status;       // device error bits: 1 = taxon map overflow
   const uint64_t *work_list;             // if set, the fused kernel processes only the fragments work_list[0 .. *work_count)
   const unsigned long long *work_count;  // (device) -- the fragments the lane kernel deferred (it appends them itself)
+  uint8_t *handled;                      // work-list passes: [i] = 1 if the long-lane pass classified work_list[i] (the wave kernel skips it)
+  uint32_t lane_short_max;               // long-lane pass: it takes fragments longer than this (the first pass's limit)
   uint32_t seg_min_len;                  // work-list passes: unpaired fragments of at least this many bases belong to the
                                          // lane-per-segment kernel (launch_segments), the others to the wave kernel; 0 = none
 };
@@ -179,6 +181,7 @@ void launch_fused(int mode, const FusedArgs &A, hipStream_t s);
 void launch_segments(const FusedArgs &A, hipStream_t s);
 // lane-per-fragment classify kernel (lane.hip); fragments it cannot take are flagged in defer[] for launch_fused
 void launch_lane(const FusedArgs &A, int32_t *defer, uint32_t max_len, hipStream_t s);
+void launch_lane_long(const FusedArgs &A, uint32_t max_len, hipStream_t s);
 
 // launchers (kernels.hip)
 void launch_table_insert(const TableBuild &t, const int64_t *keys, const int32_t *taxa, uint64_t n, hipStream_t s);

@@ -350,6 +350,7 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
   for (uint64_t unit = (uint64_t)blockIdx.x * FW + wib; unit < nunits; unit += nwaves) {
    {
     const uint64_t r = A.work_list ? A.work_list[unit] : unit;
+    if (A.work_list && A.handled && A.handled[unit]) continue;                        // classified by the long-lane pass (lane.hip)
     if (A.seg_min_len && A.offsets[r + 1] - A.offsets[r] >= A.seg_min_len) continue;  // the segment kernel's (launch_segments)
     // ---- per-fragment state (wave-uniform unless noted) ----
     int nbuf = 0, n_out = 0;
@@ -643,6 +644,7 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
     const uint64_t o = A.offsets[r];
     const uint32_t n_all = (uint32_t)(A.offsets[r + 1] - o);
     if (n_all < A.seg_min_len) continue;  // the wave kernel's
+    if (A.handled && A.handled[unit]) continue;  // (classified by the long-lane pass, should its limit reach this far)
     // ---- this lane's segment ----
     const uint32_t nwin = n_all - (uint32_t)k + 1;  // (seg_min_len > k)
     const uint32_t S = max(SEG_MIN_WINDOWS, (nwin + 63) / 64);

@@ -50,10 +50,11 @@ constexpr uint32_t OMAP_CNT_MASK = (1u << OMAP_CNT_BITS) - 1;
 
 struct __attribute__((aligned(16))) LaneLds {
   uint64_t q_key[QCAP];
-  uint32_t q_meta[QCAP];          // owner lane (6 bits) | distinct << 6 | kmers << 7 (10 bits) | displacement << 17 (6 bits)
+  uint32_t q_meta[QCAP];          // owner lane (6 bits) | distinct << 6 | kmers << 7 (13 bits) | displacement << 20 (6 bits)
   uint64_t stash[128];            // (home bucket, taxon found, tag) 16 bytes per queue entry of the batch
   uint4 sbuf[(SBLK - 1) * 64];    // read stream: the staged 16-byte sub-blocks 1.. of every lane, [sub-block - 1][lane]
   uint32_t omap[OMAP * 64];       // [slot][owner lane]: taxon << 10 | k-mer count; 0 = empty (NONE hits are not stored)
+                                  // (LONG variant: the taxon alone; the counts are a second array behind the per-wave block)
   uint32_t o_flags[64];           // low bits: hits with distinct && taxon != NONE (Classifier.scala:94); bit 31: map overflow
   uint64_t rb[64];                // hit-list output only: every lane's span region (engine.h span_region)
   uint16_t q_ord[QCAP];           // hit-list output only: the queue entry's ordinal among its fragment's spans
@@ -93,19 +94,28 @@ __device__ __forceinline__ uint64_t lmin64(uint64_t a, uint64_t b) { return a < 
 
 // Fold entry `meta`'s hit into its owner's 12-slot map: ONE round of LDS atomics per batch (NONE hits carry no information
 // for resolveTree and are dropped).
-__device__ __forceinline__ void fold_hit(LaneLds *L, bool in, uint32_t meta, int32_t taxon) {
+template <bool LONG>
+__device__ __forceinline__ void fold_hit(LaneLds *L, uint32_t *ocnt, bool in, uint32_t meta, int32_t taxon) {
   if (in && taxon != 0) {
     const int owner = meta & 63;
-    const int32_t kmers = (int32_t)((meta >> 7) & 0x3FF);
+    const int32_t kmers = (int32_t)((meta >> 7) & 0x1FFF);
     if (meta & 64) atomicAdd(&L->o_flags[owner], 1u);  // distinct && taxon != NONE (Classifier.scala:94)
     uint32_t slot = (uint32_t)(((uint64_t)((uint32_t)taxon * 0x9E3779B1u) * (uint32_t)OMAP) >> 32);  // hash -> [0, OMAP)
-    const uint32_t fresh = ((uint32_t)taxon << OMAP_CNT_BITS) | (uint32_t)kmers;
     int p = 0;
-    for (; p < OMAP; p++) {
-      uint32_t old = atomicCAS(&L->omap[slot * 64 + owner], 0u, fresh);
-      if (old == 0u) break;
-      if ((old >> OMAP_CNT_BITS) == (uint32_t)taxon) { atomicAdd(&L->omap[slot * 64 + owner], (uint32_t)kmers); break; }
-      slot = (slot + 1 == (uint32_t)OMAP) ? 0u : slot + 1;
+    if (LONG) {  // fragments of up to 8191 bases: 32-bit taxon and 32-bit count in two words
+      for (; p < OMAP; p++) {
+        uint32_t old = atomicCAS(&L->omap[slot * 64 + owner], 0u, (uint32_t)taxon);
+        if (old == 0u || old == (uint32_t)taxon) { atomicAdd(&ocnt[slot * 64 + owner], (uint32_t)kmers); break; }
+        slot = (slot + 1 == (uint32_t)OMAP) ? 0u : slot + 1;
+      }
+    } else {
+      const uint32_t fresh = ((uint32_t)taxon << OMAP_CNT_BITS) | (uint32_t)kmers;
+      for (; p < OMAP; p++) {
+        uint32_t old = atomicCAS(&L->omap[slot * 64 + owner], 0u, fresh);
+        if (old == 0u) break;
+        if ((old >> OMAP_CNT_BITS) == (uint32_t)taxon) { atomicAdd(&L->omap[slot * 64 + owner], (uint32_t)kmers); break; }
+        slot = (slot + 1 == (uint32_t)OMAP) ? 0u : slot + 1;
+      }
     }
     if (p == OMAP) atomicOr(&L->o_flags[owner], 0x80000000u);
   }
@@ -117,8 +127,8 @@ __device__ __forceinline__ void fold_hit(LaneLds *L, bool in, uint32_t meta, int
 //      instructions in flight before the first compare; the lane that finds the key writes the taxon to result[entry];
 //   3. lane i folds entry i's hit into its owner's 12-slot map: ONE round of LDS atomics per batch (NONE hits carry no
 //      information for resolveTree and are dropped).
-template <bool HITS>
-__device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int qhead, int qn, int cnt, int lane, int dbg,
+template <bool HITS, bool LONG>
+__device__ __forceinline__ int probe_batch(LaneLds *L, uint32_t *ocnt, const TableView &T, int qhead, int qn, int cnt, int lane, int dbg,
                                            int32_t *hit_meta, int32_t *hit_taxon) {
   const uint64_t NO_TAG = ~0ULL;
   const bool in = lane < cnt;
@@ -128,7 +138,7 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int q
   const uint32_t ord = HITS ? L->q_ord[qi] : 0u;  // (in a register now: re-queued entries may wrap onto this batch's slots)
   const uint64_t h = fmix64(key);
   uint4 st;
-  const uint32_t disp = (meta >> 17) & 63;                                // > 0 for an entry re-queued after a full bucket
+  const uint32_t disp = (meta >> 20) & 63;                                // > 0 for an entry re-queued after a full bucket
   st.x = (uint32_t)(((h >> T.shift) + disp) & T.bucket_mask);             // bucket to read (< 2^32)
   st.y = 0;                                                               // taxon found (filled in by step 2)
   const uint64_t tag = in ? (((h & T.rem_mask) << T.disp_bits) + disp) : NO_TAG;  // the tag's low bits are the displacement
@@ -165,7 +175,7 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int q
       // queue with its displacement raised, and takes an ordinary slot of a later batch.
       const int qj = (qhead + s * 16 + g) & (QCAP - 1);
       const uint32_t m_old = L->q_meta[qj];
-      const bool again = c == 0 && ((B >> (g * 4)) & 0xF) == 0 && (int)((m_old >> 17) & 63) < T.max_disp;
+      const bool again = c == 0 && ((B >> (g * 4)) & 0xF) == 0 && (int)((m_old >> 20) & 63) < T.max_disp;
       const uint64_t k_old = L->q_key[qj];
       const uint16_t o_old = HITS ? L->q_ord[qj] : (uint16_t)0;
       const uint64_t R = __ballot(again);
@@ -173,7 +183,7 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int q
       if (again) {
         const int slot = (qhead + qn + requeued + __builtin_amdgcn_mbcnt_hi((uint32_t)(R >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)R, 0))) & (QCAP - 1);
         L->q_key[slot] = k_old;
-        L->q_meta[slot] = m_old + (1u << 17);
+        L->q_meta[slot] = m_old + (1u << 20);
         if (HITS) L->q_ord[slot] = o_old;
       }
       requeued += __popcll(R);
@@ -182,13 +192,13 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, const TableView &T, int q
   lane_wave_sync();
   // step 3: one lane per entry
   const int32_t taxon = (int32_t)((const uint4 *)L->stash)[lane].y;
-  if (!SLK_TUNE_ON(2)) fold_hit(L, in, meta, taxon);
+  if (!SLK_TUNE_ON(2)) fold_hit<LONG>(L, ocnt, in, meta, taxon);
   if (HITS && in) {
     // the un-merged hit list (TaxonHit, KeyValueIndex.scala:436-441) in the fragment's span region.  An entry handed back
     // to the queue writes NONE here and its final taxon when a later batch resolves it.
     const uint64_t at = L->rb[meta & 63] + ord;
     hit_taxon[at] = ext_taxon(T, taxon);
-    hit_meta[at] = pack_meta((int32_t)((meta >> 7) & 0x3FF), 1, (meta >> 6) & 1);
+    hit_meta[at] = pack_meta((int32_t)((meta >> 7) & 0x1FFF), 1, (meta >> 6) & 1);
   }
   lane_wave_sync();
   return requeued;
@@ -253,36 +263,36 @@ __device__ __forceinline__ void apply_batch(LaneLds *L, const ShardIO &S, int qh
     if (mine) taxon = S.taxa[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))];
   }
   if (S.to_dense != nullptr && taxon > 0) taxon = taxon < S.n_to_dense ? S.to_dense[taxon] : 0;  // (owners answer in the caller's ids)
-  fold_hit(L, in, meta, taxon);
+  fold_hit<false>(L, nullptr, in, meta, taxon);
   lane_wave_sync();
 }
 
+template <bool LONG>
 struct OwnerMap {  // this lane's column of the LDS maps
   const LaneLds *L;
+  const uint32_t *ocnt;
   int lane;
-  __device__ __forceinline__ int32_t key(int s) const { return (int32_t)(L->omap[s * 64 + lane] >> OMAP_CNT_BITS); }  // 0 = empty
-  __device__ __forceinline__ int32_t cnt(int s) const { return (int32_t)(L->omap[s * 64 + lane] & OMAP_CNT_MASK); }
+  __device__ __forceinline__ int32_t key(int s) const {  // 0 = empty
+    return LONG ? (int32_t)L->omap[s * 64 + lane] : (int32_t)(L->omap[s * 64 + lane] >> OMAP_CNT_BITS);
+  }
+  __device__ __forceinline__ int32_t cnt(int s) const {
+    return LONG ? (int32_t)ocnt[s * 64 + lane] : (int32_t)(L->omap[s * 64 + lane] & OMAP_CNT_MASK);
+  }
   // the map is a hash table (fold_hit): follow t's probe sequence to its entry or to the first empty slot -- one or two LDS
   // reads instead of a scan of all slots, for every node of every root path resolveTree walks
-  __device__ __forceinline__ int32_t get(int32_t t) const {
-    uint32_t slot = (uint32_t)(((uint64_t)((uint32_t)t * 0x9E3779B1u) * (uint32_t)OMAP) >> 32);
-    for (int p = 0; p < OMAP; p++) {
-      const uint32_t e = L->omap[slot * 64 + lane];
-      if (e == 0) return 0;
-      if ((int32_t)(e >> OMAP_CNT_BITS) == t) return (int32_t)(e & OMAP_CNT_MASK);
-      slot = (slot + 1 == (uint32_t)OMAP) ? 0u : slot + 1;
-    }
-    return 0;
-  }
   __device__ __forceinline__ int find(int32_t t) const {  // slot of taxon t, or -1
     uint32_t slot = (uint32_t)(((uint64_t)((uint32_t)t * 0x9E3779B1u) * (uint32_t)OMAP) >> 32);
     for (int p = 0; p < OMAP; p++) {
-      const uint32_t e = L->omap[slot * 64 + lane];
-      if (e == 0) return -1;
-      if ((int32_t)(e >> OMAP_CNT_BITS) == t) return (int)slot;
+      const int32_t kk = key((int)slot);
+      if (kk == 0) return -1;
+      if (kk == t) return (int)slot;
       slot = (slot + 1 == (uint32_t)OMAP) ? 0u : slot + 1;
     }
     return -1;
+  }
+  __device__ __forceinline__ int32_t get(int32_t t) const {
+    const int sl = find(t);
+    return sl < 0 ? 0 : cnt(sl);
   }
 };
 
@@ -337,7 +347,11 @@ __device__ __forceinline__ uint4 stream_refill(LaneLds *L, int lane, const uint8
 #define LANE_BOUNDS __launch_bounds__(LW * 64)
 #endif
 
-template <bool W5, int MODE, bool HITS>
+// LONG: the second pass over the fragments the first one handed on (A.work_list): those of more than A.lane_short_max and at most
+// max_len bases are classified here, with a map of full 32-bit counts (a 1 001..4 999-base fragment has up to 4 965 k-mers for
+// one taxon; the one-word map of the hot variant counts to 1 023); what it classifies is marked in A.handled, the rest -- longer
+// ones, map overflows of either pass -- is left to the wave / segment kernels.  The hot variant is untouched by it.
+template <bool W5, int MODE, bool HITS, bool LONG>
 __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, uint32_t max_len, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
@@ -348,12 +362,15 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
   // rows, the suffix minima of the previous block in the rows the current block has not reached yet
   // (the hit-list fields are the struct's tail: kernels that do not write hit lists leave them out of their footprint)
   const size_t fixed = HITS ? sizeof(LaneLds) : offsetof(LaneLds, rb);
-  const size_t per_wave = fixed + (W5 ? 0 : (size_t)w * 64 * sizeof(uint64_t));
+  const size_t win_bytes = W5 ? 0 : (size_t)w * 64 * sizeof(uint64_t);
+  const size_t per_wave = fixed + win_bytes + (LONG ? (size_t)OMAP * 64 * sizeof(uint32_t) : 0);
   LaneLds *L = (LaneLds *)(lds_raw + (size_t)wib * per_wave);
   uint64_t *win = (uint64_t *)((unsigned char *)L + fixed);
+  uint32_t *ocnt = LONG ? (uint32_t *)((unsigned char *)L + fixed + win_bytes) : nullptr;   // LONG: k-mer counts of the map's slots
   const bool paired = A.mate_bases != nullptr;
   const uint64_t bases_end = A.offsets[A.R], mates_end = paired ? A.mate_offsets[A.R] : 0;  // (wave-uniform loads)
-  const uint64_t ntiles = (A.R + 63) / 64;
+  const uint64_t n_units = LONG ? (uint64_t)*A.work_count : A.R;   // LONG: the first pass's hand-ons (it has finished: same stream)
+  const uint64_t ntiles = (n_units + 63) / 64;
   const uint64_t nwaves = (uint64_t)gridDim.x * LW;
 
   // (The 64 lanes of a wave run in lockstep, so a tile lasts as long as its longest fragment.  Two ways of handing the tiles
@@ -362,8 +379,9 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
   // a length-bucketed order inside windows of 16 384 fragments gains 4 % on lengths uniform in 50..250 -- where a globally
   // sorted input gains 20 % -- because every lane then pays scattered loads of its offsets and scattered stores of its results.)
   for (uint64_t tile = (uint64_t)blockIdx.x * LW + wib; tile < ntiles; tile += nwaves) {
-    const uint64_t r = tile * 64 + lane;
-    const bool have = r < A.R;
+    const uint64_t unit = tile * 64 + lane;
+    bool have = unit < n_units;
+    const uint64_t r = LONG ? (have ? A.work_list[unit] : 0) : unit;
     // ---- fragment descriptor ----
     const uint8_t *seq = A.bases;
     uint32_t n = 0, n2 = 0;
@@ -376,6 +394,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       SLK_TUNE(if (dbg & 8) { seq = A.bases + A.offsets[r & 1023]; room = clamp_room(bases_end - A.offsets[r & 1023]); })  // (timing experiment 8: the read stream comes from the L2)
       if (paired) n2 = (uint32_t)(A.mate_offsets[r + 1] - A.mate_offsets[r]);  // (the mate's place is read again when the scan gets there)
     }
+    if (LONG) have = have && (uint64_t)n + n2 > A.lane_short_max && (uint64_t)n + n2 <= max_len;   // (the others are not this pass's)
     bool too_long = have && ((uint64_t)n + n2 > max_len);
     bool fin = !have || too_long;
     // sharded modes: the tile's first row in the batch log.  A tile's probes number at most its bases, and tile t starts at
@@ -387,6 +406,10 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     // ---- per-lane LDS state ----
 #pragma unroll
     for (int s = 0; s < OMAP; s++) L->omap[s * 64 + lane] = 0;
+    if (LONG) {
+#pragma unroll
+      for (int s = 0; s < OMAP; s++) ocnt[s * 64 + lane] = 0;
+    }
     L->o_flags[lane] = 0;
     // ---- scan state ----
     uint32_t pos = 0;
@@ -552,7 +575,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
           int back = 0;
           if (MODE == LANE_EMIT) emit_batch(L, S, A.status, qhead, 64, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++);
           else if (MODE == LANE_APPLY) apply_batch(L, S, qhead, 64, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++);
-          else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS>(L, A.T, qhead, qn, 64, lane, dbg, A.span_meta, A.span_taxon);
+          else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS, LONG>(L, ocnt, A.T, qhead, qn, 64, lane, dbg, A.span_meta, A.span_taxon);
           qhead = (qhead + 64) & (QCAP - 1);
           qn += back - 64;
         }
@@ -564,7 +587,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       int back = 0;
       if (MODE == LANE_EMIT) emit_batch(L, S, A.status, qhead, cnt, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++);
       else if (MODE == LANE_APPLY) apply_batch(L, S, qhead, cnt, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++);
-      else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS>(L, A.T, qhead, qn, cnt, lane, dbg, A.span_meta, A.span_taxon);
+      else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS, LONG>(L, ocnt, A.T, qhead, qn, cnt, lane, dbg, A.span_meta, A.span_taxon);
       qhead = (qhead + cnt) & (QCAP - 1);
       qn += back - cnt;
     }
@@ -573,7 +596,9 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     // ---- per-read classification (one lane per read) ------------------------------------------------------------------
     const uint32_t oflags = have ? L->o_flags[lane] : 0u;
     const bool dfr = have && (too_long || (oflags & 0x80000000u));  // re-done by the wave-per-read / segment kernels
-    if (MODE == LANE_LOCAL) {
+    if (LONG) {
+      if (have && !dfr) A.handled[unit] = 1;   // (a map overflow stays with the wave kernel)
+    } else if (MODE == LANE_LOCAL) {
       // straight into the work list of those kernels ([count] at A.work_count, indices at A.work_list; the order of the
       // list does not matter): one atomic per wave that defers anything, none otherwise
       const uint64_t DM = __ballot(dfr);
@@ -589,7 +614,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     if (have) {
       if (dfr) {
       } else if (MODE != LANE_EMIT) {
-        OwnerMap M{L, lane};
+        OwnerMap<LONG> M{L, ocnt, lane};
         const int32_t nd = (int32_t)oflags;
         int D = 0;
         int32_t t0 = 0, c0 = 0;
@@ -667,17 +692,19 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
   }
 }
 
-template <int MODE, bool HITS>
+template <int MODE, bool HITS, bool LONG>
 static void launch_lane_mode(const FusedArgs &A, const ShardIO &S, int32_t *defer, uint32_t max_len, hipStream_t s) {
   if (A.R == 0) return;
   const bool w5 = A.P.w == 5;
-  size_t per_wave = (HITS ? sizeof(LaneLds) : offsetof(LaneLds, rb)) + (w5 ? 0 : (size_t)A.P.w * 64 * sizeof(uint64_t));
+  size_t per_wave = (HITS ? sizeof(LaneLds) : offsetof(LaneLds, rb)) + (w5 ? 0 : (size_t)A.P.w * 64 * sizeof(uint64_t)) +
+                    (LONG ? (size_t)OMAP * 64 * sizeof(uint32_t) : 0);
   static const int extra_lds = getenv("SLK_LANE_EXTRA_LDS") ? atoi(getenv("SLK_LANE_EXTRA_LDS")) : 0;  // (occupancy experiment)
   size_t lds = per_wave * LW + (size_t)extra_lds;
   uint64_t tiles = (A.R + 63) / 64;
   uint64_t blocks = (tiles + LW - 1) / LW;
   static const int bpc = getenv("SLK_LANE_BLOCKS_PER_CU") ? atoi(getenv("SLK_LANE_BLOCKS_PER_CU")) : 0;  // (tuning experiment)
   if (bpc > 0 && blocks > (uint64_t)256 * bpc) blocks = (uint64_t)256 * bpc;
+  if (LONG && blocks > 256 * 5) blocks = 256 * 5;   // (the number of hand-ons is only known on the device: the waves loop over them)
   dim3 g((unsigned)blocks), b(LW * 64);
 #ifdef SLK_TUNING
   static const int dbg = getenv("SLK_DEBUG_ABLATE") ? atoi(getenv("SLK_DEBUG_ABLATE")) : 0;  // timing experiments only: 1 = no probes, 2 = no map updates
@@ -688,21 +715,26 @@ static void launch_lane_mode(const FusedArgs &A, const ShardIO &S, int32_t *defe
   if (getenv("SLK_DEBUG_OCC") && !occ_printed) {  // (tuning aid)
     occ_printed = true;
     int nb = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, w5 ? (const void *)lane_kernel<true, MODE, HITS> : (const void *)lane_kernel<false, MODE, HITS>, LW * 64, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, w5 ? (const void *)lane_kernel<true, MODE, HITS, LONG> : (const void *)lane_kernel<false, MODE, HITS, LONG>, LW * 64, lds);
     fprintf(stderr, "[slk] lane kernel: %zu B LDS per block, %d blocks (%d waves) resident per CU\n", lds, nb, nb * LW);
   }
-  if (w5) hipLaunchKernelGGL((lane_kernel<true, MODE, HITS>), g, b, lds, s, A, S, defer, max_len, dbg);
-  else hipLaunchKernelGGL((lane_kernel<false, MODE, HITS>), g, b, lds, s, A, S, defer, max_len, dbg);
+  if (w5) hipLaunchKernelGGL((lane_kernel<true, MODE, HITS, LONG>), g, b, lds, s, A, S, defer, max_len, dbg);
+  else hipLaunchKernelGGL((lane_kernel<false, MODE, HITS, LONG>), g, b, lds, s, A, S, defer, max_len, dbg);
 }
 
 // A.span_taxon set: the hit lists are written too (span_meta / span_taxon / span_count, the layout of MODE_HITS)
 void launch_lane(const FusedArgs &A, int32_t *defer, uint32_t max_len, hipStream_t s) {
-  if (A.span_taxon) launch_lane_mode<LANE_LOCAL, true>(A, ShardIO{}, defer, max_len, s);
-  else launch_lane_mode<LANE_LOCAL, false>(A, ShardIO{}, defer, max_len, s);
+  if (A.span_taxon) launch_lane_mode<LANE_LOCAL, true, false>(A, ShardIO{}, defer, max_len, s);
+  else launch_lane_mode<LANE_LOCAL, false, false>(A, ShardIO{}, defer, max_len, s);
+}
+// the pass over the first one's hand-ons (A.work_list / A.work_count / A.handled / A.lane_short_max set)
+void launch_lane_long(const FusedArgs &A, uint32_t max_len, hipStream_t s) {
+  if (A.span_taxon) launch_lane_mode<LANE_LOCAL, true, true>(A, ShardIO{}, nullptr, max_len, s);
+  else launch_lane_mode<LANE_LOCAL, false, true>(A, ShardIO{}, nullptr, max_len, s);
 }
 void launch_lane_sharded(int mode, const FusedArgs &A, const ShardIO &S, int32_t *defer, uint32_t max_len, hipStream_t s) {
-  if (mode == LANE_EMIT) launch_lane_mode<LANE_EMIT, false>(A, S, defer, max_len, s);
-  else launch_lane_mode<LANE_APPLY, false>(A, S, defer, max_len, s);
+  if (mode == LANE_EMIT) launch_lane_mode<LANE_EMIT, false, false>(A, S, defer, max_len, s);
+  else launch_lane_mode<LANE_APPLY, false, false>(A, S, defer, max_len, s);
 }
 
 }  // namespace slk
