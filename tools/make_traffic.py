@@ -17,7 +17,7 @@ vals = {}
 for f in glob.glob(os.path.join(out_dir, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     acc, cnt = {}, {}
     for r in csv.DictReader(open(f)):
-        if "lane_kernel" not in r["Kernel_Name"]:
+        if not r["Kernel_Name"].replace(" ", "").startswith("voidslk::lane_kernel<true,0,false,false>"):   # the hot variant only
             continue
         c = r["Counter_Name"]
         acc[c] = acc.get(c, 0.0) + float(r["Counter_Value"])
@@ -29,7 +29,7 @@ cfg = line["config"]
 fetch_kb, write_kb = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
 hbm = (fetch_kb + write_kb) * 1024
 doc = {
-    "kernel": "slk::lane_kernel<true, 0, false>",
+    "kernel": "slk::lane_kernel<true, 0, false, false>",
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py --no-cpu-baseline --steps 2 --warmup 1`, "
               "per-dispatch mean (tools/profile.sh, tools/make_traffic.py)",
     "kernel_source_hash": bench.kernel_source_hash(),
