@@ -274,12 +274,13 @@ class OutputSink {
     SliceOut out;
     std::map<Key, std::string> text;
     const size_t n = b->frags->size();
+    std::vector<uint64_t> hashes;
+    hashes.reserve(i1 - i0);
     for (size_t i = i0; i < i1; i++) {
       const size_t h0 = b->hit_offs[i], h1 = b->hit_offs[i + 1];
-      if (h1 == h0) continue;  // no span => no row at all (grouping is over span rows, Classifier.scala:92)
       std::string_view title = b->frags->title(i);
-      const uint64_t th = title_hash(title);
-      if (titles_.insert(th)) out.repeated.push_back(th);
+      hashes.push_back(title_hash(title));   // (every fragment, with or without a row: titles.hpp)
+      if (h1 == h0) continue;  // no span => no row at all (grouping is over span rows, Classifier.scala:92)
       std::string sample = sample_of(title);
       for (int c = 0; c < b->C; c++) {
         const bool classified = b->classified[(size_t)c * n + i] != 0;
@@ -291,6 +292,7 @@ class OutputSink {
         append_output_line(text[key], classified, title, t, &b->hits[h0], h1 - h0, o_.k, false);
       }
     }
+    titles_.insert_many(hashes, out.repeated);
     for (auto &kv : text) out.gz[kv.first] = gzip_member(kv.second);
     return out;
   }
@@ -344,6 +346,7 @@ class OutputSink {
     drained_ = true;
   }
   RepeatedTitles &repeated() { return repeated_; }
+  bool has_title(uint64_t h) { return titles_.contains(h); }   // (after drain(): a fragment of the run had this title)
   const OutputOptions &options() const { return o_; }
 
   // ---- corrections for titles that occur more than once (slacken_cli.cpp: resolve_repeated_titles); after drain() ----

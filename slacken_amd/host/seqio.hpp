@@ -567,16 +567,17 @@ class FragmentSource {
   size_t next_file_ = 0;
   std::unique_ptr<AsyncRecordStream> s1_, s2_;
   bool joined_ = false;  // the rest of the mate file has been loaded into mates_ (its order differs from the first file's)
-  std::unordered_map<std::string, std::string> mates_;
   // Paired input is an inner join on the header in the reference (InputReader.scala:104-119): a header that occurs twice in
-  // one of the files multiplies.  The walk below pairs every header once; headers seen twice on one side are reported to
-  // rep_ and regrouped afterwards (titles.hpp).
+  // one of the files multiplies.  The walk below pairs every header once.  Repeats among the fragments it makes are noticed
+  // where all fragment titles are (OutputSink); what it must report itself is the records that became NO fragment -- a record of
+  // file 1 without a partner left, records of file 2 that nobody claimed or that repeat a header of file 2: if their header is
+  // also the title of a fragment of the run, the reference's join has more products for it than this walk made (titles.hpp).
+  bool done_ = false;
   RepeatedTitles *rep_;
-  PairTitleTracker seen_;
-  void note(std::string_view title, unsigned sides) {
-    if (!rep_) return;
-    const uint64_t h = title_hash(title);
-    if (seen_.seen(h, sides)) rep_->add(h);
+  struct Mate { std::string seq; bool claimed = false; };
+  std::unordered_map<std::string, Mate> mates_;
+  void unclaimed_mates() {
+    if (rep_) for (auto &kv : mates_) if (!kv.second.claimed) rep_->add_unmatched(title_hash(kv.first));
   }
 
   bool open_next() {
@@ -584,9 +585,9 @@ class FragmentSource {
     s1_ = std::make_unique<AsyncRecordStream>(files_[next_file_]);
     if (paired_) s2_ = std::make_unique<AsyncRecordStream>(files_[next_file_ + 1]);
     next_file_ += paired_ ? 2 : 1;
+    unclaimed_mates();
     joined_ = false;
     mates_.clear();
-    seen_ = PairTitleTracker();
     return true;
   }
 
@@ -601,7 +602,7 @@ class FragmentSource {
     bp->paired = paired_;
     size_t added = 0;
     while (added < max_fragments && bp->bases.size() + bp->mate_bases.size() < max_bases) {
-      if (!s1_ && !open_next()) break;
+      if (!s1_ && !open_next()) { if (!done_) { unclaimed_mates(); mates_.clear(); done_ = true; } break; }
       size_t i1 = 0, i2 = 0;
       const FragmentBatch *c1 = s1_->current(i1);
       if (!c1) { s1_.reset(); s2_.reset(); continue; }
@@ -626,7 +627,6 @@ class FragmentSource {
           size_t ok = 0;
           while (ok < n && remove_suffix(c1->title(i1 + ok), "/1") == remove_suffix(c2->title(i2 + ok), "/2")) ok++;
           if (ok) {
-            if (rep_) for (size_t r = 0; r < ok; r++) note(remove_suffix(c1->title(i1 + r), "/1"), 3);
             bp->append(*c1, i1, ok, "/1");
             bp->append_mates(*c2, i2, ok);
             s1_->advance(ok);
@@ -637,8 +637,8 @@ class FragmentSource {
         }
         std::string_view h2, m;
         while (s2_->next(h2, m)) {
-          note(remove_suffix(h2, "/2"), 2);
-          mates_.emplace(std::string(remove_suffix(h2, "/2")), std::string(m));
+          auto ins = mates_.emplace(std::string(remove_suffix(h2, "/2")), Mate{std::string(m), false});
+          if (!ins.second && rep_) rep_->add(title_hash(ins.first->first));   // the header repeats inside file 2
         }
         joined_ = true;
         continue;
@@ -646,10 +646,13 @@ class FragmentSource {
       std::string_view h, sq;
       s1_->next(h, sq);
       h = remove_suffix(h, "/1");
-      note(h, 1);
       auto it = mates_.find(std::string(h));
-      if (it == mates_.end()) continue;  // inner join: no mate, no fragment
-      std::string_view m(it->second);
+      if (it == mates_.end()) {  // inner join: no mate, no fragment
+        if (rep_) rep_->add_unmatched(title_hash(h));
+        continue;
+      }
+      it->second.claimed = true;
+      std::string_view m(it->second.seq);
       bp->add(h, sq, &m);
       added++;
     }

@@ -690,6 +690,7 @@ static void classify_and_write(DeviceIndex &dev, const IndexParams &ip, const Ta
   classify_stream(dev, o.files, o.paired, o.min_hits, o.thresholds, false, o.detailed,   // (hit lists only feed the per-read lines)
                   [&](std::shared_ptr<const ClassifiedBatch> b) { sink.submit(std::move(b)); }, &sink.repeated());
   sink.drain();
+  sink.repeated().settle_unmatched([&](uint64_t h) { return sink.has_title(h); });
   if (!sink.repeated().empty()) resolve_repeated_titles(dev, ip, o, sink);
   sink.finish();
 }

@@ -7,6 +7,7 @@
 // regrouped exactly as the reference does (slacken_cli.cpp: resolve_repeated_titles).  A hash collision only adds a title to
 // the re-read set, where titles are compared as strings.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <mutex>
 #include <string_view>
@@ -46,6 +47,9 @@ class FlatHashSet {
       if ((c | FLAGS) == id) { const unsigned before = (unsigned)(c & FLAGS); c |= flags; return before ? before : (TAG ? 0u : 1u); }
     }
   }
+  void prefetch(uint64_t h) const {
+    if (!cells_.empty()) __builtin_prefetch(&cells_[(size_t)(h >> 20) & (cells_.size() - 1)]);
+  }
   bool contains(uint64_t h) const {
     if (cells_.empty()) return false;
     const uint64_t id = h | FLAGS;
@@ -62,8 +66,16 @@ class FlatHashSet {
 class RepeatedTitles {
   std::mutex mu_;
   std::vector<uint64_t> h_;
+  std::vector<uint64_t> unmatched_;   // headers of paired records that became no fragment (seqio.hpp: FragmentSource)
 
  public:
+  void add_unmatched(uint64_t h) { std::lock_guard<std::mutex> lk(mu_); unmatched_.push_back(h); }
+  // once every fragment title of the run is known: an unmatched record whose header is one of them makes that title repeated
+  template <class F> void settle_unmatched(F is_fragment_title) {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (uint64_t h : unmatched_) if (is_fragment_title(h)) h_.push_back(h);
+    unmatched_.clear();
+  }
   void add(uint64_t h) { std::lock_guard<std::mutex> lk(mu_); h_.push_back(h); }
   void add(const std::vector<uint64_t> &v) { if (!v.empty()) { std::lock_guard<std::mutex> lk(mu_); h_.insert(h_.end(), v.begin(), v.end()); } }
   bool empty() { std::lock_guard<std::mutex> lk(mu_); return h_.empty(); }
@@ -75,7 +87,7 @@ class RepeatedTitles {
   }
 };
 
-// every title of the run's row-producing fragments, inserted from the formatting threads: 256 independently locked shards
+// every fragment title of the run, inserted from the formatting threads: 256 independently locked shards
 class ConcurrentTitleSet {
   struct Shard { std::mutex mu; FlatHashSet<0> set; };
   std::vector<Shard> shards_;
@@ -87,15 +99,39 @@ class ConcurrentTitleSet {
     std::lock_guard<std::mutex> lk(s.mu);
     return s.set.insert(h, 0) != 0;
   }
-};
-
-// one pair of input files: which titles were seen in file 1 (flag 1) and in file 2 (flag 2); reader thread only
-class PairTitleTracker {
-  FlatHashSet<2> set_;
-
- public:
-  // true: `h` had already been seen on one of `sides` (1 = file 1, 2 = file 2, 3 = a record of each, joined in lockstep)
-  bool seen(uint64_t h, unsigned sides) { return (set_.insert(h, sides) & sides) != 0; }
+  bool contains(uint64_t h) {
+    Shard &s = shards_[h & 255];
+    std::lock_guard<std::mutex> lk(s.mu);
+    return s.set.contains(h);
+  }
+  // A slice's worth of hashes at once: grouped by shard (one lock per shard and slice) and with the cells prefetched a few
+  // inserts ahead -- an insert is otherwise one cache miss in a table of 16 bytes per read.  `hs` is reordered.  The hashes that
+  // had been seen before are appended to `repeated`.
+  void insert_many(std::vector<uint64_t> &hs, std::vector<uint64_t> &repeated) {
+    if (hs.empty()) return;
+    uint32_t start[257] = {0};
+    for (uint64_t h : hs) start[(h & 255) + 1]++;
+    for (int i = 0; i < 256; i++) start[i + 1] += start[i];
+    std::vector<uint64_t> by(hs.size());
+    {
+      uint32_t at[256];
+      for (int i = 0; i < 256; i++) at[i] = start[i];
+      for (uint64_t h : hs) by[at[h & 255]++] = h;
+    }
+    hs.swap(by);
+    for (int sh = 0; sh < 256; sh++) {
+      const uint32_t a = start[sh], b = start[sh + 1];
+      if (a == b) continue;
+      Shard &s = shards_[sh];
+      std::lock_guard<std::mutex> lk(s.mu);
+      const uint32_t AHEAD = 8;
+      for (uint32_t i = a; i < std::min(b, a + AHEAD); i++) s.set.prefetch(hs[i]);
+      for (uint32_t i = a; i < b; i++) {
+        if (i + AHEAD < b) s.set.prefetch(hs[i + AHEAD]);
+        if (s.set.insert(hs[i], 0) != 0) repeated.push_back(hs[i]);
+      }
+    }
+  }
 };
 
 }  // namespace slk_host
