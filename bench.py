@@ -327,13 +327,15 @@ def main():
 
     # HBM traffic from the PMC counters is collected by separate rocprofv3 --pmc passes of this command
     # (tools/profile.sh) and kept on file with the hash of the kernel sources it was measured on: quoted only on a match.
-    traffic, traffic_note = None, "no counter file for this build"
+    traffic, traffic_note, miss_requests = None, "no counter file for this build", None
     if os.path.exists(TRAFFIC_FILE):
         tj = json.load(open(TRAFFIC_FILE))
         same = (tj.get("reads_per_launch") == n_reads and tj.get("records") == int(args.records)
                 and tj.get("genomes") == [G, args.genome_len])
         if same and tj.get("kernel_source_hash") == kernel_source_hash():
             traffic, traffic_note = tj["hbm_bytes_per_launch"], "profiles/r02_traffic.json (same kernel sources, same workload)"
+            if tj.get("tcc_miss_x64_bytes"):
+                miss_requests = tj["tcc_miss_x64_bytes"] // 64
         else:
             traffic_note = "profiles/r02_traffic.json is for other kernel sources or another workload: not quoted"
 
@@ -374,7 +376,12 @@ def main():
                      # profiles/r02_gather_experiments.txt): what a hash-table probe can reach, as opposed to the streaming peak
                      "random_line_ceiling_Glines_per_s": GATHER_CEILING_GLPS,
                      "probe_lines_per_s_G": round(probes / (dom_ms * 1e-3) / 1e9, 2),
-                     "frac_of_random_line_ceiling": round(probes / (dom_ms * 1e-3) / 1e9 / GATHER_CEILING_GLPS, 3)},
+                     "frac_of_random_line_ceiling": round(probes / (dom_ms * 1e-3) / 1e9 / GATHER_CEILING_GLPS, 3),
+                     # every L2 miss of the kernel (probes, second-bucket probes, the read stream's lines, outputs; TCC_MISS_sum of the
+                     # same counter file) against the same ceiling: the request rate is what bounds the path
+                     "l2_miss_requests_per_launch": miss_requests,
+                     "frac_of_request_rate_ceiling": (round(miss_requests / (dom_ms * 1e-3) / 1e9 / GATHER_CEILING_GLPS, 3)
+                                                      if miss_requests else None)},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
