@@ -1480,8 +1480,10 @@ int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, 
       HIPCHK(hipEventRecord(st->up_ev[i], st->cs));
       HIPCHK(hipStreamWaitEvent(st->s, st->up_ev[i], 0));
       rc = run_classify(ix, st, st->bases.as<uint8_t>(), st->offsets.as<uint64_t>() + r0, paired ? st->mate_bases.as<uint8_t>() : nullptr,
-                        paired ? st->mate_offsets.as<uint64_t>() + r0 : nullptr, n, offsets[r1] - offsets[r0],
-                        paired ? mate_offsets[r1] - mate_offsets[r0] : 0, min_hit_groups, thresholds, C, st->out_taxon.as<int32_t>() + r0,
+                        // (the offsets stay absolute, so "total bases" is where this sub-batch ENDS: it sizes the span scratch of
+                        //  the unbounded re-run, whose regions are addressed by those offsets)
+                        paired ? st->mate_offsets.as<uint64_t>() + r0 : nullptr, n, offsets[r1],
+                        paired ? mate_offsets[r1] : 0, min_hit_groups, thresholds, C, st->out_taxon.as<int32_t>() + r0,
                         st->out_cls.as<uint8_t>() + r0, st->out_nd.as<int32_t>() + r0, st->out_tk.as<int32_t>() + r0,
                         st->out_nh.as<int32_t>() + r0, nullptr, false, R);
       if (rc) return rc;

@@ -270,6 +270,39 @@ def test_many_taxa_per_read_take_the_deferred_path(orc):
     want = orc.classify_batch(p, world2["oix"], parents, bases, offsets, thresholds=(0.0,))
     assert np.array_equal(outs[0].cpu().numpy(), want["taxon"][0]) and np.array_equal(d_c.cpu().numpy(), want["classified"][0])
     assert np.array_equal(outs[1].cpu().numpy(), want["num_distinct"]) and np.array_equal(outs[3].cpu().numpy(), want["num_hits"])
+    # two calls queued before one synchronisation, the FIRST holding the overflowing fragments: both are re-run, each with its
+    # own thresholds and into its own outputs
+    b2, o2 = synth.pack(reads[:64])
+    d_b2 = torch.from_numpy(b2).cuda()
+    d_o2 = torch.from_numpy(o2.astype(np.int64)).cuda()
+    t2 = torch.zeros(2 * 64, dtype=torch.int32, device="cuda")
+    c2 = torch.zeros(2 * 64, dtype=torch.uint8, device="cuda")
+    for t in outs:
+        t.zero_()
+    st.classify_batch_device(d_b.data_ptr(), d_o.data_ptr(), R, int(offsets[-1]), outs[0].data_ptr(), d_c.data_ptr(),
+                             outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), outs[4].data_ptr(), thresholds=(0.0,))
+    st.classify_batch_device(d_b2.data_ptr(), d_o2.data_ptr(), 64, int(o2[-1]), t2.data_ptr(), c2.data_ptr(), thresholds=(0.0, 0.3))
+    st.synchronize()
+    want2 = orc.classify_batch(p, world2["oix"], parents, b2, o2, thresholds=(0.0, 0.3))
+    assert np.array_equal(outs[0].cpu().numpy(), want["taxon"][0]) and np.array_equal(outs[1].cpu().numpy(), want["num_distinct"])
+    assert np.array_equal(t2.cpu().numpy().reshape(2, 64), want2["taxon"]) and np.array_equal(c2.cpu().numpy().reshape(2, 64), want2["classified"])
+    # the host entry cut into sub-batches (the overflow is in the first of four): the re-run addresses its span scratch by the
+    # batch's absolute offsets
+    old = os.environ.get("SLK_HOST_SUBBATCH")
+    os.environ["SLK_HOST_SUBBATCH"] = "16"
+    try:
+        order = list(range(3, R)) + [0, 1, 2]      # ... and once with the overflowing fragments in the LAST sub-batch
+        for sel in (list(range(R)), order):
+            bb, oo = synth.pack([big[i] for i in sel])
+            got = world2["st"].classify_batch(bb, oo, thresholds=(0.0, 0.5), with_hits=False, with_num_hits=True)
+            w = orc.classify_batch(p, world2["oix"], parents, bb, oo, thresholds=(0.0, 0.5))
+            for key in ("taxon", "classified", "num_distinct", "total_kmers", "num_hits"):
+                assert np.array_equal(got[key], w[key]), key
+    finally:
+        if old is None:
+            os.environ.pop("SLK_HOST_SUBBATCH", None)
+        else:
+            os.environ["SLK_HOST_SUBBATCH"] = old
 
 
 def test_streams_on_threads_share_one_index(orc, world):
