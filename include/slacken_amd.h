@@ -252,8 +252,9 @@ uint32_t slk_shard_of(int64_t key, uint32_t n_shards);
  *                            Lists that overflow their capacity make slk_stream_synchronize fail with SLK_E_CAPACITY.
  *   slk_shard_compact_device the lists back to back in (owner, sub-list) order in d_out_keys (room for the sum of the list
  *                            lengths, at most n_shards * n_sublists * capacity), d_list_offsets[n_shards * n_sublists + 1]
- *                            = where each list starts there, d_owner_counts[n_shards] = keys per owner: the all-to-all's
- *                            split sizes.
+ *                            = where each list starts there, d_owner_counts[n_shards + 1] = keys per owner (the all-to-all's
+ *                            split sizes) and, last, the number of lists that overflowed their capacity (emit again with
+ *                            longer lists if it is not zero).
  *   (all-to-all of keys, slk_lookup_device on the owners, all-to-all of taxa back, in the same order: the caller's, e.g. RCCL)
  *   slk_shard_apply_device   scans again and classifies, taking each probe's taxon from d_taxa (the answers, in the order
  *                            of d_out_keys) at the logged position: same outputs as slk_classify_batch_device.

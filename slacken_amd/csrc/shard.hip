@@ -116,6 +116,11 @@ __global__ void __launch_bounds__(256) list_prefix_kernel(const unsigned long lo
     for (uint32_t i = t * n_sub; i < (t + 1) * n_sub; i++) c += min((uint64_t)counts[i], cap);
     owner_counts[t] = c;
   }
+  if (t == 64) {  // [n_shards]: how many lists overflowed their capacity (the caller emits again with longer lists)
+    uint64_t over = 0;
+    for (uint32_t i = 0; i < n; i++) over += (uint64_t)counts[i] > cap;
+    owner_counts[n_shards] = over;
+  }
 }
 // one block column per sub-list: its keys move to their place in the contiguous array
 __global__ void __launch_bounds__(256) list_copy_kernel(const int64_t *__restrict__ send_keys, const unsigned long long *__restrict__ counts,

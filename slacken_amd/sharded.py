@@ -8,8 +8,8 @@ mode (no collective at all).
 Host plumbing only: torch for device buffers and the collectives, the engine for all compute.  Two routes:
   fast    slk_shard_emit_device -> slk_shard_compact_device -> all-to-all -> slk_lookup_device -> all-to-all ->
           slk_shard_apply_device: the fused lane-per-fragment kernel runs on both sides of the exchange, nothing but 8-byte keys
-          and 4-byte taxa moves; takes fragments of up to 1000 bases with at most 12 distinct taxa; classify_many keeps two
-          batches in flight so that the exchange of one overlaps the scans of its neighbours;
+          and 4-byte taxa moves; takes fragments of up to 1000 bases with at most 12 distinct taxa; classify_many keeps three
+          batches in flight, the scans on one stream and the memory-bound stages on another;
   staged  slk_scan_device / slk_lookup_device / slk_classify_hits_device with the exchange lists built by torch ops: takes
           everything, and the fragments the fast route hands back (`defer`)."""
 import numpy as np
@@ -94,37 +94,42 @@ class ShardedClassifier:
         return bool(int(t.item()))
 
     # ---- the fast route, in stages that are interleaved between batches (classify_many) -------------------------------------
-    # All torch work of a batch is issued on the ENGINE's stream (wrapped as a torch ExternalStream): torch kernels,
-    # collectives and engine kernels of one batch are ordered by that stream itself, whatever stream the caller works on.
-    # Two batches on two engine streams overlap where the hardware has room: emit and apply are bound by instruction issue,
-    # the owners' lookup by HBM requests, the exchange by the links.
-    N_STREAMS = int(__import__("os").environ.get("SLK_SHARD_STREAMS", "2"))   # batches in flight (classify_many)
+    # The stages of a batch are bound by different things: emit and apply (the two scans) by instruction issue, compaction and the
+    # owners' lookup by HBM, the exchange by the links.  So the scans of all batches go to ONE engine stream and the memory-bound
+    # stages to ANOTHER, each wrapped as a torch ExternalStream so that torch kernels, collectives and engine kernels are ordered
+    # by the streams themselves, with events where a stage needs the other stream's result.  In steady state the scan stream runs
+    # apply(k-1), emit(k+1) while the memory stream runs compact(k), lookup(k): three batches in flight.
+    # (Nothing here touches torch's default stream: the engine's streams are blocking streams, and an event recorded on the legacy
+    # null stream waits for all of them and holds back whatever is issued after it -- measured: it serialised the pipeline.)
+    def _two_streams(self):
+        if not hasattr(self, "_scan"):
+            torch = self.torch
+            self._scan = (self.st, torch.cuda.ExternalStream(self.st.hip_stream, device=self.device))
+            mem = self.ix.stream()
+            self._mem = (mem, torch.cuda.ExternalStream(mem.hip_stream, device=self.device))
+        return self._scan, self._mem
 
-    def _stream(self, which=0):
-        if not hasattr(self, "_streams"):
-            self._streams = [self.st] + [self.ix.stream() for _ in range(self.N_STREAMS - 1)]
-            self._ext = [self.torch.cuda.ExternalStream(s.hip_stream, device=self.device) for s in self._streams]
-        return self._streams[which], self._ext[which]
-
-    def _fast_emit(self, which, d_bases, d_offsets, R, total_bases, mates, cap_scale=1):
-        """stage 1 (asynchronous): scan + send lists + their compaction.  Returns the batch's state, or None if this index's
-        splitter only has the staged route."""
+    def _fast_emit(self, batch, cap_scale=1):
+        """stage 1 (scan stream, asynchronous): scan + send lists.  None if this index's splitter only has the staged route."""
         import slacken_amd
         from slacken_amd import capi
         torch, dev, W = self.torch, self.device, self.world
-        st, ext = self._stream(which)
+        (st, ext), _ = self._two_streams()
+        d_bases, d_offsets, R, total_bases, mates = batch
         mb, mo, mtotal = mates if mates is not None else (None, None, 0)
         mkw = dict(d_mate_bases=mb.data_ptr(), d_mate_offsets=mo.data_ptr()) if mates is not None else {}
         # about 0.26 probes per base on random sequence, spread evenly by the hash over W owners and by the tile index over SUB
         # sub-lists per owner (each fed by at least 64 tiles, so that the spread holds): 0.6 / (W * SUB) per base leaves 2x
-        # headroom; a list that overflows all the same makes the engine say so, and the batch is emitted again with more room
+        # headroom; a list that overflows all the same is reported by the compaction, and the batch is emitted again with more room
         tiles = (R + 63) // 64
         SUB = 1
         while SUB < 256 and SUB * 2 * 64 <= tiles:
             SUB *= 2
         cap = (int((total_bases + mtotal) * 0.6 / (W * SUB)) + (1 << 12)) * cap_scale
         rows = int(capi.lib().slk_shard_batch_rows(total_bases, mtotal, R, 1 if mates is not None else 0))
-        ext.wait_stream(torch.cuda.current_stream())    # the caller's tensors were produced on ITS stream
+        cur = torch.cuda.current_stream()
+        if cur != torch.cuda.default_stream(self.device):     # (the caller's tensors were produced on ITS stream)
+            ext.wait_stream(cur)
         with torch.cuda.stream(ext):
             defer = torch.empty(max(R, 1), dtype=torch.int32, device=dev)
             batch_base = torch.empty(rows * W, dtype=torch.int32, device=dev)
@@ -137,68 +142,67 @@ class ShardedClassifier:
                 if e.code != capi.E_UNSUPPORTED:
                     raise
                 return None
-            out_keys = torch.empty_like(send_keys)   # (room for every list at its capacity; the used prefix is what is sent)
-            list_off = torch.empty(W * SUB + 1, dtype=torch.int64, device=dev)
-            owner_counts = torch.empty(W, dtype=torch.int64, device=dev)
-            st.shard_compact_device(send_keys.data_ptr(), W, SUB, cap, counts.data_ptr(), out_keys.data_ptr(), list_off.data_ptr(),
-                                    owner_counts.data_ptr())
-            h_counts = torch.empty(W, dtype=torch.int64, pin_memory=True)
-            h_counts.copy_(owner_counts, non_blocking=True)
-            ready = torch.cuda.Event()
-            ready.record(ext)
-        return dict(st=st, ext=ext, R=R, SUB=SUB, defer=defer, batch_base=batch_base, send_keys=send_keys, counts=counts,
-                    out_keys=out_keys, list_off=list_off, h_counts=h_counts, ready=ready, mkw=mkw, d_bases=d_bases,
-                    d_offsets=d_offsets, mates=mates)
+            emitted = torch.cuda.Event()
+            emitted.record(ext)
+        return dict(R=R, SUB=SUB, cap=cap, defer=defer, batch_base=batch_base, send_keys=send_keys, counts=counts, emitted=emitted,
+                    mkw=mkw, batch=batch)
 
-    def _fast_ready(self, b):
-        """the batch's only host wait: W numbers (the exchange's split sizes) and the engine's status word.  False: a send list
-        overflowed its capacity."""
-        import slacken_amd
-        from slacken_amd import capi
-        b["ready"].synchronize()
-        try:
-            b["st"].synchronize()
-        except slacken_amd.SlackenError as e:
-            if e.code == capi.E_CAPACITY:
-                return False
-            raise
-        return True
+    def _fast_compact(self, b):
+        """stage 2 (memory stream, asynchronous): the send lists back to back; the split sizes on their way to the host"""
+        torch, dev, W = self.torch, self.device, self.world
+        _, (st, ext) = self._two_streams()
+        with torch.cuda.stream(ext):
+            ext.wait_event(b["emitted"])
+            b["out_keys"] = torch.empty_like(b["send_keys"])   # (room for every list at its capacity; the used prefix is what is sent)
+            b["list_off"] = torch.empty(W * b["SUB"] + 1, dtype=torch.int64, device=dev)
+            owner_counts = torch.empty(W + 1, dtype=torch.int64, device=dev)
+            st.shard_compact_device(b["send_keys"].data_ptr(), W, b["SUB"], b["cap"], b["counts"].data_ptr(), b["out_keys"].data_ptr(),
+                                    b["list_off"].data_ptr(), owner_counts.data_ptr())
+            b["h_counts"] = torch.empty(W + 1, dtype=torch.int64, pin_memory=True)
+            b["h_counts"].copy_(owner_counts, non_blocking=True)
+            b["ready"] = torch.cuda.Event()
+            b["ready"].record(ext)
 
     def _fast_exchange(self, b):
-        """stage 2 (asynchronous but for the collectives' own host side): keys to their owners, lookup, taxa back"""
+        """stage 3 (memory stream): keys to their owners, lookup, taxa back"""
         torch = self.torch
-        send_counts = [int(v) for v in b["h_counts"].tolist()]
+        _, (st, ext) = self._two_streams()
+        send_counts = [int(v) for v in b["h_counts"][:self.world].tolist()]
         n_send = sum(send_counts)
-        with torch.cuda.stream(b["ext"]):
+        with torch.cuda.stream(ext):
             recv_keys, recv_counts = self._all_to_all(b["out_keys"][:n_send], send_counts)
             found = torch.empty(max(recv_keys.numel(), 1), dtype=torch.int32, device=self.device)
             if recv_keys.numel():
                 recv_keys = recv_keys.contiguous()
-                b["st"].lookup_device(recv_keys.data_ptr(), recv_keys.numel(), found.data_ptr())
+                st.lookup_device(recv_keys.data_ptr(), recv_keys.numel(), found.data_ptr())
             back, _ = self._all_to_all(found[:recv_keys.numel()], recv_counts)
             b["taxa"] = back.contiguous() if back.numel() else torch.zeros(1, dtype=torch.int32, device=self.device)
+            b["looked_up"] = torch.cuda.Event()
+            b["looked_up"].record(ext)
         b["exchanged"] = n_send
-        b["recv_keys"] = recv_keys          # (kept alive until the lookup has run)
         del b["send_keys"], b["out_keys"]
 
     def _fast_apply(self, b, thresholds, min_hit_groups):
-        """stage 3 (asynchronous): the second scan.  The result tensors are valid once the batch's stream has been synchronised."""
+        """stage 4 (scan stream, asynchronous): the second scan.  The result tensors are valid once that stream has been synchronised."""
         torch, dev, R, W = self.torch, self.device, b["R"], self.world
+        (st, ext), _ = self._two_streams()
+        d_bases, d_offsets = b["batch"][0], b["batch"][1]
         C = len(thresholds)
-        with torch.cuda.stream(b["ext"]):
+        with torch.cuda.stream(ext):
+            ext.wait_event(b["looked_up"])
             out = dict(taxon=torch.zeros(C * max(R, 1), dtype=torch.int32, device=dev),
                        classified=torch.zeros(C * max(R, 1), dtype=torch.uint8, device=dev),
                        num_distinct=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
                        total_kmers=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
                        num_hits=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
                        exchanged_keys=b["exchanged"])
-            b["st"].shard_apply_device(b["d_bases"].data_ptr(), b["d_offsets"].data_ptr(), R, W, b["SUB"], b["taxa"].data_ptr(),
-                                       b["list_off"].data_ptr(), b["batch_base"].data_ptr(), out["taxon"].data_ptr(),
-                                       out["classified"].data_ptr(), b["defer"].data_ptr(), out["num_distinct"].data_ptr(),
-                                       out["total_kmers"].data_ptr(), out["num_hits"].data_ptr(), min_hit_groups=min_hit_groups,
-                                       thresholds=thresholds, **b["mkw"])
-            for k in ("taxa", "batch_base", "list_off", "counts", "recv_keys"):   # (their memory goes back to this stream's pool:
-                b.pop(k, None)                                                     #  whatever reuses it is ordered after the apply)
+            st.shard_apply_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, W, b["SUB"], b["taxa"].data_ptr(),
+                                  b["list_off"].data_ptr(), b["batch_base"].data_ptr(), out["taxon"].data_ptr(),
+                                  out["classified"].data_ptr(), b["defer"].data_ptr(), out["num_distinct"].data_ptr(),
+                                  out["total_kmers"].data_ptr(), out["num_hits"].data_ptr(), min_hit_groups=min_hit_groups,
+                                  thresholds=thresholds, **b["mkw"])
+            b["applied"] = torch.cuda.Event()
+            b["applied"].record(ext)
         return out
 
     def _classify_fast(self, d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups, mates=None):
@@ -206,31 +210,55 @@ class ShardedClassifier:
         return None if outs is None else outs[0]
 
     def classify_many(self, batches, thresholds=(0.0,), min_hit_groups=2):
-        """The fast route over several batches [(d_bases, d_offsets, R, total_bases, mates or None)], two in flight on two engine
-        streams: while batch i is scanned (emit), batch i-1's keys are exchanged and looked up and its answers applied.  Every rank
-        must pass the same number of batches.  Returns the list of result dicts, or None if the splitter only has the staged route."""
+        """The fast route over several batches [(d_bases, d_offsets, R, total_bases, mates or None)], three in flight (see above).
+        Every rank must pass the same number of batches.  Returns the list of result dicts, or None if the splitter only has the
+        staged route."""
+        import slacken_amd
+        from slacken_amd import capi
         states, outs = [], []
+        overflowed = False
 
-        def settle(j):   # batch j: its one host wait, then exchange + lookup + apply issued on its stream
+        def settle(j):   # batch j: its one host wait, then exchange + lookup (memory stream) and apply (scan stream)
+            nonlocal overflowed
             b, scale = states[j], 1
-            while self._any_rank(not self._fast_ready(b)):      # (rare: a send list overflowed somewhere -- every rank emits again)
+            while True:
+                b["ready"].synchronize()
+                if not self._any_rank(int(b["h_counts"][self.world]) != 0):
+                    break
+                overflowed = True                      # (rare: a send list overflowed somewhere -- every rank emits again)
                 scale *= 2
-                d_bases, d_offsets, R, total_bases, mates = batches[j]
-                b = states[j] = self._fast_emit(j % self.N_STREAMS, d_bases, d_offsets, R, total_bases, mates, scale)
+                b = states[j] = self._fast_emit(batches[j], scale)
+                self._fast_compact(b)
             self._fast_exchange(b)
             outs.append(self._fast_apply(b, thresholds, min_hit_groups))
 
-        for i, (d_bases, d_offsets, R, total_bases, mates) in enumerate(batches):
-            b = self._fast_emit(i % self.N_STREAMS, d_bases, d_offsets, R, total_bases, mates)    # asynchronous
+        def release_finished():   # batches whose apply has run give their device memory back (a long run holds three, not all)
+            for sb in states:
+                if "applied" in sb and "taxa" in sb and sb["applied"].query():
+                    for k in ("taxa", "batch_base", "list_off", "counts"):
+                        sb.pop(k, None)
+
+        for i, batch in enumerate(batches):
+            release_finished()
+            b = self._fast_emit(batch)                 # scan stream
             if i == 0 and self._any_rank(b is None):
                 return None
             states.append(b)
-            if i >= self.N_STREAMS - 1:
-                settle(i - (self.N_STREAMS - 1))     # (the emits of the batches after it are running meanwhile on the other streams)
-        for j in range(max(0, len(states) - (self.N_STREAMS - 1)), len(states)):
-            settle(j)
+            if i >= 1:
+                settle(i - 1)                          # lookup(i-1) runs beside emit(i); apply(i-1) follows emit(i) on the scan stream
+            self._fast_compact(b)                      # memory stream, behind lookup(i-1): runs beside apply(i-1)
+        if states:
+            settle(len(states) - 1)
+        (scan_st, _), (mem_st, _) = self._two_streams()
+        for st in (scan_st, mem_st):
+            try:
+                st.synchronize()
+            except slacken_amd.SlackenError as e:
+                if not (overflowed and e.code == capi.E_CAPACITY):   # (the engine's own note of an overflow that was handled above)
+                    raise
         for i, (b, batch) in enumerate(zip(states, batches)):
-            b["st"].synchronize()
+            for k in ("taxa", "batch_base", "list_off", "counts"):
+                b.pop(k, None)
             d_bases, d_offsets, R, total_bases, mates = batch
             outs[i] = self._finish_deferred(outs[i], b, d_bases, d_offsets, R, thresholds, min_hit_groups, mates)
         return outs
