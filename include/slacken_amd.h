@@ -240,24 +240,26 @@ int32_t slk_lookup_device(slk_index *ix, slk_stream *st, const int64_t *d_keys, 
 /* Which rank owns a minimizer in table-sharded mode: fmix64(key) mod n_shards (host helper; the device side of the
  * Python host uses the same bijective mixer) */
 uint32_t slk_shard_of(int64_t key, uint32_t n_shards);
-/* The fast form of the table-sharded path for fragments of up to 1000 bases (both mates together): the fused classify
- * kernel runs twice around the exchange and nothing but 8-byte keys and 4-byte taxa moves -- no span arrays in HBM, no
- * per-probe return addresses.  Both runs scan the same fragments, so they form the same batches of probes in the same order:
+/* The fast form of the table-sharded path for fragments of up to 1000 bases (both mates together): ONE scan, and nothing but
+ * 8-byte keys and 4-byte taxa on the links -- no span arrays in HBM, no per-probe return addresses.
  *   slk_shard_emit_device    scans the fragments and appends every minimizer to a send list of its owner (slk_shard_of).
  *                            Every owner has n_sublists lists (a power of two; 256 is a good value: the appending wavefronts
  *                            spread over them, so the list cursors do not serialise on one address): d_send_keys is
- *                            [n_shards][n_sublists][capacity_per_sublist], d_send_counts[n_shards][n_sublists] receives the
- *                            list lengths (zeroed by the call).  d_batch_base (uint32 [slk_shard_batch_rows(..)][n_shards],
- *                            written by the call) logs, per batch of probes, where each owner's keys went in its list.
- *                            Lists that overflow their capacity make slk_stream_synchronize fail with SLK_E_CAPACITY.
+ *                            [n_shards][n_sublists][capacity_per_sublist] (capacity < 2^25), d_send_counts[n_shards][n_sublists]
+ *                            receives the list lengths (zeroed by the call).  What the second pass needs stays on this rank:
+ *                            d_send_meta (same shape as d_send_keys, 4 bytes each: the span behind every key), d_batch_base
+ *                            (uint32 [slk_shard_batch_rows(..)][n_shards]: per batch of 64 probes, where each owner's keys went
+ *                            and how many), d_tile_rows (uint32 [(R + 63) / 64]) and d_read_info (int32 [R][2]: k-mers and spans
+ *                            of a fragment).  Lists that overflow their capacity are reported by slk_shard_compact_device.
  *   slk_shard_compact_device the lists back to back in (owner, sub-list) order in d_out_keys (room for the sum of the list
  *                            lengths, at most n_shards * n_sublists * capacity), d_list_offsets[n_shards * n_sublists + 1]
  *                            = where each list starts there, d_owner_counts[n_shards + 1] = keys per owner (the all-to-all's
  *                            split sizes) and, last, the number of lists that overflowed their capacity (emit again with
  *                            longer lists if it is not zero).
  *   (all-to-all of keys, slk_lookup_device on the owners, all-to-all of taxa back, in the same order: the caller's, e.g. RCCL)
- *   slk_shard_apply_device   scans again and classifies, taking each probe's taxon from d_taxa (the answers, in the order
- *                            of d_out_keys) at the logged position: same outputs as slk_classify_batch_device.
+ *   slk_shard_apply_device   replays the batches from the log -- no second scan: d_bases may be NULL --, takes each probe's taxon
+ *                            from d_taxa (the answers, in the order of d_out_keys) and classifies: same outputs as
+ *                            slk_classify_batch_device.
  * d_defer[R] (zeroed by slk_shard_emit_device) is set to 1 for fragments this path does not take (longer than 1000 bases,
  * or more than 12 distinct taxa): classify those with the staged calls above.  SLK_E_UNSUPPORTED if the index's splitter
  * is outside the fused kernel's range (window wider than 32 m-mers, or taxon ids beyond 22 bits that slk_index_finalize could
@@ -265,17 +267,20 @@ uint32_t slk_shard_of(int64_t key, uint32_t n_shards);
 uint64_t slk_shard_batch_rows(uint64_t total_bases, uint64_t total_mate_bases, uint64_t R, int32_t paired);
 int32_t slk_shard_emit_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
                               const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
-                              uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys,
-                              uint64_t capacity_per_sublist, uint64_t *d_send_counts, uint32_t *d_batch_base, int32_t *d_defer);
+                              uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys, uint32_t *d_send_meta,
+                              uint64_t capacity_per_sublist, uint64_t *d_send_counts, uint32_t *d_batch_base,
+                              uint32_t *d_tile_rows, int32_t *d_read_info, int32_t *d_defer);
 int32_t slk_shard_compact_device(slk_index *ix, slk_stream *st, const int64_t *d_send_keys, uint32_t n_shards, uint32_t n_sublists,
                                  uint64_t capacity_per_sublist, const uint64_t *d_send_counts, int64_t *d_out_keys,
                                  uint64_t *d_list_offsets, uint64_t *d_owner_counts);
 int32_t slk_shard_apply_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
                                const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
-                               uint32_t n_shards, uint32_t n_sublists, const int32_t *d_taxa, const uint64_t *d_list_offsets,
-                               const uint32_t *d_batch_base, int32_t min_hit_groups, const double *thresholds, int32_t C,
-                               int32_t *d_out_taxon, uint8_t *d_out_classified, int32_t *d_out_num_distinct,
-                               int32_t *d_out_total_kmers, int32_t *d_out_num_hits, int32_t *d_defer);
+                               uint32_t n_shards, uint32_t n_sublists, uint64_t capacity_per_sublist, const int32_t *d_taxa,
+                               const uint64_t *d_list_offsets, const uint32_t *d_send_meta, const uint32_t *d_batch_base,
+                               const uint32_t *d_tile_rows, const int32_t *d_read_info, int32_t min_hit_groups,
+                               const double *thresholds, int32_t C, int32_t *d_out_taxon, uint8_t *d_out_classified,
+                               int32_t *d_out_num_distinct, int32_t *d_out_total_kmers, int32_t *d_out_num_hits,
+                               int32_t *d_defer);
 /* classifyHits (Classifier.scala:124-147, 439-454) over span slots whose taxa have been filled in (d_span_taxon: record
  * taxon / NONE for SEQUENCE spans; AMBIGUOUS and MATE_PAIR_BORDER spans are recognised from d_span_meta).  d_scratch:
  * as many 8-byte entries as span slots. */

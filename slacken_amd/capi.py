@@ -110,12 +110,12 @@ def lib():
                                            C.POINTER(C.c_double), C.c_int32, i32p, u8p, i32p, i32p, i32p]
     L.slk_shard_batch_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32]
     L.slk_shard_batch_rows.restype = C.c_uint64
-    L.slk_shard_emit_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_uint32, i64p, C.c_uint64, u64p, vp,
-                                        i32p]
+    L.slk_shard_emit_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_uint32, i64p, vp, C.c_uint64, u64p, vp,
+                                        vp, i32p, i32p]
     L.slk_shard_compact_device.argtypes = [vp, vp, i64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, i64p, u64p, u64p]
     L.slk_stream_last_deferred.argtypes = [vp, C.POINTER(C.c_uint64)]
-    L.slk_shard_apply_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_uint32, i32p, u64p, vp, C.c_int32,
-                                         C.POINTER(C.c_double), C.c_int32, i32p, u8p, i32p, i32p, i32p, i32p]
+    L.slk_shard_apply_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, i32p, u64p, vp, vp,
+                                         vp, i32p, C.c_int32, C.POINTER(C.c_double), C.c_int32, i32p, u8p, i32p, i32p, i32p, i32p]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is C.c_int:  # default: int32 status
@@ -353,24 +353,27 @@ class Stream:
     def lookup_device(self, d_keys, n, d_out_taxa):
         _check(lib().slk_lookup_device(self.index.h, self.h, d_keys, n, d_out_taxa))
 
-    def shard_emit_device(self, d_bases, d_offsets, R, n_shards, n_sublists, d_send_keys, capacity_per_sublist,
-                          d_send_counts, d_batch_base, d_defer, d_mate_bases=None, d_mate_offsets=None):
+    def shard_emit_device(self, d_bases, d_offsets, R, n_shards, n_sublists, d_send_keys, d_send_meta, capacity_per_sublist,
+                          d_send_counts, d_batch_base, d_tile_rows, d_read_info, d_defer, d_mate_bases=None, d_mate_offsets=None):
         _check(lib().slk_shard_emit_device(self.index.h, self.h, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, n_shards,
-                                           n_sublists, d_send_keys, capacity_per_sublist, d_send_counts, d_batch_base, d_defer))
+                                           n_sublists, d_send_keys, d_send_meta, capacity_per_sublist, d_send_counts, d_batch_base,
+                                           d_tile_rows, d_read_info, d_defer))
 
     def shard_compact_device(self, d_send_keys, n_shards, n_sublists, capacity_per_sublist, d_send_counts, d_out_keys,
                              d_list_offsets, d_owner_counts):
         _check(lib().slk_shard_compact_device(self.index.h, self.h, d_send_keys, n_shards, n_sublists, capacity_per_sublist,
                                               d_send_counts, d_out_keys, d_list_offsets, d_owner_counts))
 
-    def shard_apply_device(self, d_bases, d_offsets, R, n_shards, n_sublists, d_taxa, d_list_offsets, d_batch_base, d_out_taxon,
-                           d_out_classified, d_defer, d_out_num_distinct=None, d_out_total_kmers=None, d_out_num_hits=None,
-                           d_mate_bases=None, d_mate_offsets=None, min_hit_groups=2, thresholds=(0.0,)):
+    def shard_apply_device(self, d_bases, d_offsets, R, n_shards, n_sublists, capacity_per_sublist, d_taxa, d_list_offsets,
+                           d_send_meta, d_batch_base, d_tile_rows, d_read_info, d_out_taxon, d_out_classified, d_defer,
+                           d_out_num_distinct=None, d_out_total_kmers=None, d_out_num_hits=None, d_mate_bases=None,
+                           d_mate_offsets=None, min_hit_groups=2, thresholds=(0.0,)):
         Cn = len(thresholds)
         thr = (C.c_double * Cn)(*thresholds)
         _check(lib().slk_shard_apply_device(self.index.h, self.h, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, n_shards,
-                                            n_sublists, d_taxa, d_list_offsets, d_batch_base, min_hit_groups, thr, Cn, d_out_taxon,
-                                            d_out_classified, d_out_num_distinct, d_out_total_kmers, d_out_num_hits, d_defer))
+                                            n_sublists, capacity_per_sublist, d_taxa, d_list_offsets, d_send_meta, d_batch_base,
+                                            d_tile_rows, d_read_info, min_hit_groups, thr, Cn, d_out_taxon, d_out_classified,
+                                            d_out_num_distinct, d_out_total_kmers, d_out_num_hits, d_defer))
 
     def classify_hits_device(self, d_offsets, R, d_span_meta, d_span_taxon, d_span_count, d_scratch, d_out_taxon,
                              d_out_classified, d_out_num_distinct=None, d_out_total_kmers=None, d_out_num_hits=None,

@@ -1129,14 +1129,17 @@ uint64_t slk_shard_batch_rows(uint64_t total_bases, uint64_t total_mate_bases, u
 
 int32_t slk_shard_emit_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
                               const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
-                              uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys,
-                              uint64_t capacity_per_sublist, uint64_t *d_send_counts, uint32_t *d_batch_base, int32_t *d_defer) {
+                              uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys, uint32_t *d_send_meta,
+                              uint64_t capacity_per_sublist, uint64_t *d_send_counts, uint32_t *d_batch_base,
+                              uint32_t *d_tile_rows, int32_t *d_read_info, int32_t *d_defer) {
   int32_t rc = check_ready(ix, st, false);
   if (rc) return rc;
   if (!lane_path_ok(ix)) return fail(SLK_E_UNSUPPORTED, "splitter outside the fused kernel's range: use the staged calls");
   if (n_sublists < 1 || n_sublists > 4096 || (n_sublists & (n_sublists - 1))) return fail(SLK_E_INVALID, "n_sublists must be a power of two <= 4096");
-  if (n_shards < 1 || n_shards > 64 || !d_send_counts || !d_defer || (R && (!d_bases || !d_offsets || !d_send_keys || !d_batch_base)))
+  if (n_shards < 1 || n_shards > 64 || !d_send_counts || !d_defer ||
+      (R && (!d_bases || !d_offsets || !d_send_keys || !d_send_meta || !d_batch_base || !d_tile_rows || !d_read_info)))
     return fail(SLK_E_INVALID, "bad argument");
+  if (capacity_per_sublist >= (1ull << 25)) return fail(SLK_E_INVALID, "capacity_per_sublist must be below 2^25 (use more sub-lists)");
   if ((d_mate_bases == nullptr) != (d_mate_offsets == nullptr))
     return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
   rc = set_device(ix);
@@ -1148,7 +1151,8 @@ int32_t slk_shard_emit_device(slk_index *ix, slk_stream *st, const uint8_t *d_ba
   A.status = st->d_status;
   ShardIO S{};
   S.n_shards = (int32_t)n_shards; S.n_sub = (int32_t)n_sublists; S.cap = capacity_per_sublist; S.send_keys = d_send_keys;
-  S.send_counts = (unsigned long long *)d_send_counts; S.batch_base = d_batch_base;
+  S.send_counts = (unsigned long long *)d_send_counts; S.batch_base = d_batch_base; S.send_meta = d_send_meta;
+  S.tile_rows = d_tile_rows; S.read_info = (int2 *)d_read_info;
   st->queued.emplace_back();  // (not re-runnable: an overflow of this call is reported as an error)
   launch_lane_sharded(LANE_EMIT, A, S, d_defer, 1000, st->s);
   HIPCHK(hipMemcpyAsync(st->h_status, st->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st->s));
@@ -1174,8 +1178,10 @@ int32_t slk_shard_compact_device(slk_index *ix, slk_stream *st, const int64_t *d
 
 int32_t slk_shard_apply_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
                                const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
-                               uint32_t n_shards, uint32_t n_sublists, const int32_t *d_taxa, const uint64_t *d_list_offsets,
-                               const uint32_t *d_batch_base, int32_t min_hit_groups, const double *thresholds, int32_t C,
+                               uint32_t n_shards, uint32_t n_sublists, uint64_t capacity_per_sublist, const int32_t *d_taxa,
+                               const uint64_t *d_list_offsets, const uint32_t *d_send_meta, const uint32_t *d_batch_base,
+                               const uint32_t *d_tile_rows, const int32_t *d_read_info, int32_t min_hit_groups,
+                               const double *thresholds, int32_t C,
                                int32_t *d_out_taxon, uint8_t *d_out_classified, int32_t *d_out_num_distinct,
                                int32_t *d_out_total_kmers, int32_t *d_out_num_hits, int32_t *d_defer) {
   int32_t rc = check_ready(ix, st, true);
@@ -1184,7 +1190,8 @@ int32_t slk_shard_apply_device(slk_index *ix, slk_stream *st, const uint8_t *d_b
   if (C < 1 || C > MAX_THRESHOLDS || !thresholds) return fail(SLK_E_INVALID, "need 1..%d thresholds", MAX_THRESHOLDS);
   if (n_sublists < 1 || n_sublists > 4096 || (n_sublists & (n_sublists - 1)) || n_shards < 1 || n_shards > 64)
     return fail(SLK_E_INVALID, "bad n_shards / n_sublists");
-  if (!d_defer || (R && (!d_bases || !d_offsets || !d_taxa || !d_list_offsets || !d_batch_base || !d_out_taxon || !d_out_classified)))
+  if (!d_defer || (R && (!d_offsets || !d_taxa || !d_list_offsets || !d_send_meta || !d_batch_base || !d_tile_rows || !d_read_info ||
+                         !d_out_taxon || !d_out_classified)))
     return fail(SLK_E_INVALID, "null argument");
   if ((d_mate_bases == nullptr) != (d_mate_offsets == nullptr))
     return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
@@ -1202,7 +1209,10 @@ int32_t slk_shard_apply_device(slk_index *ix, slk_stream *st, const uint8_t *d_b
   A.status = st->d_status;
   ShardIO S{};
   S.n_shards = (int32_t)n_shards; S.n_sub = (int32_t)n_sublists;
+  S.cap = capacity_per_sublist;
   S.batch_base = const_cast<uint32_t *>(d_batch_base); S.list_off = d_list_offsets; S.taxa = d_taxa;
+  S.send_meta = const_cast<uint32_t *>(d_send_meta); S.tile_rows = const_cast<uint32_t *>(d_tile_rows);
+  S.read_info = (int2 *)const_cast<int32_t *>(d_read_info);
   S.to_dense = ix->d_to_dense; S.n_to_dense = ix->T;
   st->queued.emplace_back();
   launch_lane_sharded(LANE_APPLY, A, S, d_defer, 1000, st->s);

@@ -157,7 +157,10 @@ struct ShardIO {
   uint64_t cap;                      // capacity of each sub-list
   int64_t *send_keys;                // LANE_EMIT: [n_shards][n_sub][cap]
   unsigned long long *send_counts;   // LANE_EMIT: [n_shards][n_sub] cursors; a cursor beyond cap raises status bit 2
-  uint32_t *batch_base;              // [rows][n_shards]: where a probe batch's keys for an owner start in its sub-list
+  uint32_t *send_meta;               // [n_shards][n_sub][cap]: the keys' span metadata (owner lane | distinct | k-mers); stays on this rank
+  uint32_t *batch_base;              // [rows][n_shards]: (where a probe batch's keys for an owner start in its sub-list) << 7 | how many
+  uint32_t *tile_rows;               // [tiles]: rows of the log the tile used
+  int2 *read_info;                   // [R]: total k-mers, spans of a fragment (TaxonCounts.totalKmers; the "no span, no row" test)
   const uint64_t *list_off;          // LANE_APPLY: [n_shards * n_sub + 1] start of every sub-list in the compacted order
   const int32_t *taxa;               // LANE_APPLY: the owners' answers, in the compacted order of the keys
   const int32_t *to_dense;           // LANE_APPLY: caller's id -> the table's dense id (nullptr: ids as given)

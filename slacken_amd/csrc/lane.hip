@@ -218,51 +218,71 @@ __device__ __forceinline__ uint32_t shard_owner(uint64_t key, uint32_t ns) {  //
   const uint64_t h = fmix64(key);
   return (ns & (ns - 1)) == 0 ? (uint32_t)(h & (ns - 1)) : (uint32_t)(h % ns);
 }
-// LANE_EMIT: append the batch's minimizers to their owners' send lists (one atomic per owner per batch)
+// LANE_EMIT: append the batch's minimizers to their owners' send lists (one atomic per owner per batch); the span metadata the
+// second pass needs (owner lane, distinct, k-mers) goes to a list of the same shape, which stays on this rank
 __device__ __forceinline__ void emit_batch(LaneLds *L, const ShardIO &S, int32_t *status, int qhead, int cnt, int lane, uint32_t sub,
                                            uint64_t row) {
-  const bool in = lane < cnt;
-  const int qi = (qhead + lane) & (QCAP - 1);
-  const uint64_t key = L->q_key[qi];
-  const uint32_t ns = (uint32_t)S.n_shards;
-  const uint32_t g = shard_owner(key, ns);
-  for (uint32_t sh = 0; sh < ns; sh++) {
-    const bool mine = in && g == sh;
-    const uint64_t m = __ballot(mine);
-    if (m == 0) continue;
-    const int leader = __ffsll((long long)m) - 1;
-    unsigned long long base = 0;
-    const uint64_t list = (uint64_t)sh * (uint32_t)S.n_sub + sub;
-    if (lane == leader) {
-      base = atomicAdd(&S.send_counts[list], (unsigned long long)__popcll(m));
-      S.batch_base[row * ns + sh] = (uint32_t)base;
-    }
-    base = lane_readlane64(base, leader);
-    if (mine) {
-      const uint64_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-      if (pos < S.cap) S.send_keys[list * S.cap + pos] = (int64_t)key;
-      else atomicOr(status, 2);
-    }
-  }
-  lane_wave_sync();
-}
-// LANE_APPLY: the batch's taxa come from the owners' answers, which arrive list by list in the order the keys were sent
-__device__ __forceinline__ void apply_batch(LaneLds *L, const ShardIO &S, int qhead, int cnt, int lane, uint32_t sub, uint64_t row) {
   const bool in = lane < cnt;
   const int qi = (qhead + lane) & (QCAP - 1);
   const uint64_t key = L->q_key[qi];
   const uint32_t meta = L->q_meta[qi];
   const uint32_t ns = (uint32_t)S.n_shards;
   const uint32_t g = shard_owner(key, ns);
-  int32_t taxon = 0;
   for (uint32_t sh = 0; sh < ns; sh++) {
     const bool mine = in && g == sh;
     const uint64_t m = __ballot(mine);
-    if (m == 0) continue;
-    const uint64_t at = S.list_off[(uint64_t)sh * (uint32_t)S.n_sub + sub] + S.batch_base[row * ns + sh];   // (wave-uniform loads)
-    if (mine) taxon = S.taxa[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))];
+    if (m == 0) {
+      if (lane == 0) S.batch_base[row * ns + sh] = 0;   // (no key of this batch goes to this owner)
+      continue;
+    }
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned long long base = 0;
+    const uint64_t list = (uint64_t)sh * (uint32_t)S.n_sub + sub;
+    if (lane == leader) {
+      base = atomicAdd(&S.send_counts[list], (unsigned long long)__popcll(m));
+      S.batch_base[row * ns + sh] = ((uint32_t)base << 7) | (uint32_t)__popcll(m);   // (cap < 2^25, checked by the host side)
+    }
+    base = lane_readlane64(base, leader);
+    if (mine) {
+      const uint64_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+      if (pos < S.cap) {
+        S.send_keys[list * S.cap + pos] = (int64_t)key;
+        S.send_meta[list * S.cap + pos] = meta;
+      } else {
+        atomicOr(status, 2);
+      }
+    }
   }
-  if (S.to_dense != nullptr && taxon > 0) taxon = taxon < S.n_to_dense ? S.to_dense[taxon] : 0;  // (owners answer in the caller's ids)
+  lane_wave_sync();
+}
+// LANE_APPLY: no second scan.  The tile's probe batches are replayed from the log: lane i takes the i-th entry of a batch in
+// (owner, rank) order, reads its span metadata from this rank's meta list and its taxon from the owners' answers (which arrive
+// list by list in the order the keys were sent), and folds it into the owner lane's map exactly as the local kernel does.
+__device__ __forceinline__ void apply_row(LaneLds *L, const ShardIO &S, int lane, uint32_t sub, uint64_t row) {
+  const uint32_t ns = (uint32_t)S.n_shards;
+  uint32_t off = 0;
+  bool in = false;
+  uint64_t meta_at = 0, taxon_at = 0;
+  for (uint32_t sh = 0; sh < ns; sh++) {
+    const uint32_t e = S.batch_base[row * ns + sh];                    // (wave-uniform loads)
+    const uint32_t cnt = e & 127u;
+    if (cnt == 0) continue;
+    const uint64_t list = (uint64_t)sh * (uint32_t)S.n_sub + sub;
+    if ((uint32_t)lane >= off && (uint32_t)lane < off + cnt) {
+      in = true;
+      const uint64_t at = (uint64_t)(e >> 7) + ((uint32_t)lane - off);
+      meta_at = list * S.cap + at;
+      taxon_at = S.list_off[list] + at;
+    }
+    off += cnt;
+  }
+  uint32_t meta = 0;
+  int32_t taxon = 0;
+  if (in) {
+    meta = S.send_meta[meta_at];
+    taxon = S.taxa[taxon_at];
+    if (S.to_dense != nullptr && taxon > 0) taxon = taxon < S.n_to_dense ? S.to_dense[taxon] : 0;  // (owners answer in the caller's ids)
+  }
   fold_hit<false>(L, nullptr, in, meta, taxon);
   lane_wave_sync();
 }
@@ -396,7 +416,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     }
     if (LONG) have = have && (uint64_t)n + n2 > A.lane_short_max && (uint64_t)n + n2 <= max_len;   // (the others are not this pass's)
     bool too_long = have && ((uint64_t)n + n2 > max_len);
-    bool fin = !have || too_long;
+    bool fin = !have || too_long || MODE == LANE_APPLY;   // (the second pass of the sharded mode does not scan)
     // sharded modes: the tile's first row in the batch log.  A tile's probes number at most its bases, and tile t starts at
     // row floor(span_region(first fragment of t) / 64) + t: rows of different tiles never overlap (capi.hip: shard_batch_rows)
     uint64_t row = 0;
@@ -435,6 +455,13 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     int tphase = 0;   // generic window: step mod w (wave-uniform)
 
     const uint32_t VM = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20) | (1u << 21);  // A C G T U, either case
+    if (MODE == LANE_APPLY) {
+      // the second pass of the table-sharded mode: what the scan of the first pass found is on file
+      const uint32_t nrows = S.tile_rows[tile];
+      lane_wave_sync();
+      for (uint32_t b = 0; b < nrows; b++) apply_row(L, S, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row + b);
+      if (have) { total = S.read_info[r].x; nhits = S.read_info[r].y; }
+    }
     while (__ballot(!fin) != 0) {
       // One event per lane per step: a character, or the end of a mate.  Straight-line predicated code: the per-read
       // control flow (Supermers.splitByAmbiguity :150-178, MinSplitter.splitRead :133-172) is data, not branches.
@@ -574,7 +601,6 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
           lane_wave_sync();
           int back = 0;
           if (MODE == LANE_EMIT) emit_batch(L, S, A.status, qhead, 64, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++);
-          else if (MODE == LANE_APPLY) apply_batch(L, S, qhead, 64, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++);
           else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS, LONG>(L, ocnt, A.T, qhead, qn, 64, lane, dbg, A.span_meta, A.span_taxon);
           qhead = (qhead + 64) & (QCAP - 1);
           qn += back - 64;
@@ -586,12 +612,15 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       const int cnt = min(qn, 64);
       int back = 0;
       if (MODE == LANE_EMIT) emit_batch(L, S, A.status, qhead, cnt, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++);
-      else if (MODE == LANE_APPLY) apply_batch(L, S, qhead, cnt, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++);
       else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS, LONG>(L, ocnt, A.T, qhead, qn, cnt, lane, dbg, A.span_meta, A.span_taxon);
       qhead = (qhead + cnt) & (QCAP - 1);
       qn += back - cnt;
     }
     lane_wave_sync();
+    if (MODE == LANE_EMIT) {   // what the second pass cannot recompute without scanning again
+      if (have) S.read_info[r] = make_int2(total, nhits);
+      if (lane == 0) S.tile_rows[tile] = (uint32_t)(row - ((span_region(A.offsets, A.mate_offsets, tile * 64) >> 6) + tile));
+    }
 
     // ---- per-read classification (one lane per read) ------------------------------------------------------------------
     const uint32_t oflags = have ? L->o_flags[lane] : 0u;

@@ -8,8 +8,8 @@ mode (no collective at all).
 Host plumbing only: torch for device buffers and the collectives, the engine for all compute.  Two routes:
   fast    slk_shard_emit_device -> slk_shard_compact_device -> all-to-all -> slk_lookup_device -> all-to-all ->
           slk_shard_apply_device: the fused lane-per-fragment kernel runs on both sides of the exchange, nothing but 8-byte keys
-          and 4-byte taxa moves; takes fragments of up to 1000 bases with at most 12 distinct taxa; classify_many keeps three
-          batches in flight, the scans on one stream and the memory-bound stages on another;
+          and 4-byte taxa moves, and the fragments are scanned once (the apply replays the emit's log); takes fragments of up to 1000
+          bases with at most 12 distinct taxa; classify_many runs the scans on one stream and the memory-bound stages on another;
   staged  slk_scan_device / slk_lookup_device / slk_classify_hits_device with the exchange lists built by torch ops: takes
           everything, and the fragments the fast route hands back (`defer`)."""
 import numpy as np
@@ -94,11 +94,11 @@ class ShardedClassifier:
         return bool(int(t.item()))
 
     # ---- the fast route, in stages that are interleaved between batches (classify_many) -------------------------------------
-    # The stages of a batch are bound by different things: emit and apply (the two scans) by instruction issue, compaction and the
-    # owners' lookup by HBM, the exchange by the links.  So the scans of all batches go to ONE engine stream and the memory-bound
-    # stages to ANOTHER, each wrapped as a torch ExternalStream so that torch kernels, collectives and engine kernels are ordered
-    # by the streams themselves, with events where a stage needs the other stream's result.  In steady state the scan stream runs
-    # apply(k-1), emit(k+1) while the memory stream runs compact(k), lookup(k): three batches in flight.
+    # The stages of a batch are bound by different things: the scan (emit) by instruction issue, compaction, the owners' lookup and
+    # the replay of the batches (apply) by HBM, the exchange by the links.  So the scans of all batches go to ONE engine stream and
+    # the other stages to ANOTHER, each wrapped as a torch ExternalStream so that torch kernels, collectives and engine kernels are ordered
+    # by the streams themselves, with an event where the memory stream needs the scan's result.  In steady state the scan stream
+    # runs emit(k+1) while the memory stream runs compact(k), lookup(k), apply(k).
     # (Nothing here touches torch's default stream: the engine's streams are blocking streams, and an event recorded on the legacy
     # null stream waits for all of them and holds back whatever is issued after it -- measured: it serialised the pipeline.)
     def _two_streams(self):
@@ -134,18 +134,22 @@ class ShardedClassifier:
             defer = torch.empty(max(R, 1), dtype=torch.int32, device=dev)
             batch_base = torch.empty(rows * W, dtype=torch.int32, device=dev)
             send_keys = torch.empty(W * SUB * cap, dtype=torch.int64, device=dev)
+            send_meta = torch.empty(W * SUB * cap, dtype=torch.int32, device=dev)
             counts = torch.empty(W * SUB, dtype=torch.int64, device=dev)
+            tile_rows = torch.empty(tiles + 1, dtype=torch.int32, device=dev)
+            read_info = torch.empty(2 * max(R, 1), dtype=torch.int32, device=dev)
             try:
-                st.shard_emit_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, W, SUB, send_keys.data_ptr(), cap, counts.data_ptr(),
-                                     batch_base.data_ptr(), defer.data_ptr(), **mkw)
+                st.shard_emit_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, W, SUB, send_keys.data_ptr(), send_meta.data_ptr(), cap,
+                                     counts.data_ptr(), batch_base.data_ptr(), tile_rows.data_ptr(), read_info.data_ptr(),
+                                     defer.data_ptr(), **mkw)
             except slacken_amd.SlackenError as e:
                 if e.code != capi.E_UNSUPPORTED:
                     raise
                 return None
             emitted = torch.cuda.Event()
             emitted.record(ext)
-        return dict(R=R, SUB=SUB, cap=cap, defer=defer, batch_base=batch_base, send_keys=send_keys, counts=counts, emitted=emitted,
-                    mkw=mkw, batch=batch)
+        return dict(R=R, SUB=SUB, cap=cap, defer=defer, batch_base=batch_base, send_keys=send_keys, send_meta=send_meta, counts=counts,
+                    tile_rows=tile_rows, read_info=read_info, emitted=emitted, mkw=mkw, batch=batch)
 
     def _fast_compact(self, b):
         """stage 2 (memory stream, asynchronous): the send lists back to back; the split sizes on their way to the host"""
@@ -183,21 +187,22 @@ class ShardedClassifier:
         del b["send_keys"], b["out_keys"]
 
     def _fast_apply(self, b, thresholds, min_hit_groups):
-        """stage 4 (scan stream, asynchronous): the second scan.  The result tensors are valid once that stream has been synchronised."""
+        """stage 4 (memory stream, behind the lookup; asynchronous): the batches of probes are replayed from the emit's log and
+        folded with the owners' answers -- no second scan.  The result tensors are valid once that stream has been synchronised."""
         torch, dev, R, W = self.torch, self.device, b["R"], self.world
-        (st, ext), _ = self._two_streams()
+        _, (st, ext) = self._two_streams()
         d_bases, d_offsets = b["batch"][0], b["batch"][1]
         C = len(thresholds)
         with torch.cuda.stream(ext):
-            ext.wait_event(b["looked_up"])
             out = dict(taxon=torch.zeros(C * max(R, 1), dtype=torch.int32, device=dev),
                        classified=torch.zeros(C * max(R, 1), dtype=torch.uint8, device=dev),
                        num_distinct=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
                        total_kmers=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
                        num_hits=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
                        exchanged_keys=b["exchanged"])
-            st.shard_apply_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, W, b["SUB"], b["taxa"].data_ptr(),
-                                  b["list_off"].data_ptr(), b["batch_base"].data_ptr(), out["taxon"].data_ptr(),
+            st.shard_apply_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, W, b["SUB"], b["cap"], b["taxa"].data_ptr(),
+                                  b["list_off"].data_ptr(), b["send_meta"].data_ptr(), b["batch_base"].data_ptr(),
+                                  b["tile_rows"].data_ptr(), b["read_info"].data_ptr(), out["taxon"].data_ptr(),
                                   out["classified"].data_ptr(), b["defer"].data_ptr(), out["num_distinct"].data_ptr(),
                                   out["total_kmers"].data_ptr(), out["num_hits"].data_ptr(), min_hit_groups=min_hit_groups,
                                   thresholds=thresholds, **b["mkw"])
@@ -210,7 +215,7 @@ class ShardedClassifier:
         return None if outs is None else outs[0]
 
     def classify_many(self, batches, thresholds=(0.0,), min_hit_groups=2):
-        """The fast route over several batches [(d_bases, d_offsets, R, total_bases, mates or None)], three in flight (see above).
+        """The fast route over several batches [(d_bases, d_offsets, R, total_bases, mates or None)], two in flight (see above).
         Every rank must pass the same number of batches.  Returns the list of result dicts, or None if the splitter only has the
         staged route."""
         import slacken_amd
@@ -235,7 +240,7 @@ class ShardedClassifier:
         def release_finished():   # batches whose apply has run give their device memory back (a long run holds three, not all)
             for sb in states:
                 if "applied" in sb and "taxa" in sb and sb["applied"].query():
-                    for k in ("taxa", "batch_base", "list_off", "counts"):
+                    for k in ("taxa", "batch_base", "list_off", "counts", "send_meta", "tile_rows", "read_info"):
                         sb.pop(k, None)
 
         for i, batch in enumerate(batches):
@@ -245,8 +250,8 @@ class ShardedClassifier:
                 return None
             states.append(b)
             if i >= 1:
-                settle(i - 1)                          # lookup(i-1) runs beside emit(i); apply(i-1) follows emit(i) on the scan stream
-            self._fast_compact(b)                      # memory stream, behind lookup(i-1): runs beside apply(i-1)
+                settle(i - 1)                          # lookup(i-1) and apply(i-1) run beside emit(i)
+            self._fast_compact(b)                      # memory stream, behind apply(i-1)
         if states:
             settle(len(states) - 1)
         (scan_st, _), (mem_st, _) = self._two_streams()
@@ -257,7 +262,7 @@ class ShardedClassifier:
                 if not (overflowed and e.code == capi.E_CAPACITY):   # (the engine's own note of an overflow that was handled above)
                     raise
         for i, (b, batch) in enumerate(zip(states, batches)):
-            for k in ("taxa", "batch_base", "list_off", "counts"):
+            for k in ("taxa", "batch_base", "list_off", "counts", "send_meta", "tile_rows", "read_info"):
                 b.pop(k, None)
             d_bases, d_offsets, R, total_bases, mates = batch
             outs[i] = self._finish_deferred(outs[i], b, d_bases, d_offsets, R, thresholds, min_hit_groups, mates)

@@ -21,7 +21,7 @@ d_b = d_all[(stt[:, None] + torch.arange(150, device="cuda")[None, :]).reshape(-
 d_o = torch.arange(0, (R + 1) * 150, 150, dtype=torch.int64, device="cuda")
 st = ix.stream()
 W = 1; total = R * 150
-SUB = int(os.environ.get("SUB", 64))
+SUB = int(os.environ.get("SUB", 256))
 cap = int(total * 0.6 / (W * SUB)) + (1 << 12)
 def T(name, f):
     torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(); st.synchronize(); torch.cuda.synchronize()
@@ -34,12 +34,14 @@ for it in range(2):
     counts = torch.zeros(W * SUB, dtype=torch.int64, device="cuda")
     batch_base = torch.empty(rows * W, dtype=torch.int32, device="cuda")
     defer = torch.empty(R, dtype=torch.int32, device="cuda")
-    T("emit", lambda: st.shard_emit_device(d_b.data_ptr(), d_o.data_ptr(), R, W, SUB, send_keys.data_ptr(), cap, counts.data_ptr(), batch_base.data_ptr(), defer.data_ptr()))
-    out_keys = torch.empty_like(send_keys); list_off = torch.empty(W * SUB + 1, dtype=torch.int64, device="cuda"); oc = torch.empty(W, dtype=torch.int64, device="cuda")
+    send_meta = torch.empty(W * SUB * cap, dtype=torch.int32, device="cuda")
+    tile_rows = torch.empty((R + 63) // 64 + 1, dtype=torch.int32, device="cuda"); read_info = torch.empty(2 * R, dtype=torch.int32, device="cuda")
+    T("emit", lambda: st.shard_emit_device(d_b.data_ptr(), d_o.data_ptr(), R, W, SUB, send_keys.data_ptr(), send_meta.data_ptr(), cap, counts.data_ptr(), batch_base.data_ptr(), tile_rows.data_ptr(), read_info.data_ptr(), defer.data_ptr()))
+    out_keys = torch.empty_like(send_keys); list_off = torch.empty(W * SUB + 1, dtype=torch.int64, device="cuda"); oc = torch.empty(W + 1, dtype=torch.int64, device="cuda")
     T("compact", lambda: st.shard_compact_device(send_keys.data_ptr(), W, SUB, cap, counts.data_ptr(), out_keys.data_ptr(), list_off.data_ptr(), oc.data_ptr()))
-    n = int(oc.sum().item()); print("keys", n)
+    n = int(oc[:W].sum().item()); print("keys", n, "overflowed lists", int(oc[W].item()))
     found = T("empty", lambda: torch.empty(n, dtype=torch.int32, device="cuda"))
     T("lookup", lambda: st.lookup_device(out_keys.data_ptr(), n, found.data_ptr()))
     out_t = torch.zeros(R, dtype=torch.int32, device="cuda"); out_c = torch.zeros(R, dtype=torch.uint8, device="cuda")
-    T("apply", lambda: st.shard_apply_device(d_b.data_ptr(), d_o.data_ptr(), R, W, SUB, found.data_ptr(), list_off.data_ptr(), batch_base.data_ptr(), out_t.data_ptr(), out_c.data_ptr(), defer.data_ptr()))
+    T("apply", lambda: st.shard_apply_device(None, d_o.data_ptr(), R, W, SUB, cap, found.data_ptr(), list_off.data_ptr(), send_meta.data_ptr(), batch_base.data_ptr(), tile_rows.data_ptr(), read_info.data_ptr(), out_t.data_ptr(), out_c.data_ptr(), defer.data_ptr()))
     T("nonzero", lambda: torch.nonzero(defer))
