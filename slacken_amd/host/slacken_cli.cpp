@@ -15,6 +15,7 @@
 #include <cstring>
 #include <filesystem>
 #include <iostream>
+#include <set>
 #include <unordered_map>
 #include <algorithm>
 
@@ -210,6 +211,46 @@ static int cmd_records(int argc, char **argv) {
     });
     report("slkrec", n, kx, ts, mt);
   }
+  return 0;
+}
+
+// repeated [-p] FILES: the read titles the classify command would regroup (titles.hpp) -- those that occur more than once among the
+// fragments, and for paired input those whose header repeats inside one file of a pair -- one per line, sorted.  Host only: lets
+// the detection be tested without a GPU (every fragment is taken to produce a row).
+static int cmd_repeated(int argc, char **argv) {
+  bool paired = false;
+  std::vector<std::string> files;
+  for (int i = 0; i < argc; i++) {
+    if (std::string(argv[i]) == "-p") paired = true;
+    else files.push_back(argv[i]);
+  }
+  if (files.empty() || (paired && files.size() % 2)) die("usage: repeated [-p] FILES...");
+  RepeatedTitles rep;
+  ConcurrentTitleSet titles;
+  const size_t unit = paired ? 2 : 1;
+  for (size_t u = 0; u + unit <= files.size(); u += unit) {
+    FragmentSource src(std::vector<std::string>(files.begin() + u, files.begin() + u + unit), paired, &rep);
+    for (;;) {
+      FragmentBatchPtr bp;
+      if (!src.fill(bp, 4096, (size_t)64 << 20)) break;
+      std::vector<uint64_t> hs, again;
+      for (size_t i = 0; i < bp->size(); i++) hs.push_back(title_hash(bp->title(i)));
+      titles.insert_many(hs, again);
+      rep.add(again);
+    }
+  }
+  rep.settle_unmatched([&](uint64_t h) { return titles.contains(h); });
+  const FlatHashSet<0> D = rep.to_set();
+  std::set<std::string> out;
+  std::string_view h, sq;
+  for (size_t i = 0; i < files.size(); i++) {
+    AsyncRecordStream rs(files[i]);
+    while (rs.next(h, sq)) {
+      if (paired) h = remove_suffix(h, i % 2 == 0 ? "/1" : "/2");
+      if (D.contains(title_hash(h))) out.insert(std::string(h));
+    }
+  }
+  for (const std::string &t : out) std::cout << t << "\n";
   return 0;
 }
 
@@ -893,7 +934,7 @@ static const char *HELP =
     "  FILES                  FASTA / FASTQ, plain, .gz or .bz2; @list.txt names a file of file names\n"
     "options of classify2 (Slacken.scala:199-260): --library DIR (DIR/library/**/*.fna, DIR/seqid2taxid.map), --rank RANK (species),\n"
     "  -R, --reads N (100) | -C, --min-count N | -D, --min-distinct N, --init-confidence X (0.15)\n"
-    "host-only helpers: report TAXONOMY_DIR COUNTS_TSV | parse FILE [MATE_FILE] | props INDEX | records INDEX\n"
+    "host-only helpers: report TAXONOMY_DIR COUNTS_TSV | parse FILE [MATE_FILE] | props INDEX | records INDEX | repeated [-p] FILES\n"
     "environment: SLK_HOST_THREADS (formatting/decoding threads), SLK_INPUT_STREAMS (input files read side by side, default 8),\n"
     "             SLK_PARSE_THREADS (threads parsing one plain input file, default min(8, cores/2)), SLK_GZIP_LEVEL (1..9, default zlib's),\n"
     "             SLK_CLASSIFY_THREADS (threads classifying batches, each with its own stream, default 2),\n"
@@ -913,6 +954,7 @@ int main(int argc, char **argv) {
     if (cmd == "parse") return cmd_parse(argc - i, argv + i);
     if (cmd == "props") return cmd_props(argc - i, argv + i);
     if (cmd == "records") return cmd_records(argc - i, argv + i);
+    if (cmd == "repeated") return cmd_repeated(argc - i, argv + i);
     if (cmd == "taxonomy") return cmd_taxonomy(argc - i, argv + i);
   } catch (const std::exception &e) {
     die(e.what());

@@ -66,3 +66,57 @@ def test_classify_hits_equals_classify_read_on_a_single_fragment():
     assert m["total_kmers"] == r1["total_kmers"] + r2["total_kmers"]
     assert m["num_distinct"] == r1["num_distinct"] + r2["num_distinct"]
     assert m["num_hits"] == len(h1) + len(h2)
+
+
+# ---- the host's detection of the titles it must regroup (`slacken-amd repeated`, no GPU): every title whose fragments the
+# reference would merge -- or whose join has more products than the streaming walk makes -- must be found
+def _repeated(tmp_path, recs1, recs2=None):
+    import subprocess
+    from test_host_cli import CLI
+    f1 = tmp_path / "a_1.fq"
+    with open(f1, "w") as f:
+        for h, q in recs1:
+            f.write(f"@{h}\n{q}\n+\n{'I' * len(q)}\n")
+    args = [str(f1)]
+    if recs2 is not None:
+        f2 = tmp_path / "a_2.fq"
+        with open(f2, "w") as f:
+            for h, q in recs2:
+                f.write(f"@{h}\n{q}\n+\n{'I' * len(q)}\n")
+        args = ["-p", str(f1), str(f2)]
+    r = subprocess.run([CLI, "repeated", *args], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return r.stdout.split()
+
+
+def test_host_finds_the_titles_to_regroup(tmp_path):
+    import random
+    rnd = random.Random(4)
+    seq = lambda: "".join(rnd.choice("ACGT") for _ in range(60))
+    # unpaired: titles that occur twice or three times, among many that occur once
+    recs = [(f"r{i}", seq()) for i in range(3000)] + [("r7", seq()), ("r2999", seq()), ("r7", seq())]
+    rnd.shuffle(recs)
+    assert _repeated(tmp_path, recs) == sorted(["r7", "r2999"])
+    assert _repeated(tmp_path, [(f"u{i}", seq()) for i in range(500)]) == []
+    # paired: every shape of a repeated header, with the two files in the same order and in different orders
+    for trial in range(6):
+        n = 400
+        r1 = [(f"p{i}", seq()) for i in range(n)]
+        r2 = [(f"p{i}", seq()) for i in range(n)]
+        r1.insert(120, ("p5", seq()))                       # 2 x 1: file 1 repeats a header
+        r2.insert(300, ("p9", seq()))                       # 1 x 2: file 2 repeats a header
+        r1.insert(10, ("p200", seq())); r2.insert(350, ("p200", seq()))   # 2 x 2
+        r1.append(("only1", seq())); r2.append(("only2", seq()))          # no partner: no fragment, nothing to regroup
+        r1.append(("dup_no_mate", seq())); r1.append(("dup_no_mate", seq()))   # repeated, but no product at all
+        if trial % 3 == 1:
+            rnd.shuffle(r2)
+        elif trial % 3 == 2:
+            rnd.shuffle(r1)
+        joined = hostmodel.paired_join([(h + "/1", q) for h, q in r1], [(h + "/2", q) for h, q in r2])
+        count = {}
+        for t, _, _ in joined:
+            count[t] = count.get(t, 0) + 1
+        want = sorted(t for t, c in count.items() if c >= 2)
+        assert want == ["p200", "p5", "p9"]
+        got = _repeated(tmp_path, [(h + "/1", q) for h, q in r1], [(h + "/2", q) for h, q in r2])
+        assert set(want) <= set(got) <= set(want) | {"dup_no_mate"}, (trial, got)
