@@ -51,7 +51,9 @@ constexpr uint32_t OMAP_CNT_MASK = (1u << OMAP_CNT_BITS) - 1;
 struct __attribute__((aligned(16))) LaneLds {
   uint64_t q_key[QCAP];
   uint32_t q_meta[QCAP];          // owner lane (6 bits) | distinct << 6 | kmers << 7 (13 bits) | displacement << 20 (6 bits)
-  uint64_t stash[128];            // (home bucket, taxon found, tag) 16 bytes per queue entry of the batch
+  uint64_t stash[128];            // (home bucket, -, tag) 16 bytes per queue entry of the batch
+  uint32_t found[64];             // taxon found per entry of the batch (a word array of its own: read by all 64 lanes at once, and
+                                  // as the second word of the 16-byte stash entries that read was a 4-way bank conflict)
   uint4 sbuf[(SBLK - 1) * 64];    // read stream: the staged 16-byte sub-blocks 1.. of every lane, [sub-block - 1][lane]
   uint32_t omap[OMAP * 64];       // [slot][owner lane]: taxon << 10 | k-mer count; 0 = empty (NONE hits are not stored)
                                   // (LONG variant: the taxon alone; the counts are a second array behind the per-wave block)
@@ -144,6 +146,7 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, uint32_t *ocnt, const Tab
   const uint64_t tag = in ? (((h & T.rem_mask) << T.disp_bits) + disp) : NO_TAG;  // the tag's low bits are the displacement
   st.z = (uint32_t)tag; st.w = (uint32_t)(tag >> 32);
   ((uint4 *)L->stash)[lane] = st;
+  L->found[lane] = 0;
   lane_wave_sync();
   const int g = lane >> 2, c = lane & 3;                                  // 16 groups of 4 lanes
   const uint64_t tmask = (1ULL << T.taxon_bits) - 1;
@@ -166,7 +169,7 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, uint32_t *ocnt, const Tab
     const bool e0 = cell[s].x == 0, e1 = cell[s].y == 0;
     const bool m0 = act && !e0 && (cell[s].x >> T.taxon_bits) == want;
     const bool m1 = act && !e1 && (cell[s].y >> T.taxon_bits) == want;
-    if (m0 || m1) ((uint4 *)L->stash)[s * 16 + g].y = (uint32_t)((m0 ? cell[s].x : cell[s].y) & tmask);
+    if (m0 || m1) L->found[s * 16 + g] = (uint32_t)((m0 ? cell[s].x : cell[s].y) & tmask);
     const uint64_t B = __ballot(m0 || m1 || e0 || e1 || !act);  // a group is resolved by a match or by an empty cell
     const uint64_t nz = (B | (B >> 1) | (B >> 2) | (B >> 3)) & 0x1111111111111111ULL;
     if (nz != 0x1111111111111111ULL) {
@@ -191,7 +194,7 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, uint32_t *ocnt, const Tab
   }
   lane_wave_sync();
   // step 3: one lane per entry
-  const int32_t taxon = (int32_t)((const uint4 *)L->stash)[lane].y;
+  const int32_t taxon = (int32_t)L->found[lane];
   if (!SLK_TUNE_ON(2)) fold_hit<LONG>(L, ocnt, in, meta, taxon);
   if (HITS && in) {
     // the un-merged hit list (TaxonHit, KeyValueIndex.scala:436-441) in the fragment's span region.  An entry handed back
