@@ -181,8 +181,6 @@ class ShardedClassifier:
                 st.lookup_device(recv_keys.data_ptr(), recv_keys.numel(), found.data_ptr())
             back, _ = self._all_to_all(found[:recv_keys.numel()], recv_counts)
             b["taxa"] = back.contiguous() if back.numel() else torch.zeros(1, dtype=torch.int32, device=self.device)
-            b["looked_up"] = torch.cuda.Event()
-            b["looked_up"].record(ext)
         b["exchanged"] = n_send
         del b["send_keys"], b["out_keys"]
 
@@ -223,7 +221,7 @@ class ShardedClassifier:
         states, outs = [], []
         overflowed = False
 
-        def settle(j):   # batch j: its one host wait, then exchange + lookup (memory stream) and apply (scan stream)
+        def settle(j):   # batch j: its one host wait, then exchange + lookup + apply on the memory stream
             nonlocal overflowed
             b, scale = states[j], 1
             while True:
@@ -237,7 +235,7 @@ class ShardedClassifier:
             self._fast_exchange(b)
             outs.append(self._fast_apply(b, thresholds, min_hit_groups))
 
-        def release_finished():   # batches whose apply has run give their device memory back (a long run holds three, not all)
+        def release_finished():   # batches whose apply has run give their device memory back (a long run holds a few, not all)
             for sb in states:
                 if "applied" in sb and "taxa" in sb and sb["applied"].query():
                     for k in ("taxa", "batch_base", "list_off", "counts", "send_meta", "tile_rows", "read_info"):
