@@ -118,6 +118,28 @@ def test_lane_and_wave_kernels_agree(big):
     assert np.array_equal(wave["num_hits"], lane["nh"].cpu().numpy())
 
 
+def test_host_entry_at_its_default_subbatch_size(big):
+    """1.5 M reads through slk_classify_batch -- cut into sub-batches of 2^18 whose upload overlaps the kernels of the one before --
+    from pageable and from pinned caller buffers: the same answers as the device entry on the resident copy of the reads."""
+    from slacken_amd import capi
+    R = min(big["R"], 1_500_000)
+    host_b = big["bases"][:R * 150].cpu().numpy()
+    host_o = np.arange(0, (R + 1) * 150, 150, dtype=np.uint64)
+    dev = run(big, big["bases"], big["offsets"][:R + 1], R)
+    got = big["st"].classify_batch(host_b, host_o, thresholds=(0.0, 0.1), with_hits=False, with_num_hits=True)
+    pb = capi.pinned_array(host_b.shape, np.uint8); pb[:] = host_b
+    po = capi.pinned_array(host_o.shape, np.uint64); po[:] = host_o
+    out = dict(taxon=capi.pinned_array((2, R), np.int32), classified=capi.pinned_array((2, R), np.uint8),
+               num_distinct=capi.pinned_array((R,), np.int32), total_kmers=capi.pinned_array((R,), np.int32))
+    big["st"].classify_batch(pb, po, thresholds=(0.0, 0.1), with_hits=False, out=out)
+    for res in (got, out):
+        assert np.array_equal(res["taxon"].reshape(-1), dev["taxon"].cpu().numpy())
+        assert np.array_equal(res["classified"].reshape(-1), dev["cls"].cpu().numpy())
+        assert np.array_equal(res["num_distinct"], dev["nd"].cpu().numpy())
+        assert np.array_equal(res["total_kmers"], dev["tk"].cpu().numpy())
+    assert np.array_equal(got["num_hits"], dev["nh"].cpu().numpy())
+
+
 def test_poly_a_known_answer(big):
     torch = big["torch"]
     R = 4096
