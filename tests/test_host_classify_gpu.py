@@ -439,3 +439,43 @@ def test_cli_devices_share_the_reads(tmp_path):
         assert open(f"{outs[0]}_c{suffix}/all_kreport.txt").read() == open(f"{outs[1]}_c{suffix}/all_kreport.txt").read()
     bad = subprocess.run([CLI, "classify", "-i", loc, "-o", str(tmp_path / "x"), "--devices", "0,99", str(fq)], capture_output=True, text=True)
     assert bad.returncode != 0 and "out of range" in bad.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SLK_TITLE_SEEDS", 4))))
+def test_cli_repeated_titles_randomised(tmp_path, seed):
+    """Random multiplicities of every title -- 0 to 3 records per file, any order, unpaired over two files or paired with the
+    join's products -- against the restatement (hostmodel.merge_by_title / paired_join over the oracle's hit lists)."""
+    import random
+    g, loc, tax, reads = make_library(tmp_path)
+    rnd = random.Random(1000 + seed)
+    paired = seed % 2 == 1
+    titles = [f"t{i}" for i in range(120)]
+    pick = lambda: reads[rnd.randrange(len(reads))][1]
+    r1 = [(t, pick()) for t in titles for _ in range(rnd.choice([0, 1, 1, 1, 1, 2, 3]))]
+    r2 = [(t, pick()) for t in titles for _ in range(rnd.choice([0, 1, 1, 1, 1, 2, 3]))]
+    if rnd.random() < 0.7:
+        rnd.shuffle(r2)
+    if rnd.random() < 0.3:
+        rnd.shuffle(r1)
+    f1, f2 = tmp_path / "x_1.fq", tmp_path / "x_2.fq"
+    for f, recs, suf in ((f1, r1, "/1"), (f2, r2, "/2")):
+        with open(f, "w") as out:
+            for t, q in recs:
+                out.write(f"@{t}{suf if paired else ''}\n{q}\n+\n{'I' * len(q)}\n")
+    if paired:
+        frags = hostmodel.paired_join([(t + "/1", q) for t, q in r1], [(t + "/2", q) for t, q in r2])
+    else:
+        frags = [(t, q, None) for t, q in r1 + r2]
+    want = _expected_rows(frags, thresholds=(0.0, 0.3))
+    out = tmp_path / "rnd"
+    classify("-i", loc, "-o", out, "-c", "0.0", "0.3", *(["-p"] if paired else []), f1, f2)
+    for thr, suffix in ((0.0, "0.0"), (0.3, "0.3")):
+        lines = read_out(f"{out}_c{suffix}") if want[thr] else []
+        assert sorted(lines) == sorted(want[thr]), (seed, thr)
+        if want[thr]:
+            assert open(f"{out}_c{suffix}/all_kreport.txt").read().rstrip("\n").split("\n") == _report_of(tax, want[thr])
+    out2 = tmp_path / "rnd_nd"
+    classify("-i", loc, "-o", out2, "-c", "0.0", "0.3", "--nodetailed", *(["-p"] if paired else []), f1, f2)
+    for suffix in ("0.0", "0.3"):
+        assert open(f"{out2}_c{suffix}/all_kreport.txt").read() == open(f"{out}_c{suffix}/all_kreport.txt").read()
