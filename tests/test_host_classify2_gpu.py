@@ -159,6 +159,14 @@ def test_classify2_default_criterion(tmp_path, orc):
     assert read_out(f"{out}_c0.1") == lines[0.1]
     # the genome with only 12 reads is not in the set: its reads are no longer classified to its species
     assert any(l.startswith("C") for l in lines[0.0]) and os.path.exists(f"{out}_c0.0/all_kreport.txt")
+    # the same over two device tables (both passes and the dynamic library's construction on each): identical files
+    out2 = tmp_path / "o" / "dyn2"
+    err2 = run2("-i", S["loc"], "-o", out2, "--library", S["lib"], "-R", 50, "-c", "0.0", "0.1", "--devices", "0,0", S["fq"])
+    assert f"dynamic index: {nrec} records" in err2
+    assert open(f"{out2}_taxonSet.txt").read() == open(f"{out}_taxonSet.txt").read()
+    for sfx in ("0.0", "0.1"):
+        assert read_out(f"{out2}_c{sfx}") == read_out(f"{out}_c{sfx}")
+        assert open(f"{out2}_c{sfx}/all_kreport.txt").read() == open(f"{out}_c{sfx}/all_kreport.txt").read()
 
 
 @pytest.mark.parametrize("flag,criterion,threshold", [("-C", "total", 400), ("-D", "distinct", 300)])
