@@ -142,6 +142,7 @@ struct FusedArgs {
   const unsigned long long *work_count;  // (device) -- the fragments the lane kernel deferred (it appends them itself)
   uint8_t *handled;                      // work-list passes: [i] = 1 if the long-lane pass classified work_list[i] (the wave kernel skips it)
   uint32_t lane_short_max;               // long-lane pass: it takes fragments longer than this (the first pass's limit)
+  unsigned long long *tile_counter;      // long-lane pass: the next tile of the hand-on list (zero at launch)
   uint32_t seg_min_len;                  // work-list passes: unpaired fragments of at least this many bases belong to the
                                          // lane-per-segment kernel (launch_segments), the others to the wave kernel; 0 = none
 };

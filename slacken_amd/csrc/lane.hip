@@ -401,7 +401,15 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
   // fragments over its four waves gains nothing, because a block's LDS and wave slots are held until its longest wave ends;
   // a length-bucketed order inside windows of 16 384 fragments gains 4 % on lengths uniform in 50..250 -- where a globally
   // sorted input gains 20 % -- because every lane then pays scattered loads of its offsets and scattered stores of its results.)
-  for (uint64_t tile = (uint64_t)blockIdx.x * LW + wib; tile < ntiles; tile += nwaves) {
+  for (uint64_t tile = (uint64_t)blockIdx.x * LW + wib;; tile += nwaves) {
+    if (LONG) {
+      // The number of hand-ons is only known here, so the grid is a fixed one and the waves draw their tiles from a counter:
+      // with a strided walk most waves would take floor(tiles / waves) tiles and a few one more, and everyone waits for those.
+      unsigned long long t = 0;
+      if (lane == 0) t = atomicAdd(A.tile_counter, 1ULL);
+      tile = lane_readlane64(t, 0);
+    }
+    if (tile >= ntiles) break;
     const uint64_t unit = tile * 64 + lane;
     bool have = unit < n_units;
     const uint64_t r = LONG ? (have ? A.work_list[unit] : 0) : unit;
