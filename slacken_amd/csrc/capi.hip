@@ -1016,9 +1016,11 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
       const char *long_env = getenv("SLK_LANE_LONG_MAX");
       const int long_max = std::min(long_env ? atoi(long_env) : 4999, 8191);
       if (long_max > 1000) {
-        const size_t counter_at = (R + 1 + 7) & ~(size_t)7;   // [0, R]: the flags; then the work counters of the hand-on passes
-        HIPCHK(st->handled.ensure(counter_at + 24));         // ([0] long lane pass, [1] segment kernel, [2] wave kernel)
-        HIPCHK(hipMemsetAsync(st->handled.p, 0, counter_at + 24, st->s));
+        const size_t counter_at = (R + 1 + 7) & ~(size_t)7;   // [0, R]: the flags; then the long pass's tile counter
+        // (the wave and segment kernels keep their strided walk over the hand-ons: drawing units from a counter was measured --
+        //  most units are skipped there, and a skip that costs an atomic is dearer than the imbalance it removes)
+        HIPCHK(st->handled.ensure(counter_at + 8));
+        HIPCHK(hipMemsetAsync(st->handled.p, 0, counter_at + 8, st->s));
         A.handled = st->handled.as<uint8_t>();
         A.tile_counter = (unsigned long long *)(st->handled.as<uint8_t>() + counter_at);
         A.lane_short_max = 1000;

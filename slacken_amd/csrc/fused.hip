@@ -88,14 +88,6 @@ __device__ __forceinline__ int lanes_below(uint64_t mask) {  // popcount(mask & 
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
-// the next `n` units of a work list for this wave (one atomic per wave; every lane gets the first of them)
-__device__ __forceinline__ uint64_t next_units(unsigned long long *counter, uint64_t n) {
-  unsigned long long t = 0;
-  if ((threadIdx.x & 63) == 0) t = atomicAdd(counter, (unsigned long long)n);
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)t), hi = __builtin_amdgcn_readfirstlane((uint32_t)(t >> 32));
-  return ((uint64_t)hi << 32) | lo;
-}
-
 // ---- staging: 256 characters -> 2-bit codes in the two rings ----------------------------------------------------------
 // returns true in lanes that saw a character outside ACGTUacgtu (BitRepresentation.isValid, BitRepresentation.scala:140-143)
 __device__ __forceinline__ bool stage_block(WaveLds *L, const uint8_t *seq, uint32_t n, uint32_t blk, int lane) {
@@ -355,15 +347,8 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
   // one per wave iteration.  (They used to be found 64 flags at a time by ballot, each wave working through its 64 one after
   // the other: with most fragments deferred -- a batch of long reads -- that left most of the chip idle.)
   const uint64_t nunits = A.work_list ? (uint64_t)*A.work_count : A.R;
-  // Hand-on pass: the grid is fixed and the units differ a hundredfold in cost (most are skipped: classified by the long lane pass or
-  // the segment kernel's), so the waves draw them from a counter -- in chunks, so that a list of a million skipped units is not a
-  // million atomics on one address, yet small enough that a few long fragments still spread over the waves.
-  const bool draw = A.work_list && A.tile_counter;
-  const uint64_t chunk = draw ? max((uint64_t)1, min((uint64_t)64, nunits / (nwaves * 4))) : 1;
-  for (uint64_t first = (uint64_t)blockIdx.x * FW + wib;; first += nwaves) {
-    if (draw) first = next_units(&A.tile_counter[2], chunk);
-    if (first >= nunits) break;
-   for (uint64_t unit = first; unit < min(nunits, first + chunk); unit++) {
+  for (uint64_t unit = (uint64_t)blockIdx.x * FW + wib; unit < nunits; unit += nwaves) {
+   {
     const uint64_t r = A.work_list ? A.work_list[unit] : unit;
     if (A.work_list && A.handled && A.handled[unit]) continue;                        // classified by the long-lane pass (lane.hip)
     if (A.seg_min_len && A.offsets[r + 1] - A.offsets[r] >= A.seg_min_len) continue;  // the segment kernel's (launch_segments)
@@ -654,12 +639,7 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
   const uint64_t nunits = (uint64_t)*A.work_count;
   const uint64_t bases_end = A.offsets[A.R];
   const uint32_t VM = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20) | (1u << 21);  // A C G T U, either case
-  const bool draw = A.tile_counter != nullptr;   // (as in fused_kernel: units drawn from a counter, in chunks)
-  const uint64_t chunk = draw ? max((uint64_t)1, min((uint64_t)64, nunits / (nwaves * 4))) : 1;
-  for (uint64_t first = (uint64_t)blockIdx.x * FW + wib;; first += nwaves) {
-    if (draw) first = next_units(&A.tile_counter[1], chunk);
-    if (first >= nunits) break;
-   for (uint64_t unit = first; unit < min(nunits, first + chunk); unit++) {
+  for (uint64_t unit = (uint64_t)blockIdx.x * FW + wib; unit < nunits; unit += nwaves) {
     const uint64_t r = A.work_list[unit];
     const uint64_t o = A.offsets[r];
     const uint32_t n_all = (uint32_t)(A.offsets[r + 1] - o);
@@ -885,7 +865,6 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
       if (A.out_np) A.out_np[r] = np;
     }
     wave_sync();
-   }
   }
 }
 
