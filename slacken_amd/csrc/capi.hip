@@ -5,6 +5,7 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <chrono>
 #include <cstdio>
@@ -236,7 +237,9 @@ struct slk_stream {
   hipStream_t s = nullptr;
   DevBuf span_keys, span_meta, span_taxon, span_count;  // per-batch scratch (sparse per-read regions)
   DevBuf bases, offsets, mate_bases, mate_offsets;      // staging for the host-pointer entry points
-  DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items, defer_list, handled;
+  DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items, defer_list;
+  hipStream_t s2 = nullptr;                 // the segment pass runs here, beside the long-lane and wave passes on s
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int32_t *d_status = nullptr;     // device error bits of the fused kernels
   int32_t *h_status = nullptr;     // pinned copy, refreshed after every classify launch
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -858,7 +861,7 @@ void slk_stream_destroy(slk_stream *st) {
   (void)hipStreamSynchronize(st->s);
   DevBuf *bufs[] = {&st->span_keys, &st->span_meta, &st->span_taxon, &st->span_count, &st->bases, &st->offsets,
                     &st->mate_bases, &st->mate_offsets, &st->out_taxon, &st->out_cls, &st->out_nd, &st->out_tk,
-                    &st->out_nh, &st->out_offsets, &st->out_items, &st->defer_list, &st->handled};
+                    &st->out_nh, &st->out_offsets, &st->out_items, &st->defer_list};
   for (DevBuf *b : bufs) b->release();
   if (st->d_status) (void)hipFree(st->d_status);
   if (st->h_status) (void)hipHostFree(st->h_status);
@@ -866,6 +869,9 @@ void slk_stream_destroy(slk_stream *st) {
   st->staging_c.release();
   for (hipEvent_t e : st->up_ev) (void)hipEventDestroy(e);
   if (st->cs) (void)hipStreamDestroy(st->cs);
+  if (st->s2) { (void)hipStreamSynchronize(st->s2); (void)hipStreamDestroy(st->s2); }
+  if (st->ev_fork) (void)hipEventDestroy(st->ev_fork);
+  if (st->ev_join) (void)hipEventDestroy(st->ev_join);
   for (int i = 0; i < 4; i++) if (st->ev[i]) (void)hipEventDestroy(st->ev[i]);
   if (st->s) (void)hipStreamDestroy(st->s);
   delete st;
@@ -1001,41 +1007,55 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
     A.span_taxon = want_hits ? st->span_taxon.as<int32_t>() : nullptr;
     A.span_count = want_hits ? st->span_count.as<int32_t>() : nullptr;
     A.status = st->d_status;
-    A.work_list = nullptr; A.work_count = nullptr;
-    if (lane_path_ok(ix) && !force_wave()) {  // (window of at most 32 m-mers, taxon ids of at most 22 bits)
+    A.work_list = nullptr; A.work_count = nullptr; A.work_draw = nullptr;
+    if (lane_path_ok(ix) && !force_wave() && R < 0xFFFFFFFFull) {  // (window of at most 32 m-mers, taxon ids of at most 22 bits)
       st->last_used_lane = true;
-      // hot path: one lane per fragment; long fragments and map overflows are deferred to the wave-per-read kernel: the lane
-      // kernel appends them to the work list itself ([0] = their number, [1..] = their indices, in no particular order)
-      HIPCHK(st->defer_list.ensure((R + 1) * sizeof(uint64_t)));
-      HIPCHK(hipMemsetAsync(st->defer_list.p, 0, sizeof(uint64_t), st->s));
-      A.work_list = st->defer_list.as<uint64_t>() + 1;
-      A.work_count = (const unsigned long long *)st->defer_list.p;
-      launch_lane(A, nullptr, 1000, st->s);  // (the one-word map entries carry 10-bit k-mer counts)
-      // of the fragments it handed on, those of up to 4999 bases take the lane kernel's long variant (32-bit counts);
-      // SLK_LANE_LONG_MAX moves the limit (at most 8191: queue entries carry 13-bit k-mer counts), 0 turns the pass off
+      // Hot path: one lane per fragment.  What that kernel does not take -- fragments over 1000 bases, taxon maps that overflow --
+      // it appends to the hand-on list of the kernel that does (engine.h: FusedArgs.hand_*): four length classes for its own long
+      // variant (1001 .. 4999 bases), the lane-per-segment kernel (unpaired, from 5000 bases, classification only, w = 5), the
+      // wave-per-fragment kernel (the rest, and what the long variant hands on in turn).  The passes run behind it on this stream;
+      // the segment pass, which depends on nothing but the first pass, on a second stream beside the other two.
+      const size_t hdr_bytes = 16 * sizeof(uint64_t);
+      HIPCHK(st->defer_list.ensure(hdr_bytes + 6 * (size_t)R * sizeof(uint32_t)));
+      HIPCHK(hipMemsetAsync(st->defer_list.p, 0, hdr_bytes, st->s));
+      A.hand_hdr = (unsigned long long *)st->defer_list.p;
+      A.hand_lists = (uint32_t *)((char *)st->defer_list.p + hdr_bytes);
+      A.hand_stride = R;
+      // SLK_LANE_LONG_MAX moves the long variant's limit (at most 8191: queue entries carry 13-bit k-mer counts; 0: no such pass),
+      // SLK_SEG_MIN_LEN the segment kernel's (5000: below that, too few of the 64 lanes have a segment of a useful length; 0: wave
+      // kernel only).  Read per call, so that tests can move them.
       const char *long_env = getenv("SLK_LANE_LONG_MAX");
       const int long_max = std::min(long_env ? atoi(long_env) : 4999, 8191);
-      if (long_max > 1000) {
-        const size_t counter_at = (R + 1 + 7) & ~(size_t)7;   // [0, R]: the flags; then the long pass's tile counter
-        // (the wave and segment kernels keep their strided walk over the hand-ons: drawing units from a counter was measured --
-        //  most units are skipped there, and a skip that costs an atomic is dearer than the imbalance it removes)
-        HIPCHK(st->handled.ensure(counter_at + 8));
-        HIPCHK(hipMemsetAsync(st->handled.p, 0, counter_at + 8, st->s));
-        A.handled = st->handled.as<uint8_t>();
-        A.tile_counter = (unsigned long long *)(st->handled.as<uint8_t>() + counter_at);
-        A.lane_short_max = 1000;
-        launch_lane_long(A, (uint32_t)long_max, st->s);
-      }
-      // of the deferred fragments, the long unpaired ones go to the lane-per-segment kernel (classification only, w = 5)
-      // (5000: below that, too few of the 64 lanes have a segment of a useful length; read per call, so that tests can move it)
       const char *seg_env = getenv("SLK_SEG_MIN_LEN");
-      const int seg_min = seg_env ? atoi(seg_env) : 5000;  // 0: wave kernel only
-      if (!want_hits && !paired && ix->sp.w == 5 && seg_min > 0) {
-        A.seg_min_len = (uint32_t)std::max(seg_min, 1001);
-        launch_segments(A, st->s);
+      const int seg_min = seg_env ? atoi(seg_env) : 5000;
+      const bool seg_on = !want_hits && !paired && ix->sp.w == 5 && seg_min > 0;
+      A.long_max = long_max > 1000 ? (uint32_t)long_max : 0;
+      if (A.long_max) {  // class borders: a geometric ladder from 1000 to the limit (a tile's lanes then differ by at most ~1.5x)
+        const double ratio = pow((double)A.long_max / 1000.0, 0.25);
+        for (int i = 0; i < 3; i++) A.long_bound[i] = (uint32_t)(1000.0 * pow(ratio, i + 1));
       }
+      A.seg_min_len = seg_on ? (uint32_t)std::max(seg_min, (int)std::max<uint32_t>(A.long_max, 1000) + 1) : 0;
+      launch_lane(A, nullptr, 1000, st->s);  // (the one-word map entries carry 10-bit k-mer counts)
+      if (seg_on) {
+        if (!st->s2) {
+          HIPCHK(hipStreamCreateWithFlags(&st->s2, hipStreamNonBlocking));
+          HIPCHK(hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming));
+          HIPCHK(hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(st->ev_fork, st->s));
+        HIPCHK(hipStreamWaitEvent(st->s2, st->ev_fork, 0));
+        FusedArgs B = A;
+        B.work_list = A.hand_lists + 4 * A.hand_stride; B.work_count = A.hand_hdr + 4; B.work_draw = A.hand_hdr + 7;
+        launch_segments(B, st->s2);
+        HIPCHK(hipEventRecord(st->ev_join, st->s2));
+      }
+      if (A.long_max) launch_lane_long(A, A.long_max, st->s);
+      A.work_list = A.hand_lists + 5 * A.hand_stride; A.work_count = A.hand_hdr + 5; A.work_draw = A.hand_hdr + 8;
+      launch_fused(want_hits ? MODE_HITS : MODE_CLASSIFY, A, st->s);
+      if (seg_on) HIPCHK(hipStreamWaitEvent(st->s, st->ev_join, 0));
+    } else {
+      launch_fused(want_hits ? MODE_HITS : MODE_CLASSIFY, A, st->s);
     }
-    launch_fused(want_hits ? MODE_HITS : MODE_CLASSIFY, A, st->s);
     HIPCHK(hipEventRecord(st->ev[1], st->s));
     HIPCHK(hipEventRecord(st->ev[2], st->s));
   } else {
@@ -1313,7 +1333,8 @@ int32_t slk_stream_last_deferred(slk_stream *st, uint64_t *out_count) {
   { int32_t rc_ = set_device(st->ix); if (rc_) return rc_; }
   *out_count = 0;
   HIPCHK(hipStreamSynchronize(st->s));
-  if (st->defer_list.p && st->last_used_lane) HIPCHK(hipMemcpy(out_count, st->defer_list.p, sizeof(uint64_t), hipMemcpyDeviceToHost));
+  if (st->defer_list.p && st->last_used_lane)   // (word 9 of the hand-on header: what the first pass handed on)
+    HIPCHK(hipMemcpy(out_count, (const uint64_t *)st->defer_list.p + 9, sizeof(uint64_t), hipMemcpyDeviceToHost));
   return SLK_OK;
 }
 

@@ -138,13 +138,21 @@ struct FusedArgs {
   int32_t *span_taxon;   // MODE_HITS output
   int32_t *span_count;   // MODE_SPANS / MODE_HITS output
   int32_t *status;       // device error bits: 1 = taxon map overflow
-  const uint64_t *work_list;             // if set, the fused kernel processes only the fragments work_list[0 .. *work_count)
-  const unsigned long long *work_count;  // (device) -- the fragments the lane kernel deferred (it appends them itself)
-  uint8_t *handled;                      // work-list passes: [i] = 1 if the long-lane pass classified work_list[i] (the wave kernel skips it)
-  uint32_t lane_short_max;               // long-lane pass: it takes fragments longer than this (the first pass's limit)
-  unsigned long long *tile_counter;      // long-lane pass: the next tile of the hand-on list (zero at launch)
-  uint32_t seg_min_len;                  // work-list passes: unpaired fragments of at least this many bases belong to the
-                                         // lane-per-segment kernel (launch_segments), the others to the wave kernel; 0 = none
+  // Hand-on lists.  The lane kernel's first pass sorts the fragments it does not take by the kernel that will: lists 0..3 = the
+  // four length classes of its own long variant (tiles of similar length: the 64 lanes of a wave run in lockstep), 4 = the
+  // lane-per-segment kernel, 5 = the wave kernel (also what the long variant hands on in turn).  uint32 fragment indices.
+  unsigned long long *hand_hdr;          // 16 words: [l] = entries of list l; [6] tile draw of the long pass, [7] / [8] unit draws of
+                                         // the segment / wave pass; [9] = fragments handed on by the first pass
+  uint32_t *hand_lists;                  // [6][hand_stride]
+  uint64_t hand_stride;
+  uint32_t long_max;                     // the long variant takes fragments of up to this many bases (0: there is no such pass)
+  uint32_t long_bound[3];                // borders of its length classes
+  uint32_t seg_min_len;                  // unpaired fragments of at least this many bases belong to the lane-per-segment kernel
+                                         // (launch_segments), 0 = none
+  // what a pass kernel (long lane, segment, wave) walks: work_list[0 .. *work_count), drawing units from *work_draw if set
+  const uint32_t *work_list;
+  const unsigned long long *work_count;
+  unsigned long long *work_draw;
 };
 
 // Table-sharded classification (BASELINE configs[3]): the lane kernel runs twice per batch.  LANE_EMIT scans the

@@ -88,6 +88,14 @@ __device__ __forceinline__ int lanes_below(uint64_t mask) {  // popcount(mask & 
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
+// the next unit of a hand-on list for this wave (one atomic per wave; every lane gets the value)
+__device__ __forceinline__ uint64_t next_unit(unsigned long long *counter) {
+  unsigned long long t = 0;
+  if ((threadIdx.x & 63) == 0) t = atomicAdd(counter, 1ULL);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)t), hi = __builtin_amdgcn_readfirstlane((uint32_t)(t >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
 // ---- staging: 256 characters -> 2-bit codes in the two rings ----------------------------------------------------------
 // returns true in lanes that saw a character outside ACGTUacgtu (BitRepresentation.isValid, BitRepresentation.scala:140-143)
 __device__ __forceinline__ bool stage_block(WaveLds *L, const uint8_t *seq, uint32_t n, uint32_t blk, int lane) {
@@ -347,11 +355,12 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
   // one per wave iteration.  (They used to be found 64 flags at a time by ballot, each wave working through its 64 one after
   // the other: with most fragments deferred -- a batch of long reads -- that left most of the chip idle.)
   const uint64_t nunits = A.work_list ? (uint64_t)*A.work_count : A.R;
-  for (uint64_t unit = (uint64_t)blockIdx.x * FW + wib; unit < nunits; unit += nwaves) {
+  for (uint64_t unit = (uint64_t)blockIdx.x * FW + wib;; unit += nwaves) {
+    // a hand-on list: every unit is work and they differ a hundredfold in length, so the (fixed) grid draws them from a counter
+    if (A.work_draw) unit = next_unit(A.work_draw);
+    if (unit >= nunits) break;
    {
-    const uint64_t r = A.work_list ? A.work_list[unit] : unit;
-    if (A.work_list && A.handled && A.handled[unit]) continue;                        // classified by the long-lane pass (lane.hip)
-    if (A.seg_min_len && A.offsets[r + 1] - A.offsets[r] >= A.seg_min_len) continue;  // the segment kernel's (launch_segments)
+    const uint64_t r = A.work_list ? (uint64_t)A.work_list[unit] : unit;
     // ---- per-fragment state (wave-uniform unless noted) ----
     int nbuf = 0, n_out = 0;
     bool first = true, have_last = false;   // Supermers.spans :72-73
@@ -639,12 +648,12 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
   const uint64_t nunits = (uint64_t)*A.work_count;
   const uint64_t bases_end = A.offsets[A.R];
   const uint32_t VM = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20) | (1u << 21);  // A C G T U, either case
-  for (uint64_t unit = (uint64_t)blockIdx.x * FW + wib; unit < nunits; unit += nwaves) {
+  for (uint64_t unit = (uint64_t)blockIdx.x * FW + wib;; unit += nwaves) {
+    if (A.work_draw) unit = next_unit(A.work_draw);   // (as in fused_kernel)
+    if (unit >= nunits) break;
     const uint64_t r = A.work_list[unit];
     const uint64_t o = A.offsets[r];
     const uint32_t n_all = (uint32_t)(A.offsets[r + 1] - o);
-    if (n_all < A.seg_min_len) continue;  // the wave kernel's
-    if (A.handled && A.handled[unit]) continue;  // (classified by the long-lane pass, should its limit reach this far)
     // ---- this lane's segment ----
     const uint32_t nwin = n_all - (uint32_t)k + 1;  // (seg_min_len > k)
     const uint32_t S = max(SEG_MIN_WINDOWS, (nwin + 63) / 64);
@@ -868,7 +877,7 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
   }
 }
 
-void launch_segments(const FusedArgs &A, hipStream_t s) {  // work-list pass; A.seg_min_len set, unpaired, window width 5
+void launch_segments(const FusedArgs &A, hipStream_t s) {  // over a hand-on list (A.work_list): unpaired, window width 5
   hipLaunchKernelGGL(segment_kernel, dim3(256 * 8), dim3(FW * 64), 0, s, A);
 }
 

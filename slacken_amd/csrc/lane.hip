@@ -370,10 +370,9 @@ __device__ __forceinline__ uint4 stream_refill(LaneLds *L, int lane, const uint8
 #define LANE_BOUNDS __launch_bounds__(LW * 64)
 #endif
 
-// LONG: the second pass over the fragments the first one handed on (A.work_list): those of more than A.lane_short_max and at most
-// max_len bases are classified here, with a map of full 32-bit counts (a 1 001..4 999-base fragment has up to 4 965 k-mers for
-// one taxon; the one-word map of the hot variant counts to 1 023); what it classifies is marked in A.handled, the rest -- longer
-// ones, map overflows of either pass -- is left to the wave / segment kernels.  The hot variant is untouched by it.
+// LONG: the second pass, over the fragments of 1 001 .. A.long_max bases that the first one handed on (hand-on lists 0..3, one per
+// length class), with a map of full 32-bit counts (such a fragment has up to 4 965 k-mers for one taxon; the one-word map of the hot
+// variant counts to 1 023).  What overflows its map too goes on to the wave kernel's list.  The hot variant is untouched by it.
 template <bool W5, int MODE, bool HITS, bool LONG>
 __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, uint32_t max_len, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -392,8 +391,14 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
   uint32_t *ocnt = LONG ? (uint32_t *)((unsigned char *)L + fixed + win_bytes) : nullptr;   // LONG: k-mer counts of the map's slots
   const bool paired = A.mate_bases != nullptr;
   const uint64_t bases_end = A.offsets[A.R], mates_end = paired ? A.mate_offsets[A.R] : 0;  // (wave-uniform loads)
-  const uint64_t n_units = LONG ? (uint64_t)*A.work_count : A.R;   // LONG: the first pass's hand-ons (it has finished: same stream)
-  const uint64_t ntiles = (n_units + 63) / 64;
+  // LONG: tiles of the four class lists one after the other (a tile never mixes classes); the first pass has finished (same stream)
+  uint64_t cls_n[4] = {0, 0, 0, 0}, cls_tiles[4] = {0, 0, 0, 0};
+  uint64_t ntiles = (A.R + 63) / 64;
+  if (LONG) {
+    ntiles = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) { cls_n[c] = A.hand_hdr[c]; cls_tiles[c] = (cls_n[c] + 63) / 64; ntiles += cls_tiles[c]; }
+  }
   const uint64_t nwaves = (uint64_t)gridDim.x * LW;
 
   // (The 64 lanes of a wave run in lockstep, so a tile lasts as long as its longest fragment.  Two ways of handing the tiles
@@ -406,13 +411,22 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       // The number of hand-ons is only known here, so the grid is a fixed one and the waves draw their tiles from a counter:
       // with a strided walk most waves would take floor(tiles / waves) tiles and a few one more, and everyone waits for those.
       unsigned long long t = 0;
-      if (lane == 0) t = atomicAdd(A.tile_counter, 1ULL);
+      if (lane == 0) t = atomicAdd(&A.hand_hdr[6], 1ULL);
       tile = lane_readlane64(t, 0);
     }
     if (tile >= ntiles) break;
-    const uint64_t unit = tile * 64 + lane;
-    bool have = unit < n_units;
-    const uint64_t r = LONG ? (have ? A.work_list[unit] : 0) : unit;
+    uint64_t unit = tile * 64 + lane;
+    bool have = unit < A.R;
+    uint64_t r = unit;
+    if (LONG) {
+      uint64_t local = tile;
+      int c = 0;
+#pragma unroll
+      for (int i = 0; i < 3; i++) if (c == i && local >= cls_tiles[i]) { local -= cls_tiles[i]; c = i + 1; }
+      unit = local * 64 + lane;
+      have = unit < cls_n[c];
+      r = have ? (uint64_t)A.hand_lists[(uint64_t)c * A.hand_stride + unit] : 0;
+    }
     // ---- fragment descriptor ----
     const uint8_t *seq = A.bases;
     uint32_t n = 0, n2 = 0;
@@ -425,7 +439,6 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       SLK_TUNE(if (dbg & 8) { seq = A.bases + A.offsets[r & 1023]; room = clamp_room(bases_end - A.offsets[r & 1023]); })  // (timing experiment 8: the read stream comes from the L2)
       if (paired) n2 = (uint32_t)(A.mate_offsets[r + 1] - A.mate_offsets[r]);  // (the mate's place is read again when the scan gets there)
     }
-    if (LONG) have = have && (uint64_t)n + n2 > A.lane_short_max && (uint64_t)n + n2 <= max_len;   // (the others are not this pass's)
     bool too_long = have && ((uint64_t)n + n2 > max_len);
     bool fin = !have || too_long || MODE == LANE_APPLY;   // (the second pass of the sharded mode does not scan)
     // sharded modes: the tile's first row in the batch log.  A tile's probes number at most its bases, and tile t starts at
@@ -636,17 +649,28 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     // ---- per-read classification (one lane per read) ------------------------------------------------------------------
     const uint32_t oflags = have ? L->o_flags[lane] : 0u;
     const bool dfr = have && (too_long || (oflags & 0x80000000u));  // re-done by the wave-per-read / segment kernels
-    if (LONG) {
-      if (have && !dfr) A.handled[unit] = 1;   // (a map overflow stays with the wave kernel)
-    } else if (MODE == LANE_LOCAL) {
-      // straight into the work list of those kernels ([count] at A.work_count, indices at A.work_list; the order of the
-      // list does not matter): one atomic per wave that defers anything, none otherwise
+    if (MODE == LANE_LOCAL) {
+      // Straight into the hand-on list of the kernel that takes such a fragment (the order inside a list does not matter): one
+      // atomic per wave and list that gets something, none otherwise.
       const uint64_t DM = __ballot(dfr);
       if (DM != 0) {
-        unsigned long long at = 0;
-        if (lane == 0) at = atomicAdd(const_cast<unsigned long long *>(A.work_count), (unsigned long long)__popcll(DM));
-        at = lane_readlane64(at, 0);
-        if (dfr) const_cast<uint64_t *>(A.work_list)[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(DM >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)DM, 0))] = r;
+        int route = 5;                                            // map overflow (of either pass): the wave kernel
+        if (!LONG && dfr && too_long) {
+          uint64_t len = A.offsets[r + 1] - A.offsets[r];         // (read again here: the scan has no register left for it)
+          if (paired) len += A.mate_offsets[r + 1] - A.mate_offsets[r];
+          if (A.long_max != 0 && len <= A.long_max) route = (len > A.long_bound[0]) + (len > A.long_bound[1]) + (len > A.long_bound[2]);
+          else if (A.seg_min_len != 0 && len >= A.seg_min_len) route = 4;
+        }
+        if (!LONG && lane == 0) atomicAdd(&A.hand_hdr[9], (unsigned long long)__popcll(DM));
+        for (int l = LONG ? 5 : 0; l < 6; l++) {
+          const uint64_t M = __ballot(dfr && route == l);
+          if (M == 0) continue;
+          unsigned long long at = 0;
+          if (lane == __ffsll((long long)M) - 1) at = atomicAdd(&A.hand_hdr[l], (unsigned long long)__popcll(M));
+          at = lane_readlane64(at, __ffsll((long long)M) - 1);
+          if (dfr && route == l)
+            A.hand_lists[(uint64_t)l * A.hand_stride + at + __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0))] = (uint32_t)r;
+        }
       }
     } else if (dfr) {
       defer[r] = 1;  // sharded modes: the caller routes these fragments
@@ -767,7 +791,7 @@ void launch_lane(const FusedArgs &A, int32_t *defer, uint32_t max_len, hipStream
   if (A.span_taxon) launch_lane_mode<LANE_LOCAL, true, false>(A, ShardIO{}, defer, max_len, s);
   else launch_lane_mode<LANE_LOCAL, false, false>(A, ShardIO{}, defer, max_len, s);
 }
-// the pass over the first one's hand-ons (A.work_list / A.work_count / A.handled / A.lane_short_max set)
+// the pass over the first one's hand-ons of 1 001 .. A.long_max bases (hand-on lists 0..3)
 void launch_lane_long(const FusedArgs &A, uint32_t max_len, hipStream_t s) {
   if (A.span_taxon) launch_lane_mode<LANE_LOCAL, true, true>(A, ShardIO{}, nullptr, max_len, s);
   else launch_lane_mode<LANE_LOCAL, false, true>(A, ShardIO{}, nullptr, max_len, s);
