@@ -370,6 +370,32 @@ __device__ __forceinline__ uint4 stream_refill(LaneLds *L, int lane, const uint8
 #define LANE_BOUNDS __launch_bounds__(LW * 64)
 #endif
 
+// A wave of the first pass (or of the long variant) hands fragments on: straight into the hand-on list of the kernel that takes such
+// a fragment (the order inside a list does not matter); one atomic per wave and list that gets something.
+__device__ __attribute__((noinline)) void hand_on(unsigned long long *hdr, uint32_t *lists, uint64_t stride, uint32_t long_max, uint32_t b0,
+                                                  uint32_t b1, uint32_t b2, uint32_t seg_min_len, const uint64_t *offsets,
+                                                  const uint64_t *mate_offsets, bool dfr, bool too_long, uint64_t r, int lane, bool from_long) {
+  const uint64_t DM = __ballot(dfr);
+  int route = 5;                                            // map overflow (of either pass): the wave kernel
+  if (!from_long && dfr && too_long) {
+    uint64_t len = offsets[r + 1] - offsets[r];
+    if (mate_offsets) len += mate_offsets[r + 1] - mate_offsets[r];
+    if (long_max != 0 && len <= long_max) route = (len > b0) + (len > b1) + (len > b2);
+    else if (seg_min_len != 0 && len >= seg_min_len) route = 4;
+  }
+  if (!from_long && lane == 0) atomicAdd(&hdr[9], (unsigned long long)__popcll(DM));
+  for (int l = from_long ? 5 : 0; l < 6; l++) {
+    const uint64_t M = __ballot(dfr && route == l);
+    if (M == 0) continue;
+    const int leader = __ffsll((long long)M) - 1;
+    unsigned long long at = 0;
+    if (lane == leader) at = atomicAdd(&hdr[l], (unsigned long long)__popcll(M));
+    at = lane_readlane64(at, leader);
+    if (dfr && route == l)
+      lists[(uint64_t)l * stride + at + __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0))] = (uint32_t)r;
+  }
+}
+
 // LONG: the second pass, over the fragments of 1 001 .. A.long_max bases that the first one handed on (hand-on lists 0..3, one per
 // length class), with a map of full 32-bit counts (such a fragment has up to 4 965 k-mers for one taxon; the one-word map of the hot
 // variant counts to 1 023).  What overflows its map too goes on to the wave kernel's list.  The hot variant is untouched by it.
@@ -406,23 +432,28 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
   // fragments over its four waves gains nothing, because a block's LDS and wave slots are held until its longest wave ends;
   // a length-bucketed order inside windows of 16 384 fragments gains 4 % on lengths uniform in 50..250 -- where a globally
   // sorted input gains 20 % -- because every lane then pays scattered loads of its offsets and scattered stores of its results.)
-  for (uint64_t tile = (uint64_t)blockIdx.x * LW + wib;; tile += nwaves) {
+  for (uint64_t tile = (uint64_t)blockIdx.x * LW + wib, it = 0;; it++) {
     if (LONG) {
       // The number of hand-ons is only known here, so the grid is a fixed one and the waves draw their tiles from a counter:
       // with a strided walk most waves would take floor(tiles / waves) tiles and a few one more, and everyone waits for those.
-      unsigned long long t = 0;
-      if (lane == 0) t = atomicAdd(&A.hand_hdr[6], 1ULL);
-      tile = lane_readlane64(t, 0);
+      // (A wave's first tile is the one of its own number: fewer tiles than waves -- usually none -- cost no atomics.)
+      if (it) {
+        unsigned long long t = 0;
+        if (lane == 0) t = atomicAdd(&A.hand_hdr[6], 1ULL);
+        tile = nwaves + lane_readlane64(t, 0);
+      }
+    } else if (it) {
+      tile += nwaves;
     }
     if (tile >= ntiles) break;
     uint64_t unit = tile * 64 + lane;
     bool have = unit < A.R;
     uint64_t r = unit;
     if (LONG) {
-      uint64_t local = tile;
-      int c = 0;
+      uint64_t local = tile;   // (the longest class first: the last tiles to start are the shortest)
+      int c = 3;
 #pragma unroll
-      for (int i = 0; i < 3; i++) if (c == i && local >= cls_tiles[i]) { local -= cls_tiles[i]; c = i + 1; }
+      for (int i = 3; i > 0; i--) if (c == i && local >= cls_tiles[i]) { local -= cls_tiles[i]; c = i - 1; }
       unit = local * 64 + lane;
       have = unit < cls_n[c];
       r = have ? (uint64_t)A.hand_lists[(uint64_t)c * A.hand_stride + unit] : 0;
@@ -650,28 +681,9 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     const uint32_t oflags = have ? L->o_flags[lane] : 0u;
     const bool dfr = have && (too_long || (oflags & 0x80000000u));  // re-done by the wave-per-read / segment kernels
     if (MODE == LANE_LOCAL) {
-      // Straight into the hand-on list of the kernel that takes such a fragment (the order inside a list does not matter): one
-      // atomic per wave and list that gets something, none otherwise.
-      const uint64_t DM = __ballot(dfr);
-      if (DM != 0) {
-        int route = 5;                                            // map overflow (of either pass): the wave kernel
-        if (!LONG && dfr && too_long) {
-          uint64_t len = A.offsets[r + 1] - A.offsets[r];         // (read again here: the scan has no register left for it)
-          if (paired) len += A.mate_offsets[r + 1] - A.mate_offsets[r];
-          if (A.long_max != 0 && len <= A.long_max) route = (len > A.long_bound[0]) + (len > A.long_bound[1]) + (len > A.long_bound[2]);
-          else if (A.seg_min_len != 0 && len >= A.seg_min_len) route = 4;
-        }
-        if (!LONG && lane == 0) atomicAdd(&A.hand_hdr[9], (unsigned long long)__popcll(DM));
-        for (int l = LONG ? 5 : 0; l < 6; l++) {
-          const uint64_t M = __ballot(dfr && route == l);
-          if (M == 0) continue;
-          unsigned long long at = 0;
-          if (lane == __ffsll((long long)M) - 1) at = atomicAdd(&A.hand_hdr[l], (unsigned long long)__popcll(M));
-          at = lane_readlane64(at, __ffsll((long long)M) - 1);
-          if (dfr && route == l)
-            A.hand_lists[(uint64_t)l * A.hand_stride + at + __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0))] = (uint32_t)r;
-        }
-      }
+      if (__ballot(dfr) != 0)   // (rare, and kept out of line: the hot loop's registers and schedule are not to know about it)
+        hand_on(A.hand_hdr, A.hand_lists, A.hand_stride, A.long_max, A.long_bound[0], A.long_bound[1], A.long_bound[2], A.seg_min_len,
+                A.offsets, A.mate_offsets, dfr, too_long, r, lane, LONG);
     } else if (dfr) {
       defer[r] = 1;  // sharded modes: the caller routes these fragments
     }

@@ -24,7 +24,9 @@ SEEDS = sorted(set(range(N_SEEDS)) | {295})
 @pytest.mark.parametrize("seed", SEEDS)
 def test_differential(orc, seed, monkeypatch):
     import slacken_amd
-    monkeypatch.setenv("SLK_SEG_MIN_LEN", "1001" if seed % 2 else "5000")   # (long fragments: segment kernel / wave kernel)
+    # fragments over 1000 bases: the lane kernel's long variant (default), or -- without it -- the segment kernel / the wave kernel
+    monkeypatch.setenv("SLK_SEG_MIN_LEN", "1001" if seed % 2 else "5000")
+    monkeypatch.setenv("SLK_LANE_LONG_MAX", "0" if seed % 4 >= 2 else "4999")
     rng = np.random.default_rng(9000 + seed)
     m = int(rng.integers(8, 33))
     wmax = 32 if seed % 4 else 16

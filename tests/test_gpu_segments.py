@@ -15,9 +15,11 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def segments_from_1001_bases(monkeypatch):
-    # the engine's default hands fragments of 5000 bases and more to the segment kernel; here everything over 1000 goes there,
-    # which makes the segments short (64 windows) and the borders many
+    # the engine's default hands fragments of 5000 bases and more to the segment kernel (those of 1001..4999 to the lane kernel's
+    # long variant); here everything over 1000 goes to the segment kernel, which makes the segments short (64 windows) and the
+    # borders many
     monkeypatch.setenv("SLK_SEG_MIN_LEN", "1001")
+    monkeypatch.setenv("SLK_LANE_LONG_MAX", "0")
 
 
 @pytest.fixture(scope="module")
@@ -80,15 +82,23 @@ def check(orc, world, reads, thresholds=(0.0, 0.1, 0.5), min_hit_groups=2):
         bad = np.nonzero(np.atleast_2d(got[key] != want[key]).any(axis=0))[0]
         assert bad.size == 0, (key, bad[:5].tolist(), [len(reads[i]) for i in bad[:5]],
                                np.atleast_2d(got[key])[:, bad[:5]].tolist(), np.atleast_2d(want[key])[:, bad[:5]].tolist())
-    # the same batch with every deferred fragment on the wave kernel
-    os.environ["SLK_SEG_MIN_LEN"] = "0"
+    # the same batch with every handed-on fragment on the wave kernel, and with the engine's default routes (1001..4999 bases: the
+    # lane kernel's long variant, from 5000: the segment kernel, map overflows: the wave kernel)
+    saved = {v: os.environ.get(v) for v in ("SLK_SEG_MIN_LEN", "SLK_LANE_LONG_MAX")}
     try:
-        wave = world["st"].classify_batch(bases, offsets, thresholds=thresholds, min_hit_groups=min_hit_groups, with_hits=False,
-                                          with_num_hits=True)
+        for name, env in (("wave kernel", dict(SLK_SEG_MIN_LEN="0", SLK_LANE_LONG_MAX="0")), ("default routes", {})):
+            for v in saved:
+                os.environ.pop(v, None)
+            os.environ.update(env)
+            other = world["st"].classify_batch(bases, offsets, thresholds=thresholds, min_hit_groups=min_hit_groups, with_hits=False,
+                                               with_num_hits=True)
+            for key in ("total_kmers", "num_hits", "num_distinct", "taxon", "classified"):
+                assert np.array_equal(other[key], got[key]), name + " vs segment kernel: " + key
     finally:
-        os.environ["SLK_SEG_MIN_LEN"] = "1001"
-    for key in ("total_kmers", "num_hits", "num_distinct", "taxon", "classified"):
-        assert np.array_equal(wave[key], got[key]), "wave kernel vs segment kernel: " + key
+        for v, x in saved.items():
+            os.environ.pop(v, None)
+            if x is not None:
+                os.environ[v] = x
     return got
 
 
@@ -137,6 +147,7 @@ def test_default_threshold_splits_the_work_between_the_two_kernels(orc, world, m
     """Default threshold (5000 bases): shorter long fragments, clean or with characters outside ACGTU (which the wave kernel takes
     run by run), stay on the wave kernel, longer ones go to the segment kernel, short ones to the lane kernel -- one batch."""
     monkeypatch.delenv("SLK_SEG_MIN_LEN")
+    monkeypatch.delenv("SLK_LANE_LONG_MAX")
     rng = np.random.default_rng(12)
     reads = []
     for _ in range(150):
@@ -151,6 +162,53 @@ def test_default_threshold_splits_the_work_between_the_two_kernels(orc, world, m
     want = orc.classify_batch(world["p"], world["oix"], world["parents"], bases, offsets, None, None, min_hit_groups=2,
                               thresholds=(0.0, 0.2))
     for key in ("total_kmers", "num_hits", "num_distinct", "taxon", "classified"):
+        assert np.array_equal(got[key], want[key]), key
+
+
+def many_slices(lib, rng, n, lo, hi):
+    """n fragments of lo..hi bases cut from the library's genomes (vectorised: these batches hold 10^4 .. 10^5.5 fragments)"""
+    cat = np.concatenate(lib.genomes)
+    glen = len(lib.genomes[0])
+    lens = rng.integers(lo, hi + 1, n)
+    offsets = np.zeros(n + 1, np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    starts = rng.integers(0, len(lib.genomes), n) * glen + rng.integers(0, glen - hi, n)
+    rid = np.repeat(np.arange(n), lens)
+    bases = cat[starts[rid] + (np.arange(int(offsets[-1])) - offsets[:-1].astype(np.int64)[rid])].copy()
+    subs = rng.random(len(bases)) < 0.01
+    bases[subs] = synth.random_dna(int(subs.sum()), rng)
+    bases[rng.random(len(bases)) < 0.0005] = ord("N")
+    return bases, offsets
+
+
+KEYS = ("total_kmers", "num_hits", "num_distinct", "taxon", "classified")
+
+
+@pytest.mark.parametrize("route", ["wave", "segment", "long"])
+def test_hand_on_lists_longer_than_the_grids(orc, world, monkeypatch, route):
+    """The kernels behind the first pass have fixed grids (8 192 waves; the long lane variant at most 5 120) and the number of
+    hand-ons is only known on the device: a wave takes the unit of its own number first and draws further ones from a counter.
+    More hand-ons than waves on each route, against the oracle."""
+    monkeypatch.setenv("SLK_SEG_MIN_LEN", {"wave": "0", "segment": "1001", "long": "5000"}[route])
+    monkeypatch.setenv("SLK_LANE_LONG_MAX", "4999" if route == "long" else "0")
+    rng = np.random.default_rng(77)
+    # the long variant's grid is one wave per 64 fragments of the BATCH, capped at 5 120: its draw needs over 327 680 hand-ons
+    n = 340_000 if route == "long" else 20_000
+    bases, offsets = many_slices(world["lib"], rng, n, 1001, 1100 if route == "long" else 1300)
+    import torch
+    st = world["st"]
+    d_b, d_o = torch.from_numpy(bases).cuda(), torch.from_numpy(offsets.astype(np.int64)).cuda()   # one undivided batch: the device entry
+    outs = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in range(3)]
+    d_t, d_c = torch.zeros(2 * n, dtype=torch.int32, device="cuda"), torch.zeros(2 * n, dtype=torch.uint8, device="cuda")
+    st.classify_batch_device(d_b.data_ptr(), d_o.data_ptr(), n, int(offsets[-1]), d_t.data_ptr(), d_c.data_ptr(), outs[0].data_ptr(),
+                             outs[1].data_ptr(), outs[2].data_ptr(), min_hit_groups=2, thresholds=(0.0, 0.2))
+    st.synchronize()
+    assert st.last_deferred() == n
+    want = orc.classify_batch(world["p"], world["oix"], world["parents"], bases, offsets, None, None, min_hit_groups=2,
+                              thresholds=(0.0, 0.2))
+    got = dict(taxon=d_t.cpu().numpy().reshape(2, n), classified=d_c.cpu().numpy().reshape(2, n), num_distinct=outs[0].cpu().numpy(),
+               total_kmers=outs[1].cpu().numpy(), num_hits=outs[2].cpu().numpy())
+    for key in KEYS:
         assert np.array_equal(got[key], want[key]), key
 
 
