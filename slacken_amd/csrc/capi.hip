@@ -197,6 +197,7 @@ struct slk_index {
   std::vector<int32_t> h_parents;  // host copy, for the dense renumbering at finalize
   // dense taxon ids (engine.h: TableView.to_orig): set up by slk_index_finalize when the caller's ids need more than 22 bits
   int32_t *d_parents_dense = nullptr, *d_to_orig = nullptr, *d_to_dense = nullptr;
+  uint4 *d_nodes = nullptr;        // kernel_parents() with an Euler tour (engine.h: FusedArgs.nodes); null: more than 2^22 ids, no lane kernel
   int32_t D = 0;                   // nodes of the taxonomy = largest dense id (0: ids are stored as given)
   bool finalized = false;
   int32_t max_disp = 0;
@@ -222,6 +223,7 @@ struct slk_index {
   }
   // what the fused kernels walk: the parents array in the ids the cells hold
   const int32_t *kernel_parents() const { return D ? d_parents_dense : d_parents; }
+  const uint4 *kernel_nodes() const { return d_nodes; }
   int32_t kernel_ntax() const { return D ? D + 1 : T; }
   int internal_taxon_bits() const {
     if (!D) return taxon_bits;
@@ -580,6 +582,47 @@ int32_t slk_index_append(slk_index *ix, const int64_t *keys, const int32_t *taxa
   return read_build_counters(ix);
 }
 
+// The taxonomy as the lane kernel reads it: per id {parent, tin, tout, 0}, tin / tout from a depth-first tour of the forest
+// (every id whose parent is NONE is a root: ROOT, unused ids, the top of a detached subtree), so that "a is an ancestor-or-self
+// of b" (Taxonomy.hasAncestor, Taxonomy.scala:236-244) is tin[a] <= tin[b] <= tout[a] -- two compares on values that are loaded
+// once per taxon of a read's map -- instead of a walk of b's root path: NCBI lineages are 25-40 nodes deep, and resolveTree
+// (LowestCommonAncestor.scala:101-146) asks it for every pair of map taxa and again at every step of the confidence walk.
+static int32_t build_tax_nodes(slk_index *ix, const int32_t *parents, int32_t n) {
+  if (ix->d_nodes) { HIPCHK(hipFree(ix->d_nodes)); ix->d_nodes = nullptr; }
+  if (n < 2 || n > (1 << 22) + 1) return SLK_OK;   // (ids beyond 22 bits do not take the lane kernel)
+  std::vector<uint32_t> first((size_t)n + 1, 0), kids;   // children of p: kids[first[p] .. first[p + 1]), in increasing id order
+  for (int32_t t = 1; t < n; t++) if (parents[t] != 0) first[(size_t)parents[t] + 1]++;
+  for (int32_t p = 0; p < n; p++) first[(size_t)p + 1] += first[p];
+  kids.resize(first[n]);
+  {
+    std::vector<uint32_t> at(first.begin(), first.end() - 1);
+    for (int32_t t = 1; t < n; t++) if (parents[t] != 0) kids[at[parents[t]]++] = (uint32_t)t;
+  }
+  std::vector<uint4> nodes((size_t)n, make_uint4(0, 0, 0, 0));
+  std::vector<std::pair<uint32_t, uint32_t>> stack;   // (node, next child)
+  uint32_t clock = 0;
+  for (int32_t r = 1; r < n; r++) {
+    if (parents[r] != 0) continue;
+    stack.emplace_back((uint32_t)r, first[r]);
+    nodes[r].y = ++clock;
+    while (!stack.empty()) {
+      auto &top = stack.back();
+      if (top.second < first[(size_t)top.first + 1]) {
+        const uint32_t c = kids[top.second++];
+        nodes[c].x = top.first;
+        nodes[c].y = ++clock;
+        stack.emplace_back(c, first[c]);
+      } else {
+        nodes[top.first].z = clock;   // the largest tin of the subtree
+        stack.pop_back();
+      }
+    }
+  }
+  HIPCHK(hipMalloc((void **)&ix->d_nodes, (size_t)n * sizeof(uint4)));
+  HIPCHK(hipMemcpy(ix->d_nodes, nodes.data(), (size_t)n * sizeof(uint4), hipMemcpyHostToDevice));
+  return SLK_OK;
+}
+
 int32_t slk_index_set_taxonomy(slk_index *ix, const int32_t *parents, int32_t T) {
   if (!ix || !parents || T < 2) return fail(SLK_E_INVALID, "taxonomy needs parents[] with at least ROOT (T >= 2)");
   int32_t rc = set_device(ix);
@@ -607,7 +650,7 @@ int32_t slk_index_set_taxonomy(slk_index *ix, const int32_t *parents, int32_t T)
   HIPCHK(hipMemcpy(ix->d_parents, parents, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice));
   ix->T = T;
   ix->h_parents.assign(parents, parents + T);
-  return SLK_OK;
+  return build_tax_nodes(ix, parents, T);
 }
 
 // bases_on_device: `bases` is resident on the index's GPU and is scanned where it lies
@@ -753,7 +796,7 @@ static int32_t make_dense_taxa(slk_index *ix) {
   HIPCHK(hipMemcpy(d_to, to_orig.data(), ((size_t)D + 1) * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d_pd, pd.data(), ((size_t)D + 1) * 4, hipMemcpyHostToDevice));
   ix->d_to_dense = d_td; ix->d_to_orig = d_to; ix->d_parents_dense = d_pd; ix->D = D;
-  return SLK_OK;
+  return build_tax_nodes(ix, pd.data(), D + 1);
 }
 
 int32_t slk_index_finalize(slk_index *ix) {
@@ -819,6 +862,7 @@ void slk_index_destroy(slk_index *ix) {
   if (ix->d_counters) (void)hipFree(ix->d_counters);
   if (ix->d_parents) (void)hipFree(ix->d_parents);
   if (ix->d_parents_dense) (void)hipFree(ix->d_parents_dense);
+  if (ix->d_nodes) (void)hipFree(ix->d_nodes);
   if (ix->d_to_orig) (void)hipFree(ix->d_to_orig);
   if (ix->d_to_dense) (void)hipFree(ix->d_to_dense);
   ix->stage_keys.release();
@@ -959,7 +1003,9 @@ static int32_t check_status(slk_stream *st) {  // call after the stream has been
   return SLK_OK;
 }
 
-static bool lane_path_ok(const slk_index *ix) { return use_fused(ix) && ix->sp.w <= 32 && ix->internal_taxon_bits() <= 22; }
+static bool lane_path_ok(const slk_index *ix) {
+  return use_fused(ix) && ix->sp.w <= 32 && ix->internal_taxon_bits() <= 22 && ix->d_nodes != nullptr;
+}
 
 static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
                             const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
@@ -996,7 +1042,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
   }
   if (fused) {
     FusedArgs A{};
-    A.P = ix->sp; A.T = ix->view(); A.parents = ix->kernel_parents(); A.ntax = ix->kernel_ntax();
+    A.P = ix->sp; A.T = ix->view(); A.parents = ix->kernel_parents(); A.ntax = ix->kernel_ntax(); A.nodes = ix->kernel_nodes();
     A.bases = d_bases; A.offsets = d_offsets; A.mate_bases = d_mate_bases; A.mate_offsets = d_mate_offsets; A.R = R;
     A.out_stride = out_stride;
     A.min_hit_groups = min_hit_groups; A.thr = thr; A.C = C;
@@ -1224,7 +1270,7 @@ int32_t slk_shard_apply_device(slk_index *ix, slk_stream *st, const uint8_t *d_b
   Thresholds thr{};
   memcpy(thr.v, thresholds, C * sizeof(double));
   FusedArgs A{};
-  A.P = ix->sp; A.T = ix->view(); A.parents = ix->kernel_parents(); A.ntax = ix->kernel_ntax();   // (A.T: for to_orig only)
+  A.P = ix->sp; A.T = ix->view(); A.parents = ix->kernel_parents(); A.ntax = ix->kernel_ntax(); A.nodes = ix->kernel_nodes();   // (A.T: for to_orig only)
   A.bases = d_bases; A.offsets = d_offsets; A.mate_bases = d_mate_bases; A.mate_offsets = d_mate_offsets; A.R = R;
   A.out_stride = R;
   A.min_hit_groups = min_hit_groups; A.thr = thr; A.C = C;

@@ -121,6 +121,9 @@ struct FusedArgs {
   TableView T;
   const int32_t *parents;
   int32_t ntax;
+  // the same forest with an Euler tour, [ntax] x {parent, tin, tout, 0}: a is an ancestor-or-self of b iff tin[a] <= tin[b] <= tout[a].
+  // The lane kernel's resolveTree asks that question of pairs of map taxa instead of walking root paths (capi.hip: build_tax_nodes)
+  const uint4 *nodes;
   const uint8_t *bases;
   const uint64_t *offsets;
   const uint8_t *mate_bases;

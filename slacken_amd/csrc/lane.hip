@@ -322,6 +322,10 @@ struct OwnerMap {  // this lane's column of the LDS maps
 __device__ __forceinline__ int32_t lane_parent(const int32_t *parents, int32_t ntax, int32_t t) {
   return ((uint32_t)t < (uint32_t)ntax) ? parents[t] : 0;
 }
+// {parent, tin, tout, -} of taxon t (engine.h: FusedArgs.nodes); an id outside the taxonomy is a tree of its own
+__device__ __forceinline__ uint4 lane_node(const uint4 *nodes, int32_t ntax, int32_t t) {
+  return ((uint32_t)t < (uint32_t)ntax) ? nodes[t] : make_uint4(0u, 0x40000000u + (uint32_t)t, 0x40000000u + (uint32_t)t, 0u);
+}
 // LowestCommonAncestor.apply :49-78 without the path buffer
 __device__ int32_t lane_lca(const int32_t *parents, int32_t ntax, int32_t a, int32_t b) {
   if (a == 0 || b == 0) return b == 0 ? a : b;
@@ -690,73 +694,115 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     if (have) {
       if (dfr) {
       } else if (MODE != LANE_EMIT) {
-        OwnerMap<LONG> M{L, ocnt, lane};
         const int32_t nd = (int32_t)oflags;
+        // The map's entries move to the front of the lane's column (their hash order has served its purpose): entry j of D.
+        uint32_t *const ecnt = LONG ? ocnt : L->omap;
         int D = 0;
-        int32_t t0 = 0, c0 = 0;
         for (int s = 0; s < OMAP; s++) {
-          int32_t kk = M.key(s);
-          if (kk != 0) { D++; t0 = kk; c0 = M.cnt(s); }
-        }
-        int32_t maxTaxon = t0;  // D <= 1: the single taxon (or NONE)
-        if (D >= 2 && !SLK_TUNE_ON(16)) {  // resolveTree step 1 (:101-123): LCA of the taxa with the maximal root-path score  (16: timing experiment)
-          // A taxon's score is the k-mer count of the map taxa on its root path.  Instead of walking every root path to
-          // the end (distinct taxa x depth parent loads), each taxon walks only to its NEAREST ancestor that is in the map;
-          // the score is then the sum along those links, which stay in LDS.  (The probe queue's LDS is idle by now: it
-          // holds the links.)  On a lineage -- the usual shape of a read's hits -- that is one or two loads per taxon.
-          uint8_t *link = (uint8_t *)L->stash;  // [slot][lane]: slot of the nearest map ancestor, 255 = none
-          for (int s = 0; s < OMAP; s++) {
-            const int32_t taxon = M.key(s);
-            if (taxon == 0) continue;
-            int up = -1;
-            for (int32_t node = lane_parent(A.parents, A.ntax, taxon); node != 0 && up < 0; node = lane_parent(A.parents, A.ntax, node))
-              up = M.find(node);
-            link[s * 64 + lane] = (uint8_t)(up < 0 ? 255 : up);
+          const uint32_t e = L->omap[s * 64 + lane];
+          if (e != 0) {
+            if (LONG) ocnt[D * 64 + lane] = ocnt[s * 64 + lane];
+            L->omap[D * 64 + lane] = e;
+            D++;
           }
+        }
+#define ENT_TAXON(j) (LONG ? (int32_t)L->omap[(j) * 64 + lane] : (int32_t)(L->omap[(j) * 64 + lane] >> OMAP_CNT_BITS))
+#define ENT_COUNT(j) (LONG ? (int32_t)ecnt[(j) * 64 + lane] : (int32_t)(ecnt[(j) * 64 + lane] & OMAP_CNT_MASK))
+        int32_t maxTaxon = D ? ENT_TAXON(0) : 0;  // D <= 1: the single taxon (or NONE)
+        const int32_t c0 = D ? ENT_COUNT(0) : 0;
+        // D >= 2: resolveTree on Euler-tour intervals (engine.h: FusedArgs.nodes).  One 16-byte load per map taxon, issued back
+        // to back, brings its interval; "is a an ancestor-or-self of b" is then two compares, for the root-path scores (step 1)
+        // as for the clade sums of the confidence walk (step 2).  The intervals live in the probe queue's LDS, idle by now.
+        uint32_t *const tin = (uint32_t *)L, *const tout = tin + OMAP * 64;
+        static_assert(offsetof(LaneLds, omap) >= 2 * OMAP * 64 * sizeof(uint32_t), "the intervals alias the queue and the read stream's slots");
+        uint32_t m_in = 0, m_out = 0;   // maxTaxon's interval
+        int32_t sum_all = c0;
+        if (D >= 2 && !SLK_TUNE_ON(16)) {  // (16: timing experiment)
+#pragma unroll
+          for (int j = 0; j < OMAP; j++) {
+            if (j < D) {
+              const uint4 nj = lane_node(A.nodes, A.ntax, ENT_TAXON(j));
+              tin[j * 64 + lane] = nj.y;
+              tout[j * 64 + lane] = nj.z;
+            }
+          }
+          // step 1 (:101-123): the LCA of the taxa with the maximal root-path score -- a taxon's score is the k-mer count of the
+          // map taxa on its root path, i.e. of the entries whose interval holds its tin
           maxTaxon = 0;
+          sum_all = 0;
           int32_t best = 0;
-          for (int s = 0; s < OMAP; s++) {
-            const int32_t taxon = M.key(s);
-            if (taxon == 0) continue;
+          for (int a = 0; a < D; a++) {
+            const uint32_t ain = tin[a * 64 + lane], aout = tout[a * 64 + lane];
             int32_t score = 0;
-            for (int u = s, guard = 0; u != 255 && guard < OMAP; u = link[u * 64 + lane], guard++) score += M.cnt(u);
-            if (score > best) { maxTaxon = taxon; best = score; }
-            else if (score == best) maxTaxon = lane_lca(A.parents, A.ntax, maxTaxon, taxon);
+            for (int b = 0; b < D; b++)
+              score += (tin[b * 64 + lane] <= ain && ain <= tout[b * 64 + lane]) ? ENT_COUNT(b) : 0;
+            sum_all += ENT_COUNT(a);
+            if (score > best) {
+              maxTaxon = ENT_TAXON(a); best = score; m_in = ain; m_out = aout;
+            } else if (score == best) {   // LowestCommonAncestor.apply :49-78 of (maxTaxon, this taxon)
+              if (m_in <= ain && ain <= m_out) {
+                // maxTaxon is an ancestor-or-self of this taxon: it stays
+              } else if (ain <= m_in && m_in <= aout) {
+                maxTaxon = ENT_TAXON(a); m_in = ain; m_out = aout;
+              } else {                   // neither: the first node above maxTaxon whose interval holds this taxon
+                int32_t x = (int32_t)lane_node(A.nodes, A.ntax, maxTaxon).x;
+                uint4 nx = make_uint4(0, 0, 0, 0);
+                while (x != 0) {
+                  nx = lane_node(A.nodes, A.ntax, x);
+                  if (nx.y <= ain && ain <= nx.z) break;
+                  x = (int32_t)nx.x;
+                }
+                if (x == 0) { x = 1; nx = lane_node(A.nodes, A.ntax, 1); }   // no common node: ROOT (:77)
+                maxTaxon = x; m_in = nx.y; m_out = nx.z;
+              }
+            }
           }
         }
         for (int32_t c = 0; c < A.C; c++) {
-          double required = ceil(__dmul_rn(A.thr.v[c], (double)total));  // Math.ceil(confidence * totalKmers) :94
+          const double required = ceil(__dmul_rn(A.thr.v[c], (double)total));  // Math.ceil(confidence * totalKmers) :94
           int32_t mt = maxTaxon;
-          int32_t ms = (D >= 2) ? M.get(mt) : c0;                             // :125
-          bool first_candidate = true;
-          while (mt != 0 && (double)ms < required) {                          // :126-144
-            if (D < 2) { mt = 0; break; }  // one taxon: its clade sum never grows (NONE is in no clade)
-            ms = 0;
-            const int sm = first_candidate ? M.find(mt) : -1;
-            first_candidate = false;
-            if (sm >= 0) {
-              // mt is a map taxon (the usual first candidate): the map taxa below it are those whose links lead to it
-              const uint8_t *link = (const uint8_t *)L->stash;
-              for (int s = 0; s < OMAP; s++) {
-                if (M.key(s) == 0) continue;
-                for (int u = s, guard = 0; u != 255 && guard < OMAP; u = link[u * 64 + lane], guard++)
-                  if (u == sm) { ms += M.cnt(s); break; }
+          if (D < 2 || SLK_TUNE_ON(16)) {
+            // one taxon: its clade sum never grows (NONE is in no clade), so it is the call or there is none (:125-144)
+            if ((double)c0 < required) mt = 0;
+          } else {
+            // step 2 (:125-144): from maxTaxon towards the root until the clade of the candidate holds `required` k-mers of the
+            // map.  The clade sum only changes where the candidate's interval comes to hold another map taxon, and once it holds
+            // them all no ancestor can do better: the walk ends there (the reference goes on to the root and finds nothing).
+            uint32_t cin = m_in, cout = m_out;
+            uint4 cur = make_uint4(0, 0, 0, 0);
+            bool have_cur = false;
+            while (mt != 0) {
+              int32_t ms = 0;
+              bool side = false;          // a map taxon outside the clade that is NOT an ancestor of the candidate
+              int up = -1;                // the nearest map taxon above the candidate
+              uint32_t up_in = 0;
+              for (int j = 0; j < D; j++) {
+                const uint32_t jin = tin[j * 64 + lane], jout = tout[j * 64 + lane];
+                const bool inside = cin <= jin && jin <= cout;
+                ms += inside ? ENT_COUNT(j) : 0;
+                const bool above = !inside && jin <= cin && cin <= jout;
+                side = side || (!inside && !above);
+                if (above && (up < 0 || jin > up_in)) { up = j; up_in = jin; }   // (deeper on one root path = later in the tour)
               }
-            } else {
-              for (int s = 0; s < OMAP; s++) {
-                int32_t taxon = M.key(s);
-                if (taxon == 0) continue;
-                for (int32_t x = taxon; x != 0; x = lane_parent(A.parents, A.ntax, x))
-                  if (x == mt) { ms += M.cnt(s); break; }                     // Taxonomy.hasAncestor :236-244
+              if ((double)ms >= required) break;
+              if (ms == sum_all) { mt = 0; break; }
+              if (!side) {
+                // everything left lies above the candidate, on its root path: the next clade that differs is the nearest of them
+                mt = ENT_TAXON(up); cin = up_in; cout = tout[up * 64 + lane];
+                have_cur = false;
+              } else {
+                if (!have_cur) cur = lane_node(A.nodes, A.ntax, mt);
+                mt = (int32_t)cur.x;                                           // Taxonomy.parents
+                if (mt != 0) { cur = lane_node(A.nodes, A.ntax, mt); have_cur = true; cin = cur.y; cout = cur.z; }
               }
             }
-            if ((double)ms >= required) break;
-            mt = lane_parent(A.parents, A.ntax, mt);
           }
           bool classified = (mt != 0) && (nd >= A.min_hit_groups);            // Classifier.scala:445
           A.out_taxon[(uint64_t)c * A.out_stride + r] = classified ? ext_taxon(A.T, mt) : 0;
           A.out_classified[(uint64_t)c * A.out_stride + r] = classified ? 1 : 0;
         }
+#undef ENT_TAXON
+#undef ENT_COUNT
         if (A.out_nd) A.out_nd[r] = nd;
         if (A.out_tk) A.out_tk[r] = total;
         if (A.out_nh) A.out_nh[r] = nhits;

@@ -1,0 +1,146 @@
+"""resolveTree on taxonomies shaped like NCBI's -- lineages tens of nodes deep, most nodes without a sibling that matters to a
+read, several trees (ids whose parent is NONE besides ROOT) -- and on reads that hit many taxa: on one root path, on side
+branches, tied scores whose LCA is a node no record names.  The lane kernel answers ancestor questions from an Euler tour of
+the taxonomy (engine.h: FusedArgs.nodes) and jumps its confidence walk from one map taxon to the next; the oracle walks parent
+pointers one by one as LowestCommonAncestor.scala:49-146 does.  Every output bit for bit, several thresholds."""
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+THRESHOLDS = (0.0, 0.05, 0.15, 0.3, 0.6, 1.0)
+
+
+def deep_forest(rng, levels=6, fan=2, chain_max=4, extra_trees=1):
+    """parents[] of a tree with `fan`-way branching on `levels` levels and 0..chain_max unary nodes above every branching node,
+    ids shuffled (a child's id may be smaller than its parent's); extra_trees more such trees hang from ids whose parent is 0."""
+    parents = [0, 0]
+    tops = [1]
+    for _ in range(extra_trees):
+        parents.append(0)                      # the root of a detached tree
+        tops.append(len(parents) - 1)
+    branching, leaves = [], []
+    for top in tops:
+        level = [top]
+        for d in range(levels if top == 1 else max(2, levels - 3)):
+            nxt = []
+            for p in level:
+                for _ in range(fan):
+                    up = p
+                    for _ in range(int(rng.integers(0, chain_max + 1))):
+                        parents.append(up)
+                        up = len(parents) - 1
+                    parents.append(up)
+                    nxt.append(len(parents) - 1)
+                    branching.append(len(parents) - 1)
+            level = nxt
+        leaves += level
+    parents = np.array(parents, np.int64)
+    n = len(parents)
+    perm = np.concatenate([[0, 1], 2 + rng.permutation(n - 2)])     # old id -> new id; NONE and ROOT keep theirs
+    out = np.zeros(n, np.int32)
+    out[perm] = perm[parents]
+    return out, [int(perm[x]) for x in branching], [int(perm[x]) for x in leaves], [int(perm[x]) for x in tops]
+
+
+def evolve_genomes(rng, parents, leaves, tops, genome_len, rate):
+    """a genome per leaf: the genome of the tree's top with `rate` substitutions per node of the leaf's root path"""
+    memo = {}
+
+    def genome(t):
+        if t in memo:
+            return memo[t]
+        if t in tops:
+            g = synth.random_dna(genome_len, rng)
+        else:
+            g = genome(int(parents[t])).copy()
+            sub = rng.random(genome_len) < rate
+            g[sub] = synth.random_dna(int(sub.sum()), rng)
+        memo[t] = g
+        return g
+
+    return [genome(t) for t in leaves]
+
+
+@pytest.fixture(scope="module", params=[(0, 1), (4, 1), (9, 2)], ids=["flat", "chains", "long-chains-forest"])
+def deep_world(orc, request):
+    import slacken_amd
+    chain_max, extra = request.param
+    rng = np.random.default_rng(4000 + chain_max)
+    p = orc.params()
+    parents, branching, leaves, tops = deep_forest(rng, levels=6, fan=2, chain_max=chain_max, extra_trees=extra)
+    genomes = evolve_genomes(rng, parents, leaves, tops, 6000, 0.006)
+    bases, offsets = synth.pack(genomes)
+    keys, taxa = orc.build_records(p, parents, bases, offsets, leaves)        # (key, LCA taxon) records at every branching level
+    assert len(set(taxa.tolist())) > len(leaves) // 2
+    ix = slacken_amd.Index(expected_records=len(keys), max_taxon=len(parents) - 1)
+    ix.append(keys, taxa)
+    ix.set_taxonomy(parents)
+    ix.finalize()
+    depth = max(len(path_to_root(parents, t)) for t in leaves)
+    return dict(p=p, parents=parents, genomes=genomes, leaves=leaves, st=ix.stream(), oix=orc.Index(1, keys, taxa), ix=ix, depth=depth)
+
+
+def path_to_root(parents, t):
+    out = []
+    while t != 0:
+        out.append(t)
+        t = int(parents[t])
+    return out
+
+
+def chimeras(world, rng, n, length=150, pieces=(1, 2, 3, 5)):
+    reads = []
+    G = world["genomes"]
+    for _ in range(n):
+        k = int(rng.choice(pieces))
+        cuts = np.sort(rng.integers(0, length, k - 1)) if k > 1 else np.array([], np.int64)
+        bounds = np.concatenate([[0], cuts, [length]])
+        parts = []
+        a = int(rng.integers(0, len(G[0]) - length))      # the same locus of several genomes: homologous minimizers, tied scores
+        for i in range(k):
+            g = G[int(rng.integers(0, len(G)))]
+            parts.append(g[a + bounds[i]:a + bounds[i + 1]])
+        r = np.concatenate(parts).copy()
+        if rng.random() < 0.3:
+            r = synth.revcomp(r).copy()
+        reads.append(r)
+    return reads
+
+
+def check(orc, world, reads, mates=None, min_hit_groups=2):
+    bases, offsets = synth.pack(reads)
+    mb = mo = None
+    if mates is not None:
+        mb, mo = synth.pack(mates)
+    got = world["st"].classify_batch(bases, offsets, mb, mo, thresholds=THRESHOLDS, min_hit_groups=min_hit_groups, with_hits=False,
+                                     with_num_hits=True)
+    want = orc.classify_batch(world["p"], world["oix"], world["parents"], bases, offsets, mb, mo, min_hit_groups=min_hit_groups,
+                              thresholds=THRESHOLDS)
+    for key in ("total_kmers", "num_hits", "num_distinct", "taxon", "classified"):
+        bad = np.nonzero(np.atleast_2d(got[key] != want[key]).any(axis=0))[0]
+        assert bad.size == 0, (key, bad[:5].tolist(), np.atleast_2d(got[key])[:, bad[:5]].tolist(), np.atleast_2d(want[key])[:, bad[:5]].tolist())
+    return got
+
+
+def test_short_reads_hitting_many_taxa(orc, deep_world):
+    rng = np.random.default_rng(1)
+    reads = chimeras(deep_world, rng, 6000)
+    reads += chimeras(deep_world, rng, 1500, length=400, pieces=(2, 4, 8))     # more taxa per read, some past the 12-slot map
+    got = check(orc, deep_world, reads)
+    assert deep_world["st"].last_deferred() < len(reads) // 2                  # it IS the lane kernel that answered
+    # the calls really sit at many levels of the tree, the walk really moves: thresholds change them
+    assert len(set(got["taxon"][0].tolist())) > 20
+    assert (got["taxon"][0] != got["taxon"][3]).mean() > 0.05
+
+
+def test_pairs_and_long_reads(orc, deep_world):
+    rng = np.random.default_rng(2)
+    reads = chimeras(deep_world, rng, 1500)
+    mates = chimeras(deep_world, rng, 1500, length=120)
+    check(orc, deep_world, reads, mates, min_hit_groups=1)
+    long_reads = chimeras(deep_world, rng, 300, length=1800, pieces=(3, 6))    # the lane kernel's long variant
+    long_reads += chimeras(deep_world, rng, 40, length=5600, pieces=(4, 9))    # segment kernel / wave kernel
+    check(orc, deep_world, long_reads)

@@ -19,14 +19,23 @@ def main():
     import slacken_amd
     rng = np.random.default_rng(11)
     # a regular tree: 8 ranks, fan-out 2 below the root's 2 children => 256 leaves
+    # CHAIN=n: n unary nodes above every branching node (NCBI lineages are 25-40 nodes deep, most of them without siblings that
+    # matter to a given read): the tree walks get longer, the LCA taxa of the records stay at the branching nodes
+    chain = int(os.environ.get("CHAIN", 0))
     parents = [0, 0]
     level = [1]
+    evolves = {1}
     for d in range(8):
         nxt = []
         for p in level:
             for _ in range(2):
-                parents.append(p)
+                up = p
+                for _ in range(chain):
+                    parents.append(up)
+                    up = len(parents) - 1
+                parents.append(up)
                 nxt.append(len(parents) - 1)
+                evolves.add(len(parents) - 1)
         level = nxt
     parents = np.array(parents, np.int32)
     leaves = level
@@ -36,6 +45,9 @@ def main():
     order = [t for t in range(2, len(parents))]
     rate = float(os.environ.get("RATE", 0.02))
     for t in order:                               # parents precede children by construction
+        if t not in evolves:                      # a unary node of a chain: its parent's genome
+            genome[t] = genome[int(parents[t])]
+            continue
         g = genome[int(parents[t])].copy()
         sub = rng.random(L) < rate
         g[sub] = acgt[rng.integers(0, 4, int(sub.sum()), dtype=np.uint8)]
@@ -66,7 +78,7 @@ def main():
     depth = np.zeros(len(parents), np.int32)
     for t in range(2, len(parents)):
         depth[t] = depth[parents[t]] + 1
-    hist = np.bincount(depth[taxa], minlength=9)
+    hist = np.bincount(depth[taxa] // (chain + 1), minlength=9)
     R = 4_000_000
     d_all = torch.from_numpy(bases).cuda()
     g = torch.Generator(device="cuda")
@@ -87,7 +99,7 @@ def main():
             st.synchronize()
             dt = time.perf_counter() - t0
         out[f"thresholds_{len(thr)}"] = dict(ms=round(dt * 1e3, 2), M_reads_per_s=round(R / dt / 1e6, 1), deferred=st.last_deferred())
-    lvl = depth[d_t[:R].cpu().numpy()]
+    lvl = depth[d_t[:R].cpu().numpy()] // (chain + 1)
     # long reads (the wave-per-read kernel: 128-slot map, resolveTree with one lane per distinct taxon)
     for L_read, R2 in ((1001, 1_000_000), (10_000, 100_000)):
         stt2 = torch.randint(0, len(bases) - L_read, (R2,), generator=g, device="cuda")
@@ -102,7 +114,8 @@ def main():
         out[f"reads_{L_read}bp"] = dict(ms=round(dt * 1e3, 2), Gbp_per_s=round(R2 * L_read / dt / 1e9, 1))
         del b2, o2
     out.update(records=int(ix.info().records), records_by_depth=hist.tolist(), classified=float(d_c[:R].float().mean()),
-               calls_by_depth=np.bincount(lvl, minlength=9).tolist(), substitution_rate_per_level=rate)
+               calls_by_depth=np.bincount(lvl, minlength=9).tolist(), substitution_rate_per_level=rate, chain=chain,
+               tree_depth=int(depth.max()))
     print(json.dumps(out))
 
 
