@@ -15,10 +15,12 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include "pargz.hpp"
 #include "titles.hpp"
 
 #include <condition_variable>
 #include <cstring>
+#include <atomic>
 #include <deque>
 #include <map>
 #include <memory>
@@ -41,15 +43,42 @@ inline std::string lower(std::string s) {
   return s;
 }
 
+// How many compressed input files are being read side by side (set by whoever opens them): a gzip file's inflate threads are
+// the cores' share of it.
+inline std::atomic<int> &gz_concurrent_files() { static std::atomic<int> v{1}; return v; }
+inline int gz_threads() {  // SLK_GZ_THREADS: threads inflating ONE gzip file (1: zlib's gzread on one thread, as before)
+  const char *e = getenv("SLK_GZ_THREADS");
+  if (e && atol(e) > 0) return (int)atol(e);
+  const unsigned hc = std::max(1u, std::thread::hardware_concurrency());
+  return (int)std::min<unsigned>(8, std::max<unsigned>(1, hc / (unsigned)std::max(1, gz_concurrent_files().load())));
+}
+inline size_t gz_chunk_bytes() {  // SLK_GZ_CHUNK: compressed bytes per chunk (the tests put chunk borders everywhere with it)
+  const char *e = getenv("SLK_GZ_CHUNK");
+  return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)1 << 20;
+}
+
 // plain / gzip (zlib reads both) / bzip2 (through the system's libbz2: this image has no bzlib.h, so the three stable
-// high-level entry points are declared here and resolved at run time)
+// high-level entry points are declared here and resolved at run time).  A gzip FILE of some size is inflated on several
+// threads (pargz.hpp); pipes, small files and SLK_GZ_THREADS=1 keep zlib's gzread.
 class ByteSource {
   gzFile g_ = nullptr;
   void *bz_ = nullptr;
   int (*bzread_)(void *, void *, int) = nullptr;
   void (*bzclose_)(void *) = nullptr;
+  std::unique_ptr<slk::pargz::Reader> pz_;
 
  public:
+  static bool gzip_file_worth_threads(const std::string &path, size_t chunk) {
+    struct stat sb;
+    if (stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode) || (size_t)sb.st_size < 2 * chunk) return false;
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    unsigned char m[3] = {0, 0, 0};
+    const size_t k = fread(m, 1, 3, f);
+    fclose(f);
+    return k == 3 && m[0] == 0x1f && m[1] == 0x8b && m[2] == 8;
+  }
+
   explicit ByteSource(const std::string &path) {
     if (ends_with(path, ".bz2")) {
       void *h = dlopen("libbz2.so.1", RTLD_NOW);
@@ -61,6 +90,8 @@ class ByteSource {
       if (!bzopen || !bzread_ || !bzclose_) throw std::runtime_error("libbz2 lacks BZ2_bzopen/BZ2_bzread/BZ2_bzclose");
       bz_ = bzopen(path.c_str(), "rb");
       if (!bz_) throw std::runtime_error("cannot open " + path);
+    } else if (gz_threads() > 1 && gzip_file_worth_threads(path, gz_chunk_bytes())) {
+      pz_ = std::make_unique<slk::pargz::Reader>(path, gz_threads(), gz_chunk_bytes());
     } else {
       g_ = gzopen(path.c_str(), "rb");
       if (!g_) throw std::runtime_error("cannot open " + path);
@@ -73,8 +104,14 @@ class ByteSource {
     if (bz_) bzclose_(bz_);
   }
   size_t read(char *dst, size_t cap) {  // 0 at the end of the file
+    if (pz_) return pz_->read(dst, cap);
     int n = g_ ? gzread(g_, dst, (unsigned)cap) : bzread_(bz_, dst, (int)cap);
     if (n < 0) throw std::runtime_error("read error (corrupt compressed input?)");
+    if (g_ && (size_t)n < cap) {   // a gzip file that ends inside a member: gzread hands out what there was and says so only here
+      int err = Z_OK;
+      (void)gzerror(g_, &err);
+      if (err == Z_BUF_ERROR) throw std::runtime_error("read error (corrupt compressed input?): unexpected end of the gzip data");
+    }
     return (size_t)n;
   }
 };
@@ -305,10 +342,13 @@ inline FragmentBatchPtr new_fragment_batch(int pool = 0) {
 // successor begins with '+' (the sliding window of next_fastq above), a FASTA record at the start of the file and after every
 // '>' -- so a file can be cut anywhere: a segment owns the records that START inside it and reads as far past its end as they
 // reach.  The records of the segments, taken in segment order, are those of the serial reader.
+// (final = false: the buffer is the part of a file that has arrived so far -- a gzip file being inflated, pargz.hpp; parse() then
+// says whether the records of the segment were all there, and the caller asks again when more has arrived.)
 class PlainSegmentParser {
   const char *d_;
   size_t n_;
   bool fastq_;
+  bool final_ = true;
   struct Line { size_t s, e, next; };  // [s, e) without its terminator; next = start of the following line
 
   Line line(size_t p) const {  // p < n_
@@ -322,12 +362,13 @@ class PlainSegmentParser {
   bool is_line_start(size_t p) const { return p == 0 || d_[p - 1] == '\n' || (d_[p - 1] == '\r' && d_[p] != '\n'); }
   static std::string_view first_token(std::string_view s) { return s.substr(0, s.find(' ')); }
 
-  void fastq(size_t a, size_t b, FragmentBatch &out) const {
-    if (a >= n_) return;
+  bool fastq(size_t a, size_t b, FragmentBatch &out) const {  // false: the data ended before the segment's records did (!final_)
+    if (a >= n_) return true;
     const size_t p = is_line_start(a) ? a : line(a).next;  // (from inside a line, line() finds where that line ends)
-    if (p >= b || p >= n_) return;
+    if (p >= b) return true;
+    if (p >= n_) return final_;
     Line l0 = line(p);
-    if (l0.next >= n_) return;
+    if (l0.next >= n_) return final_;
     Line l1 = line(l0.next);
     while (l1.next < n_) {  // (fewer than three lines left: no window can start here or later)
       Line l2 = line(l1.next);
@@ -335,19 +376,21 @@ class PlainSegmentParser {
         out.add(first_token(std::string_view(d_ + l0.s, l0.e - l0.s)).substr(1), std::string_view(d_ + l1.s, l1.e - l1.s), nullptr);
       l0 = l1;
       l1 = l2;
-      if (l0.s >= b) return;  // the window slides by one line; the next segment owns this one
+      if (l0.s >= b) return true;  // the window slides by one line; the next segment owns this one
     }
+    return final_;   // (a line that touches the end of what has arrived may go on, or be followed by the \n of a \r\n)
   }
 
-  void fasta(size_t a, size_t b, FragmentBatch &out) const {
+  bool fasta(size_t a, size_t b, FragmentBatch &out) const {
     size_t s = 0;
     if (a > 0) {
       const char *q = (const char *)memchr(d_ + a - 1, '>', n_ - (a - 1));
-      if (!q) return;
+      if (!q) return n_ >= b || final_;   // no record starts in [a, b) -- if [a, b) has arrived
       s = (size_t)(q - d_) + 1;
     }
     while (s < b) {
       const char *q = (const char *)memchr(d_ + s, '>', n_ - s);
+      if (!q && !final_) return false;   // the record may go on beyond what has arrived
       const size_t end = q ? (size_t)(q - d_) : n_;
       // String.split("[\n\r]+"): a leading empty string is kept, trailing ones are dropped; the first line is the header
       size_t i = s, nlines = 0;
@@ -370,15 +413,16 @@ class PlainSegmentParser {
         out.title_off.push_back(out.titles.size());
         out.offs.push_back(out.bases.size());
       }
-      if (end == n_) return;
+      if (end == n_) return true;
       s = end + 1;
     }
+    return true;
   }
 
  public:
-  PlainSegmentParser(const char *d, size_t n, bool fastq) : d_(d), n_(n), fastq_(fastq) {}
-  void parse(size_t a, size_t b, FragmentBatch &out) const {  // the records starting in [a, b)
-    if (fastq_) fastq(a, b, out); else fasta(a, b, out);
+  PlainSegmentParser(const char *d, size_t n, bool fastq, bool final = true) : d_(d), n_(n), fastq_(fastq), final_(final) {}
+  bool parse(size_t a, size_t b, FragmentBatch &out) const {  // the records starting in [a, b)
+    return fastq_ ? fastq(a, b, out) : fasta(a, b, out);
   }
 };
 
@@ -460,6 +504,41 @@ class AsyncRecordStream {
     }
   }
 
+  // A gzip file inflated on several threads into one buffer (pargz.hpp, region mode): segment i = the text of compressed chunk
+  // i, parsed in place by the plain file's segment parser as soon as it and its successor have arrived.
+  std::unique_ptr<slk::pargz::Reader> gz_;
+  void run_gz_segments(bool fastq) {
+    for (;;) {
+      size_t i;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || next_claim_ >= nseg_ || next_claim_ < next_out_ + depth_; });
+        if (stop_ || next_claim_ >= nseg_) return;
+        i = next_claim_++;
+      }
+      auto c = new_fragment_batch(1);
+      try {
+        slk::pargz::Reader::View v;
+        bool ok = gz_->wait_segment(i, v);
+        while (ok) {
+          c->bases.reserve((v.end - v.begin) / 2 + 256);
+          PlainSegmentParser parser(gz_->base(), v.avail, fastq, v.eof);
+          if (parser.parse(v.begin, v.end, *c) || v.eof) break;
+          c = new_fragment_batch(1);   // a record reached beyond what had arrived: again, with more
+          ok = gz_->wait_more(i, v.avail, v);
+        }
+        if (!ok) return;   // (the stream is being closed)
+        gz_->segment_parsed(i);
+      } catch (const std::exception &e) {
+        std::lock_guard<std::mutex> lk(mu_);
+        error_ = e.what();
+      }
+      std::lock_guard<std::mutex> lk(mu_);
+      done_[i] = std::move(c);
+      cv_.notify_all();
+    }
+  }
+
   static bool is_compressed(const std::string &file) {  // by name, or by the gzip magic (zlib would inflate it either way)
     if (ends_with(file, ".gz") || ends_with(file, ".bz2")) return true;
     FILE *f = fopen(file.c_str(), "rb");
@@ -501,6 +580,16 @@ class AsyncRecordStream {
   }
 
   explicit AsyncRecordStream(const std::string &file) {
+    if (regular_file(file) && !ends_with(file, ".bz2") && ByteSource::gzip_file_worth_threads(file, gz_chunk_bytes()) && gz_threads() > 1) {
+      parallel_ = true;
+      gz_ = std::make_unique<slk::pargz::Reader>(file, gz_threads(), gz_chunk_bytes(), true);
+      nseg_ = gz_->segments();
+      const size_t nt = std::max<size_t>(1, std::min(parse_threads(), nseg_));
+      depth_ = nt + 2;
+      const bool fastq = RecordStream::is_fastq_name(file);
+      for (size_t t = 0; t < nt; t++) th_.emplace_back([this, fastq] { run_gz_segments(fastq); });
+      return;
+    }
     if (!regular_file(file) || is_compressed(file)) {
       th_.emplace_back([this, file] { run_serial(file); });
       return;
@@ -531,6 +620,7 @@ class AsyncRecordStream {
   AsyncRecordStream(const AsyncRecordStream &) = delete;
   ~AsyncRecordStream() {
     { std::lock_guard<std::mutex> lk(mu_); stop_ = true; cv_.notify_all(); }
+    if (gz_) gz_->shutdown();   // (wakes the parsers that wait for data)
     for (auto &t : th_) t.join();
     if (map_) munmap((void *)map_, map_len_);
   }

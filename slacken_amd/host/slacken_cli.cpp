@@ -149,6 +149,24 @@ static int cmd_taxonomy(int argc, char **argv) {
   std::cout << '\n';
   return 0;
 }
+// gunzip FILE: the file's bytes as the input layer sees them (ByteSource: zlib, libbz2 or the parallel inflate of pargz.hpp)
+static int cmd_gunzip(int argc, char **argv) {
+  if (argc < 1) die("usage: gunzip FILE");
+  ByteSource src(argv[0]);
+  std::vector<char> buf((size_t)4 << 20);
+  uint64_t total = 0;
+  auto t0 = std::chrono::steady_clock::now();
+  const bool quiet = argc >= 2 && std::string(argv[1]) == "--count";
+  while (size_t n = src.read(buf.data(), buf.size())) {
+    if (!quiet && fwrite(buf.data(), 1, n, stdout) != n) die("write error");
+    total += n;
+  }
+  if (quiet) {
+    double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::cout << total << " bytes, " << dt << " s, " << total / dt / 1e9 << " GB/s\n";
+  }
+  return 0;
+}
 static int cmd_parse(int argc, char **argv) {  // parse <file> [<file2>]: header \t nucleotides [\t nucleotides2]
   if (argc < 1) die("usage: parse [--count] FILE [MATE_FILE]");
   if (std::string(argv[0]) == "--count") {  // read through the batch reader only: fragments, bases, a checksum, seconds
@@ -403,6 +421,7 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
   const size_t nsrc = files.size() / unit;
   const char *cenv = getenv("SLK_INPUT_STREAMS");
   const size_t conc = std::max<size_t>(1, std::min<size_t>(nsrc, cenv ? (size_t)atol(cenv) : 8));
+  gz_concurrent_files() = (int)(conc * unit);
   std::vector<std::unique_ptr<BatchPrefetcher>> active;
   size_t next_src = 0;
   auto open_next = [&]() -> std::unique_ptr<BatchPrefetcher> {
@@ -952,6 +971,7 @@ int main(int argc, char **argv) {
     if (cmd == "classify2") return cmd_classify2(argc - i, argv + i);
     if (cmd == "report") return cmd_report(argc - i, argv + i);
     if (cmd == "parse") return cmd_parse(argc - i, argv + i);
+    if (cmd == "gunzip") return cmd_gunzip(argc - i, argv + i);
     if (cmd == "props") return cmd_props(argc - i, argv + i);
     if (cmd == "records") return cmd_records(argc - i, argv + i);
     if (cmd == "repeated") return cmd_repeated(argc - i, argv + i);
