@@ -18,7 +18,8 @@
 //           (ShiftScanner.scala:90-159), RandomXOR/SpacedSeed (MinimizerPriorities.scala:144-321).
 //   probe   the left join + spanToHit (S/slacken/Classifier.scala:84-88, KeyValueIndex.scala:176-185).
 //   LCA     hits are folded (LDS atomics) into a 12-slot taxon->count map per read; NONE hits are never needed by
-//           resolveTree and are only counted; one distinct taxon is resolved without touching the tree.
+//           resolveTree and are only counted; one distinct taxon is resolved without touching the tree, several from the
+//           Euler-tour intervals of the map's taxa (one 16-byte load each; no walk of parent pointers on a lineage).
 //           Reference: TaxonCounts.toMap/totalKmers (S/slacken/TaxonCounts.scala:70-87), LowestCommonAncestor
 //           (S/slacken/LowestCommonAncestor.scala:49-146), Classifier.classify (S/slacken/Classifier.scala:439-454).
 // Fragments longer than LANE_MAX_LEN, and fragments whose 12-slot map overflows, are flagged in `defer` and re-done by the
@@ -290,51 +291,10 @@ __device__ __forceinline__ void apply_row(LaneLds *L, const ShardIO &S, int lane
   lane_wave_sync();
 }
 
-template <bool LONG>
-struct OwnerMap {  // this lane's column of the LDS maps
-  const LaneLds *L;
-  const uint32_t *ocnt;
-  int lane;
-  __device__ __forceinline__ int32_t key(int s) const {  // 0 = empty
-    return LONG ? (int32_t)L->omap[s * 64 + lane] : (int32_t)(L->omap[s * 64 + lane] >> OMAP_CNT_BITS);
-  }
-  __device__ __forceinline__ int32_t cnt(int s) const {
-    return LONG ? (int32_t)ocnt[s * 64 + lane] : (int32_t)(L->omap[s * 64 + lane] & OMAP_CNT_MASK);
-  }
-  // the map is a hash table (fold_hit): follow t's probe sequence to its entry or to the first empty slot -- one or two LDS
-  // reads instead of a scan of all slots, for every node of every root path resolveTree walks
-  __device__ __forceinline__ int find(int32_t t) const {  // slot of taxon t, or -1
-    uint32_t slot = (uint32_t)(((uint64_t)((uint32_t)t * 0x9E3779B1u) * (uint32_t)OMAP) >> 32);
-    for (int p = 0; p < OMAP; p++) {
-      const int32_t kk = key((int)slot);
-      if (kk == 0) return -1;
-      if (kk == t) return (int)slot;
-      slot = (slot + 1 == (uint32_t)OMAP) ? 0u : slot + 1;
-    }
-    return -1;
-  }
-  __device__ __forceinline__ int32_t get(int32_t t) const {
-    const int sl = find(t);
-    return sl < 0 ? 0 : cnt(sl);
-  }
-};
-
-__device__ __forceinline__ int32_t lane_parent(const int32_t *parents, int32_t ntax, int32_t t) {
-  return ((uint32_t)t < (uint32_t)ntax) ? parents[t] : 0;
-}
 // {parent, tin, tout, -} of taxon t (engine.h: FusedArgs.nodes); an id outside the taxonomy is a tree of its own
 __device__ __forceinline__ uint4 lane_node(const uint4 *nodes, int32_t ntax, int32_t t) {
   return ((uint32_t)t < (uint32_t)ntax) ? nodes[t] : make_uint4(0u, 0x40000000u + (uint32_t)t, 0x40000000u + (uint32_t)t, 0u);
 }
-// LowestCommonAncestor.apply :49-78 without the path buffer
-__device__ int32_t lane_lca(const int32_t *parents, int32_t ntax, int32_t a, int32_t b) {
-  if (a == 0 || b == 0) return b == 0 ? a : b;
-  for (int32_t y = b; y != 0; y = lane_parent(parents, ntax, y))
-    for (int32_t x = a; x != 0; x = lane_parent(parents, ntax, x))
-      if (x == y) return y;
-  return 1;
-}
-
 // BitRepresentation.charToTwobit (BitRepresentation.scala:127-135) for one character: 0..3, or 5 for anything else
 __device__ __forceinline__ int lane_code(uint32_t c) {
   const uint32_t VM = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20) | (1u << 21);  // A C G T U, either case

@@ -527,6 +527,7 @@ class Reader {
   size_t verified_ = 0;          // chunks whose CRC parts are folded into the member checks (a prefix of the done ones)
   bool last_stream_end_ = false;
   uint64_t written_ = 0;         // inflated bytes up to the last chained chunk
+  size_t span_ = 1;              // chunks a consumer takes as one segment
   int starving_ = 0;             // consumers waiting for data beyond the budget (a record longer than it)
   const uint64_t region_budget_ = (uint64_t)512 << 20;
 
@@ -563,7 +564,7 @@ class Reader {
   size_t released() const { return std::min(region_mode_ ? verified_ : consumed_, chained_ ? chained_ - 1 : 0); }
   bool may_claim() const {
     if (next_claim_ >= released() + lookahead_) return false;
-    if (!region_mode_ || starving_ > 0 || next_claim_ < consumed_ + 3) return true;   // (the slowest consumer's own chunks: always)
+    if (!region_mode_ || starving_ > 0 || next_claim_ < consumed_ + span_ + 2) return true;   // (the slowest consumer's own chunks: always)
     const uint64_t low = consumed_ ? info_[consumed_ - 1].end : 0;
     return written_ - low <= region_budget_;
   }
@@ -868,21 +869,25 @@ class Reader {
   // ---- region mode: segment i = the inflated bytes of chunk i, [begin, end) of ONE buffer that starts at base() ----
   struct View { size_t begin = 0, end = 0, avail = 0; bool eof = false; };   // avail: bytes of the file inflated and checked so far
   size_t segments() const { return nchunks_; }
+  void set_consumer_span(size_t k) { std::lock_guard<std::mutex> lk(mu_); span_ = std::max<size_t>(1, k); cv_.notify_all(); }
   const char *base() const { return (const char *)region_; }
   // Blocks until segment i and the one behind it (the records that start in i end there, usually) have arrived.  Throws on
   // corrupt input; false if the reader is being closed.
-  bool wait_segment(size_t i, View &v) {
+  // (first .. i: several segments taken as one, [begin of first, end of i))
+  bool wait_segment(size_t i, View &v, size_t first = (size_t)-1) {
+    if (first == (size_t)-1) first = i;
     std::unique_lock<std::mutex> lk(mu_);
     cv_.wait(lk, [&] { return !error_.empty() || stop_ || verified_ >= std::min(nchunks_, i + 2); });
     if (!error_.empty()) throw std::runtime_error("read error (corrupt compressed input?): " + error_);
     if (verified_ < std::min(nchunks_, i + 2)) return false;
-    v.begin = info_[i].begin; v.end = info_[i].end;
+    v.begin = info_[first].begin; v.end = info_[i].end;
     v.avail = info_[verified_ - 1].end;
     v.eof = verified_ == nchunks_;
     return true;
   }
   // ... and until more than `avail_known` bytes have (a record of segment i reached beyond what was there)
-  bool wait_more(size_t i, size_t avail_known, View &v) {
+  bool wait_more(size_t i, size_t avail_known, View &v, size_t first = (size_t)-1) {
+    if (first == (size_t)-1) first = i;
     std::unique_lock<std::mutex> lk(mu_);
     starving_++;
     cv_.notify_all();
@@ -890,7 +895,7 @@ class Reader {
     starving_--;
     if (!error_.empty()) throw std::runtime_error("read error (corrupt compressed input?): " + error_);
     if (!(verified_ == nchunks_ || info_[verified_ - 1].end > avail_known)) return false;
-    v.begin = info_[i].begin; v.end = info_[i].end;
+    v.begin = info_[first].begin; v.end = info_[i].end;
     v.avail = info_[verified_ - 1].end;
     v.eof = verified_ == nchunks_;
     return true;

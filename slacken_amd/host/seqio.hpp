@@ -11,6 +11,7 @@
 #pragma once
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -46,11 +47,35 @@ inline std::string lower(std::string s) {
 // How many compressed input files are being read side by side (set by whoever opens them): a gzip file's inflate threads are
 // the cores' share of it.
 inline std::atomic<int> &gz_concurrent_files() { static std::atomic<int> v{1}; return v; }
+// the cores this process may really use: the machine's, its affinity mask, its cgroup's CPU quota -- whichever is least
+inline unsigned effective_cpus() {
+  static const unsigned n = [] {
+    unsigned v = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) v = std::min<unsigned>(v, std::max(1, CPU_COUNT(&set)));
+    long quota = -1, period = 100000;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "max 100000" or "<quota> <period>"
+      char q[64] = {0};
+      if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atol(q);
+      fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+      if (fscanf(g, "%ld", &quota) != 1) quota = -1;
+      fclose(g);
+      if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%ld", &period) != 1) period = 100000; fclose(h); }
+    }
+    if (quota > 0 && period > 0) v = std::min<unsigned>(v, (unsigned)std::max<long>(1, (quota + period - 1) / period));
+    return v;
+  }();
+  return n;
+}
 inline int gz_threads() {  // SLK_GZ_THREADS: threads inflating ONE gzip file (1: zlib's gzread on one thread, as before)
   const char *e = getenv("SLK_GZ_THREADS");
   if (e && atol(e) > 0) return (int)atol(e);
-  const unsigned hc = std::max(1u, std::thread::hardware_concurrency());
-  return (int)std::min<unsigned>(8, std::max<unsigned>(1, hc / (unsigned)std::max(1, gz_concurrent_files().load())));
+  return (int)std::min<unsigned>(8, std::max<unsigned>(1, effective_cpus() / (unsigned)std::max(1, gz_concurrent_files().load())));
+}
+inline size_t gz_group() {  // SLK_GZ_GROUP: compressed chunks whose text is parsed as one segment (= one batch for the device)
+  const char *e = getenv("SLK_GZ_GROUP");
+  return e && atol(e) > 0 ? (size_t)atol(e) : 4;
 }
 inline size_t gz_chunk_bytes() {  // SLK_GZ_CHUNK: compressed bytes per chunk (the tests put chunk borders everywhere with it)
   const char *e = getenv("SLK_GZ_CHUNK");
@@ -430,8 +455,7 @@ inline size_t parse_threads() {  // SLK_PARSE_THREADS: threads that parse one pl
   const char *e = getenv("SLK_PARSE_THREADS");
   long v = e ? atol(e) : 0;
   if (v > 0) return (size_t)v;
-  unsigned hc = std::thread::hardware_concurrency();
-  return std::min<size_t>(8, std::max<unsigned>(2, hc / 2));
+  return std::min<size_t>(8, std::max<unsigned>(2, effective_cpus() / 2));
 }
 
 // The records of one file, read ahead and handed over in chunks, in file order.  Compressed input is inflated and split on one
@@ -507,6 +531,7 @@ class AsyncRecordStream {
   // A gzip file inflated on several threads into one buffer (pargz.hpp, region mode): segment i = the text of compressed chunk
   // i, parsed in place by the plain file's segment parser as soon as it and its successor have arrived.
   std::unique_ptr<slk::pargz::Reader> gz_;
+  size_t gz_group_ = 1;
   void run_gz_segments(bool fastq) {
     for (;;) {
       size_t i;
@@ -519,16 +544,17 @@ class AsyncRecordStream {
       auto c = new_fragment_batch(1);
       try {
         slk::pargz::Reader::View v;
-        bool ok = gz_->wait_segment(i, v);
+        const size_t first = i * gz_group_, last = std::min(gz_->segments(), first + gz_group_) - 1;
+        bool ok = gz_->wait_segment(last, v, first);
         while (ok) {
           c->bases.reserve((v.end - v.begin) / 2 + 256);
           PlainSegmentParser parser(gz_->base(), v.avail, fastq, v.eof);
           if (parser.parse(v.begin, v.end, *c) || v.eof) break;
           c = new_fragment_batch(1);   // a record reached beyond what had arrived: again, with more
-          ok = gz_->wait_more(i, v.avail, v);
+          ok = gz_->wait_more(last, v.avail, v, first);
         }
         if (!ok) return;   // (the stream is being closed)
-        gz_->segment_parsed(i);
+        for (size_t k = first; k <= last; k++) gz_->segment_parsed(k);
       } catch (const std::exception &e) {
         std::lock_guard<std::mutex> lk(mu_);
         error_ = e.what();
@@ -583,7 +609,9 @@ class AsyncRecordStream {
     if (regular_file(file) && !ends_with(file, ".bz2") && ByteSource::gzip_file_worth_threads(file, gz_chunk_bytes()) && gz_threads() > 1) {
       parallel_ = true;
       gz_ = std::make_unique<slk::pargz::Reader>(file, gz_threads(), gz_chunk_bytes(), true);
-      nseg_ = gz_->segments();
+      gz_group_ = gz_group();
+      gz_->set_consumer_span(gz_group_);
+      nseg_ = (gz_->segments() + gz_group_ - 1) / gz_group_;
       const size_t nt = std::max<size_t>(1, std::min(parse_threads(), nseg_));
       depth_ = nt + 2;
       const bool fastq = RecordStream::is_fastq_name(file);

@@ -92,14 +92,24 @@ def main():
     one = os.path.join(d, "all.fq.gz")
     with gzip.open(one, "wb", compresslevel=1) as f:
         f.write(open(fq, "rb").read())
+    # each with zlib on one thread per file (SLK_GZ_THREADS=1: how the input was read until round 2's pargz.hpp) and with the
+    # parallel inflate (default); SLK_CLI_GZ_VARIANTS='{"name": {"ENV": "value"}, ...}' adds settings; best of two runs each
+    variants = {"zlib_one_thread_per_file": {"SLK_GZ_THREADS": "1"}, "": {}}
+    variants.update(json.loads(os.environ.get("SLK_CLI_GZ_VARIANTS", "{}")))
     for name, inputs in (("gz_one_file", [one]), ("gz_eight_files", parts)):
-        t0 = time.perf_counter()
-        r = subprocess.run([os.path.join(ROOT, "slacken_amd", "bin", "slacken-amd"), "classify", "-i", loc, "-o",
-                            os.path.join(d, "out_" + name), *inputs], capture_output=True, text=True)
-        dt = time.perf_counter() - t0
-        assert r.returncode == 0, r.stderr
-        out[name + "_log"] = [l for l in r.stderr.split("\n") if "host timing" in l]
-        out[name] = dict(reads=R, seconds=round(dt, 2), M_reads_per_s=round(R / dt / 1e6, 3))
+        for vname, venv in variants.items():
+            best = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                r = subprocess.run([os.path.join(ROOT, "slacken_amd", "bin", "slacken-amd"), "classify", "-i", loc, "-o",
+                                    os.path.join(d, "out_" + name), *inputs], capture_output=True, text=True, env=dict(os.environ, **venv))
+                dt = time.perf_counter() - t0
+                assert r.returncode == 0, r.stderr
+                if best is None or dt < best[0]:
+                    best = (dt, [l for l in r.stderr.split("\n") if "host timing" in l])
+            key = name + ("_" + vname if vname else "")
+            out[key + "_log"] = best[1]
+            out[key] = dict(reads=R, seconds=round(best[0], 2), M_reads_per_s=round(R / best[0] / 1e6, 3))
     # classify2: the two-step run with a dynamic library built on the device from the genome FASTA files
     libdir = os.path.join(d, "k2")
     os.makedirs(os.path.join(libdir, "library", "bacteria"))
