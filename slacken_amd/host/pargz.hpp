@@ -744,13 +744,17 @@ class Reader {
             }
             const uint8_t *const lt = lut.data();
 #if defined(__SSE2__)
-            const __m128i hi_bits = _mm_set1_epi16((short)0xFF00);
+            const __m128i hi_bits = _mm_set1_epi16((short)0xFF00), zero = _mm_setzero_si128();
             for (; k + 16 <= b; k += 16) {
               const __m128i x = _mm_loadu_si128((const __m128i *)(sp + k)), y = _mm_loadu_si128((const __m128i *)(sp + k + 8));
-              if (_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_and_si128(_mm_or_si128(x, y), hi_bits), _mm_setzero_si128())) == 0xFFFF) {
-                _mm_storeu_si128((__m128i *)(by + k), _mm_packus_epi16(x, y));
-              } else {
-                for (int j = 0; j < 16; j++) by[k + j] = lt[sp[k + j]];
+              // bytes narrow (a marker saturates to 255 for the moment); then the markers of the group, one by one
+              _mm_storeu_si128((__m128i *)(by + k), _mm_packus_epi16(x, y));
+              const __m128i mx = _mm_cmpeq_epi16(_mm_and_si128(x, hi_bits), zero), my = _mm_cmpeq_epi16(_mm_and_si128(y, hi_bits), zero);
+              unsigned m = ~(unsigned)_mm_movemask_epi8(_mm_packs_epi16(mx, my)) & 0xFFFFu;
+              while (m) {
+                const int j = __builtin_ctz(m);
+                m &= m - 1;
+                by[k + j] = lt[sp[k + j]];
               }
             }
 #endif
