@@ -3,6 +3,8 @@ read, several trees (ids whose parent is NONE besides ROOT) -- and on reads that
 branches, tied scores whose LCA is a node no record names.  The lane kernel answers ancestor questions from an Euler tour of
 the taxonomy (engine.h: FusedArgs.nodes) and jumps its confidence walk from one map taxon to the next; the oracle walks parent
 pointers one by one as LowestCommonAncestor.scala:49-146 does.  Every output bit for bit, several thresholds."""
+import os
+
 import numpy as np
 import pytest
 
@@ -144,3 +146,32 @@ def test_pairs_and_long_reads(orc, deep_world):
     long_reads = chimeras(deep_world, rng, 300, length=1800, pieces=(3, 6))    # the lane kernel's long variant
     long_reads += chimeras(deep_world, rng, 40, length=5600, pieces=(4, 9))    # segment kernel / wave kernel
     check(orc, deep_world, long_reads)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SLK_DEEP_SEEDS", 3))))   # (SLK_DEEP_SEEDS: soak runs)
+def test_random_shapes(orc, seed):
+    """taxonomy shape, library, reads, thresholds and minHitGroups drawn at random"""
+    import slacken_amd
+    rng = np.random.default_rng(7000 + seed)
+    p = orc.params()
+    parents, branching, leaves, tops = deep_forest(rng, levels=int(rng.integers(3, 7)), fan=int(rng.integers(2, 4)),
+                                                   chain_max=int(rng.integers(0, 12)), extra_trees=int(rng.integers(0, 3)))
+    if len(leaves) > 160:
+        keep = rng.choice(len(leaves), 160, replace=False)
+        leaves = [leaves[i] for i in keep]
+    genomes = evolve_genomes(rng, parents, leaves, tops, int(rng.integers(2500, 5000)), float(rng.choice([0.002, 0.006, 0.02])))
+    bases, offsets = synth.pack(genomes)
+    keys, taxa = orc.build_records(p, parents, bases, offsets, leaves)
+    ix = slacken_amd.Index(expected_records=len(keys), max_taxon=len(parents) - 1)
+    ix.append(keys, taxa)
+    ix.set_taxonomy(parents)
+    ix.finalize()
+    world = dict(p=p, parents=parents, genomes=genomes, leaves=leaves, st=ix.stream(), oix=orc.Index(1, keys, taxa), ix=ix)
+    reads = chimeras(world, rng, 2500, length=int(rng.integers(60, 260)), pieces=(1, 2, 3, 4, 6))
+    thr = tuple(sorted(float(x) for x in rng.choice([0.0, 0.01, 0.05, 0.1, 0.15, 0.25, 0.4, 0.7, 1.0], size=4, replace=False)))
+    bases, offsets = synth.pack(reads)
+    mhg = int(rng.integers(1, 4))
+    got = world["st"].classify_batch(bases, offsets, thresholds=thr, min_hit_groups=mhg, with_hits=False, with_num_hits=True)
+    want = orc.classify_batch(p, world["oix"], parents, bases, offsets, None, None, min_hit_groups=mhg, thresholds=thr)
+    for key in ("total_kmers", "num_hits", "num_distinct", "taxon", "classified"):
+        assert np.array_equal(got[key], want[key]), (seed, key)
