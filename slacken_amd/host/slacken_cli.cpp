@@ -414,7 +414,7 @@ struct DeviceIndex {
 template <class F>
 static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &files, bool paired, int min_hits,
                             const std::vector<double> &thresholds, bool want_spans, bool want_hits, F f, RepeatedTitles *rep = nullptr) {
-  // Several input files (or pairs) are read side by side, each on its own threads -- a gzip stream inflates on one core -- and
+  // Several input files (or pairs) are read side by side, each on its own threads (a gzip file on the cores' share of it, pargz.hpp), and
   // their batches are taken in turn: the order of the output is deterministic, though interleaved between files at batch
   // granularity (the reference's output order is whatever Spark's partitions give).
   const size_t unit = paired ? 2 : 1;
@@ -956,6 +956,7 @@ static const char *HELP =
     "host-only helpers: report TAXONOMY_DIR COUNTS_TSV | parse FILE [MATE_FILE] | props INDEX | records INDEX | repeated [-p] FILES\n"
     "environment: SLK_HOST_THREADS (formatting/decoding threads), SLK_INPUT_STREAMS (input files read side by side, default 8),\n"
     "             SLK_PARSE_THREADS (threads parsing one plain input file, default min(8, cores/2)), SLK_GZIP_LEVEL (1..9, default zlib's),\n"
+    "             SLK_GZ_THREADS (threads inflating one gzip input file, default min(8, cores / files read side by side); 1: zlib),\n"
     "             SLK_CLASSIFY_THREADS (threads classifying batches, each with its own stream, default 2),\n"
     "             SLK_HOST_TIMING (report where the wall clock of the classify loop went)\n";
 

@@ -110,6 +110,27 @@ def main():
             key = name + ("_" + vname if vname else "")
             out[key + "_log"] = best[1]
             out[key] = dict(reads=R, seconds=round(best[0], 2), M_reads_per_s=round(R / best[0] / 1e6, 3))
+    # the paired sample as two gzip files (how paired-end runs usually arrive): two parallel inflates side by side; same report
+    if "paired_detailed" in cases:
+        pz = []
+        for src in (p1, p2):
+            dst = src + ".gz"
+            with gzip.open(dst, "wb", compresslevel=1) as f:
+                f.write(open(src, "rb").read())
+            pz.append(dst)
+        for vname, venv in (("zlib_one_thread_per_file", {"SLK_GZ_THREADS": "1"}), ("", {})):
+            best = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                r = subprocess.run([os.path.join(ROOT, "slacken_amd", "bin", "slacken-amd"), "classify", "-i", loc, "-o",
+                                    os.path.join(d, "out_paired_gz"), "-p", *pz], capture_output=True, text=True, env=dict(os.environ, **venv))
+                dt = time.perf_counter() - t0
+                assert r.returncode == 0, r.stderr
+                best = dt if best is None else min(best, dt)
+            a = open(os.path.join(d, "out_paired_gz_c0.0", "all_kreport.txt")).read()
+            b = open(os.path.join(d, "out_paired_detailed_c0.0", "all_kreport.txt")).read()
+            assert a == b, "paired gzip input: the report differs from the plain files'"
+            out["paired_gz" + ("_" + vname if vname else "")] = dict(fragments=half, seconds=round(best, 2), M_fragments_per_s=round(half / best / 1e6, 3))
     # classify2: the two-step run with a dynamic library built on the device from the genome FASTA files
     libdir = os.path.join(d, "k2")
     os.makedirs(os.path.join(libdir, "library", "bacteria"))
