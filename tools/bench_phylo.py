@@ -105,13 +105,14 @@ def main():
         stt2 = torch.randint(0, len(bases) - L_read, (R2,), generator=g, device="cuda")
         b2 = torch.cat([d_all[(stt2[:, None] + torch.arange(L_read, device="cuda")[None, :]).reshape(-1)], torch.zeros(64, dtype=torch.uint8, device="cuda")])
         o2 = torch.arange(0, (R2 + 1) * L_read, L_read, dtype=torch.int64, device="cuda")
-        for _ in range(2):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            st.classify_batch_device(b2.data_ptr(), o2.data_ptr(), R2, R2 * L_read, d_t.data_ptr(), d_c.data_ptr(), d_nd.data_ptr())
-            st.synchronize()
-            dt = time.perf_counter() - t0
-        out[f"reads_{L_read}bp"] = dict(ms=round(dt * 1e3, 2), Gbp_per_s=round(R2 * L_read / dt / 1e9, 1))
+        for thr in ((0.0,), (0.0, 0.15)):
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                st.classify_batch_device(b2.data_ptr(), o2.data_ptr(), R2, R2 * L_read, d_t.data_ptr(), d_c.data_ptr(), d_nd.data_ptr(), thresholds=thr)
+                st.synchronize()
+                dt = time.perf_counter() - t0
+            out[f"reads_{L_read}bp" + ("" if len(thr) == 1 else "_two_thresholds")] = dict(ms=round(dt * 1e3, 2), Gbp_per_s=round(R2 * L_read / dt / 1e9, 1))
         del b2, o2
     out.update(records=int(ix.info().records), records_by_depth=hist.tolist(), classified=float(d_c[:R].float().mean()),
                calls_by_depth=np.bincount(lvl, minlength=9).tolist(), substitution_rate_per_level=rate, chain=chain,
