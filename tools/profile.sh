@@ -8,7 +8,8 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py "$@" > $OUT/bench_trace.json 2> $OUT/trace.err
+# (20 timed steps: the one warm-up launch, cold and a tenth slower, then weighs 1/21 in the trace's average per launch)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 1 "$@" > $OUT/bench_trace.json 2> $OUT/trace.err
 echo "trace rc=$?"
 i=0
 for PMC in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" \
