@@ -574,7 +574,7 @@ class Reader {
   void speculate(size_t i, Chunk &c, Tables &tab) {
     c.found = false;
     const uint64_t lo = lo_bit(i), hi = lo_bit(i + 1);
-    const size_t cap = (size_t)64 * chunk_bytes_ + ((size_t)64 << 20);
+    const size_t cap = (size_t)24 * chunk_bytes_ + ((size_t)8 << 20);   // (text inflates 3-6 fold; what goes far beyond is left to the serial route)
     auto attempt = [&](Boundary from) {
       const uint64_t t0 = timing_ ? now_ns() : 0;
       struct Stop { Timing &tm; uint64_t t0; bool on; ~Stop() { if (on) tm.decode += now_ns() - t0; } } stopwatch{tm_, t0, timing_};
