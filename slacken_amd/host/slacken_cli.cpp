@@ -765,20 +765,30 @@ static void load_index(const std::string &location, IndexParams &ip, Taxonomy &t
   uint64_t n_records = 0;
   if (!fs::exists(location + ".slkrec") && parquet_available() && fs::is_directory(location)) {
     int64_t mt = -1;
+    const double tl0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     n_records = parquet_count_rows(location, W, &mt);
+    const double tl1 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     int32_t max_taxon = std::max<int32_t>(tax.size() - 1, (int32_t)std::max<int64_t>(mt, 0));
     if (mt < 0)  // no column statistics: one pass over the taxon column
       parquet_for_each_batch(location, W, [&](const int64_t *, const int32_t *taxa, uint64_t c) { for (uint64_t i = 0; i < c; i++) max_taxon = std::max(max_taxon, taxa[i]); });
     dev.create(ip, tax, n_records, max_taxon);
+    const double tl2 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (getenv("SLK_HOST_TIMING")) std::cerr << "host timing: library load: footers of the bucket files " << tl1 - tl0 << " s, device table " << tl2 - tl1 << " s\n";
     // bucket files are decoded on several threads (whole files: a bucket file of a standard library is ~60 MB) and appended
     // here in file order
     struct FileRecords { std::vector<int64_t> keys; std::vector<int32_t> taxa; };
     ThreadPool pool(host_threads());
     std::deque<std::future<FileRecords>> pending;
+    const bool timing = getenv("SLK_HOST_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_wait = 0, t_append = 0;
     auto drain_one = [&]() {
+      const double t0 = now();
       FileRecords fr = pending.front().get();
       pending.pop_front();
+      const double t1 = now();
       dev.append(fr.keys.data(), fr.taxa.data(), fr.taxa.size());
+      t_wait += t1 - t0; t_append += now() - t1;
     };
     for (auto &file : parquet_list_files(location)) {
       pending.push_back(pool.submit([file, W]() {
@@ -792,6 +802,7 @@ static void load_index(const std::string &location, IndexParams &ip, Taxonomy &t
       while (pending.size() >= 2 * pool.size()) drain_one();
     }
     while (!pending.empty()) drain_one();
+    if (timing) std::cerr << "host timing: library load: waiting for decoded bucket files " << t_wait << " s, appending them to the table " << t_append << " s (" << pool.size() << " decoding threads)\n";
   } else {
     RecordFile rec(location, W);
     n_records = rec.n;
@@ -801,7 +812,12 @@ static void load_index(const std::string &location, IndexParams &ip, Taxonomy &t
     dev.create(ip, tax, rec.n, max_taxon);
     rec.for_each_chunk(true, [&](const int64_t *keys, const int32_t *taxa, uint64_t c) { dev.append(keys, taxa, c); });
   }
-  dev.finalize();
+  {
+    const double tf0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    dev.finalize();
+    if (getenv("SLK_HOST_TIMING"))
+      std::cerr << "host timing: library load: finalize " << std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - tf0 << " s\n";
+  }
   std::cerr << "index: " << n_records << " records, k=" << ip.k << " m=" << ip.m << " spaces=" << ip.spaces << std::endl;
 }
 

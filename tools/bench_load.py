@@ -46,7 +46,8 @@ def main():
                            capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr
         load = [l for l in r.stderr.split("\n") if "Load index" in l][0]
-        out["threads_%s" % (threads or "default")] = dict(wall=round(time.perf_counter() - t0, 2), load=load.split("[")[1].rstrip("]"))
+        tim = [l for l in r.stderr.split("\n") if "library load" in l]
+        out["threads_%s" % (threads or "default")] = dict(wall=round(time.perf_counter() - t0, 2), load=load.split("[")[1].rstrip("]"), timing=tim)
     out.update(records=per * F, files=F, parquet_GB=round(size / 1e9, 2))
     print(json.dumps(out))
 
