@@ -75,7 +75,7 @@ typedef struct {
 typedef struct {
   uint64_t expected_records; /* upper bound on records that will be appended */
   int32_t max_taxon;         /* largest taxon id that will be appended (0 = derive from nothing: 2^22-1) */
-  float load_factor;         /* target cells-used fraction, 0 = default 0.70 */
+  float load_factor;         /* target cells-used fraction, 0 = default: 0.70, less for tables whose cells leave under 6 bits to the displacement */
 } slk_table_config;
 
 typedef struct {

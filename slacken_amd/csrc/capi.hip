@@ -473,6 +473,12 @@ int32_t slk_index_create(const slk_params *p, const slk_table_config *cfg, int32
   if (lf > 0.95f) lf = 0.95f;
   uint64_t cells_needed = (uint64_t)((double)std::max<uint64_t>(cfg->expected_records, 1) / lf) + 8;
   int bb = std::max(tb + 4, ceil_log2_u64((cells_needed + 7) / 8));  // >= 4 displacement bits: 15 buckets of linear probing
+  // A cell holds remainder + displacement + taxon in 64 bits, so the displacement field has bucket_bits - taxon_bits bits (6 at
+  // most are used: 63 buckets).  Where that leaves fewer -- mid-size tables under wide taxon ids: 3e8 records with NCBI's ids have
+  // 4, i.e. 15 buckets -- a table filled to 0.7 can run out of reach (one in ~800 random tables of the test suite did, loudly:
+  // SLK_E_CAPACITY).  With the default load factor such a table is made larger until either field or load is comfortable.
+  if (!(cfg->load_factor > 0))
+    while (bb - tb < 6 && bb < 40 && (double)cfg->expected_records / ((double)(1ULL << bb) * 8.0) > 0.45) bb++;
   if (bb > 40) { delete ix; return fail(SLK_E_CAPACITY, "table of 2^%d buckets is too large", bb); }
   ix->bucket_bits = bb;
   ix->taxon_bits = tb;
