@@ -205,3 +205,44 @@ def test_corrupt_file_inflated_in_place_fails(cases, tmp_path):
         env = dict(os.environ, SLK_GZ_THREADS="4", SLK_GZ_CHUNK="50000")
         p = subprocess.run([CLI, "parse", f], env=env, capture_output=True, timeout=300)
         assert p.returncode != 0 and b"read error" in p.stderr, name
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SLK_GZ_SEEDS", 4))))   # (SLK_GZ_SEEDS: soak runs)
+def test_random_streams(tmp_path, seed):
+    """content, compression level and strategy (default, filtered, Huffman only, RLE, fixed codes), member cuts, chunk size and
+    thread count drawn at random"""
+    rng = np.random.default_rng(9000 + seed)
+    pieces = []
+    for _ in range(int(rng.integers(1, 6))):
+        kind = int(rng.integers(0, 5))
+        n = int(rng.integers(1, 600_000))
+        if kind == 0:
+            pieces.append(fastq_text(rng, n // 320 + 1, read_len=int(rng.integers(30, 300))))
+        elif kind == 1:
+            pieces.append(rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+        elif kind == 2:
+            unit = rng.integers(65, 91, int(rng.integers(1, 40)), dtype=np.uint8).tobytes()
+            pieces.append(unit * (n // len(unit) + 1))
+        elif kind == 3:
+            pieces.append(bytes(n))
+        else:
+            pieces.append(rng.integers(0, 4, n, dtype=np.uint8).tobytes())     # low entropy, no structure
+    data = b"".join(pieces)
+    members, a = [], 0
+    while a < len(data) or not members:
+        b = len(data) if rng.random() < 0.5 else min(len(data), a + int(rng.integers(0, max(2, len(data)))))
+        c = zlib.compressobj(int(rng.integers(1, 10)), zlib.DEFLATED, 31, 8, int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED])))
+        blob = c.compress(data[a:b])
+        if rng.random() < 0.3:
+            blob += c.flush(zlib.Z_SYNC_FLUSH)
+        members.append(blob + c.flush())
+        a = b
+        if a >= len(data):
+            break
+    path = str(tmp_path / "r.gz")
+    open(path, "wb").write(b"".join(members))
+    chunk = int(rng.choice([300, 2_000, 17_000, 90_000, 400_000]))
+    if os.path.getsize(path) < 2 * chunk:
+        chunk = max(64, os.path.getsize(path) // 3)
+    got = gunzip(path, threads=int(rng.integers(2, 9)), chunk=chunk)
+    assert got == data, (seed, len(got), len(data), chunk)
