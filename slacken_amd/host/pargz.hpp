@@ -17,7 +17,9 @@
 //     spans several chunks -- the worker decodes its chunk again from where its predecessor stopped, with the window known.  No
 //     guess survives unchecked: the chain only accepts positions the true decode reaches.
 //   * per member CRC-32 and ISIZE are verified as zlib's gzread does (parts per chunk, crc32_combine in file order).
-// read() hands the bytes out in file order.  Memory: `lookahead` chunks in flight.
+// read() hands the bytes out in file order (memory: `lookahead` chunks in flight).  In REGION mode the workers write the text at its
+// final offset into one reserved stretch of address space instead, and the consumers -- the segment parsers of seqio.hpp --
+// treat it like a mapped plain file that fills while they read it (wait_segment / wait_more / segment_parsed).
 #pragma once
 #include <zlib.h>
 
@@ -490,7 +492,6 @@ class Reader {
     std::array<uint8_t, 32768> win;
     size_t win_len = 0;
     uint64_t total = 0;   // inflated bytes up to and including this chunk
-    bool ready = false;
   };
   struct Info {   // region mode: what stays known of a chunk after its slot has moved on
     uint64_t begin = 0, end = 0;
@@ -836,7 +837,7 @@ class Reader {
       p_ = (const uint8_t *)m;
     }
     build_fixed(fixed_);
-    start_.E.bit = 0; start_.E.member = true; start_.win_len = 0; start_.ready = true;
+    start_.E.bit = 0; start_.E.member = true; start_.win_len = 0;
     nchunks_ = (n_ + chunk_bytes_ - 1) / chunk_bytes_;
     threads = std::max(1, threads);
     lookahead_ = (size_t)threads + 3;
