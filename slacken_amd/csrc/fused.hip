@@ -269,6 +269,115 @@ __device__ int32_t lca_uniform(const int32_t *parents, int32_t ntax, int32_t a, 
   return 1;
 }
 
+// {parent, tin, tout, -} of taxon t (engine.h: FusedArgs.nodes); wave-uniform t: a scalar load.  An id outside the taxonomy is a
+// tree of its own.
+__device__ __forceinline__ uint4 tax_node(const FusedArgs &A, int32_t t) {
+  return ((uint32_t)t < (uint32_t)A.ntax) ? A.nodes[t] : make_uint4(0u, 0x40000000u + (uint32_t)t, 0x40000000u + (uint32_t)t, 0u);
+}
+
+// resolveTree over the LDS map on the taxonomy's Euler-tour intervals (lane.hip has the same for its 12-slot maps):
+// one lane per distinct taxon.  Each loads its taxon's interval once; a taxon's root-path score is the count of the entries whose
+// interval holds its tin, a candidate's clade sum that of the entries whose tin its interval holds; the confidence walk jumps to
+// the nearest map taxon above the candidate when nothing else is left outside its clade, and ends when the clade holds the whole
+// map.  No walk of parent pointers except towards a tie's LCA and past side branches.  (The intervals live in the span buffer's
+// key array, empty by now.)
+__device__ __forceinline__ void resolve_map_intervals(WaveLds *L, const FusedArgs &A, uint64_t r, int lane, int32_t total, int32_t nd,
+                                                      const int2 *dense, int D) {
+  uint32_t *const tin = (uint32_t *)L->span_key, *const tout = tin + MAP_CAP;
+  static_assert(SPAN_CAP * sizeof(uint64_t) >= 2 * MAP_CAP * sizeof(uint32_t), "the intervals alias the span keys");
+  for (int b0 = 0; b0 < D; b0 += 64) {
+    const int i = b0 + lane;
+    if (i < D) {
+      const uint4 n = tax_node(A, dense[i].x);
+      tin[i] = n.y; tout[i] = n.z;
+    }
+  }
+  wave_sync();
+  // step 1 (:101-123): the LCA of the taxa with the maximal root-path score
+  int32_t maxTaxon = 0, best = 0, sum_all = 0;
+  uint32_t m_in = 0, m_out = 0;
+  for (int b0 = 0; b0 < D; b0 += 64) {
+    const int i = b0 + lane;
+    const int32_t t = i < D ? dense[i].x : 0;
+    const bool act = t != 0;   // (the map of this kernel keeps NONE, as TaxonCounts.toMap does: it is on no root path and in no clade)
+    const uint32_t ain = act ? tin[i] : 0u, aout = act ? tout[i] : 0u;
+    int32_t score = 0;
+    for (int j = 0; j < D; j++) score += (act && tin[j] <= ain && ain <= tout[j]) ? dense[j].y : 0;   // (uniform j: LDS broadcasts)
+    sum_all += wave_sum(act ? dense[i].y : 0);
+    const int32_t mx = wave_max(act ? score : -1);
+    if (mx > best) { best = mx; maxTaxon = 0; }
+    if (mx == best && best > 0) {
+      uint64_t tie = __ballot(act && score == best && t != 0);
+      while (tie) {
+        const int bl = __builtin_ctzll(tie);
+        tie &= tie - 1;
+        const int32_t tt = __builtin_amdgcn_readlane(t, bl);
+        const uint32_t tin_t = __builtin_amdgcn_readlane(ain, bl), tout_t = __builtin_amdgcn_readlane(aout, bl);
+        if (maxTaxon == 0 || (tin_t <= m_in && m_in <= tout_t)) {   // LowestCommonAncestor.apply :49-78 by intervals
+          maxTaxon = tt; m_in = tin_t; m_out = tout_t;
+        } else if (!(m_in <= tin_t && tin_t <= m_out)) {          // neither holds the other: the first node above that holds tt
+          int32_t x = (int32_t)tax_node(A, maxTaxon).x;
+          uint4 nx = make_uint4(0, 0, 0, 0);
+          while (x != 0) {
+            nx = tax_node(A, x);
+            if (nx.y <= tin_t && tin_t <= nx.z) break;
+            x = (int32_t)nx.x;
+          }
+          if (x == 0) { x = 1; nx = tax_node(A, 1); }             // no common node: ROOT (:77)
+          maxTaxon = x; m_in = nx.y; m_out = nx.z;
+        }
+      }
+    }
+  }
+  for (int32_t c = 0; c < A.C; c++) {
+    const double required = ceil(__dmul_rn(A.thr.v[c], (double)total));  // Math.ceil(confidence * totalKmers) :94
+    int32_t mt = maxTaxon;
+    uint32_t cin = m_in, cout = m_out;
+    uint4 cur = make_uint4(0, 0, 0, 0);
+    bool have_cur = false;
+    while (mt != 0) {  // :125-144
+      int32_t sum = 0;
+      bool side = false;
+      uint32_t up_in = 0;
+      for (int b0 = 0; b0 < D; b0 += 64) {
+        const int i = b0 + lane;
+        if (i < D && dense[i].x != 0) {
+          const uint32_t jin = tin[i], jout = tout[i];
+          const bool inside = cin <= jin && jin <= cout;
+          const bool above = !inside && jin <= cin && cin <= jout;
+          sum += inside ? dense[i].y : 0;
+          side = side || (!inside && !above);
+          if (above && jin > up_in) up_in = jin;   // (deeper on the candidate's root path = later in the tour)
+        }
+      }
+      const int32_t ms = wave_sum(sum);
+      if ((double)ms >= required) break;
+      if (ms == sum_all) { mt = 0; break; }        // the clade holds the whole map: no ancestor can do better
+      if (__ballot(side) == 0) {
+        // everything left lies above the candidate, on its root path: the next clade that differs is the nearest of them
+        const uint32_t nearest = (uint32_t)wave_max((int)up_in);
+        for (int b0 = 0; b0 < D; b0 += 64) {
+          const int i = b0 + lane;
+          if (i < D && dense[i].x != 0 && tin[i] == nearest) { L->result[0] = dense[i].x; L->result[1] = (int32_t)tout[i]; }
+        }
+        wave_sync();
+        mt = L->result[0]; cin = nearest; cout = (uint32_t)L->result[1];
+        have_cur = false;
+        wave_sync();
+      } else {
+        if (!have_cur) cur = tax_node(A, mt);
+        mt = (int32_t)cur.x;                       // Taxonomy.parents
+        if (mt != 0) { cur = tax_node(A, mt); have_cur = true; cin = cur.y; cout = cur.z; }
+      }
+    }
+    const bool classified = (mt != 0) && (nd >= A.min_hit_groups);  // Classifier.scala:445
+    if (lane == 0) {
+      A.out_taxon[(uint64_t)c * A.out_stride + r] = classified ? ext_taxon(A.T, mt) : 0;
+      A.out_classified[(uint64_t)c * A.out_stride + r] = classified ? 1 : 0;
+    }
+  }
+}
+
 // resolveTree over the LDS map (the general case: at least two distinct non-NONE taxa)
 __device__ __forceinline__ void resolve_map(WaveLds *L, const FusedArgs &A, uint64_t r, int lane, int32_t total, int32_t nd) {
   int2 *dense = (int2 *)L->stash;
@@ -283,6 +392,8 @@ __device__ __forceinline__ void resolve_map(WaveLds *L, const FusedArgs &A, uint
     D += __popcll(mask);
   }
   wave_sync();
+  if (A.nodes != nullptr) { resolve_map_intervals(L, A, r, lane, total, nd, dense, D); return; }
+  // (no Euler tour: a taxonomy of more than 2^22 ids whose records could not be renumbered -- the walks of the reference)
   // step 1 (:101-123): LCA of the taxa with the maximal root-path score
   int32_t maxTaxon = 0, best = 0;
   for (int b0 = 0; b0 < D; b0 += 64) {
