@@ -71,7 +71,7 @@ inline unsigned effective_cpus() {
 inline int gz_threads() {  // SLK_GZ_THREADS: threads inflating ONE gzip file (1: zlib's gzread on one thread, as before)
   const char *e = getenv("SLK_GZ_THREADS");
   if (e && atol(e) > 0) return (int)atol(e);
-  return (int)std::min<unsigned>(8, std::max<unsigned>(1, effective_cpus() / (unsigned)std::max(1, gz_concurrent_files().load())));
+  return (int)std::min<unsigned>(16, std::max<unsigned>(1, effective_cpus() / (unsigned)std::max(1, gz_concurrent_files().load())));
 }
 inline size_t gz_group() {  // SLK_GZ_GROUP: compressed chunks whose text is parsed as one segment (= one batch for the device)
   const char *e = getenv("SLK_GZ_GROUP");
