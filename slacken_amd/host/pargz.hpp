@@ -482,7 +482,7 @@ class Reader {
     std::vector<Seg> segs;
     bool found = false;
     Boundary F, specE;
-    bool spec_end = false;
+    bool spec_end = false, spec_bytes = false;   // spec_bytes: the speculative output is in `bytes` already (entered at a member start)
     size_t spec_len = 0, marker_end = 0;
     bool done = false;
   };
@@ -580,11 +580,27 @@ class Reader {
       const uint64_t t0 = timing_ ? now_ns() : 0;
       struct Stop { Timing &tm; uint64_t t0; bool on; ~Stop() { if (on) tm.decode += now_ns() - t0; } } stopwatch{tm_, t0, timing_};
       c.ends.clear();
+      if (from.member) {
+        // a chunk entered where a gzip member starts has nothing unknown before it: bytes at once, no markers to replace
+        // (every chunk of a BGZF file -- bgzip, bcl2fastq -- is such a chunk)
+        Inflater<uint8_t> inf(p_, n_, c.bytes, c.ends, tab, fixed_, cap);
+        try {
+          c.specE = inf.run(from, hi, c.spec_end);
+          c.spec_len = inf.pos;
+          c.spec_bytes = true;
+          c.F = from;
+          c.found = true;
+          return 2;
+        } catch (const Error &) {
+          return inf.blocks_done >= 2 ? 1 : 0;
+        }
+      }
       Inflater<uint16_t> inf(p_, n_, c.spec, c.ends, tab, fixed_, cap);
-      inf.lowest = from.member ? 0 : -32768;
+      inf.lowest = -32768;
       try {
         c.specE = inf.run(from, hi, c.spec_end);
         c.spec_len = inf.pos;
+        c.spec_bytes = false;
         c.marker_end = std::min(inf.marker_end, inf.pos);
         c.F = from;
         c.found = true;
@@ -712,6 +728,20 @@ class Reader {
           next.E = prev->E; next.stream_end = prev->stream_end; next.win = prev->win; next.win_len = prev->win_len;
           next.total = prev->total;
           c.ends.clear();
+        } else if (c.found && c.F == prev->E && c.spec_bytes) {
+          // entered at a member start and decoded to bytes: they are the truth as they stand
+          const size_t len = c.spec_len;
+          c.nbytes = len;
+          next.total = prev->total + len;
+          next.E = c.specE; next.stream_end = c.spec_end;
+          const size_t member_start = c.ends.empty() ? 0 : (size_t)c.ends.back().out_pos;
+          window_after(*prev, c.bytes.data(), len, member_start, next);
+          publish();
+          early = true;
+          if (region_mode_) {
+            ensure_writable(next.total);
+            memcpy(region_ + prev->total, c.bytes.data(), len);
+          }
         } else if (c.found && c.F == prev->E) {
           // the speculative symbols are the truth: markers <- the predecessor's window, the tail first
           const size_t len = c.spec_len;
