@@ -696,7 +696,9 @@ class Reader {
         Chain &mine = chains_[i % lookahead_];
         c.nbytes = 0;
         c.ends.clear();
-        {
+        if (th_.size() == 1 && i > 0) {
+          c.found = false;   // one worker: it would only guess at what it is about to know -- it decodes on from where it stopped
+        } else {
           const uint64_t t0 = timing_ ? now_ns() : 0;
           speculate(i, c, *tab);
           if (timing_) tm_.search += now_ns() - t0;   // (includes the decode attempts: subtracted when printed)

@@ -68,9 +68,9 @@ inline unsigned effective_cpus() {
   }();
   return n;
 }
-inline int gz_threads() {  // SLK_GZ_THREADS: threads inflating ONE gzip file (1: zlib's gzread on one thread, as before)
+inline int gz_threads() {  // SLK_GZ_THREADS: threads inflating ONE gzip file (1: this decoder without the guessing; 0: zlib's gzread)
   const char *e = getenv("SLK_GZ_THREADS");
-  if (e && atol(e) > 0) return (int)atol(e);
+  if (e && atol(e) >= 0 && (e[0] >= '0' && e[0] <= '9')) return (int)atol(e);
   return (int)std::min<unsigned>(16, std::max<unsigned>(1, effective_cpus() / (unsigned)std::max(1, gz_concurrent_files().load())));
 }
 inline size_t gz_group() {  // SLK_GZ_GROUP: compressed chunks whose text is parsed as one segment (= one batch for the device)
@@ -84,7 +84,7 @@ inline size_t gz_chunk_bytes() {  // SLK_GZ_CHUNK: compressed bytes per chunk (t
 
 // plain / gzip (zlib reads both) / bzip2 (through the system's libbz2: this image has no bzlib.h, so the three stable
 // high-level entry points are declared here and resolved at run time).  A gzip FILE of some size is inflated on several
-// threads (pargz.hpp); pipes, small files and SLK_GZ_THREADS=1 keep zlib's gzread.
+// threads (pargz.hpp); pipes, small files and SLK_GZ_THREADS=0 keep zlib's gzread.
 class ByteSource {
   gzFile g_ = nullptr;
   void *bz_ = nullptr;
@@ -115,7 +115,7 @@ class ByteSource {
       if (!bzopen || !bzread_ || !bzclose_) throw std::runtime_error("libbz2 lacks BZ2_bzopen/BZ2_bzread/BZ2_bzclose");
       bz_ = bzopen(path.c_str(), "rb");
       if (!bz_) throw std::runtime_error("cannot open " + path);
-    } else if (gz_threads() > 1 && gzip_file_worth_threads(path, gz_chunk_bytes())) {
+    } else if (gz_threads() >= 1 && gzip_file_worth_threads(path, gz_chunk_bytes())) {
       pz_ = std::make_unique<slk::pargz::Reader>(path, gz_threads(), gz_chunk_bytes());
     } else {
       g_ = gzopen(path.c_str(), "rb");
@@ -606,7 +606,7 @@ class AsyncRecordStream {
   }
 
   explicit AsyncRecordStream(const std::string &file) {
-    if (regular_file(file) && !ends_with(file, ".bz2") && ByteSource::gzip_file_worth_threads(file, gz_chunk_bytes()) && gz_threads() > 1) {
+    if (regular_file(file) && !ends_with(file, ".bz2") && ByteSource::gzip_file_worth_threads(file, gz_chunk_bytes()) && gz_threads() >= 1) {
       parallel_ = true;
       gz_ = std::make_unique<slk::pargz::Reader>(file, gz_threads(), gz_chunk_bytes(), true);
       gz_group_ = gz_group();

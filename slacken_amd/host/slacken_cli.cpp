@@ -972,7 +972,7 @@ static const char *HELP =
     "host-only helpers: report TAXONOMY_DIR COUNTS_TSV | parse FILE [MATE_FILE] | props INDEX | records INDEX | repeated [-p] FILES\n"
     "environment: SLK_HOST_THREADS (formatting/decoding threads), SLK_INPUT_STREAMS (input files read side by side, default 8),\n"
     "             SLK_PARSE_THREADS (threads parsing one plain input file, default min(8, cores/2)), SLK_GZIP_LEVEL (1..9, default zlib's),\n"
-    "             SLK_GZ_THREADS (threads inflating one gzip input file, default min(16, cores / files read side by side); 1: zlib),\n"
+    "             SLK_GZ_THREADS (threads inflating one gzip input file, default min(16, cores / files read side by side); 0: zlib),\n"
     "             SLK_CLASSIFY_THREADS (threads classifying batches, each with its own stream, default 2),\n"
     "             SLK_HOST_TIMING (report where the wall clock of the classify loop went)\n";
 

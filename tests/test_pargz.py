@@ -108,7 +108,7 @@ def test_equals_zlib(cases, chunk):
         assert got == want, (name, chunk, len(got), len(want))
 
 
-@pytest.mark.parametrize("threads", [2, 16])
+@pytest.mark.parametrize("threads", [1, 2, 16])
 def test_thread_counts(cases, threads):
     path, want = cases["text_l6.gz"]
     assert gunzip(path, threads=threads, chunk=20_000) == want
@@ -135,9 +135,10 @@ def test_corrupt_and_cut_files_fail_as_with_zlib(cases, tmp_path):
     b3[len(b3) // 3] ^= 0x10                                           # somewhere in the deflate data
     open(flipped, "wb").write(b3)
     assert "read error" in gunzip(flipped, chunk=50_000, expect_fail=True)
-    # the same files through zlib alone fail too (SLK_GZ_THREADS=1)
+    # the same files through zlib alone (SLK_GZ_THREADS=0) and through this decoder on one thread (1) fail too
     for f in (cut, cut8, bad_crc, flipped):
-        assert "read error" in gunzip(f, threads=1, expect_fail=True)
+        assert "read error" in gunzip(f, threads=0, expect_fail=True)
+        assert "read error" in gunzip(f, threads=1, chunk=50_000, expect_fail=True)
 
 
 def test_reads_parse_the_same_through_both_inflaters(cases):
@@ -147,14 +148,14 @@ def test_reads_parse_the_same_through_both_inflaters(cases):
     if not os.path.exists(fq):
         os.symlink(path, fq)
     outs = []
-    for threads, chunk in ((1, None), (4, 30_000)):
+    for threads, chunk in ((0, None), (1, 30_000), (4, 30_000)):
         env = dict(os.environ, SLK_GZ_THREADS=str(threads))
         if chunk:
             env["SLK_GZ_CHUNK"] = str(chunk)
         p = subprocess.run([CLI, "parse", fq], env=env, capture_output=True, timeout=300)
         assert p.returncode == 0, p.stderr.decode()
         outs.append(p.stdout)
-    assert outs[0] == outs[1] and outs[0].count(b"\n") == 12000
+    assert outs[0] == outs[1] == outs[2] and outs[0].count(b"\n") == 12000
 
 
 def fasta_text(rng, n_records, max_len, width=60, eol=b"\n"):
@@ -187,12 +188,12 @@ def test_records_of_files_inflated_in_place(tmp_path, chunk):
         path = str(tmp_path / name)
         open(path, "wb").write(blob)
         outs = []
-        for threads in (1, 4):
+        for threads in (0, 1, 4):
             env = dict(os.environ, SLK_GZ_THREADS=str(threads), SLK_GZ_CHUNK=str(chunk), SLK_PARSE_THREADS="3")
             p = subprocess.run([CLI, "parse", path], env=env, capture_output=True, timeout=300)
             assert p.returncode == 0, (name, p.stderr.decode())
             outs.append(p.stdout)
-        assert outs[0] == outs[1], (name, chunk, outs[0].count(b"\n"), outs[1].count(b"\n"))
+        assert outs[0] == outs[1] == outs[2], (name, chunk, outs[0].count(b"\n"), outs[1].count(b"\n"), outs[2].count(b"\n"))
         assert outs[0].count(b"\n") > 0
 
 
@@ -244,5 +245,5 @@ def test_random_streams(tmp_path, seed):
     chunk = int(rng.choice([300, 2_000, 17_000, 90_000, 400_000]))
     if os.path.getsize(path) < 2 * chunk:
         chunk = max(64, os.path.getsize(path) // 3)
-    got = gunzip(path, threads=int(rng.integers(2, 9)), chunk=chunk)
+    got = gunzip(path, threads=int(rng.integers(1, 9)), chunk=chunk)
     assert got == data, (seed, len(got), len(data), chunk)

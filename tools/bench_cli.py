@@ -92,9 +92,9 @@ def main():
     one = os.path.join(d, "all.fq.gz")
     with gzip.open(one, "wb", compresslevel=1) as f:
         f.write(open(fq, "rb").read())
-    # each with zlib on one thread per file (SLK_GZ_THREADS=1: how the input was read until round 2's pargz.hpp) and with the
+    # each with zlib on one thread per file (SLK_GZ_THREADS=0: how the input was read until round 2's pargz.hpp) and with the
     # parallel inflate (default); SLK_CLI_GZ_VARIANTS='{"name": {"ENV": "value"}, ...}' adds settings; best of two runs each
-    variants = {"zlib_one_thread_per_file": {"SLK_GZ_THREADS": "1"}, "": {}}
+    variants = {"zlib_one_thread_per_file": {"SLK_GZ_THREADS": "0"}, "": {}}
     variants.update(json.loads(os.environ.get("SLK_CLI_GZ_VARIANTS", "{}")))
     for name, inputs in (("gz_one_file", [one]), ("gz_eight_files", parts)):
         for vname, venv in variants.items():
@@ -118,7 +118,7 @@ def main():
             with gzip.open(dst, "wb", compresslevel=1) as f:
                 f.write(open(src, "rb").read())
             pz.append(dst)
-        for vname, venv in (("zlib_one_thread_per_file", {"SLK_GZ_THREADS": "1"}), ("", {})):
+        for vname, venv in (("zlib_one_thread_per_file", {"SLK_GZ_THREADS": "0"}), ("", {})):
             best = None
             for _ in range(2):
                 t0 = time.perf_counter()
