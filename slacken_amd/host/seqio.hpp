@@ -71,7 +71,10 @@ inline unsigned effective_cpus() {
 inline int gz_threads() {  // SLK_GZ_THREADS: threads inflating ONE gzip file (1: this decoder without the guessing; 0: zlib's gzread)
   const char *e = getenv("SLK_GZ_THREADS");
   if (e && atol(e) >= 0 && (e[0] >= '0' && e[0] <= '9')) return (int)atol(e);
-  return (int)std::min<unsigned>(16, std::max<unsigned>(1, effective_cpus() / (unsigned)std::max(1, gz_concurrent_files().load())));
+  // (under four threads per file the guessing costs about what it gains -- twice the CPU per byte: one thread then, which decodes
+  // straight on and is still faster than zlib)
+  const unsigned share = effective_cpus() / (unsigned)std::max(1, gz_concurrent_files().load());
+  return share < 4 ? 1 : (int)std::min<unsigned>(16, share);
 }
 inline size_t gz_group() {  // SLK_GZ_GROUP: compressed chunks whose text is parsed as one segment (= one batch for the device)
   const char *e = getenv("SLK_GZ_GROUP");
