@@ -511,6 +511,7 @@ class Reader {
   bool stop_ = false;
   std::string error_;
   std::vector<std::thread> th_;
+  size_t nthreads_ = 1;   // (fixed before the first worker starts: they read it)
   Tables fixed_;
   Chain start_;
   Timing tm_;
@@ -696,7 +697,7 @@ class Reader {
         Chain &mine = chains_[i % lookahead_];
         c.nbytes = 0;
         c.ends.clear();
-        if (th_.size() == 1 && i > 0) {
+        if (nthreads_ == 1 && i > 0) {
           c.found = false;   // one worker: it would only guess at what it is about to know -- it decodes on from where it stopped
         } else {
           const uint64_t t0 = timing_ ? now_ns() : 0;
@@ -885,7 +886,9 @@ class Reader {
       }
       if (!region_) { if (p_) munmap((void *)p_, n_); ::close(fd_); throw std::runtime_error("cannot reserve address space to inflate " + path); }
     }
-    for (int t = 0; t < threads && (size_t)t < std::max<size_t>(1, nchunks_); t++) th_.emplace_back([this] { worker(); });
+    nthreads_ = std::min<size_t>((size_t)threads, std::max<size_t>(1, nchunks_));
+    th_.reserve(nthreads_);
+    for (size_t t = 0; t < nthreads_; t++) th_.emplace_back([this] { worker(); });
   }
   Reader(const Reader &) = delete;
   void shutdown() {   // stops the workers and wakes every waiter (they return false)
@@ -896,7 +899,7 @@ class Reader {
     shutdown();
     if (timing_)
       fprintf(stderr, "[pargz] %zu chunks of %zu bytes, %zu threads; thread-seconds: boundary search %.3f, speculative decode %.3f, "
-              "waiting for the predecessor %.3f, markers %.3f (%.1f %% of the symbols may be markers), decoding again %.3f, crc %.3f\n", nchunks_, chunk_bytes_, th_.size(),
+              "waiting for the predecessor %.3f, markers %.3f (%.1f %% of the symbols may be markers), decoding again %.3f, crc %.3f\n", nchunks_, chunk_bytes_, nthreads_,
               (tm_.search - tm_.decode) / 1e9, tm_.decode / 1e9, tm_.wait / 1e9, tm_.resolve / 1e9, 100.0 * tm_.marked / std::max<uint64_t>(1, tm_.total), tm_.redo / 1e9, tm_.crc / 1e9);
     if (p_) munmap((void *)p_, n_);
     if (region_) munmap(region_, region_cap_);
