@@ -739,11 +739,12 @@ class Reader {
           next.E = c.specE; next.stream_end = c.spec_end;
           const size_t member_start = c.ends.empty() ? 0 : (size_t)c.ends.back().out_pos;
           window_after(*prev, c.bytes.data(), len, member_start, next);
+          const uint64_t at = prev->total;   // (read before the chain is published: the predecessor's slot may move on after that)
           publish();
           early = true;
           if (region_mode_) {
             ensure_writable(next.total);
-            memcpy(region_ + prev->total, c.bytes.data(), len);
+            memcpy(region_ + at, c.bytes.data(), len);
           }
         } else if (c.found && c.F == prev->E) {
           // the speculative symbols are the truth: markers <- the predecessor's window, the tail first
