@@ -60,6 +60,8 @@ def main():
             for old in glob.glob(out + "_c*"):
                 subprocess.call(["rm", "-rf", old])
             extra = ["-p"] if name == "pairs_gz" else []
+            if run and rng.random() < 0.3:
+                extra += ["--devices", "0,0,0" if rng.random() < 0.5 else "0,0"]   # (the same GPU as several devices: the multi-device host)
             r = subprocess.run([CLI, "classify", "-i", loc, "-o", out, "-c", "0.0", "0.15", *extra, *map(str, inputs)], capture_output=True, text=True, env=env)
             if r.returncode != 0:
                 bad += 1
