@@ -198,6 +198,7 @@ struct slk_index {
   // dense taxon ids (engine.h: TableView.to_orig): set up by slk_index_finalize when the caller's ids need more than 22 bits
   int32_t *d_parents_dense = nullptr, *d_to_orig = nullptr, *d_to_dense = nullptr;
   uint4 *d_nodes = nullptr;        // kernel_parents() with an Euler tour (engine.h: FusedArgs.nodes); null: more than 2^22 ids, no lane kernel
+  uint4 *d_nodes_orig = nullptr;   // the same for the taxonomy as given (the staged classify kernel works in the caller's ids); may BE d_nodes
   int32_t D = 0;                   // nodes of the taxonomy = largest dense id (0: ids are stored as given)
   bool finalized = false;
   int32_t max_disp = 0;
@@ -593,9 +594,9 @@ int32_t slk_index_append(slk_index *ix, const int64_t *keys, const int32_t *taxa
 // of b" (Taxonomy.hasAncestor, Taxonomy.scala:236-244) is tin[a] <= tin[b] <= tout[a] -- two compares on values that are loaded
 // once per taxon of a read's map -- instead of a walk of b's root path: NCBI lineages are 25-40 nodes deep, and resolveTree
 // (LowestCommonAncestor.scala:101-146) asks it for every pair of map taxa and again at every step of the confidence walk.
-static int32_t build_tax_nodes(slk_index *ix, const int32_t *parents, int32_t n) {
-  if (ix->d_nodes) { HIPCHK(hipFree(ix->d_nodes)); ix->d_nodes = nullptr; }
-  if (n < 2 || n > (1 << 22) + 1) return SLK_OK;   // (ids beyond 22 bits do not take the lane kernel)
+static int32_t build_tax_nodes(const int32_t *parents, int32_t n, int32_t max_n, uint4 **out) {
+  *out = nullptr;
+  if (n < 2 || n > max_n) return SLK_OK;
   std::vector<uint32_t> first((size_t)n + 1, 0), kids;   // children of p: kids[first[p] .. first[p + 1]), in increasing id order
   for (int32_t t = 1; t < n; t++) if (parents[t] != 0) first[(size_t)parents[t] + 1]++;
   for (int32_t p = 0; p < n; p++) first[(size_t)p + 1] += first[p];
@@ -624,9 +625,14 @@ static int32_t build_tax_nodes(slk_index *ix, const int32_t *parents, int32_t n)
       }
     }
   }
-  HIPCHK(hipMalloc((void **)&ix->d_nodes, (size_t)n * sizeof(uint4)));
-  HIPCHK(hipMemcpy(ix->d_nodes, nodes.data(), (size_t)n * sizeof(uint4), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc((void **)out, (size_t)n * sizeof(uint4)));
+  HIPCHK(hipMemcpy(*out, nodes.data(), (size_t)n * sizeof(uint4), hipMemcpyHostToDevice));
   return SLK_OK;
+}
+static void free_tax_nodes(slk_index *ix) {
+  if (ix->d_nodes_orig && ix->d_nodes_orig != ix->d_nodes) (void)hipFree(ix->d_nodes_orig);
+  if (ix->d_nodes) (void)hipFree(ix->d_nodes);
+  ix->d_nodes = ix->d_nodes_orig = nullptr;
 }
 
 int32_t slk_index_set_taxonomy(slk_index *ix, const int32_t *parents, int32_t T) {
@@ -656,7 +662,13 @@ int32_t slk_index_set_taxonomy(slk_index *ix, const int32_t *parents, int32_t T)
   HIPCHK(hipMemcpy(ix->d_parents, parents, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice));
   ix->T = T;
   ix->h_parents.assign(parents, parents + T);
-  return build_tax_nodes(ix, parents, T);
+  // Euler tours: for the fused kernels (ids of at most 22 bits take the lane kernel; wider ones are renumbered at finalize, which
+  // builds that tour then) and, in the caller's ids, for the staged classify kernel (up to 2^26 ids: 1 GiB of node records)
+  free_tax_nodes(ix);
+  int32_t rcn = build_tax_nodes(parents, T, (1 << 22) + 1, &ix->d_nodes);
+  if (rcn) return rcn;
+  if (ix->d_nodes) { ix->d_nodes_orig = ix->d_nodes; return SLK_OK; }
+  return build_tax_nodes(parents, T, 1 << 26, &ix->d_nodes_orig);
 }
 
 // bases_on_device: `bases` is resident on the index's GPU and is scanned where it lies
@@ -802,7 +814,9 @@ static int32_t make_dense_taxa(slk_index *ix) {
   HIPCHK(hipMemcpy(d_to, to_orig.data(), ((size_t)D + 1) * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d_pd, pd.data(), ((size_t)D + 1) * 4, hipMemcpyHostToDevice));
   ix->d_to_dense = d_td; ix->d_to_orig = d_to; ix->d_parents_dense = d_pd; ix->D = D;
-  return build_tax_nodes(ix, pd.data(), D + 1);
+  if (ix->d_nodes && ix->d_nodes != ix->d_nodes_orig) (void)hipFree(ix->d_nodes);
+  if (ix->d_nodes == ix->d_nodes_orig) ix->d_nodes = nullptr;   // (the tour of the ids as given stays with the staged kernel)
+  return build_tax_nodes(pd.data(), D + 1, (1 << 22) + 1, &ix->d_nodes);
 }
 
 int32_t slk_index_finalize(slk_index *ix) {
@@ -868,7 +882,7 @@ void slk_index_destroy(slk_index *ix) {
   if (ix->d_counters) (void)hipFree(ix->d_counters);
   if (ix->d_parents) (void)hipFree(ix->d_parents);
   if (ix->d_parents_dense) (void)hipFree(ix->d_parents_dense);
-  if (ix->d_nodes) (void)hipFree(ix->d_nodes);
+  free_tax_nodes(ix);
   if (ix->d_to_orig) (void)hipFree(ix->d_to_orig);
   if (ix->d_to_dense) (void)hipFree(ix->d_to_dense);
   ix->stage_keys.release();
@@ -976,7 +990,7 @@ static int32_t run_unbounded(slk_stream *st, const slk_stream::LastCall &L) {
               st->span_meta.as<int32_t>(), st->span_count.as<int32_t>(), st->s);
   launch_probe(ix->view(), L.offsets, L.mate_offsets, L.R, st->span_keys.as<uint64_t>(), st->span_meta.as<int32_t>(),
                st->span_count.as<int32_t>(), st->span_taxon.as<int32_t>(), st->s);
-  launch_classify(ix->d_parents, ix->T, L.offsets, L.mate_offsets, L.R, st->span_meta.as<int32_t>(),
+  launch_classify(ix->d_parents, ix->d_nodes_orig, ix->T, L.offsets, L.mate_offsets, L.R, st->span_meta.as<int32_t>(),
                   st->span_taxon.as<int32_t>(), st->span_count.as<int32_t>(), st->span_keys.as<uint64_t>(),
                   L.min_hit_groups, L.thr, L.C, L.out_stride, L.out_taxon, L.out_cls, L.out_nd, L.out_tk, L.out_nh, L.out_np, st->s);
   HIPCHK(hipGetLastError());
@@ -1126,7 +1140,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
     }
     HIPCHK(hipEventRecord(st->ev[2], st->s));
     // the key slots are dead after the probe: the per-read taxon->count map reuses them
-    launch_classify(ix->d_parents, ix->T, d_offsets, d_mate_offsets, R, st->span_meta.as<int32_t>(),
+    launch_classify(ix->d_parents, ix->d_nodes_orig, ix->T, d_offsets, d_mate_offsets, R, st->span_meta.as<int32_t>(),
                     st->span_taxon.as<int32_t>(), st->span_count.as<int32_t>(), st->span_keys.as<uint64_t>(),
                     min_hit_groups, thr, C, out_stride, d_out_taxon, d_out_classified, d_out_num_distinct,
                     d_out_total_kmers, d_out_num_hits, d_out_num_probes, st->s);
@@ -1312,7 +1326,7 @@ int32_t slk_classify_hits_device(slk_index *ix, slk_stream *st, const uint64_t *
   if (rc) return rc;
   Thresholds thr{};
   memcpy(thr.v, thresholds, C * sizeof(double));
-  launch_classify(ix->d_parents, ix->T, d_offsets, d_mate_offsets, R, d_span_meta, d_span_taxon, d_span_count, d_scratch,
+  launch_classify(ix->d_parents, ix->d_nodes_orig, ix->T, d_offsets, d_mate_offsets, R, d_span_meta, d_span_taxon, d_span_count, d_scratch,
                   min_hit_groups, thr, C, R, d_out_taxon, d_out_classified, d_out_num_distinct,
                   d_out_total_kmers, d_out_num_hits, nullptr, st->s);
   HIPCHK(hipGetLastError());
@@ -1366,7 +1380,7 @@ int32_t slk_classify_hits(slk_index *ix, slk_stream *st, uint64_t R, const uint6
   if (rc) return rc;
   Thresholds thr{};
   memcpy(thr.v, thresholds, C * sizeof(double));
-  launch_classify(ix->d_parents, ix->T, st->offsets.as<uint64_t>(), nullptr, R, st->span_meta.as<int32_t>(),
+  launch_classify(ix->d_parents, ix->d_nodes_orig, ix->T, st->offsets.as<uint64_t>(), nullptr, R, st->span_meta.as<int32_t>(),
                   st->span_taxon.as<int32_t>(), st->span_count.as<int32_t>(), st->span_keys.as<uint64_t>(), min_hit_groups,
                   thr, C, R, st->out_taxon.as<int32_t>(), st->out_cls.as<uint8_t>(), st->out_nd.as<int32_t>(),
                   st->out_tk.as<int32_t>(), nullptr, nullptr, st->s);

@@ -215,7 +215,7 @@ void launch_scan(const ScanParams &P, const uint8_t *bases, const uint64_t *offs
 void launch_probe(const TableView &T, const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R,
                   const uint64_t *span_keys, const int32_t *span_meta, const int32_t *span_count, int32_t *span_taxon,
                   hipStream_t s);
-void launch_classify(const int32_t *parents, int32_t T, const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R,
+void launch_classify(const int32_t *parents, const uint4 *nodes, int32_t T, const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R,
                      const int32_t *span_meta, const int32_t *span_taxon, const int32_t *span_count,
                      uint64_t *map_scratch, int32_t min_hit_groups, const Thresholds &thr, int32_t C, uint64_t out_stride,
                      int32_t *out_taxon, uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers,

@@ -260,8 +260,12 @@ __global__ void __launch_bounds__(256) probe_kernel(TableView T, const uint64_t 
 // ---------------------------------------------------------------------------------------------------------------
 struct Tax {
   const int32_t *parents;
+  const uint4 *nodes;   // {parent, tin, tout, -} per id from a depth-first tour (capi.hip: build_tax_nodes), or null
   int32_t T;
   __device__ __forceinline__ int32_t parent(int32_t t) const { return ((uint32_t)t < (uint32_t)T) ? parents[t] : 0; }
+  __device__ __forceinline__ uint4 node(int32_t t) const {   // an id outside the taxonomy is a tree of its own
+    return ((uint32_t)t < (uint32_t)T) ? nodes[t] : make_uint4(0u, 0x40000000u + (uint32_t)t, 0x40000000u + (uint32_t)t, 0u);
+  }
 };
 
 // LowestCommonAncestor.apply :49-78 without the path buffer: first node on b's path that lies on a's path.
@@ -318,6 +322,78 @@ __global__ void __launch_bounds__(256) classify_kernel(Tax tx, const uint64_t *_
     else map.e[i].y += count;
   }
 
+  if (tx.nodes != nullptr) {
+    // resolveTree on the taxonomy's Euler-tour intervals (a is an ancestor-or-self of b iff tin[a] <= tin[b] <= tout[a]; lane.hip
+    // and fused.hip do the same on their LDS maps): no walks of root paths.  The intervals are loaded again where
+    // they are needed -- this map lives in HBM and has no room for them; the loads hit the L2.  NONE is kept in the map
+    // (TaxonCounts.toMap) and is on no root path and in no clade.
+    int32_t maxTaxon = 0, best = 0, sum_all = 0;
+    uint32_t m_in = 0, m_out = 0;
+    for (int32_t it = 0; it < map.n; it++) {           // step 1 (:101-123)
+      const int2 a = map.e[it];
+      if (a.x == 0) continue;
+      sum_all += a.y;
+      const uint4 na = tx.node(a.x);
+      int32_t score = 0;
+      for (int32_t j = 0; j < map.n; j++) {
+        const int2 b = map.e[j];
+        if (b.x == 0) continue;
+        const uint4 nb = tx.node(b.x);
+        score += (nb.y <= na.y && na.y <= nb.z) ? b.y : 0;
+      }
+      if (score > best) { maxTaxon = a.x; best = score; m_in = na.y; m_out = na.z; }
+      else if (score == best) {                          // LowestCommonAncestor.apply :49-78 of (maxTaxon, a.x)
+        if (m_in <= na.y && na.y <= m_out) {
+        } else if (na.y <= m_in && m_in <= na.z) { maxTaxon = a.x; m_in = na.y; m_out = na.z; }
+        else {
+          int32_t x = (int32_t)tx.node(maxTaxon).x;
+          uint4 nx = make_uint4(0, 0, 0, 0);
+          while (x != 0) { nx = tx.node(x); if (nx.y <= na.y && na.y <= nx.z) break; x = (int32_t)nx.x; }
+          if (x == 0) { x = 1; nx = tx.node(1); }
+          maxTaxon = x; m_in = nx.y; m_out = nx.z;
+        }
+      }
+    }
+    for (int32_t c = 0; c < C; c++) {                    // step 2 (:125-144), jumping from map taxon to map taxon
+      const double required = ceil(__dmul_rn(thr.v[c], (double)total));
+      int32_t mt = maxTaxon;
+      uint32_t cin = m_in, cout = m_out;
+      uint4 cur = make_uint4(0, 0, 0, 0);
+      bool have_cur = false;
+      while (mt != 0) {
+        int32_t ms = 0, up_taxon = 0;
+        bool side = false;
+        uint32_t up_in = 0, up_out = 0;
+        for (int32_t j = 0; j < map.n; j++) {
+          const int2 b = map.e[j];
+          if (b.x == 0) continue;
+          const uint4 nb = tx.node(b.x);
+          const bool inside = cin <= nb.y && nb.y <= cout;
+          const bool above = !inside && nb.y <= cin && cin <= nb.z;
+          ms += inside ? b.y : 0;
+          side = side || (!inside && !above);
+          if (above && (up_taxon == 0 || nb.y > up_in)) { up_taxon = b.x; up_in = nb.y; up_out = nb.z; }
+        }
+        if ((double)ms >= required) break;
+        if (ms == sum_all) { mt = 0; break; }
+        if (!side) { mt = up_taxon; cin = up_in; cout = up_out; have_cur = false; }
+        else {
+          if (!have_cur) cur = tx.node(mt);
+          mt = (int32_t)cur.x;
+          if (mt != 0) { cur = tx.node(mt); have_cur = true; cin = cur.y; cout = cur.z; }
+        }
+      }
+      const bool classified = (mt != 0) && (nd >= min_hit_groups);   // Classifier.scala:445
+      out_taxon[(uint64_t)c * out_stride + r] = classified ? mt : 0;
+      out_classified[(uint64_t)c * out_stride + r] = classified ? 1 : 0;
+    }
+    if (out_num_distinct) out_num_distinct[r] = nd;
+    if (out_total_kmers) out_total_kmers[r] = total;
+    if (out_num_hits) out_num_hits[r] = n;
+    if (out_num_probes) out_num_probes[r] = nprobe;
+    return;
+  }
+  // (no Euler tour -- a taxonomy of more than 2^26 ids: the reference's walks)
   // resolveTree step 1 (:101-123): LCA of all taxa with the maximal root-path score; threshold independent
   int32_t maxTaxon = 0, maxScore = 0;
   for (int32_t it = 0; it < map.n; it++) {
@@ -469,13 +545,13 @@ void launch_probe(const TableView &T, const uint64_t *offsets, const uint64_t *m
   hipLaunchKernelGGL(probe_kernel, dim3((unsigned)blocks), dim3(256), 0, s, T, offsets, mate_offsets, R, span_keys,
                      span_meta, span_count, span_taxon);
 }
-void launch_classify(const int32_t *parents, int32_t T, const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R,
+void launch_classify(const int32_t *parents, const uint4 *nodes, int32_t T, const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R,
                      const int32_t *span_meta, const int32_t *span_taxon, const int32_t *span_count,
                      uint64_t *map_scratch, int32_t min_hit_groups, const Thresholds &thr, int32_t C, uint64_t out_stride,
                      int32_t *out_taxon, uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers,
                      int32_t *out_num_hits, int32_t *out_num_probes, hipStream_t s) {
   if (R == 0) return;
-  Tax tx{parents, T};
+  Tax tx{parents, nodes, T};
   uint64_t blocks = (R + 255) / 256;
   hipLaunchKernelGGL(classify_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tx, offsets, mate_offsets, R, span_meta,
                      span_taxon, span_count, map_scratch, min_hit_groups, thr, C, out_stride, out_taxon, out_classified,

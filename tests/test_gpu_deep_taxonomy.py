@@ -175,3 +175,40 @@ def test_random_shapes(orc, seed):
     want = orc.classify_batch(p, world["oix"], parents, bases, offsets, None, None, min_hit_groups=mhg, thresholds=thr)
     for key in ("total_kmers", "num_hits", "num_distinct", "taxon", "classified"):
         assert np.array_equal(got[key], want[key]), (seed, key)
+
+
+def test_classify_hits_entry_on_deep_taxonomies(orc, deep_world):
+    """slk_classify_hits (kernel 3 alone, the staged classify kernel: Euler-tour intervals in the caller's ids) on hit lists whose
+    taxa sit on one lineage, on side branches and in another tree, NONE among them, against the oracle's walks."""
+    import slacken_amd
+    rng = np.random.default_rng(17)
+    parents = deep_world["parents"]
+    leaves = deep_world["leaves"]
+    lists, flags = [], []
+    for r in range(1500):
+        kind = rng.random()
+        pool = []
+        for _ in range(int(rng.integers(1, 4))):                       # one to three lineages
+            path = path_to_root(parents, int(rng.choice(leaves)))
+            pool += [path[i] for i in sorted(rng.choice(len(path), size=min(len(path), int(rng.integers(1, 6))), replace=False))]
+        if kind < 0.1:
+            pool = pool[:1]
+        hits, dis = [], []
+        for _ in range(int(rng.integers(1, 60))):
+            u = rng.random()
+            if u < 0.05:
+                hits.append((-1, int(rng.integers(1, 40)))); dis.append(0)
+            elif u < 0.4:
+                hits.append((0, int(rng.integers(1, 8)))); dis.append(int(rng.random() < 0.7))
+            else:
+                hits.append((int(rng.choice(pool)), int(rng.integers(1, 6)))); dis.append(int(rng.random() < 0.7))
+        lists.append(hits)
+        flags.append(dis)
+    offs = np.cumsum([0] + [len(h) for h in lists]).astype(np.uint64)
+    flat = np.array([h for hs in lists for h in hs], slacken_amd.capi.HIT_DTYPE)
+    dflat = np.array([d for ds in flags for d in ds], np.uint8)
+    got = deep_world["st"].classify_hits(offs, flat, dflat, min_hit_groups=1, thresholds=THRESHOLDS)
+    for c, t in enumerate(THRESHOLDS):
+        for r, (hits, dis) in enumerate(zip(lists, flags)):
+            want = orc.classify_hits(parents, hits, dis, 1, t)
+            assert (int(got["taxon"][c, r]), bool(got["classified"][c, r])) == (want["taxon"], want["classified"]), (t, r, hits)
