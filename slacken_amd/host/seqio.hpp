@@ -16,6 +16,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include "parbz2.hpp"
 #include "pargz.hpp"
 #include "titles.hpp"
 
@@ -85,17 +86,98 @@ inline size_t gz_chunk_bytes() {  // SLK_GZ_CHUNK: compressed bytes per chunk (t
   return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)1 << 20;
 }
 
-// plain / gzip (zlib reads both) / bzip2 (through the system's libbz2: this image has no bzlib.h, so the three stable
-// high-level entry points are declared here and resolved at run time).  A gzip FILE of some size is inflated on several
-// threads (pargz.hpp); pipes, small files and SLK_GZ_THREADS=0 keep zlib's gzread.
-class ByteSource {
-  gzFile g_ = nullptr;
-  void *bz_ = nullptr;
-  int (*bzread_)(void *, void *, int) = nullptr;
-  void (*bzclose_)(void *) = nullptr;
-  std::unique_ptr<slk::pargz::Reader> pz_;
+// bzip2 from a pipe (or with SLK_GZ_THREADS=0): libbz2's streaming decoder, stream after stream -- a .bz2 file may be several
+// concatenated streams (pbzip2 writes such files; Hadoop's codec reads them through), which the library's BZ2_bzread stops after the
+// first of, silently.  This image has no bzlib.h: bz_stream is declared here as bzlib.h 1.0 declares it and the three entry points
+// are resolved at run time.
+class Bz2Stream {
+  struct bz_stream {
+    char *next_in; unsigned int avail_in, total_in_lo32, total_in_hi32;
+    char *next_out; unsigned int avail_out, total_out_lo32, total_out_hi32;
+    void *state;
+    void *(*bzalloc)(void *, int, int); void (*bzfree)(void *, void *); void *opaque;
+  };
+  int (*init_)(bz_stream *, int, int) = nullptr;
+  int (*run_)(bz_stream *) = nullptr;
+  int (*end_)(bz_stream *) = nullptr;
+  FILE *f_ = nullptr;
+  bz_stream z_{};
+  bool open_ = false, eof_ = false, any_stream_ = false;
+  std::vector<char> in_;
 
  public:
+  explicit Bz2Stream(const std::string &path) : in_((size_t)1 << 20) {
+    void *h = dlopen("libbz2.so.1", RTLD_NOW);
+    if (!h) h = dlopen("libbz2.so.1.0", RTLD_NOW);
+    if (!h) throw std::runtime_error("bzip2 input needs libbz2.so.1: " + path);
+    init_ = (int (*)(bz_stream *, int, int))dlsym(h, "BZ2_bzDecompressInit");
+    run_ = (int (*)(bz_stream *))dlsym(h, "BZ2_bzDecompress");
+    end_ = (int (*)(bz_stream *))dlsym(h, "BZ2_bzDecompressEnd");
+    if (!init_ || !run_ || !end_) throw std::runtime_error("libbz2 lacks BZ2_bzDecompressInit/BZ2_bzDecompress/BZ2_bzDecompressEnd");
+    f_ = fopen(path.c_str(), "rb");
+    if (!f_) throw std::runtime_error("cannot open " + path);
+  }
+  Bz2Stream(const Bz2Stream &) = delete;
+  ~Bz2Stream() {
+    if (open_) end_(&z_);
+    if (f_) fclose(f_);
+  }
+  size_t read(char *dst, size_t cap) {
+    size_t got = 0;
+    while (got < cap) {
+      if (z_.avail_in == 0 && !eof_) {
+        const size_t k = fread(in_.data(), 1, in_.size(), f_);
+        if (k == 0) eof_ = true;
+        z_.next_in = in_.data();
+        z_.avail_in = (unsigned int)k;
+      }
+      if (!open_) {
+        if (z_.avail_in == 0) {   // no further stream
+          if (!any_stream_) throw std::runtime_error("read error (corrupt compressed input?): not a bzip2 file");
+          break;
+        }
+        char *ni = z_.next_in;
+        const unsigned int ai = z_.avail_in;
+        z_ = bz_stream{};
+        z_.next_in = ni; z_.avail_in = ai;
+        if (init_(&z_, 0, 0) != 0) throw std::runtime_error("read error (corrupt compressed input?): libbz2 initialisation");
+        open_ = true;
+      }
+      z_.next_out = dst + got;
+      z_.avail_out = (unsigned int)std::min<size_t>(cap - got, 0x7FFFFFFF);
+      const unsigned int before = z_.avail_out;
+      const int rc = run_(&z_);
+      got += before - z_.avail_out;
+      if (rc == 4 /* BZ_STREAM_END */) {
+        end_(&z_);
+        open_ = false;
+        any_stream_ = true;
+        continue;
+      }
+      if (rc != 0) throw std::runtime_error("read error (corrupt compressed input?): bzip2 data");
+      if (eof_ && z_.avail_in == 0 && before == z_.avail_out) throw std::runtime_error("read error (corrupt compressed input?): unexpected end of the bzip2 data");
+    }
+    return got;
+  }
+};
+
+// plain / gzip (zlib reads both) / bzip2.  A gzip or bzip2 FILE is decompressed on several threads (pargz.hpp, parbz2.hpp);
+// pipes, small gzip files and SLK_GZ_THREADS=0 keep zlib's gzread and libbz2's streaming decoder.
+class ByteSource {
+  gzFile g_ = nullptr;
+  std::unique_ptr<Bz2Stream> bz_;
+  std::unique_ptr<slk::pargz::Reader> pz_;
+  std::unique_ptr<slk::parbz2::Reader> pb_;
+
+ public:
+  static size_t bz2_chunk_bytes() {  // SLK_BZ2_CHUNK: compressed bytes per chunk of a bzip2 file (tests: chunk borders everywhere)
+    const char *e = getenv("SLK_BZ2_CHUNK");
+    return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)2 << 20;
+  }
+  static bool regular_file(const std::string &path) {
+    struct stat sb;
+    return stat(path.c_str(), &sb) == 0 && S_ISREG(sb.st_mode);
+  }
   static bool gzip_file_worth_threads(const std::string &path, size_t chunk) {
     struct stat sb;
     if (stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode) || (size_t)sb.st_size < 2 * chunk) return false;
@@ -108,16 +190,11 @@ class ByteSource {
   }
 
   explicit ByteSource(const std::string &path) {
-    if (ends_with(path, ".bz2")) {
-      void *h = dlopen("libbz2.so.1", RTLD_NOW);
-      if (!h) h = dlopen("libbz2.so.1.0", RTLD_NOW);
-      if (!h) throw std::runtime_error("bzip2 input needs libbz2.so.1: " + path);
-      auto bzopen = (void *(*)(const char *, const char *))dlsym(h, "BZ2_bzopen");
-      bzread_ = (int (*)(void *, void *, int))dlsym(h, "BZ2_bzread");
-      bzclose_ = (void (*)(void *))dlsym(h, "BZ2_bzclose");
-      if (!bzopen || !bzread_ || !bzclose_) throw std::runtime_error("libbz2 lacks BZ2_bzopen/BZ2_bzread/BZ2_bzclose");
-      bz_ = bzopen(path.c_str(), "rb");
-      if (!bz_) throw std::runtime_error("cannot open " + path);
+    if (ends_with(path, ".bz2") && gz_threads() >= 1 && regular_file(path)) {
+      // blocks of a bzip2 file are independent: several threads (parbz2.hpp), as Hadoop's splittable codec gives the reference
+      pb_ = std::make_unique<slk::parbz2::Reader>(path, gz_threads(), bz2_chunk_bytes());
+    } else if (ends_with(path, ".bz2")) {
+      bz_ = std::make_unique<Bz2Stream>(path);
     } else if (gz_threads() >= 1 && gzip_file_worth_threads(path, gz_chunk_bytes())) {
       pz_ = std::make_unique<slk::pargz::Reader>(path, gz_threads(), gz_chunk_bytes());
     } else {
@@ -129,13 +206,14 @@ class ByteSource {
   ByteSource(const ByteSource &) = delete;
   ~ByteSource() {
     if (g_) gzclose(g_);
-    if (bz_) bzclose_(bz_);
   }
   size_t read(char *dst, size_t cap) {  // 0 at the end of the file
     if (pz_) return pz_->read(dst, cap);
-    int n = g_ ? gzread(g_, dst, (unsigned)cap) : bzread_(bz_, dst, (int)cap);
+    if (pb_) return pb_->read(dst, cap);
+    if (bz_) return bz_->read(dst, cap);
+    int n = gzread(g_, dst, (unsigned)cap);
     if (n < 0) throw std::runtime_error("read error (corrupt compressed input?)");
-    if (g_ && (size_t)n < cap) {   // a gzip file that ends inside a member: gzread hands out what there was and says so only here
+    if ((size_t)n < cap) {   // a gzip file that ends inside a member: gzread hands out what there was and says so only here
       int err = Z_OK;
       (void)gzerror(g_, &err);
       if (err == Z_BUF_ERROR) throw std::runtime_error("read error (corrupt compressed input?): unexpected end of the gzip data");

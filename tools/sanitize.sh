@@ -14,7 +14,7 @@ trap 'cp $T/oracle.orig oracle/libslacken_oracle.so; cp $T/cli.orig slacken_amd/
 cp $T/libslacken_oracle.so oracle/libslacken_oracle.so; cp $T/slacken-amd slacken_amd/bin/slacken-amd
 export ASAN_OPTIONS=detect_leaks=0
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) python -m pytest tests/test_oracle_kat.py tests/test_oracle_props.py tests/test_oracle_lca.py tests/test_oracle_build.py tests/test_golden.py tests/test_config1.py -x -q -m "not gpu"
-python -m pytest tests/test_host_cli.py tests/test_host_classify_gpu.py tests/test_pargz.py -x -q -m "not gpu"
+python -m pytest tests/test_host_cli.py tests/test_host_classify_gpu.py tests/test_pargz.py tests/test_parbz2.py -x -q -m "not gpu"
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) python -m pytest tests/test_title_grouping.py -x -q   # (loads the instrumented oracle too)
 SLK_IO_CHUNK=3 python -m pytest tests/test_host_cli.py -x -q
 # ThreadSanitizer over the threaded readers (segment parser, per-file inflate threads, batch prefetcher, recyclers)
@@ -25,4 +25,4 @@ cp $T/slacken-amd-tsan slacken_amd/bin/slacken-amd
 cp $T/oracle.orig oracle/libslacken_oracle.so
 TSAN_OPTIONS=halt_on_error=1 SLK_PARSE_THREADS=6 python -m pytest tests/test_host_cli.py tests/test_title_grouping.py -x -q -k "parse or parser or round_trip or regroup"
 # ... and over the parallel inflate (workers chained in file order, consumers parsing the buffer while it fills)
-TSAN_OPTIONS=halt_on_error=1 python -m pytest tests/test_pargz.py -x -q
+TSAN_OPTIONS=halt_on_error=1 python -m pytest tests/test_pargz.py tests/test_parbz2.py -x -q
