@@ -7,7 +7,8 @@
 // 0x177245385090; a block carries its own CRC.  So: the file is cut into chunks, a worker scans its chunk for block magics bit by
 // bit, and for every block that STARTS in its chunk builds a one-block stream in memory -- "BZh9", the block's bits shifted to a
 // byte boundary, the end-of-stream magic, the block's CRC as the stream's -- and hands it to BZ2_bzBuffToBuffDecompress.  (A
-// false magic inside compressed data has probability 2^-48 per position and fails the CRC.)  Concatenated streams are just more
+// false magic inside compressed data has probability 2^-48 per bit position -- about 0.003 per 100 GB of file -- and fails loudly, on
+// the block's CRC; SLK_GZ_THREADS=0 reads such a file through libbz2's own streaming decoder.)  Concatenated streams are just more
 // blocks.  read() hands the text out in file order.
 #pragma once
 #include <dlfcn.h>
