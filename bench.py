@@ -23,6 +23,13 @@ Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused
 `cpu_baseline` times the CPU restatement under oracle/ (OpenMP, all host cores) on a bounded sample -- a reported
 baseline, not the target.
 
+--table-sharded (BASELINE.json configs[3]): the library is larger than one GPU's HBM, so rank g holds only the records whose key
+falls to it (fmix64(key) mod N; slk_index_set_shard) -- by default 5.0e9 records per rank, 4.0e10 at N = 8 (> 288 GB of table) --
+and a step is one 10 M-read batch per rank through scan -> keys to their owners (all-to-all over RCCL / xGMI) -> lookup -> taxa
+back -> per-read LCA (slacken_amd/sharded.py).  The K timed steps are K batches in the two-stream pipeline.  The line carries the
+stages' device times, the bytes exchanged per read, the per-link rate against the 153 GB/s xGMI link and the lookup stage's share
+of the part's random-request rate.
+
 --dry-run: no GPU, no engine: every rank times a trivial numpy step and goes through the same rendezvous (gloo), barrier,
 max-over-ranks and reporting code, so that the N-rank plumbing can be tested on a CPU box.
 """
@@ -181,6 +188,212 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+XGMI_LINK_GBPS = 153.0   # per direction and link; a GPU has 7 (one to each peer of an 8-GPU node)
+
+
+def dry_run_sharded(args, rank, world):
+    """The table-sharded exchange without a GPU: every rank owns the keys that fall to it (slacken_amd.sharded.shard_of_numpy),
+    sends its queries to their owners through the same Exchange the GPU path uses (split sizes with the overflow flag riding on
+    them, keys out, answers back in the same order; gloo here), and checks every answer against the whole table."""
+    import torch
+    from slacken_amd import dist as sdist
+    from slacken_amd import sharded
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    ex = sharded.Exchange(rank, world, dist, torch.device("cpu"))
+    rng = np.random.default_rng(224)
+    table_keys = np.unique(rng.integers(-2**62, 2**62, 50000, dtype=np.int64))
+    table_taxa = rng.integers(1, 1000, len(table_keys)).astype(np.int32)
+    mine = sharded.shard_of_numpy(table_keys, world) == rank
+    my_keys, my_taxa = table_keys[mine], table_taxa[mine]          # (sorted: np.unique)
+    n_reads = int(args.reads)
+    qrng = np.random.default_rng(150 + rank)
+
+    def step(flag):
+        q = np.where(qrng.random(n_reads) < 0.7, qrng.choice(table_keys, n_reads), qrng.integers(-2**62, 2**62, n_reads, dtype=np.int64))
+        owner = sharded.shard_of_numpy(q, world)
+        order = np.argsort(owner, kind="stable")
+        send_counts = np.bincount(owner, minlength=world).tolist()
+        recv_counts, any_flag = ex.split_sizes(send_counts, flag)
+        got = ex.all_to_all(torch.from_numpy(q[order]), send_counts, recv_counts).numpy()
+        at = np.searchsorted(my_keys, got)
+        at[at >= len(my_keys)] = 0
+        ans = np.where(len(my_keys) and my_keys[at] == got, my_taxa[at], 0).astype(np.int32) if len(my_keys) else np.zeros(len(got), np.int32)
+        back = ex.all_to_all(torch.from_numpy(ans), recv_counts, send_counts).numpy()
+        taxa = np.empty(n_reads, np.int32)
+        taxa[order] = back
+        ref_at = np.searchsorted(table_keys, q)
+        ref_at[ref_at >= len(table_keys)] = 0
+        want = np.where(table_keys[ref_at] == q, table_taxa[ref_at], 0)
+        if not np.array_equal(taxa, want):
+            raise SystemExit(f"rank {rank}: the exchange returned wrong answers")
+        return any_flag, len(q)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    flags = []
+    for i in range(args.warmup):
+        flags.append(step(rank == world - 1 and i == 0)[0])      # the last rank raises its flag once: every rank must see it
+    barrier()
+    t0 = time.perf_counter()
+    sent = 0
+    for _ in range(args.steps):
+        f, n = step(False)
+        flags.append(f)
+        sent += n
+    barrier()
+    elapsed = sdist.max_over_ranks(time.perf_counter() - t0, dist, None)
+    counts = sdist.allreduce_counts(np.array([n_reads, sent], np.int64), dist, None)
+    if args.warmup and flags[:1] != [True] or any(flags[1:]):
+        raise SystemExit(f"rank {rank}: overflow flags {flags}")
+    if rank == 0:
+        print(json.dumps({"metric": "classify_throughput_150bp_standard224scale", "value": None, "unit": "M reads/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "dry run of the table-sharded exchange: no GPU work, every answer checked",
+                                     "parallelism": f"table-sharded x{world}", "reads_all_ranks_per_step": int(counts[0]),
+                                     "keys_exchanged_all_ranks": int(counts[1])}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def table_sharded(args, rank, world, local_rank):
+    """BASELINE.json configs[3] (module docstring).  One rank = one GPU = 1/N of the table."""
+    import torch
+    from slacken_amd import dist as sdist
+    from slacken_amd import sharded
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")     # (RCCL refuses two ranks on one GPU; the exchange is staged through host memory)
+        else:
+            dist.init_process_group("nccl", device_id=device)
+    import slacken_amd
+    n_reads, per_rank = int(args.reads), int(args.records_per_rank)
+    t0 = time.time()
+    parents, taxa, leaves = build_taxonomy()
+    rng = np.random.default_rng(224)
+    G = min(args.genomes, len(leaves))
+    genome_taxa = rng.choice(leaves, size=G, replace=False).astype(np.int32)
+    genome_cat = make_genomes_device(torch, G, args.genome_len, 224 + 1, device)     # (the same genomes on every rank)
+    g_offsets = np.arange(0, (G + 1) * args.genome_len, args.genome_len, dtype=np.uint64)
+
+    # ---- this rank's shard of the table: every rank scans all genomes and draws the same padding keys, and keeps its share
+    expect_genome = int(G * args.genome_len * 0.36 / world * 1.1) + 4096
+    ix = slacken_amd.Index(k=K, m=M, spaces=SPACES, expected_records=max(per_rank, expect_genome), max_taxon=TAX_EXTENT - 1,
+                           load_factor=args.load_factor, device=local_rank)
+    ix.set_shard(rank, world)
+    ix.set_taxonomy(parents)
+    ix.add_sequences_device(genome_cat.data_ptr(), g_offsets, genome_taxa)
+    n_genome_records = int(ix.info().records)
+    log(f"rank {rank}: {n_genome_records} genome records of this shard ({time.time() - t0:.1f}s)")
+    smask = ((2**62 - 1) & ~0x0CCCCCCC) << 2
+    smask_i64 = smask - (1 << 64) if smask >= (1 << 63) else smask
+    d_taxa = torch.from_numpy(taxa).to(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(224 + 7)                                   # (one global key stream; a rank keeps the keys that fall to it)
+    CH = 1 << 27
+    while int(ix.info().records) < per_rank:
+        hi = torch.randint(0, 2**32, (CH,), generator=gen, device=device, dtype=torch.int64)
+        lo = torch.randint(0, 2**32, (CH,), generator=gen, device=device, dtype=torch.int64)
+        keys = ((hi << 32) | lo) & smask_i64
+        del hi, lo
+        tx = d_taxa[torch.randint(0, len(taxa), (CH,), generator=gen, device=device)]
+        if world > 1:                                          # (the engine would drop the others itself; this spares it the copy)
+            keep = sharded.shard_of_torch(keys, world) == rank
+            keys, tx = keys[keep].contiguous(), tx[keep].contiguous()
+        n = min(int(keys.numel()), per_rank - int(ix.info().records))
+        torch.cuda.synchronize()
+        ix.append_device(keys.data_ptr(), tx.data_ptr(), n)
+        del keys, tx
+    ix.finalize()
+    info = ix.info()
+    torch.cuda.empty_cache()
+    log(f"rank {rank}: shard {rank}/{world}: {info.records} records in {info.table_bytes / 2**30:.1f} GiB, load "
+        f"{info.records / (info.buckets * info.bucket_cells):.2f} ({time.time() - t0:.1f}s)")
+
+    d_bases, d_offsets = make_reads_device(torch, genome_cat, args.genome_len, G, n_reads, 150 + rank, device)
+    del genome_cat
+    torch.cuda.empty_cache()
+    total_bases = n_reads * READ_LEN
+    sc = sharded.ShardedClassifier(ix, rank, world, dist, device, exchange_on_cpu=args.rehearse_on_one_gpu)
+    batch = (d_bases, d_offsets, n_reads, total_bases, None)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    outs = sc.classify_many([batch] * max(1, args.warmup), thresholds=(0.0,), min_hit_groups=2)
+    if outs is None:
+        raise SystemExit("the fast sharded route does not take this splitter")
+    barrier()
+    t_start = time.perf_counter()
+    outs = sc.classify_many([batch] * args.steps, thresholds=(0.0,), min_hit_groups=2, profile=True)   # K steps = K batches in the pipeline
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    elapsed = sdist.max_over_ranks(elapsed, dist, None if args.rehearse_on_one_gpu else device)
+    ms_per_step = elapsed / args.steps * 1e3
+    reads_per_s = world * n_reads / (elapsed / args.steps)
+    o = outs[-1]
+    stage = sc.stage_ms or {}
+    keys_per_batch, remote = int(o["exchanged_keys"]), int(o["sent_remote_keys"])
+    looked_up = int(o["looked_up_keys"])
+    classified = float(o["classified"][:n_reads].float().mean().item())
+    x_ms = stage.get("exchange_keys", 0.0)
+    per_link = (remote / max(1, world - 1)) * 8 / (x_ms * 1e-3) / 1e9 if world > 1 and x_ms > 0 else None
+    lookup_ms = stage.get("lookup", 0.0)
+    lookup_rate = looked_up / (lookup_ms * 1e-3) / 1e9 if lookup_ms > 0 else None
+    # algorithmic bytes of a step on one rank (SURVEY 8d's B(r), with the probes served by whichever rank owns them) against the
+    # WHOLE pipeline's time per step: the path has four kernels here, and none of them is "the" kernel
+    bytes_per_step = total_bases + 64 * looked_up + 8 * n_reads
+    out = {
+        "metric": "classify_throughput_150bp_standard224scale", "value": round(reads_per_s / 1e6, 3), "unit": "M reads/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        **({"rehearsal": "all ranks on GPU 0, exchange through host memory (gloo): not a measurement"} if args.rehearse_on_one_gpu else {}),
+        "config": {
+            "workload": "oversized custom library, hash-sharded over the GPUs (k=35,m=31,s=7), synthetic 150 bp single-end reads; "
+                        "minimizers to their owners and taxa back by all-to-all (BASELINE.json configs[3])",
+            "parallelism": f"table-sharded x{world}", "records_per_rank": int(info.records), "records_all_ranks": int(info.records) * world,
+            "table_GiB_per_rank": round(info.table_bytes / 2**30, 1), "table_GB_all_ranks": round(info.table_bytes * world / 1e9, 1),
+            "exceeds_one_gpu_288GB": bool(info.table_bytes * world > 288e9),
+            "bucket_bytes": int(info.bucket_cells) * 8, "table_load": round(info.records / (info.buckets * info.bucket_cells), 3),
+            "genomes": G, "genome_len": args.genome_len, "reads_per_gpu_per_step": n_reads, "read_len": READ_LEN,
+            "classified_fraction": round(classified, 4), "deferred_to_staged_route": int(o.get("deferred", 0)),
+            "stage_ms_in_pipeline": {k: round(v, 3) for k, v in stage.items()},
+            "keys_per_read": round(keys_per_batch / n_reads, 3),
+            "exchanged_bytes_per_read": round(12.0 * keys_per_batch / n_reads, 1),     # 8-byte key out, 4-byte taxon back
+            "remote_bytes_per_read": round(12.0 * remote / n_reads, 1),
+            "xgmi_link_GBps_keys": None if per_link is None else round(per_link, 1), "xgmi_link_peak_GBps": XGMI_LINK_GBPS,
+            "xgmi_link_frac": None if per_link is None else round(per_link / XGMI_LINK_GBPS, 3),
+        },
+        "roofline": {"bound": "hbm", "kernel": "the sharded pipeline: lane_kernel<EMIT>, list compaction, lookup_coop_kernel, lane_kernel<APPLY> "
+                                               "on two streams, beside the exchange", "achieved": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9, 1),
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                     "traffic": None, "algorithmic_bytes_per_launch": bytes_per_step, "kernel_ms": round(ms_per_step, 3),
+                     "lookup_stage_Grequests_per_s": None if lookup_rate is None else round(lookup_rate, 2),
+                     "random_line_ceiling_Glines_per_s": GATHER_CEILING_GLPS,
+                     "lookup_stage_frac_of_request_rate_ceiling": None if lookup_rate is None else round(lookup_rate / GATHER_CEILING_GLPS, 3)},
+    }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,7 +403,11 @@ def main():
     ap.add_argument("--reads", type=float, default=1.0e7, help="150 bp reads per GPU per step")
     ap.add_argument("--genomes", type=int, default=8192)
     ap.add_argument("--genome-len", type=int, default=1 << 20)
+    ap.add_argument("--load-factor", type=float, default=0.0, help="cells-used fraction of the table (0: the engine's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--table-sharded", action="store_true",
+                    help="BASELINE configs[3]: every rank holds 1/N of the table, minimizers and taxa cross the links (RCCL all-to-all)")
+    ap.add_argument("--records-per-rank", type=float, default=5.0e9, help="--table-sharded: records of one rank's shard")
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing only (gloo, no GPU)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N ranks that all use GPU 0 (gloo for the rendezvous): rehearses the N-rank GPU path on a one-GPU box; "
@@ -207,7 +424,9 @@ def main():
         raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}; start it as `python bench.py --gpus N` or "
                          f"under torch.distributed.run with --nproc-per-node equal to --gpus")
     if args.dry_run:
-        return dry_run(args, rank, world)
+        return dry_run_sharded(args, rank, world) if args.table_sharded else dry_run(args, rank, world)
+    if args.table_sharded:
+        return table_sharded(args, rank, world, local_rank)
 
     import torch
     if not torch.cuda.is_available():
@@ -240,7 +459,7 @@ def main():
     # distinct minimizers of the genomes: about 2/(w+1) per k-mer window on random sequence (w = 5)
     expect_genome = int(G * args.genome_len * 0.36) + 1024
     ix = slacken_amd.Index(k=K, m=M, spaces=SPACES, expected_records=max(n_records, expect_genome),
-                           max_taxon=TAX_EXTENT - 1, device=local_rank)
+                           max_taxon=TAX_EXTENT - 1, load_factor=args.load_factor, device=local_rank)
     ix.set_taxonomy(parents)
     ix.add_sequences_device(genome_cat.data_ptr(), g_offsets, genome_taxa)
     n_genome_records = int(ix.info().records)
@@ -263,9 +482,11 @@ def main():
         del keys, tx
     ix.finalize()
     info = ix.info()
+    if not info.bucket_cells:   # (an A/B library of an earlier round: 64-byte buckets, no such field)
+        info.bucket_cells = 8
     torch.cuda.empty_cache()
     log(f"rank {rank}: table {info.records} records in {info.table_bytes / 2**30:.1f} GiB "
-        f"(2^{info.bucket_bits} buckets, load {info.records / (info.buckets * 8):.2f}, max displacement "
+        f"({info.buckets} buckets of {info.bucket_cells * 8} bytes, load {info.records / (info.buckets * info.bucket_cells):.2f}, max displacement "
         f"{info.max_displacement}, {info.duplicate_keys} duplicate pad keys dropped) ({time.time() - t0:.1f}s)")
 
     # ---- reads resident in HBM
@@ -356,7 +577,8 @@ def main():
         "config": {
             "workload": "standard-224-scale synthetic library (k=35,m=31,s=7), synthetic 150 bp single-end reads, "
                         "full table resident in HBM (BASELINE.json configs[1])",
-            "records": int(info.records), "table_GiB": round(info.table_bytes / 2**30, 1),
+            "records": int(info.records), "table_GiB": round(info.table_bytes / 2**30, 1), "bucket_bytes": int(info.bucket_cells) * 8,
+            "table_load": round(info.records / (info.buckets * info.bucket_cells), 3), "max_displacement": int(info.max_displacement),
             "genomes": G, "genome_len": args.genome_len, "genome_records": n_genome_records,
             "reads_per_gpu_per_step": n_reads, "read_len": READ_LEN, "parallelism": f"read-sharded x{world}, table replicated",
             "probes_per_read": round(probes / n_reads, 3), "classified_fraction": round(classified, 4),

@@ -75,21 +75,22 @@ typedef struct {
 typedef struct {
   uint64_t expected_records; /* upper bound on records that will be appended */
   int32_t max_taxon;         /* largest taxon id that will be appended (0 = derive from nothing: 2^22-1) */
-  float load_factor;         /* target cells-used fraction, 0 = default: 0.70, less for tables whose cells leave under 6 bits to the displacement */
+  float load_factor;         /* target cells-used fraction, 0 = default: 0.55 while the table then takes at most 55 % of the device's
+                                memory, more for larger libraries (0.80 at most); less for tables whose cells leave a short displacement field */
 } slk_table_config;
 
 typedef struct {
   uint64_t records;       /* records stored (taxon != NONE) */
-  uint64_t buckets;       /* 64-byte buckets */
+  uint64_t buckets;       /* buckets of bucket_cells 8-byte cells (any number: not a power of two) */
   uint64_t table_bytes;
-  int32_t bucket_bits, taxon_bits, disp_bits;
+  int32_t bucket_bits, taxon_bits, disp_bits; /* bucket_bits = ceil(log2(buckets)) */
   int32_t max_displacement; /* largest bucket displacement in use (0 = every record in its home bucket) */
   uint64_t duplicate_keys;  /* appended records whose key was already present (contract violation; first kept) */
   int32_t taxonomy_size;
   int32_t device;
   int32_t dense_taxa;       /* > 0: taxon ids beyond 22 bits were renumbered internally at slk_index_finalize (the number of
                                taxonomy nodes); every taxon that crosses this ABI is still the caller's id */
-  int32_t reserved;
+  int32_t bucket_cells;     /* 8-byte cells per bucket: 8 (64-byte buckets; a build option makes it 16) */
 } slk_index_info;
 
 /* OrdinalSpan (S/slacken/package.scala:61-62) without the title; ordinal = position in the read's span list.
@@ -128,6 +129,12 @@ int32_t slk_index_create(const slk_params *params, const slk_table_config *cfg, 
  * groupBy, KeyValueIndex.scala:85-93).  Records with taxon == NONE are skipped (indistinguishable from a miss). */
 int32_t slk_index_append(slk_index *ix, const int64_t *keys, const int32_t *taxa, uint64_t n);
 int32_t slk_index_append_device(slk_index *ix, const int64_t *d_keys, const int32_t *d_taxa, uint64_t n);
+/* Table-sharded libraries (a table beyond one GPU's memory; BASELINE.json configs[3], the exchange that replaces the shuffle of
+ * the join at S/slacken/Classifier.scala:84): this index keeps only the records whose key falls to `shard` of `n_shards`
+ * (slk_shard_of) and drops the others where they arrive, in slk_index_append[_device] and slk_index_add_sequences[_device] alike --
+ * every rank / device is handed the same record stream or the same genomes and ends up with its share.  Call before the first
+ * record; slk_table_config.expected_records then bounds this shard's records. */
+int32_t slk_index_set_shard(slk_index *ix, uint32_t shard, uint32_t n_shards);
 /* parents[t] = parent taxon, parents[ROOT] = NONE, unused ids = NONE: Taxonomy.parents (S/slacken/Taxonomy.scala:81-109,159);
  * replaces the bcTaxonomy broadcast (KeyValueIndex.scala:44-47). */
 int32_t slk_index_set_taxonomy(slk_index *ix, const int32_t *parents, int32_t T);
@@ -157,6 +164,12 @@ int32_t slk_index_finalize(slk_index *ix);
  * `capacity` were written and SLK_E_CAPACITY is returned.  keys/taxa may be NULL with capacity 0 to query the count. */
 int32_t slk_index_export(const slk_index *ix, int64_t *keys, int32_t *taxa, uint64_t capacity, uint64_t *n_records);
 int32_t slk_index_get_info(const slk_index *ix, slk_index_info *out);
+/* The table's bucket choice as host arithmetic (no GPU): the range reduction of a 64-bit hash onto ANY number of buckets
+ * (32 <= nbuckets <= 2^32) -- home = (top q bits of hash) * nbuckets >> q, q = ceil(log2(nbuckets)) -- with the remainder a cell
+ * keeps so that (home, rem) still identifies the hash (the table is lossless, unlike a compact hash table with truncated keys),
+ * and its inverse.  For tests and for tools that lay out tables offline. */
+int32_t slk_table_slot(uint64_t nbuckets, uint64_t hash, uint32_t *home, uint64_t *rem);
+int32_t slk_table_hash_of(uint64_t nbuckets, uint32_t home, uint64_t rem, uint64_t *hash);
 /* Point lookups (host arrays), for tests and tooling: taxon or NONE per key -- the left join + spanToHit's
  * otherwise(NONE) (KeyValueIndex.scala:176-185). */
 int32_t slk_index_lookup(const slk_index *ix, const int64_t *keys, uint64_t n, int32_t *out_taxa);

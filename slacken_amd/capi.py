@@ -35,7 +35,7 @@ class IndexInfo(C.Structure):
     _fields_ = [("records", C.c_uint64), ("buckets", C.c_uint64), ("table_bytes", C.c_uint64),
                 ("bucket_bits", C.c_int32), ("taxon_bits", C.c_int32), ("disp_bits", C.c_int32),
                 ("max_displacement", C.c_int32), ("duplicate_keys", C.c_uint64), ("taxonomy_size", C.c_int32),
-                ("device", C.c_int32), ("dense_taxa", C.c_int32), ("reserved", C.c_int32)]
+                ("device", C.c_int32), ("dense_taxa", C.c_int32), ("bucket_cells", C.c_int32)]
 
 
 SPAN_DTYPE = np.dtype([("key", "<i8"), ("kmers", "<i4"), ("flag", "i1"), ("distinct", "u1"), ("pad", "<u2")])
@@ -43,12 +43,12 @@ HIT_DTYPE = np.dtype([("taxon", "<i4"), ("count", "<i4")])
 
 # every symbol include/slacken_amd.h declares
 EXPORTS = ["slk_device_count", "slk_last_error", "slk_version", "slk_host_alloc", "slk_host_register", "slk_host_free", "slk_index_create", "slk_index_append",
-           "slk_index_append_device", "slk_index_set_taxonomy", "slk_index_finalize", "slk_index_get_info",
+           "slk_index_append_device", "slk_index_set_shard", "slk_index_set_taxonomy", "slk_index_finalize", "slk_index_get_info",
            "slk_index_lookup", "slk_index_add_sequences", "slk_index_add_sequences_device", "slk_index_export", "slk_index_destroy", "slk_stream_create", "slk_stream_synchronize",
            "slk_stream_hip_stream", "slk_stream_destroy", "slk_spans_batch", "slk_classify_batch",
            "slk_classify_batch_device", "slk_classify_hits", "slk_stream_last_stage_ms", "slk_scan_device", "slk_lookup_device",
            "slk_shard_of", "slk_classify_hits_device", "slk_shard_batch_rows", "slk_shard_emit_device", "slk_shard_compact_device",
-           "slk_shard_apply_device", "slk_stream_last_deferred"]
+           "slk_shard_apply_device", "slk_stream_last_deferred", "slk_table_slot", "slk_table_hash_of"]
 
 
 def lib_path():
@@ -80,6 +80,9 @@ def lib():
     L.slk_index_append.argtypes = [vp, i64p, i32p, C.c_uint64]
     L.slk_index_append_device.argtypes = [vp, i64p, i32p, C.c_uint64]
     L.slk_index_set_taxonomy.argtypes = [vp, i32p, C.c_int32]
+    L.slk_table_slot.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    L.slk_table_hash_of.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.slk_index_set_shard.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.slk_index_finalize.argtypes = [vp]
     L.slk_index_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
     L.slk_index_lookup.argtypes = [vp, i64p, C.c_uint64, i32p]
@@ -190,6 +193,10 @@ class Index:
 
     def append_device(self, d_keys_ptr, d_taxa_ptr, n):
         _check(lib().slk_index_append_device(self.h, d_keys_ptr, d_taxa_ptr, n))
+
+    def set_shard(self, shard, n_shards):
+        """Table-sharded library: keep only the records whose key falls to `shard` of `n_shards` (before the first record)."""
+        _check(lib().slk_index_set_shard(self.h, shard, n_shards))
 
     def set_taxonomy(self, parents):
         parents = _np(parents, np.int32)

@@ -42,18 +42,21 @@ __device__ int32_t tax_lca(const int32_t *parents, int32_t ntax, int32_t a, int3
   return a != 0 ? a : 1;
 }
 
-// Insert (key, taxon) or merge the taxon into the existing record.  Returns 1 if a new record was created, 0 if merged,
-// -1 if no cell could be found within the displacement limit.
+// Insert (key, taxon) or merge the taxon into the existing record.  Returns 1 if a new record was created, 0 if merged (or
+// the key belongs to another rank's shard of the table), -1 if no cell could be found within the displacement limit.
 __device__ int insert_merge(const TableBuild &t, const int32_t *parents, int32_t ntax, uint64_t key, int32_t taxon, int &max_d) {
   const uint64_t h = fmix64(key);
-  const uint64_t home = h >> t.shift;
-  const uint64_t rem_hi = (h & t.rem_mask) << t.disp_bits;
-  const unsigned long long tmask = (1ULL << t.taxon_bits) - 1;
+  if (!shard_keeps(t, h)) return 0;
+  uint32_t home;
+  uint64_t rem_hi;
+  table_slot(t.g, h, home, rem_hi);
+  const unsigned long long tmask = (1ULL << t.g.taxon_bits) - 1;
   for (int d = 0; d <= t.disp_limit; d++) {
-    unsigned long long *bucket = (unsigned long long *)(t.cells + (((home + d) & t.bucket_mask) << 3));
+    unsigned long long *bucket = (unsigned long long *)(t.cells + ((uint64_t)table_bucket(t.g, home, (uint32_t)d) * CELLS));
     const unsigned long long tag = rem_hi | (uint64_t)d;
-    const unsigned long long val = (tag << t.taxon_bits) | (uint32_t)taxon;
-    for (int c = 0; c < 8; c++) {
+    const unsigned long long val = (tag << t.g.taxon_bits) | (uint32_t)taxon;
+    unsigned long long first = 0;
+    for (int c = 0; c < CELLS; c++) {
       unsigned long long cur = __hip_atomic_load(&bucket[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (cur == 0) {
         unsigned long long old = atomicCAS(&bucket[c], 0ULL, val);
@@ -63,18 +66,21 @@ __device__ int insert_merge(const TableBuild &t, const int32_t *parents, int32_t
         }
         cur = old;  // somebody else took this cell: it may be this very key
       }
-      if ((cur >> t.taxon_bits) == tag) {
+      if (c == 0) first = cur;
+      if (cell_tag(t.g, cur) == tag) {
         for (;;) {
           int32_t old_taxon = (int32_t)(cur & tmask);
           int32_t merged = tax_lca(parents, ntax, old_taxon, taxon);
           if (merged == old_taxon) return 0;
-          unsigned long long want = (cur & ~tmask) | (uint32_t)merged;
+          unsigned long long want = (cur & ~tmask) | (uint32_t)merged;   // (the bucket flag in a first cell's top bit stays)
           unsigned long long prev = atomicCAS(&bucket[c], cur, want);
           if (prev == cur) return 0;
-          cur = prev;
+          cur = prev;    // (the taxon was merged by another lane, or the bucket flag was raised meanwhile: again)
         }
       }
     }
+    // full, and the key is not here: the record goes on, and the bucket says so from now on (engine.h: TableGeom.flag)
+    if (t.g.flag && !(first & t.g.flag)) atomicOr(&bucket[0], (unsigned long long)t.g.flag);
   }
   return -1;
 }
@@ -203,13 +209,13 @@ __host__ __device__ inline uint64_t fmix64_inverse(uint64_t x) {
 }
 
 // Every occupied cell back to its (key, taxon) record: the cell holds the hash remainder and its displacement, the bucket
-// index gives the home bucket, and fmix64 is a bijection.
+// index gives the home bucket, and both the range reduction (engine.h: table_hash_of) and fmix64 are invertible.
 __global__ void __launch_bounds__(256) export_kernel(TableView T, uint64_t ncells, int64_t *__restrict__ keys,
                                                      int32_t *__restrict__ taxa, uint64_t capacity,
                                                      unsigned long long *__restrict__ counter) {
   uint64_t i;
   const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t tmask = (1ULL << T.taxon_bits) - 1, dmask = (1ULL << T.disp_bits) - 1;
+  const uint64_t tmask = (1ULL << T.g.taxon_bits) - 1, dmask = (1ULL << T.g.disp_bits) - 1;
   for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < ncells; base += step) {  // wave-uniform trip count
     i = base + threadIdx.x;
     uint64_t cell = i < ncells ? T.cells[i] : 0;
@@ -223,9 +229,10 @@ __global__ void __launch_bounds__(256) export_kernel(TableView T, uint64_t ncell
     const int leader = __ffsll((long long)mask) - 1;
     first = ((unsigned long long)(uint32_t)__shfl((int)(first >> 32), leader) << 32) | (uint32_t)__shfl((int)first, leader);
     if (!has) continue;
-    uint64_t tag = cell >> T.taxon_bits;
-    uint64_t home = ((i >> 3) - (tag & dmask)) & T.bucket_mask;
-    uint64_t h = (T.shift >= 64 ? 0 : (home << T.shift)) | (tag >> T.disp_bits);
+    const uint64_t tag = cell_tag(T.g, cell);
+    const uint64_t bucket = i / CELLS, d = tag & dmask;
+    const uint32_t home = (uint32_t)(bucket >= d ? bucket - d : bucket + T.g.nbuckets - d);
+    const uint64_t h = table_hash_of(T.g, home, tag >> T.g.disp_bits);
     unsigned long long slot = first + before;
     if (slot < capacity) {
       keys[slot] = (int64_t)fmix64_inverse(h);
@@ -249,7 +256,7 @@ void launch_build(const ScanParams &P, const TableBuild &T, const int32_t *paren
 
 void launch_export(const TableView &T, uint64_t nbuckets, int64_t *keys, int32_t *taxa, uint64_t capacity,
                    unsigned long long *counter, hipStream_t s) {
-  uint64_t ncells = nbuckets * 8;
+  uint64_t ncells = nbuckets * CELLS;
   uint64_t blocks = std::min<uint64_t>((ncells + 255) / 256, 256 * 64);
   hipLaunchKernelGGL(export_kernel, dim3((unsigned)blocks), dim3(256), 0, s, T, ncells, keys, taxa, capacity, counter);
 }

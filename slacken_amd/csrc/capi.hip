@@ -189,7 +189,9 @@ struct slk_index {
   ScanParams sp{};
   uint64_t *cells = nullptr;
   uint64_t nbuckets = 0;
-  int32_t bucket_bits = 0, taxon_bits = 0, disp_bits = 0;
+  int32_t bucket_bits = 0, taxon_bits = 0, disp_bits = 0;   // bucket_bits = ceil(log2(nbuckets)): the hash bits that choose the bucket
+  bool bucket_flag = false;        // the cells keep their top bit for the buckets' "a record went past" flag (engine.h: TableGeom.flag)
+  uint32_t shard = 0, n_shards = 0;  // slk_index_set_shard: keep only the records of this shard
   int32_t *d_max_disp = nullptr;
   unsigned long long *d_counters = nullptr;  // inserted, duplicate, overflow
   int32_t *d_parents = nullptr;   // the taxonomy as given (ids of the caller)
@@ -210,14 +212,20 @@ struct slk_index {
   WideParams wp{};
   WideTable wt{};
 
+  TableGeom geom() const {
+    TableGeom g{};
+    g.nbuckets = nbuckets;
+    g.q = bucket_bits;
+    g.rem_mask = (1ULL << (64 - bucket_bits)) - 1;
+    g.flag = bucket_flag ? (1ULL << 63) : 0;
+    g.taxon_bits = taxon_bits;
+    g.disp_bits = disp_bits;
+    return g;
+  }
   TableView view() const {
     TableView v;
     v.cells = cells;
-    v.bucket_mask = nbuckets - 1;
-    v.shift = 64 - bucket_bits;
-    v.rem_mask = (v.shift >= 64) ? ~0ULL : ((1ULL << v.shift) - 1);
-    v.taxon_bits = taxon_bits;
-    v.disp_bits = disp_bits;
+    v.g = geom();
     v.max_disp = max_disp;
     v.to_orig = d_to_orig;
     return v;
@@ -470,22 +478,52 @@ int32_t slk_index_create(const slk_params *p, const slk_table_config *cfg, int32
   int32_t max_taxon = cfg->max_taxon > 0 ? cfg->max_taxon : ((1 << 22) - 1);
   int tb = 1;
   while (tb < 31 && (1LL << tb) <= (long long)max_taxon) tb++;
-  float lf = cfg->load_factor > 0 ? cfg->load_factor : 0.70f;
-  if (lf > 0.95f) lf = 0.95f;
-  uint64_t cells_needed = (uint64_t)((double)std::max<uint64_t>(cfg->expected_records, 1) / lf) + 8;
-  int bb = std::max(tb + 4, ceil_log2_u64((cells_needed + 7) / 8));  // >= 4 displacement bits: 15 buckets of linear probing
-  // A cell holds remainder + displacement + taxon in 64 bits, so the displacement field has bucket_bits - taxon_bits bits (6 at
-  // most are used: 63 buckets).  Where that leaves fewer -- mid-size tables under wide taxon ids: 3e8 records with NCBI's ids have
-  // 4, i.e. 15 buckets -- a table filled to 0.7 can run out of reach (one in ~800 random tables of the test suite did, loudly:
-  // SLK_E_CAPACITY).  With the default load factor such a table is made larger until either field or load is comfortable.
-  if (!(cfg->load_factor > 0))
-    while (bb - tb < 6 && bb < 40 && (double)cfg->expected_records / ((double)(1ULL << bb) * 8.0) > 0.45) bb++;
-  if (bb > 40) { delete ix; return fail(SLK_E_CAPACITY, "table of 2^%d buckets is too large", bb); }
-  ix->bucket_bits = bb;
+  // Load factor.  Given: as given (at most 0.95).  Default: the table takes the memory the device has -- filled to 0.55 where that
+  // costs at most 55 % of the HBM, fuller for larger libraries, 0.8 at most (2.0e10 records on a 288 GB part: 200 GB).  Measured
+  // at 1.0e10 records, 64-byte buckets (profiles/r03_bucket_geometry.txt): load 0.45 1 124 M reads/s, 0.55 1 118, 0.70 1 028 --
+  // what a fuller table costs is second-bucket probes.
+  const bool default_lf = !(cfg->load_factor > 0);
+  const uint64_t expected = std::max<uint64_t>(cfg->expected_records, 1);
+  double lf = cfg->load_factor;
+  if (default_lf) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) { (void)hipGetLastError(); total_b = (size_t)288 << 30; }
+    lf = std::min(0.80, std::max(0.55, (double)expected * 8.0 / (0.55 * (double)total_b)));
+  }
+  if (lf > 0.95) lf = 0.95;
+  // Geometry.  Any number of buckets (engine.h: the multiply-shift range reduction); a cell holds
+  //   [flag] remainder (64 - q, + 1 unless the count is a power of two) | displacement | taxon     in 64 bits,
+  // so the displacement field gets what the other fields leave (6 bits at most are used: 63 buckets of linear probing), and the
+  // buckets' "a record went past" flag exists where a bit is left for it.  A table whose cells leave fewer than DISP_MIN
+  // displacement bits is made larger (to the next power of two: one bit back from the remainder).
+  const int DISP_MIN = CELLS == 16 ? 3 : 4;
+  struct Shape { uint64_t nb; int q, disp; bool flag; };
+  auto shape_of = [&](uint64_t nb) {
+    Shape sh{std::max<uint64_t>(nb, 32), 0, 0, false};
+    sh.q = ceil_log2_u64(sh.nb);
+    const bool pow2 = sh.nb == (1ULL << sh.q);
+    const int avail = 64 - tb - (64 - sh.q + (pow2 ? 0 : 1));
+    static const bool no_flag = getenv("SLK_NO_BUCKET_FLAG") != nullptr && getenv("SLK_NO_BUCKET_FLAG")[0] == '1';   // (A/B switch)
+    sh.flag = avail - 1 >= DISP_MIN && !no_flag;
+    sh.disp = std::min(6, avail - (sh.flag ? 1 : 0));
+    return sh;
+  };
+  auto grow = [&](uint64_t nb) { const int q = ceil_log2_u64(nb); return nb == (1ULL << q) ? nb * 2 : (1ULL << q); };
+  const uint64_t cells_needed = (uint64_t)((double)expected / lf) + CELLS;
+  Shape sh = shape_of((cells_needed + CELLS - 1) / CELLS);
+  while (sh.disp < DISP_MIN && sh.nb < (1ULL << 33)) sh = shape_of(grow(sh.nb));
+  // With the default load factor, a table whose cells leave a short displacement field (mid-size tables under wide taxon ids) is
+  // made larger until either the field or the load is comfortable: filled to 0.7, a record of a table with 4 displacement bits
+  // can find no cell within reach (one in ~800 random tables of a soak did, loudly: SLK_E_CAPACITY).
+  if (default_lf)
+    while (sh.disp < (CELLS == 16 ? 5 : 6) && sh.nb < (1ULL << 32) && (double)expected / ((double)sh.nb * CELLS) > 0.45) sh = shape_of(grow(sh.nb));
+  if (sh.nb > (1ULL << 32) || sh.disp < DISP_MIN) { delete ix; return fail(SLK_E_CAPACITY, "a table of %llu buckets is too large", (unsigned long long)sh.nb); }
+  ix->bucket_bits = sh.q;
   ix->taxon_bits = tb;
-  ix->disp_bits = std::min(6, bb - tb);
-  ix->nbuckets = 1ULL << bb;
-  size_t bytes = (size_t)ix->nbuckets * 64;
+  ix->disp_bits = sh.disp;
+  ix->bucket_flag = sh.flag;
+  ix->nbuckets = sh.nb;
+  size_t bytes = (size_t)ix->nbuckets * CELLS * 8;
   hipError_t e = hipMalloc((void **)&ix->cells, bytes);
   if (e != hipSuccess) {
     delete ix;
@@ -522,17 +560,28 @@ static int32_t read_build_counters(slk_index *ix) {
 static TableBuild build_view(slk_index *ix) {
   TableBuild t;
   t.cells = ix->cells;
-  t.bucket_mask = ix->nbuckets - 1;
-  t.shift = 64 - ix->bucket_bits;
-  t.rem_mask = (1ULL << t.shift) - 1;
-  t.taxon_bits = ix->taxon_bits;
-  t.disp_bits = ix->disp_bits;
+  t.g = ix->geom();
   t.disp_limit = (1 << ix->disp_bits) - 1;
+  t.shard = ix->shard;
+  t.n_shards = ix->n_shards;
   t.max_disp = ix->d_max_disp;
   t.n_inserted = ix->d_counters;
   t.n_duplicate = ix->d_counters + 1;
   t.n_overflow = ix->d_counters + 2;
   return t;
+}
+
+// Table-sharded libraries (BASELINE configs[3]): the index keeps the records whose key falls to `shard` of `n_shards`
+// (slk_shard_of) and drops the others where they arrive -- in slk_index_append[_device] and in slk_index_add_sequences[_device] --
+// so that every rank can be handed the same record stream or the same genomes.  Before the first record.
+int32_t slk_index_set_shard(slk_index *ix, uint32_t shard, uint32_t n_shards) {
+  if (!ix) return fail(SLK_E_INVALID, "null argument");
+  if (n_shards < 1 || n_shards > 64 || shard >= n_shards) return fail(SLK_E_INVALID, "shard %u of %u", shard, n_shards);
+  if (ix->W > 1) return fail(SLK_E_UNSUPPORTED, "the sharded entry points support minimizers of up to 32 nt (one id column)");
+  if (ix->finalized || ix->records != 0) return fail(SLK_E_STATE, "slk_index_set_shard must precede the first record");
+  ix->shard = shard;
+  ix->n_shards = n_shards;
+  return SLK_OK;
 }
 
 int32_t slk_index_append_device(slk_index *ix, const int64_t *d_keys, const int32_t *d_taxa, uint64_t n) {
@@ -797,7 +846,7 @@ static int32_t make_dense_taxa(slk_index *ix) {
   HIPCHK(hipMalloc((void **)&d_bad, 8));
   HIPCHK(hipMemcpy(d_td, to_dense.data(), (size_t)T * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(d_bad, 0, 8));
-  launch_remap_cells(ix->cells, ix->nbuckets * 8, ix->taxon_bits, d_td, T, d_bad, false, ix->build_stream);
+  launch_remap_cells(ix->cells, ix->nbuckets * CELLS, ix->taxon_bits, d_td, T, d_bad, false, ix->build_stream);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ix->build_stream));
   HIPCHK(hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost));
@@ -805,7 +854,7 @@ static int32_t make_dense_taxa(slk_index *ix) {
     (void)hipFree(d_td); (void)hipFree(d_bad);
     return SLK_OK;
   }
-  launch_remap_cells(ix->cells, ix->nbuckets * 8, ix->taxon_bits, d_td, T, d_bad, true, ix->build_stream);
+  launch_remap_cells(ix->cells, ix->nbuckets * CELLS, ix->taxon_bits, d_td, T, d_bad, true, ix->build_stream);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ix->build_stream));
   (void)hipFree(d_bad);
@@ -841,7 +890,7 @@ int32_t slk_index_get_info(const slk_index *ix, slk_index_info *out) {
   memset(out, 0, sizeof(*out));
   out->records = ix->records;
   out->buckets = ix->nbuckets;
-  out->table_bytes = ix->W > 1 ? ix->nbuckets * (8 * ix->W + 4) : ix->nbuckets * 64;
+  out->table_bytes = ix->W > 1 ? ix->nbuckets * (8 * ix->W + 4) : ix->nbuckets * CELLS * 8;
   out->bucket_bits = ix->bucket_bits;
   out->taxon_bits = ix->taxon_bits;
   out->disp_bits = ix->disp_bits;
@@ -850,6 +899,7 @@ int32_t slk_index_get_info(const slk_index *ix, slk_index_info *out) {
   out->taxonomy_size = ix->T;
   out->device = ix->device;
   out->dense_taxa = ix->D;
+  out->bucket_cells = ix->W > 1 ? 1 : CELLS;
   return SLK_OK;
 }
 
@@ -1204,6 +1254,25 @@ int32_t slk_lookup_device(slk_index *ix, slk_stream *st, const int64_t *d_keys, 
   if (rc) return rc;
   launch_lookup_coop(ix->view(), d_keys, n, d_out_taxa, st->s);
   HIPCHK(hipGetLastError());
+  return SLK_OK;
+}
+
+// The table's range reduction and its inverse as plain host arithmetic (engine.h: table_slot / table_hash_of), for tests.
+static TableGeom geom_for_tests(uint64_t nbuckets) {
+  TableGeom g{};
+  g.nbuckets = nbuckets;
+  g.q = std::max(5, ceil_log2_u64(nbuckets));
+  g.rem_mask = (1ULL << (64 - g.q)) - 1;
+  return g;
+}
+int32_t slk_table_slot(uint64_t nbuckets, uint64_t hash, uint32_t *home, uint64_t *rem) {
+  if (nbuckets < 32 || nbuckets > (1ULL << 32) || !home || !rem) return fail(SLK_E_INVALID, "32 <= nbuckets <= 2^32");
+  table_slot(geom_for_tests(nbuckets), hash, *home, *rem);
+  return SLK_OK;
+}
+int32_t slk_table_hash_of(uint64_t nbuckets, uint32_t home, uint64_t rem, uint64_t *hash) {
+  if (nbuckets < 32 || nbuckets > (1ULL << 32) || home >= nbuckets || !hash) return fail(SLK_E_INVALID, "32 <= nbuckets <= 2^32, home < nbuckets");
+  *hash = table_hash_of(geom_for_tests(nbuckets), home, rem);
   return SLK_OK;
 }
 

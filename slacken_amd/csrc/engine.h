@@ -40,19 +40,61 @@ void launch_wide_probe(const WideTable &t, int W, const uint64_t *offsets, const
                        const uint64_t *span_keys, const int32_t *span_meta, const int32_t *span_count, int32_t *span_taxon,
                        hipStream_t s);
 
-// HBM-resident record table: 64-byte buckets of eight 8-byte cells, bucket-level linear probing.
+// HBM-resident record table: buckets of CELLS 8-byte cells, bucket-level linear probing.  SLK_BUCKET_CELLS = 8 (the default):
+// 64-byte buckets, one HBM access granule, four lanes x 16 B per probe.  16: 128-byte buckets, one L2 line, eight lanes per probe
+// -- a gather microbenchmark serves random requests of either size at the same rate, but the classify kernel with 128-byte
+// buckets measured 3-4 % SLOWER at every load factor (twice the load instructions and bytes per probe for a tenth of the
+// second-bucket probes; profiles/r03_bucket_geometry.txt), so that variant is a build option kept for the record.  The number of buckets is ANY number (not a power of two: a 1.2e10-record library must not cost
+// twice the memory of a 1.0e10-record one), chosen by a multiply-shift range reduction of the hash's top q bits:
 //   h      = fmix64(key)                       (bijective, so (home bucket, remainder) identifies the key: lossless)
-//   home   = h >> (64 - bucket_bits)
-//   cell   = (((h & rem_mask) << disp_bits | displacement) << taxon_bits) | taxon        (0 = empty; taxon != 0)
-// A record lives in the first bucket home+d (d <= max_disp) that had a free cell when it was inserted; cells are never
-// freed, so a lookup may stop at the first bucket that still has an empty cell.
-struct TableView {
-  const uint64_t *cells;
-  uint64_t bucket_mask;
-  uint64_t rem_mask;
-  int32_t shift;      // 64 - bucket_bits
+//   x      = h >> (64 - q),  q = ceil(log2(nbuckets))
+//   home   = (x * nbuckets) >> q               (at most two consecutive x share a home bucket, since 2^(q-1) < nbuckets <= 2^q)
+//   extra  = ((x * nbuckets) mod 2^q) >= nbuckets      (1 for the second of two x that share a home: tells them apart)
+//   rem    = extra << (64 - q) | (h mod 2^(64 - q))
+//   cell   = flag << 63 | ((rem << disp_bits | displacement) << taxon_bits) | taxon        (0 = empty; taxon != 0)
+// A record lives in the first bucket home+d (d <= max_disp, wrapping at nbuckets) that had a free cell when it was inserted;
+// cells are never freed, so a lookup may stop at the first bucket that still has an empty cell.  The top bit of a bucket's
+// FIRST cell (where the cell layout leaves a bit: TableGeom.flag) says that some record found this bucket full and went on to the
+// next: a lookup that finds its home bucket full but unflagged is a miss without a second probe.
+#ifndef SLK_BUCKET_CELLS
+#define SLK_BUCKET_CELLS 8
+#endif
+constexpr int CELLS = SLK_BUCKET_CELLS;               // 8-byte cells per bucket
+constexpr int LPB = CELLS / 2;                        // lanes (16 bytes each) that read one bucket together
+constexpr int BUCKET_SHIFT = CELLS == 16 ? 7 : 6;     // log2(bytes per bucket)
+static_assert(CELLS == 8 || CELLS == 16, "buckets of 64 or 128 bytes");
+struct TableGeom {
+  uint64_t nbuckets;   // 32 .. 2^32
+  uint64_t rem_mask;   // 2^(64 - q) - 1
+  uint64_t flag;       // 1 << 63, or 0 when the cells have no bit to spare
+  int32_t q;           // ceil(log2(nbuckets)), 5 .. 32
   int32_t taxon_bits;
   int32_t disp_bits;
+  int32_t pad;
+};
+// home bucket of hash h and the remainder field of its cells, already shifted past the displacement field
+__host__ __device__ __forceinline__ void table_slot(const TableGeom &g, uint64_t h, uint32_t &home, uint64_t &rem_hi) {
+  const uint64_t prod = (h >> (64 - g.q)) * g.nbuckets;                // (both factors below 2^32 + 1)
+  home = (uint32_t)(prod >> g.q);
+  const uint64_t extra = (prod & ((1ULL << g.q) - 1)) >= g.nbuckets ? 1 : 0;
+  rem_hi = ((h & g.rem_mask) | (extra << (64 - g.q))) << g.disp_bits;
+}
+__host__ __device__ __forceinline__ uint32_t table_bucket(const TableGeom &g, uint32_t home, uint32_t d) {   // home + d, wrapping
+  const uint64_t b = (uint64_t)home + d;
+  return (uint32_t)(b >= g.nbuckets ? b - g.nbuckets : b);
+}
+// the (remainder, displacement) tag of a cell: what a probe compares
+__host__ __device__ __forceinline__ uint64_t cell_tag(const TableGeom &g, uint64_t cell) { return (cell & ~g.flag) >> g.taxon_bits; }
+// table_slot's inverse (export_kernel): the hash whose home bucket and remainder these are
+__host__ __device__ inline uint64_t table_hash_of(const TableGeom &g, uint32_t home, uint64_t rem) {
+  const uint64_t extra = rem >> (64 - g.q);
+  const uint64_t num = (uint64_t)home << g.q;                          // first x with home(x) == home: ceil(home * 2^q / nbuckets)
+  const uint64_t x = (num + g.nbuckets - 1) / g.nbuckets + extra;      // (home < 2^32, q <= 32; the sum cannot wrap: num <= 2^64 - 2^32)
+  return (x << (64 - g.q)) | (rem & g.rem_mask);
+}
+struct TableView {
+  const uint64_t *cells;
+  TableGeom g;
   int32_t max_disp;   // largest displacement in use
   // Dense taxon ids (slk_index_finalize): when the caller's ids need more than 22 bits, the cells hold the rank of the taxon
   // among the taxonomy's nodes instead (the lane kernel packs taxon << 10 | count into one LDS word), the kernels walk a
@@ -100,15 +142,20 @@ __device__ __forceinline__ uint4 load_block16(const uint8_t *src, uint32_t room)
 }
 __device__ __forceinline__ uint32_t clamp_room(uint64_t bytes) { return bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)bytes; }
 
-// build-time view of the table (table_insert_kernel)
+// build-time view of the table (table_insert_kernel, build_kernel)
 struct TableBuild {
   uint64_t *cells;
-  uint64_t bucket_mask, rem_mask;
-  int32_t shift, taxon_bits, disp_bits;
+  TableGeom g;
   int32_t disp_limit;          // (1 << disp_bits) - 1
+  // Table-sharded libraries (slk_index_set_shard): this index keeps the records with fmix64(key) mod n_shards == shard and drops
+  // the others where they arrive, so every rank can be fed the same record stream / the same genomes.  n_shards <= 1: keeps all.
+  uint32_t shard, n_shards;
   int32_t *max_disp;           // device: running maximum displacement
   unsigned long long *n_inserted, *n_duplicate, *n_overflow;
 };
+__host__ __device__ __forceinline__ bool shard_keeps(const TableBuild &t, uint64_t h) {
+  return t.n_shards <= 1 || (uint32_t)(h % t.n_shards) == t.shard;
+}
 
 // Confidence thresholds travel BY VALUE in the kernel arguments: several classify calls may be queued on a stream, each with
 // its own list, and none of them shares a staging buffer with another.

@@ -178,66 +178,70 @@ __device__ __forceinline__ int32_t map_get(const WaveLds *L, int32_t taxon) {
 }
 
 // Look up the (<= 64) buffered spans [s0, s0+cnt) and return this lane's taxon (lane l <-> span s0+l).  The access shape of
-// lane.hip's probe_batch: FOUR lanes read one 64-byte bucket (4 x 16 B = one HBM line), sixteen probes per wave instruction,
-// all four instructions in flight before the first compare.
+// lane.hip's probe_batch: LPB lanes read one bucket together (LPB x 16 B), 64 / LPB probes per wave instruction, all LPB
+// instructions in flight before the first compare.
 __device__ __forceinline__ int32_t probe_chunk(WaveLds *L, const TableView &T, int s0, int cnt, int lane, int32_t meta) {
+  constexpr int PG = 64 / LPB;
   const uint64_t NO_TAG = ~0ULL;  // a real tag has at most 64 - taxon_bits significant bits
   uint64_t key = (lane < cnt) ? L->span_key[s0 + lane] : 0;
   int32_t flag = meta_flag(meta);
   bool seq = (lane < cnt) && flag == 1;
   uint64_t h = fmix64(key);
+  uint32_t home;
+  uint64_t rem_hi;
+  table_slot(T.g, h, home, rem_hi);
   ulonglong2 st;
-  st.x = (h >> T.shift) << 6;                                      // byte offset of the home bucket
-  st.y = seq ? ((h & T.rem_mask) << T.disp_bits) : NO_TAG;         // tag at displacement 0
+  st.x = home;                                                     // home bucket
+  st.y = seq ? rem_hi : NO_TAG;                                    // tag at displacement 0
   ((ulonglong2 *)L->stash)[lane] = st;
   L->result[lane] = 0;
   wave_sync();
-  const int g = lane >> 2, c = lane & 3;                           // 16 groups of 4 lanes
-  const uint64_t tmask = (1ULL << T.taxon_bits) - 1;
+  const int g = lane / LPB, c = lane % LPB;                        // 64 / LPB groups of LPB lanes
+  const uint64_t tmask = (1ULL << T.g.taxon_bits) - 1;
+  const uint32_t gmask = (1u << LPB) - 1;
   const char *cellbase = (const char *)T.cells + c * 16;
-  uint32_t more = 0;  // bit s: my group's span s*16+g overflowed its home bucket and is still unresolved
+  uint32_t more = 0;  // bit s: my group's span s*PG+g overflowed its home bucket and is still unresolved
   {
-    ulonglong2 cell[4];
+    ulonglong2 cell[LPB];
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-      ulonglong2 e = ((const ulonglong2 *)L->stash)[s * 16 + g];
+    for (int s = 0; s < LPB; s++) {
+      ulonglong2 e = ((const ulonglong2 *)L->stash)[s * PG + g];
       cell[s] = make_ulonglong2(0, 0);
-      if (e.y != NO_TAG) cell[s] = *(const ulonglong2 *)(cellbase + e.x);
+      if (e.y != NO_TAG) cell[s] = *(const ulonglong2 *)(cellbase + (e.x << BUCKET_SHIFT));
     }
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-      const uint64_t want = L->stash[2 * (s * 16 + g) + 1];
+    for (int s = 0; s < LPB; s++) {
+      const uint64_t want = L->stash[2 * (s * PG + g) + 1];
       const bool act = want != NO_TAG;
       const bool e0 = cell[s].x == 0, e1 = cell[s].y == 0;
-      const bool m0 = act && !e0 && (cell[s].x >> T.taxon_bits) == want;
-      const bool m1 = act && !e1 && (cell[s].y >> T.taxon_bits) == want;
-      if (m0 || m1) L->result[s * 16 + g] = (int32_t)((m0 ? cell[s].x : cell[s].y) & tmask);
-      // a group is resolved once one of its lanes matched or saw an empty cell (cells are never freed)
-      const uint64_t B = __ballot(m0 || m1 || e0 || e1 || !act);
-      const uint64_t nz = (B | (B >> 1) | (B >> 2) | (B >> 3)) & 0x1111111111111111ULL;
-      if (nz != 0x1111111111111111ULL) {  // some group saw a full bucket without its key (rare)
-        if (((B >> (g * 4)) & 0xF) == 0) more |= 1u << s;
-      }
+      const bool m0 = act && !e0 && cell_tag(T.g, cell[s].x) == want;
+      const bool m1 = act && !e1 && cell_tag(T.g, cell[s].y) == want;
+      if (m0 || m1) L->result[s * PG + g] = (int32_t)((m0 ? cell[s].x : cell[s].y) & tmask);
+      // a group is resolved once one of its lanes matched or saw an empty cell (cells are never freed), or when the bucket is
+      // full but no record ever went past it (the flag in its first cell)
+      const bool closed = T.g.flag != 0 && c == 0 && (cell[s].x & T.g.flag) == 0;
+      const uint64_t B = __ballot(m0 || m1 || e0 || e1 || !act || closed);
+      if (((B >> (g * LPB)) & gmask) == 0) more |= 1u << s;
     }
   }
   if (__ballot(more != 0) != 0) {  // rare: bucket-level linear probing
     for (int d = 1; d <= T.max_disp && __ballot(more != 0) != 0; d++) {
-      for (int s = 0; s < 4; s++) {
+      for (int s = 0; s < LPB; s++) {
         const bool act = (more >> s) & 1;
         ulonglong2 cl = make_ulonglong2(0, 0);
         uint64_t want = 0;
         if (act) {
-          ulonglong2 e = ((const ulonglong2 *)L->stash)[s * 16 + g];
+          ulonglong2 e = ((const ulonglong2 *)L->stash)[s * PG + g];
           want = e.y + (uint64_t)d;
-          uint64_t off = (e.x + ((uint64_t)d << 6)) & ((T.bucket_mask << 6) | 63);
-          cl = *(const ulonglong2 *)(cellbase + off);
+          cl = *(const ulonglong2 *)(cellbase + ((uint64_t)table_bucket(T.g, (uint32_t)e.x, (uint32_t)d) << BUCKET_SHIFT));
         }
         const bool e0 = cl.x == 0, e1 = cl.y == 0;
-        const bool m0 = act && !e0 && (cl.x >> T.taxon_bits) == want;
-        const bool m1 = act && !e1 && (cl.y >> T.taxon_bits) == want;
-        if (m0 || m1) L->result[s * 16 + g] = (int32_t)((m0 ? cl.x : cl.y) & tmask);
-        const uint64_t B = __ballot(m0 || m1 || e0 || e1);
-        if (act && ((B >> (g * 4)) & 0xF) != 0) more &= ~(1u << s);
+        const bool m0 = act && !e0 && cell_tag(T.g, cl.x) == want;
+        const bool m1 = act && !e1 && cell_tag(T.g, cl.y) == want;
+        if (m0 || m1) L->result[s * PG + g] = (int32_t)((m0 ? cl.x : cl.y) & tmask);
+        const bool closed = act && T.g.flag != 0 && c == 0 && (cl.x & T.g.flag) == 0;
+        const uint64_t B = __ballot(act && (m0 || m1 || e0 || e1 || closed));
+        if (act && ((B >> (g * LPB)) & gmask) != 0) more &= ~(1u << s);
       }
     }
   }

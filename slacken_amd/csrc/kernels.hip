@@ -32,14 +32,17 @@ __global__ void __launch_bounds__(256) table_insert_kernel(TableBuild t, const i
     int32_t taxon = taxa[i];
     if (taxon == 0) continue;  // a record with taxon NONE is indistinguishable from a miss
     uint64_t h = fmix64((uint64_t)keys[i]);
-    uint64_t home = h >> t.shift;
-    uint64_t rem_hi = (h & t.rem_mask) << t.disp_bits;
+    if (!shard_keeps(t, h)) continue;  // table-sharded library: another rank's record
+    uint32_t home;
+    uint64_t rem_hi;
+    table_slot(t.g, h, home, rem_hi);
     bool done = false;
     for (int d = 0; d <= t.disp_limit && !done; d++) {
-      unsigned long long *bucket = (unsigned long long *)(t.cells + (((home + d) & t.bucket_mask) << 3));
+      unsigned long long *bucket = (unsigned long long *)(t.cells + ((uint64_t)table_bucket(t.g, home, (uint32_t)d) * CELLS));
       uint64_t tag = rem_hi | (uint64_t)d;
-      unsigned long long val = (tag << t.taxon_bits) | (uint32_t)taxon;
-      for (int c = 0; c < 8 && !done; c++) {
+      unsigned long long val = (tag << t.g.taxon_bits) | (uint32_t)taxon;
+      unsigned long long first = 0;
+      for (int c = 0; c < CELLS && !done; c++) {
         unsigned long long cur = __hip_atomic_load(&bucket[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == 0) {
           unsigned long long old = atomicCAS(&bucket[c], 0ULL, val);
@@ -51,11 +54,14 @@ __global__ void __launch_bounds__(256) table_insert_kernel(TableBuild t, const i
           }
           cur = old;
         }
-        if ((cur >> t.taxon_bits) == tag) {  // same key already present: contract violation, keep the first
+        if (c == 0) first = cur;
+        if (cell_tag(t.g, cur) == tag) {  // same key already present: contract violation, keep the first
           done = true;
           n_dup++;
         }
       }
+      // the bucket is full and does not hold the key: the record goes on, and the bucket says so from now on
+      if (!done && t.g.flag && !(first & t.g.flag)) atomicOr(&bucket[0], (unsigned long long)t.g.flag);
     }
     if (!done) n_ovf++;
   }
@@ -73,26 +79,29 @@ __global__ void __launch_bounds__(256) table_insert_kernel(TableBuild t, const i
   }
 }
 
-// One 64-byte bucket per probe step; returns the stored taxon or 0 (NONE).
+// One bucket per probe step; returns the stored taxon or 0 (NONE).
 __device__ __forceinline__ int32_t table_lookup(const TableView &t, uint64_t key) {
   uint64_t h = fmix64(key);
-  uint64_t home = h >> t.shift;
-  uint64_t rem_hi = (h & t.rem_mask) << t.disp_bits;
-  uint64_t tmask = (1ULL << t.taxon_bits) - 1;
+  uint32_t home;
+  uint64_t rem_hi;
+  table_slot(t.g, h, home, rem_hi);
+  uint64_t tmask = (1ULL << t.g.taxon_bits) - 1;
   for (int d = 0; d <= t.max_disp; d++) {
-    const ulonglong2 *b = (const ulonglong2 *)(t.cells + (((home + d) & t.bucket_mask) << 3));
-    ulonglong2 c0 = b[0], c1 = b[1], c2 = b[2], c3 = b[3];
+    const ulonglong2 *b = (const ulonglong2 *)(t.cells + ((uint64_t)table_bucket(t.g, home, (uint32_t)d) * CELLS));
     uint64_t tag = rem_hi | (uint64_t)d;
-    uint64_t cells[8] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y, c3.x, c3.y};
+    uint64_t cells[CELLS];
+#pragma unroll
+    for (int c = 0; c < LPB; c++) { ulonglong2 v = b[c]; cells[2 * c] = v.x; cells[2 * c + 1] = v.y; }
     bool has_empty = false;
     int32_t found = 0;
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
+    for (int c = 0; c < CELLS; c++) {
       has_empty |= (cells[c] == 0);
-      if (cells[c] != 0 && (cells[c] >> t.taxon_bits) == tag) found = (int32_t)(cells[c] & tmask);
+      if (cells[c] != 0 && cell_tag(t.g, cells[c]) == tag) found = (int32_t)(cells[c] & tmask);
     }
     if (found) return found;
     if (has_empty) return 0;
+    if (t.g.flag && !(cells[0] & t.g.flag)) return 0;  // full, but no record ever went past it
   }
   return 0;
 }
@@ -496,7 +505,7 @@ __global__ void __launch_bounds__(256) remap_cells_kernel(uint64_t *__restrict__
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncells; i += step) {
     const uint64_t c = cells[i];
     if (c == 0) continue;
-    const uint64_t t = c & tmask;
+    const uint64_t t = c & tmask;   // (the bits above the taxon field -- tag, bucket flag -- stay as they are)
     const int32_t d = t < (uint64_t)n_to_dense ? to_dense[t] : 0;
     if (d == 0) bad++;
     else if (apply) cells[i] = (c & ~tmask) | (uint64_t)(uint32_t)d;

@@ -125,11 +125,13 @@ __device__ __forceinline__ void fold_hit(LaneLds *L, uint32_t *ocnt, bool in, ui
 }
 
 // Probe `cnt` (<= 64) entries of the ring queue starting at `qhead` and fold the hits into their owners' maps.
-//   1. lane i hashes entry i and parks (home bucket, tag) in LDS;
-//   2. FOUR lanes read one 64-byte bucket (4 x 16 B = one HBM line), sixteen probes per wave instruction, four
-//      instructions in flight before the first compare; the lane that finds the key writes the taxon to result[entry];
+//   1. lane i hashes entry i and parks (bucket, tag) in LDS;
+//   2. LPB lanes read one bucket together (LPB x 16 B: one 64-byte access granule with 8-cell buckets, one 128-byte line with
+//      16-cell ones), 64 / LPB probes per wave instruction, all LPB instructions of the batch in flight before the first compare;
+//      the lane that finds the key writes the taxon to found[entry];
 //   3. lane i folds entry i's hit into its owner's 12-slot map: ONE round of LDS atomics per batch (NONE hits carry no
 //      information for resolveTree and are dropped).
+constexpr int PG = 64 / LPB;   // probes per wave instruction
 template <bool HITS, bool LONG>
 __device__ __forceinline__ int probe_batch(LaneLds *L, uint32_t *ocnt, const TableView &T, int qhead, int qn, int cnt, int lane, int dbg,
                                            int32_t *hit_meta, int32_t *hit_taxon) {
@@ -140,46 +142,53 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, uint32_t *ocnt, const Tab
   const uint32_t meta = L->q_meta[qi];
   const uint32_t ord = HITS ? L->q_ord[qi] : 0u;  // (in a register now: re-queued entries may wrap onto this batch's slots)
   const uint64_t h = fmix64(key);
+  uint32_t home;
+  uint64_t rem_hi;
+  table_slot(T.g, h, home, rem_hi);
   uint4 st;
   const uint32_t disp = (meta >> 20) & 63;                                // > 0 for an entry re-queued after a full bucket
-  st.x = (uint32_t)(((h >> T.shift) + disp) & T.bucket_mask);             // bucket to read (< 2^32)
-  st.y = 0;                                                               // taxon found (filled in by step 2)
-  const uint64_t tag = in ? (((h & T.rem_mask) << T.disp_bits) + disp) : NO_TAG;  // the tag's low bits are the displacement
+  st.x = table_bucket(T.g, home, disp);                                   // bucket to read
+  st.y = 0;
+  const uint64_t tag = in ? (rem_hi + disp) : NO_TAG;                     // the tag's low bits are the displacement
   st.z = (uint32_t)tag; st.w = (uint32_t)(tag >> 32);
   ((uint4 *)L->stash)[lane] = st;
   L->found[lane] = 0;
   lane_wave_sync();
-  const int g = lane >> 2, c = lane & 3;                                  // 16 groups of 4 lanes
-  const uint64_t tmask = (1ULL << T.taxon_bits) - 1;
+  const int g = lane / LPB, c = lane % LPB;                               // 64 / LPB groups of LPB lanes
+  const uint64_t tmask = (1ULL << T.g.taxon_bits) - 1;
   const char *cellbase = (const char *)T.cells + c * 16;
-  ulonglong2 cell[4];
+  ulonglong2 cell[LPB];
 #pragma unroll
-  for (int s = 0; s < 4; s++) {
-    uint32_t bkt = ((const uint4 *)L->stash)[s * 16 + g].x;
+  for (int s = 0; s < LPB; s++) {
+    uint32_t bkt = ((const uint4 *)L->stash)[s * PG + g].x;
     SLK_TUNE(if (dbg & 4) bkt &= 1023u;)                                  // (timing experiment 4: every probe hits the L2)
-    // non-temporal: a bucket is touched once; keeping it out of the L2's way leaves the read stream's lines resident
-    // between a lane's consecutive 16-byte loads (inactive entries read some bucket: harmless)
-    cell[s] = SLK_PROBE_LOAD((const ulonglong2 *)(cellbase + ((uint64_t)bkt << 6)));
+    // (inactive entries read some bucket: harmless)
+    cell[s] = SLK_PROBE_LOAD((const ulonglong2 *)(cellbase + ((uint64_t)bkt << BUCKET_SHIFT)));
   }
+  constexpr uint64_t GROUP_LSB = LPB == 4 ? 0x1111111111111111ULL : 0x0101010101010101ULL;
   int requeued = 0;
 #pragma unroll
-  for (int s = 0; s < 4; s++) {
-    const uint2 tg = *(const uint2 *)&((const uint4 *)L->stash)[s * 16 + g].z;
+  for (int s = 0; s < LPB; s++) {
+    const uint2 tg = *(const uint2 *)&((const uint4 *)L->stash)[s * PG + g].z;
     const uint64_t want = ((uint64_t)tg.y << 32) | tg.x;
     const bool act = want != NO_TAG;
     const bool e0 = cell[s].x == 0, e1 = cell[s].y == 0;
-    const bool m0 = act && !e0 && (cell[s].x >> T.taxon_bits) == want;
-    const bool m1 = act && !e1 && (cell[s].y >> T.taxon_bits) == want;
-    if (m0 || m1) L->found[s * 16 + g] = (uint32_t)((m0 ? cell[s].x : cell[s].y) & tmask);
-    const uint64_t B = __ballot(m0 || m1 || e0 || e1 || !act);  // a group is resolved by a match or by an empty cell
-    const uint64_t nz = (B | (B >> 1) | (B >> 2) | (B >> 3)) & 0x1111111111111111ULL;
-    if (nz != 0x1111111111111111ULL) {
-      // Some bucket was full without holding its key (3 % of the probes): bucket-level linear probing continues in the
+    const bool m0 = act && !e0 && cell_tag(T.g, cell[s].x) == want;
+    const bool m1 = act && !e1 && cell_tag(T.g, cell[s].y) == want;
+    if (m0 || m1) L->found[s * PG + g] = (uint32_t)((m0 ? cell[s].x : cell[s].y) & tmask);
+    // a group is resolved by a match, by an empty cell, or by a full bucket that no record ever went past (its first cell's flag)
+    const bool closed = T.g.flag != 0 && c == 0 && (cell[s].x & T.g.flag) == 0;
+    const uint64_t B = __ballot(m0 || m1 || e0 || e1 || !act || closed);
+    uint64_t any = B;
+#pragma unroll
+    for (int i = 1; i < LPB; i <<= 1) any |= any >> i;
+    if ((any & GROUP_LSB) != GROUP_LSB) {
+      // Some bucket was full without holding its key and has overflowed: bucket-level linear probing continues in the
       // next bucket.  Rather than following it here with a dependent load, the entry goes back to the tail of the
       // queue with its displacement raised, and takes an ordinary slot of a later batch.
-      const int qj = (qhead + s * 16 + g) & (QCAP - 1);
+      const int qj = (qhead + s * PG + g) & (QCAP - 1);
       const uint32_t m_old = L->q_meta[qj];
-      const bool again = c == 0 && ((B >> (g * 4)) & 0xF) == 0 && (int)((m_old >> 20) & 63) < T.max_disp;
+      const bool again = c == 0 && ((B >> (g * LPB)) & ((1u << LPB) - 1)) == 0 && (int)((m_old >> 20) & 63) < T.max_disp;
       const uint64_t k_old = L->q_key[qj];
       const uint16_t o_old = HITS ? L->q_ord[qj] : (uint16_t)0;
       const uint64_t R = __ballot(again);

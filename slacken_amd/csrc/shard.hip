@@ -20,69 +20,73 @@ __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// 64 keys per wave iteration: lane i hashes key i; FOUR lanes then read one 64-byte bucket (4 x 16 B = one HBM line),
-// sixteen buckets per wave instruction, four instructions in flight -- the access shape of the classify kernel's probe.
-// A key whose home bucket is full without holding it (about 3 % at the usual load) continues alone in the next buckets.
+// 64 keys per wave iteration: lane i hashes key i; LPB lanes then read one bucket together (LPB x 16 B), 64 / LPB buckets per
+// wave instruction, LPB instructions in flight -- the access shape of the classify kernel's probe.  A key whose home bucket
+// is full without holding it, and has overflowed (its flag), continues alone in the next buckets.
 __global__ void __launch_bounds__(SW * 64) lookup_coop_kernel(TableView T, const int64_t *__restrict__ keys, uint64_t n,
                                                               int32_t *__restrict__ out) {
+  constexpr int PG = 64 / LPB;
   __shared__ __attribute__((aligned(16))) uint4 stash_all[SW][64];
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint4 *stash = stash_all[wib];
   const uint64_t nwaves = (uint64_t)gridDim.x * SW;
-  const uint64_t tmask = (1ULL << T.taxon_bits) - 1;
-  const int g = lane >> 2, c = lane & 3;
+  const uint64_t tmask = (1ULL << T.g.taxon_bits) - 1;
+  const int g = lane / LPB, c = lane % LPB;
   const char *cellbase = (const char *)T.cells + c * 16;
   for (uint64_t base = ((uint64_t)blockIdx.x * SW + wib) * 64; base < n; base += nwaves * 64) {
     const uint64_t i = base + lane;
     const bool in = i < n;
     const uint64_t key = in ? (uint64_t)keys[i] : 0;
     const uint64_t h = fmix64(key);
-    const uint64_t tag = in ? ((h & T.rem_mask) << T.disp_bits) : ~0ULL;  // displacement 0
+    uint32_t home;
+    uint64_t rem_hi;
+    table_slot(T.g, h, home, rem_hi);
+    const uint64_t tag = in ? rem_hi : ~0ULL;  // displacement 0
     uint4 st;
-    st.x = (uint32_t)((h >> T.shift) & T.bucket_mask);
+    st.x = home;
     st.y = 0;                // taxon found
     st.z = (uint32_t)tag;
     st.w = (uint32_t)(tag >> 32);
     stash[lane] = st;
     wsync();
-    ulonglong2 cell[4];
+    ulonglong2 cell[LPB];
 #pragma unroll
-    for (int s = 0; s < 4; s++) cell[s] = *(const ulonglong2 *)(cellbase + ((uint64_t)stash[s * 16 + g].x << 6));
-    uint32_t unresolved = 0;  // bit s: this lane's group of step s found neither its key nor an empty cell
+    for (int s = 0; s < LPB; s++) cell[s] = *(const ulonglong2 *)(cellbase + ((uint64_t)stash[s * PG + g].x << BUCKET_SHIFT));
+    uint32_t unresolved = 0;  // bit s: this lane's group of step s found neither its key nor the end of its probe sequence
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-      const uint64_t want = ((uint64_t)stash[s * 16 + g].w << 32) | stash[s * 16 + g].z;
+    for (int s = 0; s < LPB; s++) {
+      const uint64_t want = ((uint64_t)stash[s * PG + g].w << 32) | stash[s * PG + g].z;
       const bool act = want != ~0ULL;
       const bool e0 = cell[s].x == 0, e1 = cell[s].y == 0;
-      const bool m0 = act && !e0 && (cell[s].x >> T.taxon_bits) == want;
-      const bool m1 = act && !e1 && (cell[s].y >> T.taxon_bits) == want;
-      if (m0 || m1) stash[s * 16 + g].y = (uint32_t)((m0 ? cell[s].x : cell[s].y) & tmask);
-      const uint64_t B = __ballot(m0 || m1 || e0 || e1 || !act);
-      if (((B >> (g * 4)) & 0xF) == 0) unresolved |= 1u << s;
+      const bool m0 = act && !e0 && cell_tag(T.g, cell[s].x) == want;
+      const bool m1 = act && !e1 && cell_tag(T.g, cell[s].y) == want;
+      if (m0 || m1) stash[s * PG + g].y = (uint32_t)((m0 ? cell[s].x : cell[s].y) & tmask);
+      const bool closed = T.g.flag != 0 && c == 0 && (cell[s].x & T.g.flag) == 0;   // full, but no record ever went past it
+      const uint64_t B = __ballot(m0 || m1 || e0 || e1 || !act || closed);
+      if (((B >> (g * LPB)) & ((1u << LPB) - 1)) == 0) unresolved |= 1u << s;
     }
     wsync();
     int32_t taxon = (int32_t)stash[lane].y;
-    // was entry `lane` unresolved?  its group was g' = lane & 15 of step s' = lane >> 4: ask lane 4 * g'
-    const uint32_t ur = (uint32_t)__shfl((int)unresolved, (lane & 15) * 4);
-    if (in && ((ur >> (lane >> 4)) & 1)) {
+    // was entry `lane` unresolved?  its group was g' = lane % PG of step s' = lane / PG: ask lane LPB * g'
+    const uint32_t ur = (uint32_t)__shfl((int)unresolved, (lane % PG) * LPB);
+    if (in && ((ur >> (lane / PG)) & 1)) {
       // bucket-level linear probing continues in the next buckets (cells are never freed: stop at an empty cell)
-      const uint64_t home = h >> T.shift;
-      const uint64_t rem_hi = (h & T.rem_mask) << T.disp_bits;
       for (int d = 1; d <= T.max_disp; d++) {
-        const ulonglong2 *b = (const ulonglong2 *)(T.cells + (((home + d) & T.bucket_mask) << 3));
+        const ulonglong2 *b = (const ulonglong2 *)(T.cells + ((uint64_t)table_bucket(T.g, home, (uint32_t)d) * CELLS));
         const uint64_t want = rem_hi | (uint64_t)d;
-        bool has_empty = false;
+        bool has_empty = false, closed = false;
         int32_t found = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < LPB; q++) {
           ulonglong2 v = b[q];
           has_empty |= (v.x == 0) | (v.y == 0);
-          if (v.x != 0 && (v.x >> T.taxon_bits) == want) found = (int32_t)(v.x & tmask);
-          if (v.y != 0 && (v.y >> T.taxon_bits) == want) found = (int32_t)(v.y & tmask);
+          if (q == 0) closed = T.g.flag != 0 && (v.x & T.g.flag) == 0;
+          if (v.x != 0 && cell_tag(T.g, v.x) == want) found = (int32_t)(v.x & tmask);
+          if (v.y != 0 && cell_tag(T.g, v.y) == want) found = (int32_t)(v.y & tmask);
         }
         if (found) { taxon = found; break; }
-        if (has_empty) break;
+        if (has_empty || closed) break;
       }
     }
     if (in) out[i] = ext_taxon(T, taxon);

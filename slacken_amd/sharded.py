@@ -50,6 +50,78 @@ def shard_of_numpy(keys, world):
     return (x % np.uint64(world)).astype(np.int64)
 
 
+class _StageSpan:
+    """with-block that brackets a stage with two timing events on its stream and files them in the batch's profile list (nothing
+    if that is None).  A plain module-level class: the batch's tensors live on the ENGINE's streams, and must die by reference
+    count, before their stream does -- an object that only the cycle collector frees (a class made per call is one) would keep
+    them past it."""
+    __slots__ = ("torch", "prof", "name", "ext", "e0")
+
+    def __init__(self, torch, prof, name, ext):
+        self.torch, self.prof, self.name, self.ext, self.e0 = torch, prof, name, ext, None
+
+    def __enter__(self):
+        if self.prof is not None:
+            self.e0 = self.torch.cuda.Event(enable_timing=True)
+            self.e0.record(self.ext)
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if self.prof is not None and exc_type is None:
+            e1 = self.torch.cuda.Event(enable_timing=True)
+            e1.record(self.ext)
+            self.prof.append((self.name, self.e0, e1))
+        return False
+
+
+class Exchange:
+    """The two all-to-all(v) steps of the table-sharded mode and nothing else: no engine, no GPU needed (bench.py --dry-run and the
+    CPU tests run it over gloo).  Keys go to their owners sorted by destination rank, answers come back in the same order.  The
+    split sizes travel first, and with them one flag word per rank (a send list overflowed: emit again) -- so the decision every
+    rank must take alike costs no collective of its own and nothing touches torch's default stream."""
+
+    def __init__(self, rank=0, world=1, dist=None, device=None, on_cpu=False):
+        import torch
+        self.torch, self.rank, self.world, self.dist = torch, rank, world, dist
+        self.device = device if device is not None else torch.device("cpu")
+        self.on_cpu = on_cpu or self.device.type == "cpu"  # gloo has no device all-to-all: stage through host memory (tests)
+
+    @property
+    def single(self):
+        return self.world == 1 or self.dist is None
+
+    def split_sizes(self, send_counts, flag=False):
+        """-> (recv_counts, any rank's flag).  One all-to-all of [count for that peer, my flag] pairs."""
+        if self.single:
+            return list(send_counts), bool(flag)
+        torch = self.torch
+        dev = "cpu" if self.on_cpu else self.device
+        sc = torch.tensor([[int(c), 1 if flag else 0] for c in send_counts], dtype=torch.int64, device=dev)
+        rc = torch.empty_like(sc)
+        self.dist.all_to_all_single(rc, sc)
+        rc = rc.tolist()
+        return [int(r[0]) for r in rc], any(int(r[1]) for r in rc) or bool(flag)
+
+    def all_to_all(self, send, send_counts, recv_counts):
+        """send: tensor sorted by destination rank -> what the other ranks sent here, sorted by source rank"""
+        if self.single:
+            return send
+        torch = self.torch
+        dev = "cpu" if self.on_cpu else self.device
+        src = send.to(dev)
+        out = torch.empty(sum(recv_counts), dtype=send.dtype, device=dev)
+        self.dist.all_to_all_single(out, src, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts))
+        return out.to(self.device)
+
+    def any_rank(self, flag):
+        """logical OR of a host flag over all ranks (every rank must take the same sequence of collectives)"""
+        if self.single:
+            return bool(flag)
+        t = self.torch.tensor([1 if flag else 0], dtype=self.torch.int64, device="cpu" if self.on_cpu else self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return bool(int(t.item()))
+
+
 class ShardedClassifier:
     """index: this rank's slacken_amd.Index holding ONLY the records with shard_of(key) == rank (plus the taxonomy)."""
 
@@ -58,22 +130,14 @@ class ShardedClassifier:
         self.torch, self.ix, self.st = torch, index, index.stream()
         self.rank, self.world, self.dist = rank, world, dist
         self.device = device if device is not None else torch.device("cuda", 0)
-        self.on_cpu = exchange_on_cpu  # gloo has no device all-to-all: stage the exchange through host memory (tests)
+        self.on_cpu = exchange_on_cpu
+        self.ex = Exchange(rank, world, dist, self.device, exchange_on_cpu)
+        self.stage_ms = None   # classify_many(profile=True): per-stage device times of the batches
 
     def _all_to_all(self, send, send_counts):
         """send: tensor sorted by destination rank; returns (received tensor, recv_counts list)."""
-        torch = self.torch
-        if self.world == 1 or self.dist is None:
-            return send, list(send_counts)
-        dev = "cpu" if self.on_cpu else self.device
-        sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
-        rcnt = torch.empty(self.world, dtype=torch.int64, device=dev)
-        self.dist.all_to_all_single(rcnt, sc)
-        recv_counts = [int(v) for v in rcnt.tolist()]
-        src = send.to(dev)
-        out = torch.empty(sum(recv_counts), dtype=send.dtype, device=dev)
-        self.dist.all_to_all_single(out, src, output_split_sizes=recv_counts, input_split_sizes=list(send_counts))
-        return out.to(self.device), recv_counts
+        recv_counts, _ = self.ex.split_sizes(send_counts)
+        return self.ex.all_to_all(send, send_counts, recv_counts), recv_counts
 
     def classify(self, d_bases, d_offsets, R, total_bases, thresholds=(0.0,), min_hit_groups=2, fast=True, d_mate_bases=None,
                  d_mate_offsets=None, total_mate_bases=0):
@@ -86,12 +150,12 @@ class ShardedClassifier:
         return self._classify_staged(d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups, mates)
 
     def _any_rank(self, flag):
-        """logical OR of a host flag over all ranks (every rank must take the same sequence of collectives)"""
-        if self.world == 1 or self.dist is None:
+        """logical OR of a host flag over all ranks, on the memory stream (never torch's default stream, see _two_streams)"""
+        if self.ex.single:
             return bool(flag)
-        t = self.torch.tensor([1 if flag else 0], dtype=self.torch.int64, device="cpu" if self.on_cpu else self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return bool(int(t.item()))
+        _, (_, ext) = self._two_streams()
+        with self.torch.cuda.stream(ext):
+            return self.ex.any_rank(flag)
 
     # ---- the fast route, in stages that are interleaved between batches (classify_many) -------------------------------------
     # The stages of a batch are bound by different things: the scan (emit) by instruction issue, compaction, the owners' lookup and
@@ -109,7 +173,11 @@ class ShardedClassifier:
             self._mem = (mem, torch.cuda.ExternalStream(mem.hip_stream, device=self.device))
         return self._scan, self._mem
 
-    def _fast_emit(self, batch, cap_scale=1):
+    def _ev(self, b, name, ext):
+        """(profile) an event pair around a stage of batch b on stream ext: a context manager"""
+        return _StageSpan(self.torch, b["prof"] if b is not None else None, name, ext)
+
+    def _fast_emit(self, batch, cap_scale=1, profile=False):
         """stage 1 (scan stream, asynchronous): scan + send lists.  None if this index's splitter only has the staged route."""
         import slacken_amd
         from slacken_amd import capi
@@ -130,6 +198,7 @@ class ShardedClassifier:
         cur = torch.cuda.current_stream()
         if cur != torch.cuda.default_stream(self.device):     # (the caller's tensors were produced on ITS stream)
             ext.wait_stream(cur)
+        b = dict(R=R, SUB=SUB, cap=cap, mkw=mkw, batch=batch, prof=[] if profile else None)
         with torch.cuda.stream(ext):
             defer = torch.empty(max(R, 1), dtype=torch.int32, device=dev)
             batch_base = torch.empty(rows * W, dtype=torch.int32, device=dev)
@@ -139,17 +208,19 @@ class ShardedClassifier:
             tile_rows = torch.empty(tiles + 1, dtype=torch.int32, device=dev)
             read_info = torch.empty(2 * max(R, 1), dtype=torch.int32, device=dev)
             try:
-                st.shard_emit_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, W, SUB, send_keys.data_ptr(), send_meta.data_ptr(), cap,
-                                     counts.data_ptr(), batch_base.data_ptr(), tile_rows.data_ptr(), read_info.data_ptr(),
-                                     defer.data_ptr(), **mkw)
+                with self._ev(b, "emit", ext):
+                    st.shard_emit_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, W, SUB, send_keys.data_ptr(), send_meta.data_ptr(), cap,
+                                         counts.data_ptr(), batch_base.data_ptr(), tile_rows.data_ptr(), read_info.data_ptr(),
+                                         defer.data_ptr(), **mkw)
             except slacken_amd.SlackenError as e:
                 if e.code != capi.E_UNSUPPORTED:
                     raise
                 return None
             emitted = torch.cuda.Event()
             emitted.record(ext)
-        return dict(R=R, SUB=SUB, cap=cap, defer=defer, batch_base=batch_base, send_keys=send_keys, send_meta=send_meta, counts=counts,
-                    tile_rows=tile_rows, read_info=read_info, emitted=emitted, mkw=mkw, batch=batch)
+        b.update(defer=defer, batch_base=batch_base, send_keys=send_keys, send_meta=send_meta, counts=counts,
+                 tile_rows=tile_rows, read_info=read_info, emitted=emitted)
+        return b
 
     def _fast_compact(self, b):
         """stage 2 (memory stream, asynchronous): the send lists back to back; the split sizes on their way to the host"""
@@ -160,28 +231,32 @@ class ShardedClassifier:
             b["out_keys"] = torch.empty_like(b["send_keys"])   # (room for every list at its capacity; the used prefix is what is sent)
             b["list_off"] = torch.empty(W * b["SUB"] + 1, dtype=torch.int64, device=dev)
             owner_counts = torch.empty(W + 1, dtype=torch.int64, device=dev)
-            st.shard_compact_device(b["send_keys"].data_ptr(), W, b["SUB"], b["cap"], b["counts"].data_ptr(), b["out_keys"].data_ptr(),
-                                    b["list_off"].data_ptr(), owner_counts.data_ptr())
+            with self._ev(b, "compact", ext):
+                st.shard_compact_device(b["send_keys"].data_ptr(), W, b["SUB"], b["cap"], b["counts"].data_ptr(), b["out_keys"].data_ptr(),
+                                        b["list_off"].data_ptr(), owner_counts.data_ptr())
             b["h_counts"] = torch.empty(W + 1, dtype=torch.int64, pin_memory=True)
             b["h_counts"].copy_(owner_counts, non_blocking=True)
             b["ready"] = torch.cuda.Event()
             b["ready"].record(ext)
 
-    def _fast_exchange(self, b):
+    def _fast_exchange(self, b, send_counts, recv_counts):
         """stage 3 (memory stream): keys to their owners, lookup, taxa back"""
         torch = self.torch
         _, (st, ext) = self._two_streams()
-        send_counts = [int(v) for v in b["h_counts"][:self.world].tolist()]
-        n_send = sum(send_counts)
+        n_send, n_recv = sum(send_counts), sum(recv_counts)
         with torch.cuda.stream(ext):
-            recv_keys, recv_counts = self._all_to_all(b["out_keys"][:n_send], send_counts)
-            found = torch.empty(max(recv_keys.numel(), 1), dtype=torch.int32, device=self.device)
-            if recv_keys.numel():
+            with self._ev(b, "exchange_keys", ext):
+                recv_keys = self.ex.all_to_all(b["out_keys"][:n_send], send_counts, recv_counts)
+            found = torch.empty(max(n_recv, 1), dtype=torch.int32, device=self.device)
+            if n_recv:
                 recv_keys = recv_keys.contiguous()
-                st.lookup_device(recv_keys.data_ptr(), recv_keys.numel(), found.data_ptr())
-            back, _ = self._all_to_all(found[:recv_keys.numel()], recv_counts)
+                with self._ev(b, "lookup", ext):
+                    st.lookup_device(recv_keys.data_ptr(), n_recv, found.data_ptr())
+            with self._ev(b, "exchange_taxa", ext):
+                back = self.ex.all_to_all(found[:n_recv], recv_counts, send_counts)
             b["taxa"] = back.contiguous() if back.numel() else torch.zeros(1, dtype=torch.int32, device=self.device)
-        b["exchanged"] = n_send
+        b["exchanged"], b["looked_up"] = n_send, n_recv
+        b["sent_remote"] = n_send - (send_counts[self.rank] if self.world > 1 else n_send)
         del b["send_keys"], b["out_keys"]
 
     def _fast_apply(self, b, thresholds, min_hit_groups):
@@ -197,13 +272,14 @@ class ShardedClassifier:
                        num_distinct=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
                        total_kmers=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
                        num_hits=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
-                       exchanged_keys=b["exchanged"])
-            st.shard_apply_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, W, b["SUB"], b["cap"], b["taxa"].data_ptr(),
-                                  b["list_off"].data_ptr(), b["send_meta"].data_ptr(), b["batch_base"].data_ptr(),
-                                  b["tile_rows"].data_ptr(), b["read_info"].data_ptr(), out["taxon"].data_ptr(),
-                                  out["classified"].data_ptr(), b["defer"].data_ptr(), out["num_distinct"].data_ptr(),
-                                  out["total_kmers"].data_ptr(), out["num_hits"].data_ptr(), min_hit_groups=min_hit_groups,
-                                  thresholds=thresholds, **b["mkw"])
+                       exchanged_keys=b["exchanged"], looked_up_keys=b["looked_up"], sent_remote_keys=b["sent_remote"])
+            with self._ev(b, "apply", ext):
+                st.shard_apply_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, W, b["SUB"], b["cap"], b["taxa"].data_ptr(),
+                                      b["list_off"].data_ptr(), b["send_meta"].data_ptr(), b["batch_base"].data_ptr(),
+                                      b["tile_rows"].data_ptr(), b["read_info"].data_ptr(), out["taxon"].data_ptr(),
+                                      out["classified"].data_ptr(), b["defer"].data_ptr(), out["num_distinct"].data_ptr(),
+                                      out["total_kmers"].data_ptr(), out["num_hits"].data_ptr(), min_hit_groups=min_hit_groups,
+                                      thresholds=thresholds, **b["mkw"])
             b["applied"] = torch.cuda.Event()
             b["applied"].record(ext)
         return out
@@ -212,27 +288,34 @@ class ShardedClassifier:
         outs = self.classify_many([(d_bases, d_offsets, R, total_bases, mates)], thresholds, min_hit_groups)
         return None if outs is None else outs[0]
 
-    def classify_many(self, batches, thresholds=(0.0,), min_hit_groups=2):
+    def classify_many(self, batches, thresholds=(0.0,), min_hit_groups=2, profile=False):
         """The fast route over several batches [(d_bases, d_offsets, R, total_bases, mates or None)], two in flight (see above).
         Every rank must pass the same number of batches.  Returns the list of result dicts, or None if the splitter only has the
-        staged route."""
+        staged route.  profile: self.stage_ms = {stage: mean device ms per batch} from events around every stage (the stages of
+        neighbouring batches overlap on the two streams: these are their durations IN the pipeline, not alone)."""
         import slacken_amd
         from slacken_amd import capi
+        torch = self.torch
         states, outs = [], []
         overflowed = False
+        _, (_, mem_ext) = self._two_streams()
 
         def settle(j):   # batch j: its one host wait, then exchange + lookup + apply on the memory stream
             nonlocal overflowed
             b, scale = states[j], 1
             while True:
                 b["ready"].synchronize()
-                if not self._any_rank(int(b["h_counts"][self.world]) != 0):
+                send_counts = [int(v) for v in b["h_counts"][:self.world].tolist()]
+                # (the split sizes carry every rank's overflow flag: all ranks take the same branch without a collective of its own)
+                with torch.cuda.stream(mem_ext):
+                    recv_counts, over = self.ex.split_sizes(send_counts, int(b["h_counts"][self.world]) != 0)
+                if not over:
                     break
                 overflowed = True                      # (rare: a send list overflowed somewhere -- every rank emits again)
                 scale *= 2
-                b = states[j] = self._fast_emit(batches[j], scale)
+                b = states[j] = self._fast_emit(batches[j], scale, profile)
                 self._fast_compact(b)
-            self._fast_exchange(b)
+            self._fast_exchange(b, send_counts, recv_counts)
             outs.append(self._fast_apply(b, thresholds, min_hit_groups))
 
         def release_finished():   # batches whose apply has run give their device memory back (a long run holds a few, not all)
@@ -243,7 +326,7 @@ class ShardedClassifier:
 
         for i, batch in enumerate(batches):
             release_finished()
-            b = self._fast_emit(batch)                 # scan stream
+            b = self._fast_emit(batch, 1, profile)     # scan stream
             if i == 0 and self._any_rank(b is None):
                 return None
             states.append(b)
@@ -259,6 +342,12 @@ class ShardedClassifier:
             except slacken_amd.SlackenError as e:
                 if not (overflowed and e.code == capi.E_CAPACITY):   # (the engine's own note of an overflow that was handled above)
                     raise
+        if profile:
+            acc = {}
+            for sb in states:
+                for name, e0, e1 in sb["prof"]:
+                    acc.setdefault(name, []).append(e0.elapsed_time(e1))
+            self.stage_ms = {k: float(np.mean(v)) for k, v in acc.items()}
         for i, (b, batch) in enumerate(zip(states, batches)):
             for k in ("taxa", "batch_base", "list_off", "counts", "send_meta", "tile_rows", "read_info"):
                 b.pop(k, None)

@@ -76,3 +76,42 @@ def test_release_library_has_no_result_changing_switches():
     import slacken_amd
     blob = open(slacken_amd.lib_path(), "rb").read()
     assert b"SLK_DEBUG_ABLATE" not in blob
+
+
+def test_table_range_reduction_is_a_bijection():
+    """The record table has ANY number of buckets (no power-of-two jumps in its size): home = top-q-bits * nbuckets >> q.  For the
+    table to stay lossless, (home, remainder) must identify the 64-bit hash: checked against an independent Python restatement and
+    by the inverse the export kernel uses (engine.h: table_slot / table_hash_of; pure host arithmetic, no GPU)."""
+    import ctypes as C
+    import numpy as np
+    L = slacken_amd.lib()
+    rng = np.random.default_rng(11)
+    sizes = [32, 33, 63, 64, 65, 1000, 12345, 2**20, 2**20 + 1, 3 * 2**19, 2**31 - 1, 2**31, 2**31 + 12345, 2**32 - 1, 2**32,
+             int(8.93e8), int(1.12e9)] + [int(v) for v in rng.integers(32, 2**32, 20)]
+    for nb in sizes:
+        q = max(5, (nb - 1).bit_length())
+        hs = [int(v) for v in rng.integers(0, 2**64, 300, dtype=np.uint64)] + [0, 2**64 - 1, 2**63, 2**(64 - q), 2**(64 - q) - 1]
+        seen = {}
+        for h in hs:
+            home, rem, back = C.c_uint32(), C.c_uint64(), C.c_uint64()
+            assert L.slk_table_slot(nb, h, C.byref(home), C.byref(rem)) == 0
+            # restatement: x = top q bits; home = x * nb >> q; extra tells the (at most) two x of one home apart
+            x = h >> (64 - q)
+            prod = x * nb
+            want_home, extra = prod >> q, int((prod & ((1 << q) - 1)) >= nb)
+            want_rem = (h & ((1 << (64 - q)) - 1)) | (extra << (64 - q))
+            assert (home.value, rem.value) == (want_home, want_rem)
+            assert home.value < nb and rem.value < (1 << (64 - q + 1))
+            if nb == 1 << q:
+                assert extra == 0 and home.value == x      # a power of two: the plain prefix
+            assert L.slk_table_hash_of(nb, home.value, rem.value, C.byref(back)) == 0
+            assert back.value == h
+            assert seen.setdefault((home.value, rem.value), h) == h
+    # every bucket of a small table is some hash's home, and consecutive top-bit values never skip one
+    nb, q = 1000, 10
+    homes = set()
+    for x in range(1 << q):
+        home, rem = C.c_uint32(), C.c_uint64()
+        L.slk_table_slot(nb, x << (64 - q), C.byref(home), C.byref(rem))
+        homes.add(home.value)
+    assert homes == set(range(nb))

@@ -86,3 +86,52 @@ def test_bench_refuses_a_world_size_mismatch():
 def test_bench_single_rank_dry_line():
     p, lines = _bench("--dry-run", "--steps", "2")
     assert p.returncode == 0 and len(lines) == 1 and lines[0]["n_gpus"] == 1
+
+
+def test_bench_table_sharded_dry_two_ranks():
+    """configs[3] without a GPU: `bench.py --gpus 2 --table-sharded --dry-run` starts its two ranks, each owns the keys that fall to
+    it, queries travel to their owners and the answers back through slacken_amd.sharded.Exchange (the GPU path's own exchange code,
+    over gloo), every answer is checked against the whole table, and the overflow flag that rides on the split sizes reaches
+    every rank."""
+    p, lines = _bench("--gpus", "2", "--table-sharded", "--steps", "3", "--warmup", "1", "--reads", "4000", "--dry-run")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["config"]["parallelism"] == "table-sharded x2"
+    assert line["config"]["reads_all_ranks_per_step"] == 8000 and line["config"]["keys_exchanged_all_ranks"] == 3 * 8000
+
+
+def test_bench_table_sharded_dry_single_rank():
+    p, lines = _bench("--table-sharded", "--steps", "2", "--warmup", "1", "--reads", "1000", "--dry-run")
+    assert p.returncode == 0 and len(lines) == 1 and lines[0]["config"]["parallelism"] == "table-sharded x1"
+
+
+def _exchange_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from slacken_amd import sharded
+    ex = sharded.Exchange(rank, world, dist, torch.device("cpu"))
+    # rank r sends (r + 1) * (d + 1) items to rank d, each item = 1000 * r + d
+    send_counts = [(rank + 1) * (d + 1) for d in range(world)]
+    send = torch.cat([torch.full((c,), 1000 * rank + d, dtype=torch.int64) for d, c in enumerate(send_counts)])
+    recv_counts, flag = ex.split_sizes(send_counts, flag=(rank == 1))
+    assert recv_counts == [(s + 1) * (rank + 1) for s in range(world)] and flag is True
+    got = ex.all_to_all(send, send_counts, recv_counts)
+    want = torch.cat([torch.full(((s + 1) * (rank + 1),), 1000 * s + rank, dtype=torch.int64) for s in range(world)])
+    assert torch.equal(got, want)
+    back = ex.all_to_all((got * 2).to(torch.int32), recv_counts, send_counts)     # answers return in the order the keys were sent
+    assert torch.equal(back.long(), send * 2)
+    _, flag2 = ex.split_sizes(send_counts, flag=False)
+    assert flag2 is False and ex.any_rank(rank == 2) is True and ex.any_rank(False) is False
+    if rank == 0:
+        np.save(out, np.array([1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_three_ranks(tmp_path):
+    """Exchange on three gloo ranks with uneven split sizes (also a non-power-of-two world): sizes, order of the received items,
+    the way back, and the flag that rides on the split sizes."""
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_exchange_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    assert os.path.exists(out)

@@ -3,7 +3,10 @@
   * determinism and batch-split invariance
   * reverse-complement invariance (canonical minimizers: MinSplitterProps.scala:101-114 lifted to the whole path)
   * the two independently written kernels (lane-per-read hot path, wave-per-read path) agree read for read
-  * a poly-A read is one super-mer of L-k+1 k-mers; per-taxon read counts add up to the classified reads"""
+  * a poly-A read is one super-mer of L-k+1 k-mers; per-taxon read counts add up to the classified reads
+and ONE comparison with the oracle itself at full size: a sample of the reads (the N-bearing ones among them) is classified by the
+oracle against a mini-index that holds, for exactly the sample's minimizers, what POINT LOOKUPS of the big table returned (a different
+kernel from the classify kernels' probe) -- so bucket addressing at 2^31 buckets / 128 GiB offsets is checked against the oracle too."""
 import os
 
 import numpy as np
@@ -45,7 +48,7 @@ def big():
     ix.finalize()
     bases, offsets = bench.make_reads_device(torch, genome_cat, GL, G, n_reads, 150, dev)
     return dict(torch=torch, ix=ix, st=ix.stream(), bases=bases, offsets=offsets, R=n_reads, dev=dev,
-                ntax=bench.TAX_EXTENT)
+                ntax=bench.TAX_EXTENT, parents=parents)
 
 
 def run(big, bases, offsets, R, thresholds=(0.0, 0.1)):
@@ -147,6 +150,94 @@ def test_poly_a_known_answer(big):
     out = run(big, bases, big["offsets"][:R + 1], R)
     assert bool((out["nh"] == 1).all()) and bool((out["tk"] == 116).all()) and bool((out["np_"] == 1).all())
     assert bool((out["taxon"] == out["taxon"][0]).all())
+
+
+def test_sampled_reads_against_the_oracle_through_point_lookups(big, orc):
+    """configs[1] pinned to the oracle at full size (Classifier.classify, Classifier.scala:439-454).  >= 20 000 of the 10 M reads --
+    a random draw plus reads that hold an N or a run of Ns -- are scanned by the ORACLE; the SEQUENCE-span minimizers it finds are
+    looked up in the 1.0e10-record table with slk_index_lookup (table_lookup_kernel: one lane per key, not the cooperative probe
+    of the classify kernels); an oracle index is built from exactly those (key, taxon) answers; the oracle classifies the sample
+    against it, two thresholds; and the lane kernel's rows for the same reads (taken from its pass over ALL reads) must be
+    identical: taxon, classified, distinct hit groups, total k-mers, number of spans.  The table-sharded route at world = 1 (emit ->
+    compact -> lookup_coop -> apply) classifies the same sample and must agree as well."""
+    torch = big["torch"]
+    R = big["R"]
+    thr = (0.0, 0.1)
+    full = run(big, big["bases"], big["offsets"], R, thresholds=thr)
+    rows = big["bases"][:R * 150].view(R, 150)
+    rng = np.random.default_rng(20)
+    with_n = torch.nonzero((rows[:2_000_000] == ord("N")).any(1)).flatten().cpu().numpy()
+    pick = np.unique(np.concatenate([rng.choice(R, 20000, replace=False), with_n[:3000]]))
+    assert len(pick) >= 20000 and len(with_n) >= 100
+    sample = rows[torch.from_numpy(pick).to(big["dev"])].cpu().numpy()          # [S, 150]
+    S = len(pick)
+    p = orc.params()
+    keys = np.unique(np.concatenate([orc.minimizer_keys(p, bytes(sample[i])) for i in range(S)]))
+    taxa = big["ix"].lookup(keys)
+    hit = taxa != 0
+    assert 0.3 < hit.mean() < 1.0                   # genome-derived reads hit, random ones do not
+    oix = orc.Index(1, keys[hit], taxa[hit])
+    s_bases = sample.reshape(-1)
+    s_off = np.arange(0, (S + 1) * 150, 150, dtype=np.uint64)
+    want = orc.classify_batch(p, oix, big["parents"], s_bases, s_off, thresholds=thr)
+    idx = torch.from_numpy(pick).to(big["dev"])
+    for c in range(2):
+        assert np.array_equal(full["taxon"][c * R + idx].cpu().numpy(), want["taxon"][c])
+        assert np.array_equal(full["cls"][c * R + idx].cpu().numpy(), want["classified"][c])
+    assert np.array_equal(full["nd"][idx].cpu().numpy(), want["num_distinct"])
+    assert np.array_equal(full["tk"][idx].cpu().numpy(), want["total_kmers"])
+    assert np.array_equal(full["nh"][idx].cpu().numpy(), want["num_hits"])
+    assert int(want["classified"][0].sum()) > S // 2 and int((want["num_hits"] > 1).sum()) > S // 2
+    # the sharded route, one rank (no exchange): same table, other kernels (lookup_coop_kernel, lane_kernel<EMIT / APPLY>)
+    from slacken_amd.sharded import ShardedClassifier
+    sc = ShardedClassifier(big["ix"], 0, 1, None, big["dev"])
+    d_b = torch.from_numpy(s_bases).to(big["dev"])
+    d_o = torch.from_numpy(s_off.astype(np.int64)).to(big["dev"])
+    got = sc.classify(d_b, d_o, S, S * 150, thresholds=thr, fast=True)
+    assert got["deferred"] == 0
+    assert np.array_equal(got["taxon"].cpu().numpy().reshape(2, S), want["taxon"])
+    assert np.array_equal(got["classified"].cpu().numpy().reshape(2, S), want["classified"])
+    assert np.array_equal(got["num_distinct"].cpu().numpy(), want["num_distinct"])
+    assert np.array_equal(got["total_kmers"].cpu().numpy(), want["total_kmers"])
+    del sc, d_b, d_o, got
+
+
+def _run_bench(*args, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], capture_output=True, text=True, env=env, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return lines[0]
+
+
+def test_bench_table_sharded_two_ranks_rehearsal():
+    """BASELINE configs[3] end to end: `python bench.py --gpus 2 --table-sharded` starts two ranks, each builds ITS HALF of the
+    table (slk_index_set_shard: both scan all genomes and draw the same padding keys, each keeps what falls to it), classifies its
+    own batches through emit -> all-to-all -> lookup -> all-to-all -> apply, and rank 0 prints ONE line.  Both ranks share GPU 0
+    here (gloo, exchange through host memory): a rehearsal of the N-rank path, not a measurement."""
+    line = _run_bench("--gpus", "2", "--table-sharded", "--steps", "3", "--warmup", "1", "--records-per-rank", "1e8", "--reads", "1e6",
+                      "--genomes", "64", "--genome-len", "262144", "--rehearse-on-one-gpu")
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and cfg["parallelism"] == "table-sharded x2"
+    assert cfg["records_per_rank"] == 100_000_000 and cfg["reads_per_gpu_per_step"] == 1_000_000
+    assert 30 < cfg["keys_per_read"] < 45 and 0.3 < cfg["remote_bytes_per_read"] / cfg["exchanged_bytes_per_read"] < 0.7
+    assert cfg["classified_fraction"] > 0.5         # the other rank's half of the genome records answers too
+    for stage in ("emit", "compact", "exchange_keys", "lookup", "exchange_taxa", "apply"):
+        assert cfg["stage_ms_in_pipeline"][stage] > 0
+    assert abs(line["value"] - 2 * 1.0 / (line["ms_per_step"] * 1e-3)) < 0.01 * line["value"]
+
+
+def test_bench_table_sharded_one_rank():
+    line = _run_bench("--table-sharded", "--steps", "3", "--warmup", "1", "--records-per-rank", "2e8", "--reads", "1e6",
+                      "--genomes", "64", "--genome-len", "262144")
+    cfg = line["config"]
+    assert line["n_gpus"] == 1 and cfg["parallelism"] == "table-sharded x1" and cfg["remote_bytes_per_read"] == 0
+    assert cfg["xgmi_link_GBps_keys"] is None and line["roofline"]["lookup_stage_frac_of_request_rate_ceiling"] > 0
 
 
 def test_bench_two_ranks_rehearsal():
