@@ -9,7 +9,11 @@
 // byte boundary, the end-of-stream magic, the block's CRC as the stream's -- and hands it to BZ2_bzBuffToBuffDecompress.  (A
 // false magic inside compressed data has probability 2^-48 per bit position -- about 0.003 per 100 GB of file -- and fails loudly, on
 // the block's CRC; SLK_GZ_THREADS=0 reads such a file through libbz2's own streaming decoder.)  Concatenated streams are just more
-// blocks.  read() hands the text out in file order.
+// blocks.  read() hands the text out in file order, and checks on the way what a serial decoder checks between the blocks: every
+// stream's COMBINED CRC (the 32 bits behind its end-of-stream magic against the fold of its blocks' CRCs, c = rotl(c, 1) ^ crc),
+// that a stream header stands wherever a stream starts, that the file ends behind an end-of-stream marker and nowhere else -- a
+// file cut at a block boundary, a stream with a block missing and bytes behind the last stream are errors here as they are for
+// libbz2's streaming decoder (the other route), and so is an empty file.
 #pragma once
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -34,8 +38,14 @@ constexpr uint64_t BLOCK_MAGIC = 0x314159265359ull, EOS_MAGIC = 0x177245385090ul
 
 class Reader {
   typedef int (*decompress_t)(char *, unsigned int *, char *, unsigned int, int, int);
+  struct Magic {            // a block or end-of-stream marker found at bit position `bit`, with the 32 bits behind it
+    uint64_t bit;
+    uint32_t crc;           // the block's CRC / the stream's combined CRC
+    bool is_block;
+  };
   struct Slot {
     std::vector<uint8_t> out;
+    std::vector<Magic> magics;   // those that START in this chunk, in file order
     bool done = false;
   };
   const uint8_t *p_ = nullptr;
@@ -51,6 +61,12 @@ class Reader {
   std::string error_;
   std::vector<std::thread> th_;
   size_t out_chunk_ = 0, out_off_ = 0;
+  // consumer side: the stream structure, checked chunk by chunk in file order
+  bool entered_ = false;        // the current chunk's markers have been checked
+  bool in_stream_ = false;      // between a stream header and its end-of-stream marker
+  uint32_t combined_ = 0;       // fold of the block CRCs of the current stream
+  uint64_t header_byte_ = 0;    // where the next stream header must stand (valid when !in_stream_)
+  bool finished_ = false;
 
   // bit i of the file (most significant bit of a byte first, as bzip2 writes them)
   inline uint64_t bits48_at(uint64_t bit) const {   // the 48 bits starting at `bit` (zero beyond the end)
@@ -147,6 +163,7 @@ class Reader {
         }
         Slot &s = slots_[i % lookahead_];
         s.out.clear();
+        s.magics.clear();
         const uint64_t lo = (uint64_t)std::min(n_, i * chunk_bytes_) * 8, hi = (uint64_t)std::min(n_, (i + 1) * chunk_bytes_) * 8;
         const uint64_t file_end = (uint64_t)n_ * 8;
         bool is_block = false;
@@ -154,6 +171,7 @@ class Reader {
         while (at < hi) {
           bool next_is_block = false;
           const uint64_t next = next_magic(at + 48, file_end, &next_is_block);   // the block runs to the next magic (or the end)
+          s.magics.push_back(Magic{at, (uint32_t)((bits48_at(at + 48) >> 16) & 0xFFFFFFFFull), is_block});
           if (is_block) decode_block(at, next, s.out, tmp);
           if (next >= hi) break;
           at = next;
@@ -189,8 +207,8 @@ class Reader {
       madvise(m, n_, MADV_SEQUENTIAL);
       p_ = (const uint8_t *)m;
     }
-    if (n_ && (n_ < 4 || p_[0] != 'B' || p_[1] != 'Z' || p_[2] != 'h' || p_[3] < '1' || p_[3] > '9')) {
-      munmap((void *)p_, n_);
+    if (n_ < 4 || p_[0] != 'B' || p_[1] != 'Z' || p_[2] != 'h' || p_[3] < '1' || p_[3] > '9') {   // (an empty file too)
+      if (p_) munmap((void *)p_, n_);
       ::close(fd_);
       throw std::runtime_error("read error (corrupt compressed input?): not a bzip2 file: " + path);
     }
@@ -209,6 +227,33 @@ class Reader {
     if (fd_ >= 0) ::close(fd_);
   }
 
+  // what a serial decoder checks between the blocks (header comment), for the markers of one chunk
+  void check_structure(const std::vector<Magic> &magics) {
+    auto bad = [](const char *what) { throw std::runtime_error(std::string("read error (corrupt compressed input?): ") + what); };
+    for (const Magic &m : magics) {
+      if (!in_stream_) {   // a stream starts: "BZh1".."BZh9" at header_byte_, its first marker right behind
+        const size_t h = (size_t)header_byte_;
+        if (m.bit != (uint64_t)h * 8 + 32 || h + 4 > n_ || p_[h] != 'B' || p_[h + 1] != 'Z' || p_[h + 2] != 'h' || p_[h + 3] < '1' || p_[h + 3] > '9')
+          bad("bzip2 data (bytes that are no bzip2 stream)");
+        in_stream_ = true;
+        combined_ = 0;
+      }
+      if (m.is_block) {
+        combined_ = ((combined_ << 1) | (combined_ >> 31)) ^ m.crc;
+      } else {
+        if (combined_ != m.crc) bad("bzip2 data (a stream's combined CRC does not match its blocks)");
+        in_stream_ = false;
+        header_byte_ = (m.bit + 48 + 32 + 7) / 8;
+      }
+    }
+  }
+  void check_end() {
+    if (finished_) return;
+    finished_ = true;
+    if (in_stream_) throw std::runtime_error("read error (corrupt compressed input?): unexpected end of the bzip2 data");
+    if (header_byte_ != (uint64_t)n_) throw std::runtime_error("read error (corrupt compressed input?): bzip2 data (bytes behind the last stream)");
+  }
+
   // the next bytes of the decompressed file; 0 at its end
   size_t read(char *dst, size_t cap) {
     size_t got = 0;
@@ -219,6 +264,7 @@ class Reader {
         cv_.wait(lk, [&] { return !error_.empty() || (next_claim_ > out_chunk_ && s.done); });
         if (!error_.empty()) throw std::runtime_error("read error (corrupt compressed input?): " + error_);
       }
+      if (!entered_) { check_structure(s.magics); entered_ = true; }
       const size_t k = std::min(cap - got, s.out.size() - out_off_);
       memcpy(dst + got, s.out.data() + out_off_, k);
       got += k;
@@ -227,10 +273,12 @@ class Reader {
         std::lock_guard<std::mutex> lk(mu_);
         out_chunk_++;
         out_off_ = 0;
+        entered_ = false;
         consumed_ = out_chunk_;
         cv_.notify_all();
       }
     }
+    if (out_chunk_ >= nchunks_) check_end();
     return got;
   }
 };

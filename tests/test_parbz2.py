@@ -106,3 +106,64 @@ def test_streaming_decoder_reads_every_stream(cases, tmp_path):
     blob[len(blob) // 3] ^= 0x08
     open(bad, "wb").write(blob)
     assert "read error" in bunzip(bad, threads=0, expect_fail=True)
+
+
+def _bits(blob):
+    return "".join(format(b, "08b") for b in blob)
+
+
+def _bytes_of(bits):
+    bits = bits + "0" * (-len(bits) % 8)
+    return int(bits, 2).to_bytes(len(bits) // 8, "big") if bits else b""
+
+
+BLOCK = format(0x314159265359, "048b")
+EOS = format(0x177245385090, "048b")
+
+
+def test_stream_structure_is_checked_on_both_routes(tmp_path):
+    """What a serial decoder checks BETWEEN the blocks, the parallel route must check too (block CRCs alone let these pass):
+      * a file cut at a block boundary that falls on a byte boundary  -> every block decodes, the stream never ends
+      * a stream with a whole block missing                          -> every block decodes, the combined CRC is wrong
+      * bytes behind the last stream (zeros, text)                    -> no bzip2 data
+      * an empty file
+    Errors on the threaded route (SLK_GZ_THREADS=4) and on libbz2's streaming decoder (SLK_GZ_THREADS=0) alike."""
+    rng = np.random.default_rng(12)
+    text = fastq_text(rng, 30000)
+    blob = bz2.compress(text, 1)                      # ~100 kB of text per block
+    bits = _bits(blob)
+    starts = []
+    at = bits.find(BLOCK)
+    while at >= 0:
+        starts.append(at)
+        at = bits.find(BLOCK, at + 48)
+    eos = bits.rfind(EOS)
+    assert len(starts) > 40 and eos > starts[-1]
+
+    def both_fail(name, data):
+        path = str(tmp_path / name)
+        open(path, "wb").write(data)
+        for threads in (4, 0):
+            err = bunzip(path, threads=threads, chunk=100_000, expect_fail=True)
+            assert "read error" in err, (name, threads, err)
+
+    def both_ok(name, data, want):
+        path = str(tmp_path / name)
+        open(path, "wb").write(data)
+        for threads in (4, 0):
+            assert bunzip(path, threads=threads, chunk=100_000) == want, (name, threads)
+
+    aligned = [s for s in starts[1:] if s % 8 == 0]
+    assert aligned, "no block boundary of this file falls on a byte boundary: change the seed"
+    both_fail("cut_at_block.bz2", blob[:aligned[0] // 8])
+    # one block spliced out, the rest moved up bit by bit (the stream's CRC at its end now belongs to other blocks)
+    i = len(starts) // 2
+    both_fail("block_missing.bz2", _bytes_of(bits[:starts[i]] + bits[starts[i + 1]:eos + 80]))
+    both_fail("zeros_behind.bz2", blob + bytes(1000))
+    both_fail("text_behind.bz2", blob + b"@r\nACGT\n+\nIIII\n")
+    both_fail("empty_file.bz2", b"")
+    both_fail("header_only.bz2", b"BZh9")
+    # and what must still pass: the file itself, two streams back to back, an empty stream in the middle
+    both_ok("whole.bz2", blob, text)
+    both_ok("two_streams.bz2", blob + bz2.compress(text[:50_000], 9), text + text[:50_000])
+    both_ok("empty_stream_between.bz2", blob + bz2.compress(b"") + blob, text + text)
