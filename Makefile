@@ -13,9 +13,9 @@ CLI := slacken_amd/bin/slacken-amd
 
 all: $(LIB) $(CLI) oracle
 
-$(LIB): $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/build.hip $(CSRC)/shard.hip $(CSRC)/wide.hip $(CSRC)/capi.hip $(CSRC)/engine.h include/slacken_amd.h
+$(LIB): $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/build.hip $(CSRC)/shard.hip $(CSRC)/wide.hip $(CSRC)/capi.hip $(CSRC)/shardset.hip $(CSRC)/engine.h $(CSRC)/hostside.h include/slacken_amd.h
 	@mkdir -p slacken_amd/lib
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/build.hip $(CSRC)/shard.hip $(CSRC)/wide.hip $(CSRC)/capi.hip
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/build.hip $(CSRC)/shard.hip $(CSRC)/wide.hip $(CSRC)/capi.hip $(CSRC)/shardset.hip -ldl
 
 # Parquet input of the CLI: the Arrow C++ libraries inside the pyarrow wheel, if there is one (no Arrow dev package here)
 PYARROW_DIR := $(shell python3 -c "import pyarrow, os; print(os.path.dirname(pyarrow.__file__))" 2>/dev/null)

@@ -304,6 +304,40 @@ int32_t slk_classify_hits_device(slk_index *ix, slk_stream *st, const uint64_t *
                                  uint8_t *d_out_classified, int32_t *d_out_num_distinct, int32_t *d_out_total_kmers,
                                  int32_t *d_out_num_hits);
 
+/* ---- table-sharded classification in ONE process (BASELINE.json configs[3]: a library whose table exceeds one GPU's HBM).
+ * The host counterpart of the exchange the reference's join implies (S/slacken/Classifier.scala:84-95: the span rows are shuffled to
+ * the records by minimizer, the hits shuffled back and regrouped by title).  n indices -- member g created on its device with
+ * slk_index_set_shard(g, n), fed the whole record stream, finalized, all with the same splitter and taxonomy -- form a set; one
+ * slk_shardset_classify call is one ROUND: member g classifies batches[g] (R may be 0: the member still answers the others' keys).
+ * Every member scans its own fragments; 8-byte minimizers travel to their owners, 4-byte taxa travel back, nothing else moves.
+ * The exchange is RCCL's (ncclSend / ncclRecv grouped over the members' streams; librccl is loaded at run time) when every member
+ * has a device of its own, device-to-device copies otherwise (SLK_EXCHANGE_AUTO chooses) -- several members on ONE device is
+ * how a one-GPU box tests this path.  A batch's arguments mean what slk_classify_batch's do (host pointers; hit lists optional),
+ * and so do the results: bit-identical to the replicated mode.  One thread per set at a time; several sets may share members. */
+typedef struct slk_shardset slk_shardset;
+#define SLK_EXCHANGE_AUTO 0
+#define SLK_EXCHANGE_RCCL 1
+#define SLK_EXCHANGE_COPY 2
+typedef struct {
+  const uint8_t *bases;
+  const uint64_t *offsets;
+  const uint8_t *mate_bases;    /* nullable (single-end) */
+  const uint64_t *mate_offsets; /* nullable */
+  uint64_t R;
+  int32_t *out_taxon;           /* [C*R] threshold-major */
+  uint8_t *out_classified;      /* [C*R] */
+  int32_t *out_num_distinct;    /* [R] nullable */
+  int32_t *out_total_kmers;     /* [R] nullable */
+  uint64_t *out_hit_offsets;    /* [R+1] nullable */
+  slk_hit *out_hits;            /* nullable */
+  uint64_t hits_capacity;
+} slk_shard_batch;
+int32_t slk_shardset_create(slk_index *const *members, int32_t n_members, int32_t exchange, slk_shardset **out);
+int32_t slk_shardset_classify(slk_shardset *set, slk_shard_batch *batches /* [n_members] */, int32_t min_hit_groups,
+                              const double *thresholds, int32_t C);
+int32_t slk_shardset_exchange_mode(const slk_shardset *set); /* SLK_EXCHANGE_RCCL or SLK_EXCHANGE_COPY: what AUTO chose */
+void slk_shardset_destroy(slk_shardset *set);
+
 /* Per-stage device timing of the last slk_classify_batch_device call on st, in milliseconds (HIP events on the
  * stream the kernels ran on): [0]=scan, [1]=probe, [2]=classify.  Synchronises st. */
 int32_t slk_stream_last_stage_ms(slk_stream *st, float out_ms[3]);

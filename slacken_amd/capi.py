@@ -38,6 +38,14 @@ class IndexInfo(C.Structure):
                 ("device", C.c_int32), ("dense_taxa", C.c_int32), ("bucket_cells", C.c_int32)]
 
 
+class _ShardBatch(C.Structure):
+    _fields_ = [("bases", C.c_void_p), ("offsets", C.c_void_p), ("mate_bases", C.c_void_p), ("mate_offsets", C.c_void_p),
+                ("R", C.c_uint64), ("out_taxon", C.c_void_p), ("out_classified", C.c_void_p), ("out_num_distinct", C.c_void_p),
+                ("out_total_kmers", C.c_void_p), ("out_hit_offsets", C.c_void_p), ("out_hits", C.c_void_p),
+                ("hits_capacity", C.c_uint64)]
+
+
+EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_COPY = 0, 1, 2
 SPAN_DTYPE = np.dtype([("key", "<i8"), ("kmers", "<i4"), ("flag", "i1"), ("distinct", "u1"), ("pad", "<u2")])
 HIT_DTYPE = np.dtype([("taxon", "<i4"), ("count", "<i4")])
 
@@ -48,7 +56,8 @@ EXPORTS = ["slk_device_count", "slk_last_error", "slk_version", "slk_host_alloc"
            "slk_stream_hip_stream", "slk_stream_destroy", "slk_spans_batch", "slk_classify_batch",
            "slk_classify_batch_device", "slk_classify_hits", "slk_stream_last_stage_ms", "slk_scan_device", "slk_lookup_device",
            "slk_shard_of", "slk_classify_hits_device", "slk_shard_batch_rows", "slk_shard_emit_device", "slk_shard_compact_device",
-           "slk_shard_apply_device", "slk_stream_last_deferred", "slk_table_slot", "slk_table_hash_of"]
+           "slk_shard_apply_device", "slk_stream_last_deferred", "slk_table_slot", "slk_table_hash_of",
+           "slk_shardset_create", "slk_shardset_classify", "slk_shardset_exchange_mode", "slk_shardset_destroy"]
 
 
 def lib_path():
@@ -82,6 +91,11 @@ def lib():
     L.slk_index_set_taxonomy.argtypes = [vp, i32p, C.c_int32]
     L.slk_table_slot.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     L.slk_table_hash_of.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.slk_shardset_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.slk_shardset_classify.argtypes = [vp, C.POINTER(_ShardBatch), C.c_int32, C.POINTER(C.c_double), C.c_int32]
+    L.slk_shardset_exchange_mode.argtypes = [vp]
+    L.slk_shardset_destroy.argtypes = [vp]
+    L.slk_shardset_destroy.restype = None
     L.slk_index_set_shard.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.slk_index_finalize.argtypes = [vp]
     L.slk_index_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
@@ -244,6 +258,73 @@ class Index:
     def close(self):
         if getattr(self, "h", None):
             lib().slk_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShardSet:
+    """Table-sharded classification in one process (slk_shardset_*): members[g] is an Index with set_shard(g, n), finalized."""
+
+    def __init__(self, members, exchange=EXCHANGE_AUTO):
+        self.members = list(members)
+        arr = (C.c_void_p * len(self.members))(*[m.h for m in self.members])
+        h = C.c_void_p()
+        _check(lib().slk_shardset_create(arr, len(self.members), exchange, C.byref(h)))
+        self.h = h
+
+    @property
+    def exchange_mode(self):
+        return int(lib().slk_shardset_exchange_mode(self.h))
+
+    def classify(self, batches, min_hit_groups=2, thresholds=(0.0,), with_hits=True):
+        """One round: batches[g] = (bases, offsets) or (bases, offsets, mate_bases, mate_offsets) or None for member g.
+        -> list of result dicts as Stream.classify_batch returns them (None for members without a batch)."""
+        n = len(self.members)
+        assert len(batches) == n
+        Cn = len(thresholds)
+        thr = (C.c_double * Cn)(*thresholds)
+        arr = (_ShardBatch * n)()
+        keep, outs = [], []
+        for g, b in enumerate(batches):
+            if b is None:
+                outs.append(None)
+                continue
+            bases, offsets = _np(b[0], np.uint8), _np(b[1], np.uint64)
+            mb = mo = None
+            if len(b) > 2 and b[2] is not None:
+                mb, mo = _np(b[2], np.uint8), _np(b[3], np.uint64)
+            R = offsets.size - 1
+            o = dict(taxon=np.zeros((Cn, R), np.int32), classified=np.zeros((Cn, R), np.uint8), num_distinct=np.zeros(R, np.int32),
+                     total_kmers=np.zeros(R, np.int32))
+            hit_off = hits = None
+            cap = 0
+            if with_hits:
+                cap = int(bases.size + (mb.size + R if mb is not None else 0)) + 1
+                hit_off, hits = np.zeros(R + 1, np.uint64), np.zeros(cap, HIT_DTYPE)
+            keep.append((bases, offsets, mb, mo, hit_off, hits))
+            arr[g] = _ShardBatch(_ptr(bases), _ptr(offsets), _ptr(mb), _ptr(mo), R, _ptr(o["taxon"]), _ptr(o["classified"]),
+                                 _ptr(o["num_distinct"]), _ptr(o["total_kmers"]), _ptr(hit_off), _ptr(hits), cap)
+            o["_hit"] = (hit_off, hits)
+            outs.append(o)
+        _check(lib().slk_shardset_classify(self.h, arr, min_hit_groups, thr, Cn))
+        for o in outs:
+            if o is None:
+                continue
+            hit_off, hits = o.pop("_hit")
+            if hit_off is not None:
+                o["hit_offsets"] = hit_off
+                o["hits"] = hits[:int(hit_off[-1])]
+                o["num_hits"] = np.diff(hit_off.astype(np.int64)).astype(np.int32)
+        return outs
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().slk_shardset_destroy(self.h)
             self.h = None
 
     def __del__(self):

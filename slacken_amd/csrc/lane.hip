@@ -51,7 +51,7 @@ constexpr uint32_t OMAP_CNT_MASK = (1u << OMAP_CNT_BITS) - 1;
 
 struct __attribute__((aligned(16))) LaneLds {
   uint64_t q_key[QCAP];
-  uint32_t q_meta[QCAP];          // owner lane (6 bits) | distinct << 6 | kmers << 7 (13 bits) | displacement << 20 (6 bits)
+  uint32_t q_meta[QCAP];          // owner lane (6 bits) | distinct << 6 | kmers << 7 (13 bits) | displacement << 20 (8 bits)
   uint64_t stash[128];            // (home bucket, -, tag) 16 bytes per queue entry of the batch
   uint32_t found[64];             // taxon found per entry of the batch (a word array of its own: read by all 64 lanes at once, and
                                   // as the second word of the 16-byte stash entries that read was a 4-way bank conflict)
@@ -146,7 +146,7 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, uint32_t *ocnt, const Tab
   uint64_t rem_hi;
   table_slot(T.g, h, home, rem_hi);
   uint4 st;
-  const uint32_t disp = (meta >> 20) & 63;                                // > 0 for an entry re-queued after a full bucket
+  const uint32_t disp = (meta >> 20) & 255;                               // > 0 for an entry re-queued after a full bucket
   st.x = table_bucket(T.g, home, disp);                                   // bucket to read
   st.y = 0;
   const uint64_t tag = in ? (rem_hi + disp) : NO_TAG;                     // the tag's low bits are the displacement
@@ -188,7 +188,7 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, uint32_t *ocnt, const Tab
       // queue with its displacement raised, and takes an ordinary slot of a later batch.
       const int qj = (qhead + s * PG + g) & (QCAP - 1);
       const uint32_t m_old = L->q_meta[qj];
-      const bool again = c == 0 && ((B >> (g * LPB)) & ((1u << LPB) - 1)) == 0 && (int)((m_old >> 20) & 63) < T.max_disp;
+      const bool again = c == 0 && ((B >> (g * LPB)) & ((1u << LPB) - 1)) == 0 && (int)((m_old >> 20) & 255) < T.max_disp;
       const uint64_t k_old = L->q_key[qj];
       const uint16_t o_old = HITS ? L->q_ord[qj] : (uint16_t)0;
       const uint64_t R = __ballot(again);
@@ -233,12 +233,15 @@ __device__ __forceinline__ uint32_t shard_owner(uint64_t key, uint32_t ns) {  //
 }
 // LANE_EMIT: append the batch's minimizers to their owners' send lists (one atomic per owner per batch); the span metadata the
 // second pass needs (owner lane, distinct, k-mers) goes to a list of the same shape, which stays on this rank
+template <bool HITS>
 __device__ __forceinline__ void emit_batch(LaneLds *L, const ShardIO &S, int32_t *status, int qhead, int cnt, int lane, uint32_t sub,
                                            uint64_t row) {
   const bool in = lane < cnt;
   const int qi = (qhead + lane) & (QCAP - 1);
   const uint64_t key = L->q_key[qi];
-  const uint32_t meta = L->q_meta[qi];
+  // (nothing is re-queued in this mode, so the displacement field of the entry is free: with hit lists it carries the span's
+  //  ordinal -- a fragment this kernel takes has fewer than 1000 spans -- for the second pass to write the hit where it belongs)
+  const uint32_t meta = L->q_meta[qi] | (HITS ? (uint32_t)L->q_ord[qi] << 20 : 0u);
   const uint32_t ns = (uint32_t)S.n_shards;
   const uint32_t g = shard_owner(key, ns);
   for (uint32_t sh = 0; sh < ns; sh++) {
@@ -271,7 +274,8 @@ __device__ __forceinline__ void emit_batch(LaneLds *L, const ShardIO &S, int32_t
 // LANE_APPLY: no second scan.  The tile's probe batches are replayed from the log: lane i takes the i-th entry of a batch in
 // (owner, rank) order, reads its span metadata from this rank's meta list and its taxon from the owners' answers (which arrive
 // list by list in the order the keys were sent), and folds it into the owner lane's map exactly as the local kernel does.
-__device__ __forceinline__ void apply_row(LaneLds *L, const ShardIO &S, int lane, uint32_t sub, uint64_t row) {
+template <bool HITS>
+__device__ __forceinline__ void apply_row(LaneLds *L, const ShardIO &S, int lane, uint32_t sub, uint64_t row, int32_t *hit_meta, int32_t *hit_taxon) {
   const uint32_t ns = (uint32_t)S.n_shards;
   uint32_t off = 0;
   bool in = false;
@@ -294,6 +298,11 @@ __device__ __forceinline__ void apply_row(LaneLds *L, const ShardIO &S, int lane
   if (in) {
     meta = S.send_meta[meta_at];
     taxon = S.taxa[taxon_at];
+    if (HITS) {   // the un-merged hit list, as probe_batch writes it (the owners answer in the caller's ids)
+      const uint64_t at = L->rb[meta & 63] + (meta >> 20);
+      hit_taxon[at] = taxon;
+      hit_meta[at] = pack_meta((int32_t)((meta >> 7) & 0x1FFF), 1, (meta >> 6) & 1);
+    }
     if (S.to_dense != nullptr && taxon > 0) taxon = taxon < S.n_to_dense ? S.to_dense[taxon] : 0;  // (owners answer in the caller's ids)
   }
   fold_hit<false>(L, nullptr, in, meta, taxon);
@@ -487,7 +496,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       // the second pass of the table-sharded mode: what the scan of the first pass found is on file
       const uint32_t nrows = S.tile_rows[tile];
       lane_wave_sync();
-      for (uint32_t b = 0; b < nrows; b++) apply_row(L, S, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row + b);
+      for (uint32_t b = 0; b < nrows; b++) apply_row<HITS>(L, S, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row + b, A.span_meta, A.span_taxon);
       if (have) { total = S.read_info[r].x; nhits = S.read_info[r].y; }
     }
     while (__ballot(!fin) != 0) {
@@ -628,7 +637,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
         while (qn >= 64) {
           lane_wave_sync();
           int back = 0;
-          if (MODE == LANE_EMIT) emit_batch(L, S, A.status, qhead, 64, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++);
+          if (MODE == LANE_EMIT) emit_batch<HITS>(L, S, A.status, qhead, 64, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++);
           else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS, LONG>(L, ocnt, A.T, qhead, qn, 64, lane, dbg, A.span_meta, A.span_taxon);
           qhead = (qhead + 64) & (QCAP - 1);
           qn += back - 64;
@@ -639,7 +648,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       lane_wave_sync();
       const int cnt = min(qn, 64);
       int back = 0;
-      if (MODE == LANE_EMIT) emit_batch(L, S, A.status, qhead, cnt, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++);
+      if (MODE == LANE_EMIT) emit_batch<HITS>(L, S, A.status, qhead, cnt, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++);
       else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS, LONG>(L, ocnt, A.T, qhead, qn, cnt, lane, dbg, A.span_meta, A.span_taxon);
       qhead = (qhead + cnt) & (QCAP - 1);
       qn += back - cnt;
@@ -662,6 +671,8 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     }
     if (have) {
       if (dfr) {
+        // (sharded mode: the caller routes this fragment through the staged kernels; until then it has no spans on file)
+        if (MODE == LANE_APPLY) { if (A.out_nh) A.out_nh[r] = 0; if (HITS) A.span_count[r] = 0; }
       } else if (MODE != LANE_EMIT) {
         const int32_t nd = (int32_t)oflags;
         // The map's entries move to the front of the lane's column (their hash order has served its purpose): entry j of D.
@@ -823,9 +834,11 @@ void launch_lane_long(const FusedArgs &A, uint32_t max_len, hipStream_t s) {
   if (A.span_taxon) launch_lane_mode<LANE_LOCAL, true, true>(A, ShardIO{}, nullptr, max_len, s);
   else launch_lane_mode<LANE_LOCAL, false, true>(A, ShardIO{}, nullptr, max_len, s);
 }
+// A.span_taxon set (both passes): the hit lists are written too -- the flagged spans by the first pass, the hits by the second
 void launch_lane_sharded(int mode, const FusedArgs &A, const ShardIO &S, int32_t *defer, uint32_t max_len, hipStream_t s) {
-  if (mode == LANE_EMIT) launch_lane_mode<LANE_EMIT, false, false>(A, S, defer, max_len, s);
-  else launch_lane_mode<LANE_APPLY, false, false>(A, S, defer, max_len, s);
+  const bool hits = A.span_taxon != nullptr;
+  if (mode == LANE_EMIT) { if (hits) launch_lane_mode<LANE_EMIT, true, false>(A, S, defer, max_len, s); else launch_lane_mode<LANE_EMIT, false, false>(A, S, defer, max_len, s); }
+  else { if (hits) launch_lane_mode<LANE_APPLY, true, false>(A, S, defer, max_len, s); else launch_lane_mode<LANE_APPLY, false, false>(A, S, defer, max_len, s); }
 }
 
 }  // namespace slk
