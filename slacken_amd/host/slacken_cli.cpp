@@ -287,6 +287,7 @@ struct ClassifyOpts {
   std::vector<double> thresholds;
   std::vector<std::string> files;
   std::vector<int> devices{0};  // --devices: the GPUs that share the reads (table replicated on each)
+  bool shard_table = false;     // --shard-table: the table is spread over the devices instead (a library beyond one GPU's memory)
   // classify2 (Slacken.scala:199-260)
   std::string library, rank = "species";
   int min_count = -1, min_distinct = -1, reads = -1;
@@ -325,6 +326,7 @@ static ClassifyOpts parse_classify_opts(int argc, char **argv, bool two_step) {
         }
       }
     }
+    else if (a == "--shard-table") { if (two_step) die("--shard-table is for classify (the dynamic library of classify2 is small)"); o.shard_table = true; }
     else if (two_step && (a == "-l" || a == "--library")) o.library = next();
     else if (two_step && a == "--rank") o.rank = next();
     else if (two_step && (a == "-C" || a == "--min-count")) o.min_count = std::stoi(next());
@@ -354,16 +356,35 @@ static ClassifyOpts parse_classify_opts(int argc, char **argv, bool two_step) {
 // the reference's counterpart is the fan-out of the span rows over the partitions, KeyValueIndex.scala:169-172): there is
 // no exchange between devices, only the host-side merge of the per-taxon counts that the report is made of.  The same
 // device may be listed more than once (two tables on it): that is how the multi-device path is tested on a one-GPU box.
+// --shard-table (BASELINE configs[3]): a library whose table does not fit one GPU is SPREAD over the devices
+// instead -- device i keeps the records whose minimizer falls to it (slk_index_set_shard; every device is handed the whole record
+// stream and drops the rest), and the batches are classified in rounds of one batch per device by slk_shardset_classify: minimizers
+// travel to their owners and taxa back (RCCL, or copies when devices repeat).  The output is byte for byte that of the other mode.
 struct DeviceIndex {
   std::vector<slk_index *> ixs;   // one per device of the list
   slk_index *ix = nullptr;        // = ixs[0]
   slk_stream *st = nullptr;       // a stream on ixs[0]
   std::vector<int> devices{0};
+  bool sharded = false;
+  std::vector<slk_shardset *> sets;   // sharded: the rounds of several host threads overlap, each on a set (streams, buffers) of its own
   ~DeviceIndex() { reset(); }
   void reset() {
+    for (slk_shardset *s : sets) slk_shardset_destroy(s);
+    sets.clear();
     if (st) slk_stream_destroy(st);
     for (slk_index *i : ixs) slk_index_destroy(i);
     ixs.clear(); st = nullptr; ix = nullptr;
+  }
+  // slk_classify_batch on this library, whichever way it is laid out (single caller: the passes after the stream of batches)
+  void classify_one(const uint8_t *bases, const uint64_t *offs, const uint8_t *mb, const uint64_t *mo, uint64_t n, int min_hits,
+                    const double *thr, int C, int32_t *taxon, uint8_t *cls, int32_t *nd, int32_t *tk, uint64_t *hit_offs, slk_hit *hits, uint64_t cap) {
+    if (!sharded) {
+      SLK_CALL(slk_classify_batch(ix, st, bases, offs, mb, mo, n, min_hits, thr, C, taxon, cls, nd, tk, hit_offs, hits, cap));
+      return;
+    }
+    std::vector<slk_shard_batch> round(ixs.size(), slk_shard_batch{});
+    round[0] = slk_shard_batch{bases, offs, mb, mo, n, taxon, cls, nd, tk, hit_offs, hits, cap};
+    SLK_CALL(slk_shardset_classify(sets[0], round.data(), min_hits, thr, C));
   }
   template <class F> void on_each(F f) {  // f(index) on every replica, side by side
     if (ixs.size() == 1) { f(ixs[0]); return; }
@@ -376,12 +397,15 @@ struct DeviceIndex {
   }
   void create(const IndexParams &ip, const Taxonomy &tax, uint64_t expected_records, int32_t max_taxon) {
     slk_params sp{ip.k, ip.m, ip.spaces, ip.canonical ? 1 : 0, ip.xorMask, (ip.m + 31) / 32, 0};
-    slk_table_config cfg{expected_records, max_taxon, 0.0f};
+    // (sharded: a device's share of the records, with room for the hash's unevenness)
+    const uint64_t share = sharded ? expected_records / devices.size() + expected_records / (4 * devices.size()) + 4096 : expected_records;
+    slk_table_config cfg{share, max_taxon, 0.0f};
     std::vector<int32_t> parents(tax.parents.begin(), tax.parents.end());
     if (max_taxon + 1 > (int32_t)parents.size()) parents.resize(max_taxon + 1, 0);
     for (int d : devices) {
       slk_index *one = nullptr;
       SLK_CALL(slk_index_create(&sp, &cfg, d, &one));
+      if (sharded) SLK_CALL(slk_index_set_shard(one, (uint32_t)ixs.size(), (uint32_t)devices.size()));
       ixs.push_back(one);
       SLK_CALL(slk_index_set_taxonomy(one, parents.data(), (int32_t)parents.size()));
     }
@@ -406,6 +430,17 @@ struct DeviceIndex {
   void finalize() {
     for (slk_index *i : ixs) SLK_CALL(slk_index_finalize(i));
     SLK_CALL(slk_stream_create(ix, &st));
+    if (sharded) {
+      const char *e = getenv("SLK_SHARD_SETS");
+      const size_t n_sets = std::max<size_t>(1, std::min<size_t>(4, e ? (size_t)atol(e) : 2));
+      for (size_t i = 0; i < n_sets; i++) {
+        slk_shardset *s = nullptr;
+        SLK_CALL(slk_shardset_create(ixs.data(), (int32_t)ixs.size(), SLK_EXCHANGE_AUTO, &s));
+        sets.push_back(s);
+      }
+      std::cerr << "table sharded over " << ixs.size() << " device table(s), exchange by "
+                << (slk_shardset_exchange_mode(sets[0]) == SLK_EXCHANGE_RCCL ? "RCCL" : "device-to-device copies") << std::endl;
+    }
   }
 };
 
@@ -454,7 +489,7 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
   std::vector<slk_index *> stream_ix(n_workers, nullptr);
   for (size_t i = 0; i < n_workers; i++) stream_ix[i] = dev.ixs[i % dev.ixs.size()];
   streams[0] = dev.st;
-  for (size_t i = 1; i < n_workers; i++) SLK_CALL(slk_stream_create(stream_ix[i], &streams[i]));
+  for (size_t i = 1; i < n_workers && !dev.sharded; i++) SLK_CALL(slk_stream_create(stream_ix[i], &streams[i]));
   std::atomic<size_t> total{0}, n_batches{0};
   const bool timing = getenv("SLK_HOST_TIMING") != nullptr;  // where the wall clock of the workers goes, by stage
   std::mutex mu_in, mu_out, mu_stat;
@@ -523,10 +558,87 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
     std::lock_guard<std::mutex> lk(mu_stat);
     t_input += w_input; t_device += w_device; t_hand_over += w_hand_over;
   };
+  // --shard-table: a worker takes up to one batch per device table, classifies them as ONE round of its shard set, and hands them
+  // on in input order; a second worker's round (its own set) overlaps the first one's copies and host work
+  auto work_sharded = [&](slk_shardset *set, slk_stream *span_st) {
+    const size_t W = dev.ixs.size();
+    std::vector<int32_t> nd, tk;
+    try {
+      for (;;) {
+        std::vector<FragmentBatchPtr> in;
+        size_t ticket0;
+        if (failed) break;
+        {
+          std::lock_guard<std::mutex> lk(mu_in);
+          ticket0 = next_ticket;
+          while (in.size() < W) {
+            FragmentBatchPtr fb = next_batch();
+            if (!fb) break;
+            in.push_back(std::move(fb));
+            next_ticket++;
+          }
+        }
+        if (in.empty()) break;
+        std::vector<std::shared_ptr<ClassifiedBatch>> out;
+        std::vector<slk_shard_batch> round(W, slk_shard_batch{});
+        std::vector<std::vector<int32_t>> nds(in.size()), tks(in.size());
+        for (size_t g = 0; g < in.size(); g++) {
+          n_batches++;
+          auto b = new_classified_batch();
+          b->frags = std::move(in[g]);
+          b->C = C;
+          const FragmentBatch &fb = *b->frags;
+          const size_t n = fb.size();
+          total += n;
+          b->taxon.resize((size_t)C * n); b->classified.resize((size_t)C * n); nds[g].resize(n); tks[g].resize(n);
+          b->hit_offs.resize(n + 1);
+          const size_t cap = fb.bases.size() + fb.mate_bases.size() + n + 1;
+          if (want_hits) b->reserve_hits(cap);
+          round[g] = slk_shard_batch{fb.bases.data(), fb.offs.data(), fb.paired ? fb.mate_bases.data() : nullptr, fb.paired ? fb.mate_offs.data() : nullptr,
+                                     n, b->taxon.data(), b->classified.data(), nds[g].data(), tks[g].data(), b->hit_offs.data(),
+                                     want_hits ? b->hits.get() : nullptr, cap};
+          out.push_back(b);
+        }
+        SLK_CALL(slk_shardset_classify(set, round.data(), min_hits, thresholds.data(), C));
+        for (size_t g = 0; g < out.size(); g++) {
+          std::shared_ptr<ClassifiedBatch> b = out[g];
+          if (want_spans) {
+            const FragmentBatch &fb = *b->frags;
+            const size_t n = fb.size(), cap = fb.bases.size() + fb.mate_bases.size() + n + 1;
+            b->span_offs.resize(n + 1);
+            b->spans.resize(cap);
+            SLK_CALL(slk_spans_batch(dev.ix, span_st, fb.bases.data(), fb.offs.data(), fb.paired ? fb.mate_bases.data() : nullptr,
+                                     fb.paired ? fb.mate_offs.data() : nullptr, n, b->span_offs.data(), b->spans.data(), cap));
+          }
+          std::unique_lock<std::mutex> lk(mu_out);
+          cv_out.wait(lk, [&] { return next_out == ticket0 + g || failure; });
+          if (!failure) f(std::shared_ptr<const ClassifiedBatch>(b));
+          next_out = ticket0 + g + 1;
+          cv_out.notify_all();
+        }
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(mu_out);
+      if (!failure) failure = std::current_exception();
+      failed = true;
+      next_out = (size_t)-1;
+      cv_out.notify_all();
+    }
+  };
   std::vector<std::thread> workers;
-  for (size_t i = 1; i < n_workers; i++) workers.emplace_back(work, stream_ix[i], streams[i]);
-  work(stream_ix[0], streams[0]);
-  for (auto &t : workers) t.join();
+  if (dev.sharded) {
+    std::vector<slk_stream *> span_streams(dev.sets.size(), nullptr);
+    span_streams[0] = dev.st;
+    for (size_t i = 1; i < dev.sets.size(); i++) SLK_CALL(slk_stream_create(dev.ix, &span_streams[i]));
+    for (size_t i = 1; i < dev.sets.size(); i++) workers.emplace_back(work_sharded, dev.sets[i], span_streams[i]);
+    work_sharded(dev.sets[0], span_streams[0]);
+    for (auto &t : workers) t.join();
+    for (size_t i = 1; i < dev.sets.size(); i++) slk_stream_destroy(span_streams[i]);
+  } else {
+    for (size_t i = 1; i < n_workers; i++) workers.emplace_back(work, stream_ix[i], streams[i]);
+    work(stream_ix[0], streams[0]);
+    for (auto &t : workers) t.join();
+  }
   for (size_t i = 1; i < n_workers; i++) slk_stream_destroy(streams[i]);
   if (failure) std::rethrow_exception(failure);
   if (timing)
@@ -585,8 +697,8 @@ static std::vector<RepeatResult> classify_fragments(DeviceIndex &dev, const std:
     std::vector<slk_span> spans(want_distinct ? cap : 0);
     const uint8_t *mb = paired ? fb.mate_bases.data() : nullptr;
     const uint64_t *mo = paired ? fb.mate_offs.data() : nullptr;
-    SLK_CALL(slk_classify_batch(dev.ix, dev.st, fb.bases.data(), fb.offs.data(), mb, mo, n, min_hits, thresholds.data(), C, taxon.data(),
-                                cls.data(), nd.data(), tk.data(), hit_offs.data(), hits.data(), cap));
+    dev.classify_one(fb.bases.data(), fb.offs.data(), mb, mo, n, min_hits, thresholds.data(), C, taxon.data(), cls.data(), nd.data(), tk.data(),
+                     hit_offs.data(), hits.data(), cap);
     if (want_distinct) SLK_CALL(slk_spans_batch(dev.ix, dev.st, fb.bases.data(), fb.offs.data(), mb, mo, n, span_offs.data(), spans.data(), cap));
     for (size_t i = 0; i < n; i++) {
       RepeatResult &r = out[i0 + i];
@@ -827,6 +939,7 @@ static int cmd_classify(int argc, char **argv) {
   Taxonomy tax;
   DeviceIndex dev;
   dev.devices = o.devices;
+  dev.sharded = o.shard_table;
   load_index(o.index, ip, tax, dev);
   classify_and_write(dev, ip, tax, o);
   return 0;
@@ -966,6 +1079,8 @@ static const char *HELP =
     "      --[no]unclassified keep (default) or drop unclassified reads\n"
     "      --[no]detailed     per-read output (default) or reports only\n"
     "      --devices LIST     GPUs that share the reads, `all` or e.g. 0,1,2,3 (default 0); the library is replicated on each\n"
+    "      --shard-table      classify: spread the library over the devices instead (each holds the records whose minimizer falls to it;\n"
+    "                         minimizers travel to their owners and taxa back): for a library beyond one GPU's memory\n"
     "  FILES                  FASTA / FASTQ, plain, .gz or .bz2; @list.txt names a file of file names\n"
     "options of classify2 (Slacken.scala:199-260): --library DIR (DIR/library/**/*.fna, DIR/seqid2taxid.map), --rank RANK (species),\n"
     "  -R, --reads N (100) | -C, --min-count N | -D, --min-distinct N, --init-confidence X (0.15)\n"

@@ -442,6 +442,52 @@ def test_cli_devices_share_the_reads(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_shard_table_gives_the_same_files(tmp_path):
+    """--shard-table: the library is SPREAD over the devices of --devices (each keeps the records whose minimizer falls to it) and
+    the batches are classified in rounds through slk_shardset_classify -- minimizers to their owners, taxa back.  Per-read files
+    and reports are byte for byte those of the replicated mode: single-end with long reads among them, pairs, a title that occurs
+    twice (its merged row is classified from hit lists that come through the sharded route), reports only.  (One GPU: the device is
+    listed two or three times, the exchange is device-to-device copies; the RCCL leg needs a device per table.)"""
+    g, loc, tax, reads = make_library(tmp_path)
+    rng = np.random.default_rng(3)
+    fq = tmp_path / "reads.fq"
+    with open(fq, "w") as f:
+        for rep in range(12):
+            for t, s in reads:
+                f.write(f"@{t}.{rep}\n{s}\n+\n{'I' * len(s)}\n")
+        long_read = "".join(s for _, s in reads[:40])           # > 1000 bases: the staged round
+        f.write(f"@long\n{long_read}\n+\n{'I' * len(long_read)}\n")
+        t0, s0 = reads[0]
+        f.write(f"@{t0}.0\n{reads[1][1]}\n+\n{'I' * len(reads[1][1])}\n")      # a title for the second time
+    f1, f2 = tmp_path / "r1.fq", tmp_path / "r2.fq"
+    with open(f1, "w") as a, open(f2, "w") as b:
+        for i in range(0, len(reads) - 1, 2):
+            a.write(f"@p{i}/1\n{reads[i][1]}\n+\n{'I' * len(reads[i][1])}\n")
+            b.write(f"@p{i}/2\n{reads[i + 1][1]}\n+\n{'I' * len(reads[i + 1][1])}\n")
+    env = dict(os.environ, SLK_IO_CHUNK=str(1 << 17))   # small segments => many batches => several rounds
+    runs = {}
+    for name, extra in (("rep", []), ("sh2", ["--devices", "0,0", "--shard-table"]), ("sh3", ["--devices", "0,0,0", "--shard-table"])):
+        for kind, args in (("se", [str(fq)]), ("pe", ["-p", str(f1), str(f2)]), ("nd", ["--nodetailed", str(fq)])):
+            out = tmp_path / f"{name}_{kind}"
+            r = subprocess.run([CLI, "classify", "-i", loc, "-o", str(out), "-c", "0.0", "0.15", *extra, *args], capture_output=True, text=True, env=env)
+            assert r.returncode == 0, r.stderr
+            if extra:
+                assert f"table sharded over {len(extra[1].split(','))} device table(s), exchange by device-to-device copies" in r.stderr
+            runs[(name, kind)] = out
+    for kind in ("se", "pe", "nd"):
+        for suffix in ("0.00", "0.15"):
+            want_report = open(f"{runs[('rep', kind)]}_c{suffix}/all_kreport.txt").read()
+            for name in ("sh2", "sh3"):
+                assert open(f"{runs[(name, kind)]}_c{suffix}/all_kreport.txt").read() == want_report, (name, kind, suffix)
+                if kind != "nd":
+                    a, b = (gzip.open(f"{runs[(n, kind)]}_c{suffix}/sample=all/part-00000.txt.gz", "rb").read() for n in ("rep", name))
+                    assert a == b and a.count(b"\n") > 100, (name, kind, suffix)
+    bad = subprocess.run([CLI, "classify2", "-i", loc, "-o", str(tmp_path / "x"), "--library", str(tmp_path), "--shard-table", str(fq)],
+                         capture_output=True, text=True)
+    assert bad.returncode != 0 and "--shard-table is for classify" in bad.stderr
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SLK_TITLE_SEEDS", 4))))
 def test_cli_repeated_titles_randomised(tmp_path, seed):
     """Random multiplicities of every title -- 0 to 3 records per file, any order, unpaired over two files or paired with the
