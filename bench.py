@@ -274,12 +274,16 @@ def table_sharded(args, rank, world, local_rank):
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.collectives_at_one_rank:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")     # (RCCL refuses two ranks on one GPU; the exchange is staged through host memory)
+            dist.init_process_group("gloo", rank=rank, world_size=world)     # (RCCL refuses two ranks on one GPU; the exchange is staged through host memory)
         else:
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     import slacken_amd
     n_reads, per_rank = int(args.reads), int(args.records_per_rank)
     t0 = time.time()
@@ -328,7 +332,8 @@ def table_sharded(args, rank, world, local_rank):
     del genome_cat
     torch.cuda.empty_cache()
     total_bases = n_reads * READ_LEN
-    sc = sharded.ShardedClassifier(ix, rank, world, dist, device, exchange_on_cpu=args.rehearse_on_one_gpu)
+    sc = sharded.ShardedClassifier(ix, rank, world, dist, device, exchange_on_cpu=args.rehearse_on_one_gpu,
+                                   force_collectives=args.collectives_at_one_rank)
     batch = (d_bases, d_offsets, n_reads, total_bases, None)
 
     def barrier():
@@ -364,6 +369,8 @@ def table_sharded(args, rank, world, local_rank):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         **({"rehearsal": "all ranks on GPU 0, exchange through host memory (gloo): not a measurement"} if args.rehearse_on_one_gpu else {}),
+        **({"collectives": "one rank sends to itself through the RCCL all-to-all: the exchange stages are device-local copies"}
+           if args.collectives_at_one_rank and world == 1 else {}),
         "config": {
             "workload": "oversized custom library, hash-sharded over the GPUs (k=35,m=31,s=7), synthetic 150 bp single-end reads; "
                         "minimizers to their owners and taxa back by all-to-all (BASELINE.json configs[3])",
@@ -408,6 +415,9 @@ def main():
     ap.add_argument("--table-sharded", action="store_true",
                     help="BASELINE configs[3]: every rank holds 1/N of the table, minimizers and taxa cross the links (RCCL all-to-all)")
     ap.add_argument("--records-per-rank", type=float, default=5.0e9, help="--table-sharded: records of one rank's shard")
+    ap.add_argument("--collectives-at-one-rank", action="store_true",
+                    help="--table-sharded with ONE rank: the keys and taxa go through the RCCL all-to-all all the same (the rank sends to "
+                         "itself), so that the `nccl` process group and its device collectives run on a one-GPU box")
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing only (gloo, no GPU)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N ranks that all use GPU 0 (gloo for the rendezvous): rehearses the N-rank GPU path on a one-GPU box; "

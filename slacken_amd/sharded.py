@@ -80,15 +80,16 @@ class Exchange:
     split sizes travel first, and with them one flag word per rank (a send list overflowed: emit again) -- so the decision every
     rank must take alike costs no collective of its own and nothing touches torch's default stream."""
 
-    def __init__(self, rank=0, world=1, dist=None, device=None, on_cpu=False):
+    def __init__(self, rank=0, world=1, dist=None, device=None, on_cpu=False, force=False):
         import torch
         self.torch, self.rank, self.world, self.dist = torch, rank, world, dist
+        self.force = force   # a world of ONE rank goes through the collectives all the same (it sends to itself): runs that code on one GPU
         self.device = device if device is not None else torch.device("cpu")
         self.on_cpu = on_cpu or self.device.type == "cpu"  # gloo has no device all-to-all: stage through host memory (tests)
 
     @property
     def single(self):
-        return self.world == 1 or self.dist is None
+        return self.dist is None or (self.world == 1 and not self.force)
 
     def split_sizes(self, send_counts, flag=False):
         """-> (recv_counts, any rank's flag).  One all-to-all of [count for that peer, my flag] pairs."""
@@ -125,13 +126,13 @@ class Exchange:
 class ShardedClassifier:
     """index: this rank's slacken_amd.Index holding ONLY the records with shard_of(key) == rank (plus the taxonomy)."""
 
-    def __init__(self, index, rank=0, world=1, dist=None, device=None, exchange_on_cpu=False):
+    def __init__(self, index, rank=0, world=1, dist=None, device=None, exchange_on_cpu=False, force_collectives=False):
         import torch
         self.torch, self.ix, self.st = torch, index, index.stream()
         self.rank, self.world, self.dist = rank, world, dist
         self.device = device if device is not None else torch.device("cuda", 0)
         self.on_cpu = exchange_on_cpu
-        self.ex = Exchange(rank, world, dist, self.device, exchange_on_cpu)
+        self.ex = Exchange(rank, world, dist, self.device, exchange_on_cpu, force_collectives)
         self.stage_ms = None   # classify_many(profile=True): per-stage device times of the batches
 
     def _all_to_all(self, send, send_counts):
@@ -256,7 +257,7 @@ class ShardedClassifier:
                 back = self.ex.all_to_all(found[:n_recv], recv_counts, send_counts)
             b["taxa"] = back.contiguous() if back.numel() else torch.zeros(1, dtype=torch.int32, device=self.device)
         b["exchanged"], b["looked_up"] = n_send, n_recv
-        b["sent_remote"] = n_send - (send_counts[self.rank] if self.world > 1 else n_send)
+        b["sent_remote"] = n_send - send_counts[self.rank]
         del b["send_keys"], b["out_keys"]
 
     def _fast_apply(self, b, thresholds, min_hit_groups):

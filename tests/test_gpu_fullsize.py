@@ -233,6 +233,16 @@ def test_bench_table_sharded_two_ranks_rehearsal():
     assert abs(line["value"] - 2 * 1.0 / (line["ms_per_step"] * 1e-3)) < 0.01 * line["value"]
 
 
+def test_bench_table_sharded_one_rank_through_rccl():
+    """the `nccl` process group and its device all_to_all_single, on the one GPU there is: a world of one rank that sends its keys
+    and taxa to itself through RCCL"""
+    line = _run_bench("--table-sharded", "--collectives-at-one-rank", "--steps", "3", "--warmup", "1", "--records-per-rank", "1e8", "--reads", "1e6",
+                      "--genomes", "64", "--genome-len", "262144")
+    cfg = line["config"]
+    assert line["n_gpus"] == 1 and "collectives" in line and cfg["classified_fraction"] > 0.5
+    assert cfg["stage_ms_in_pipeline"]["exchange_keys"] > 0.01 and cfg["stage_ms_in_pipeline"]["exchange_taxa"] > 0.005
+
+
 def test_bench_table_sharded_one_rank():
     line = _run_bench("--table-sharded", "--steps", "3", "--warmup", "1", "--records-per-rank", "2e8", "--reads", "1e6",
                       "--genomes", "64", "--genome-len", "262144")

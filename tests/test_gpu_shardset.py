@@ -168,3 +168,54 @@ def test_set_refuses_what_is_not_a_sharding(orc, world):
     ix.append(lib.keys[:10], lib.taxa[:10])
     with pytest.raises(slacken_amd.SlackenError):
         ix.set_shard(0, 2)                                 # after the first record
+
+
+RCCL_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+import torch  # (as in the test session: PyTorch's HIP runtime first)
+import slacken_amd, synth, taxgen
+from slacken_amd import capi
+rng = np.random.default_rng(5)
+parents = taxgen.taxonomy(8 * 16, rng)
+taxa = np.array(taxgen.defined_taxa(parents))
+reads = [synth.random_dna(int(rng.integers(60, 300)), rng) for _ in range(800)] + [synth.random_dna(1500, rng) for _ in range(5)]
+keys = np.unique((rng.integers(0, 2**62, 20000, dtype=np.int64) * 4) & ~np.int64(0x33333330))
+tx = rng.choice(taxa, size=len(keys)).astype(np.int32)
+ix = slacken_amd.Index(expected_records=len(keys), max_taxon=len(parents) - 1)
+ix.set_shard(0, 1)
+ix.append(keys, tx); ix.set_taxonomy(parents); ix.finalize()
+# the reads' own minimizers cannot be had without the oracle here: plant records by classifying spans instead
+st = ix.stream()
+bases, offsets = synth.pack(reads)
+so, spans = st.spans_batch(bases, offsets)
+rk = np.unique(spans["key"][spans["flag"] == 1])
+ix2 = slacken_amd.Index(expected_records=len(rk) + len(keys), max_taxon=len(parents) - 1)
+ix2.set_shard(0, 1)
+ix2.append(rk, rng.choice(taxa, size=len(rk)).astype(np.int32)); ix2.set_taxonomy(parents); ix2.finalize()
+want = ix2.stream().classify_batch(bases, offsets, thresholds=(0.0, 0.2))
+sset = capi.ShardSet([ix2], exchange=capi.EXCHANGE_RCCL)
+assert sset.exchange_mode == capi.EXCHANGE_RCCL
+for _ in range(2):
+    got = sset.classify([(bases, offsets)], thresholds=(0.0, 0.2))[0]
+    for k in ("taxon", "classified", "num_distinct", "total_kmers", "hit_offsets", "hits"):
+        assert np.array_equal(got[k], want[k]), k
+assert int(want["classified"][0].sum()) > 700
+sset.close()
+print("RCCL-OK")
+"""
+
+
+def test_rccl_leg_runs_with_one_member(tmp_path):
+    """The RCCL leg of the exchange -- librccl loaded at run time, ncclCommInitAll, grouped ncclSend / ncclRecv on the member's
+    stream -- cannot span devices on a one-GPU box, but it can RUN: a set of one member sends its keys to itself through RCCL.
+    Both rounds (fast, and staged for the long fragments) must give what the plain classify call gives.  In a child process with a
+    time limit: a collective library that does not come up must not take the test session with it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_one.py"
+    script.write_text(RCCL_SCRIPT.format(root=root))
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0 and "RCCL-OK" in p.stdout, p.stderr[-3000:]
