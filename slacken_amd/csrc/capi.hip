@@ -777,7 +777,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
       st->last_used_lane = true;
       // Hot path: one lane per fragment.  What that kernel does not take -- fragments over 1000 bases, taxon maps that overflow --
       // it appends to the hand-on list of the kernel that does (engine.h: FusedArgs.hand_*): four length classes for its own long
-      // variant (1001 .. 4999 bases), the lane-per-segment kernel (unpaired, from 5000 bases, classification only, w = 5), the
+      // variant (1001 .. 4999 bases), the lane-per-segment kernel (unpaired, from 5000 bases, w = 5), the
       // wave-per-fragment kernel (the rest, and what the long variant hands on in turn).  The passes run behind it on this stream;
       // the segment pass, which depends on nothing but the first pass, on a second stream beside the other two.
       const size_t hdr_bytes = 16 * sizeof(uint64_t);
@@ -793,7 +793,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
       const int long_max = std::min(long_env ? atoi(long_env) : 4999, 8191);
       const char *seg_env = getenv("SLK_SEG_MIN_LEN");
       const int seg_min = seg_env ? atoi(seg_env) : 5000;
-      const bool seg_on = !want_hits && !paired && ix->sp.w == 5 && seg_min > 0;
+      const bool seg_on = !paired && ix->sp.w == 5 && seg_min > 0;
       A.long_max = long_max > 1000 ? (uint32_t)long_max : 0;
       if (A.long_max) {  // class borders: a geometric ladder from 1000 to the limit (a tile's lanes then differ by at most ~1.5x)
         const double ratio = pow((double)A.long_max / 1000.0, 0.25);
@@ -810,6 +810,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
         HIPCHK(hipEventRecord(st->ev_fork, st->s));
         HIPCHK(hipStreamWaitEvent(st->s2, st->ev_fork, 0));
         FusedArgs B = A;
+        if (want_hits) B.span_keys = st->span_keys.as<uint64_t>();   // (scratch of the hit lists: the spans' places before the borders are settled)
         B.work_list = A.hand_lists + 4 * A.hand_stride; B.work_count = A.hand_hdr + 4; B.work_draw = A.hand_hdr + 7;
         launch_segments(B, st->s2);
         HIPCHK(hipEventRecord(st->ev_join, st->s2));

@@ -729,13 +729,20 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
 //   * `distinct` of a segment's first super-mer (Supermers.spans :84-90) compares with the last super-mer BEFORE it, which
 //     another lane produced: it is counted as distinct first and taken back if the keys turn out equal;
 //   * a super-mer or an ambiguous span cut by a border was counted twice in the number of spans (out_nh).
-// The order of the spans is not kept: classification only (no hit lists), window width 5 (the register window of lane.hip).
+// Window width 5 (the register window of lane.hip).  The wave's span buffer does not keep the spans in order; for the HIT LISTS
+// (HITS: TaxonHit per span in ordinal order, TaxonCounts.scala:94-121 is formatted from them) every span therefore carries its
+// place -- lane j's i-th span goes to slot w0(j) + i of the fragment's span region, which a lane cannot overrun: a span holds at
+// least one of its windows -- in a scratch copy of the region (A.span_keys, 8 bytes per slot: taxon, meta), and once the borders
+// are settled the lanes' stretches are moved up against each other into span_taxon / span_meta: lane j's entries start at the
+// sum of the earlier lanes' counts less their merges, and an entry that a border had cut in two (a super-mer, an ambiguous span)
+// adds its k-mers to the last entry before it.
 constexpr int SEG_SBLK = 5;       // 16-byte sub-blocks fetched per refill of a lane's read stream (as lane.hip)
 constexpr uint32_t SEG_MIN_WINDOWS = 64;
 struct __attribute__((aligned(16))) SegLds {
   uint4 sbuf[(SEG_SBLK - 1) * 64];
   uint64_t first_key[64], last_key[64];
   uint32_t flags[64];
+  uint32_t span_dst[SPAN_CAP];   // HITS: where in the fragment's span region the buffered span belongs (w0 of its lane + its number there)
 };
 enum { SEGF_HAS = 1, SEGF_ENDS_OPEN = 2, SEGF_END_AMB = 4 };
 
@@ -752,6 +759,7 @@ __device__ __forceinline__ uint4 seg_refill(SegLds *G, int lane, const uint8_t *
   return v[0];
 }
 
+template <bool HITS>
 __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
   __shared__ WaveLds lds[FW];
   __shared__ SegLds seg[FW];
@@ -779,6 +787,8 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
     const uint8_t *seq = A.bases + o + (exists ? w0 : 0);
     const uint32_t n = exists ? (min(nwin, w0 + S) - w0) + (uint32_t)k - 1 : 0;
     const uint32_t room = clamp_room(bases_end - o - (exists ? w0 : 0));  // bytes from seq to the end of the caller's buffer
+    uint2 *const prov = HITS ? (uint2 *)A.span_keys + o : nullptr;        // (unpaired: the fragment's span region starts at offsets[r])
+    uint32_t lcount = 0;                                                   // spans of this lane so far
     // ---- wave state (as fused_kernel) ----
     int nbuf = 0, n_out = 0;
     int32_t nd = 0, np = 0, t0 = 0;
@@ -828,6 +838,8 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
         const bool amb_close = run_end && !seqrun && run_len >= (uint32_t)k;
         total += amb_close ? (int32_t)run_len - (k - 1) : 0;
         namb += amb_close ? 1 : 0;
+        if (HITS && amb_close) prov[w0 + lcount] = make_uint2((uint32_t)-1, (uint32_t)pack_meta((int32_t)run_len - (k - 1), 2, 0));  // spanToHit: AMBIGUOUS_SPAN
+        lcount += amb_close ? 1u : 0u;
         first_run_amb = (run_end && !first_run_done) ? amb_close : first_run_amb;
         first_run_done = first_run_done || run_end;
         ends_open = (act && is_end) ? seq_close : ends_open;
@@ -887,8 +899,10 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
           if (emit) {
             const int slot = nbuf + lanes_below(E);
             put_span(L, slot, ekey, ekmers, 1, distinct);
+            if (HITS) G->span_dst[slot] = w0 + lcount;
             if (is_first && lane > 0) first_slot = slot;
           }
+          lcount += emit ? 1u : 0u;
           nbuf += __popcll(E);
         }
       }
@@ -903,6 +917,7 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
         const int32_t taxon = probe_chunk(L, A.T, s0, cnt, lane, meta);
         const int32_t count = meta_kmers(meta);
         const bool real = in && taxon >= 0;
+        if (HITS && in) prov[G->span_dst[s0 + lane]] = make_uint2((uint32_t)ext_taxon(A.T, taxon), (uint32_t)meta);
         nd += __popcll(__ballot(in && meta_distinct(meta) && taxon != 0));
         np += __popcll(__ballot(real));
         {  // the lanes whose first super-mer is in this chunk learn its taxon
@@ -936,10 +951,10 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
       // the spans short of a whole chunk move to the front of the buffer
       const int rest = nbuf - nflush;
       if (nflush > 0 && rest > 0) {
-        uint64_t kk = 0; int32_t mm = 0;
-        if (lane < rest) { kk = L->span_key[nflush + lane]; mm = L->span_meta[nflush + lane]; }
+        uint64_t kk = 0; int32_t mm = 0; uint32_t dd = 0;
+        if (lane < rest) { kk = L->span_key[nflush + lane]; mm = L->span_meta[nflush + lane]; if (HITS) dd = G->span_dst[nflush + lane]; }
         wave_sync();
-        if (lane < rest) { L->span_key[lane] = kk; L->span_meta[lane] = mm; }
+        if (lane < rest) { L->span_key[lane] = kk; L->span_meta[lane] = mm; if (HITS) G->span_dst[lane] = dd; }
         if (first_slot >= 0) first_slot -= nflush;
         wave_sync();
       }
@@ -966,6 +981,27 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
     nd -= __popcll(__ballot(undo_distinct));
     n_out += wave_sum(namb) - wave_sum(merged);
     total = wave_sum(total);
+    if (HITS) {
+      // the hit list in ordinal order: lane j's entries start where the earlier lanes' end
+      const uint32_t mine = lcount - (uint32_t)merged;        // (merged implies lcount >= 1: the cut span is this lane's first)
+      uint32_t incl = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += up;
+      }
+      const uint32_t off = incl - mine;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");     // the scratch entries of the whole wave are written
+      for (uint32_t i = (uint32_t)merged; i < lcount; i++) {
+        const uint2 e = prov[w0 + i];
+        A.span_taxon[o + off + i - (uint32_t)merged] = (int32_t)e.x;
+        A.span_meta[o + off + i - (uint32_t)merged] = (int32_t)e.y;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+      wave_sync();
+      if (merged) atomicAdd(&A.span_meta[o + off - 1], meta_kmers((int32_t)prov[w0].y) << 4);   // (engine.h pack_meta: k-mers << 4)
+      if (lane == 0) A.span_count[r] = n_out;
+    }
 
     // ---- per-read classification (as fused_kernel) ----
     if (map_mode) {
@@ -994,8 +1030,10 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
   }
 }
 
-void launch_segments(const FusedArgs &A, hipStream_t s) {  // over a hand-on list (A.work_list): unpaired, window width 5
-  hipLaunchKernelGGL(segment_kernel, dim3(256 * 8), dim3(FW * 64), 0, s, A);
+// over a hand-on list (A.work_list): unpaired, window width 5; A.span_taxon set: the hit lists too (A.span_keys is their scratch)
+void launch_segments(const FusedArgs &A, hipStream_t s) {
+  if (A.span_taxon) hipLaunchKernelGGL(segment_kernel<true>, dim3(256 * 8), dim3(FW * 64), 0, s, A);
+  else hipLaunchKernelGGL(segment_kernel<false>, dim3(256 * 8), dim3(FW * 64), 0, s, A);
 }
 
 void launch_fused(int mode, const FusedArgs &A, hipStream_t s) {

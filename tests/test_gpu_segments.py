@@ -1,7 +1,9 @@
 """Long unpaired fragments on the hot path run with one lane per SEGMENT of the fragment (fused.hip: segment_kernel): what a
 lane cannot see -- whether its first super-mer equals the last one before it, whether a super-mer or an ambiguous span was cut
 by a segment border -- is settled at the end.  Reads built to hit those borders, against the oracle: taxon, classified,
-distinct hit groups, k-mer total and the number of spans (classification only; the hit lists keep the wave kernel)."""
+distinct hit groups, k-mer total and the number of spans -- and the un-merged hit lists in ordinal order, which the segment kernel
+puts together from its lanes' stretches once the borders are settled (a span cut by a border is ONE hit with the k-mers of both
+parts)."""
 import os
 
 import numpy as np
@@ -102,6 +104,38 @@ def check(orc, world, reads, thresholds=(0.0, 0.1, 0.5), min_hit_groups=2):
     return got
 
 
+def check_hits(orc, world, reads, every=1):
+    """hit lists (TaxonHit per span, ordinal order; TaxonCounts.scala:94-121 is formatted from them) of a batch on the segment
+    route against the oracle's, and against the wave kernel's for the same batch"""
+    bases, offsets = synth.pack(reads)
+    got = world["st"].classify_batch(bases, offsets, thresholds=(0.0, 0.2), with_hits=True)
+    want = orc.classify_batch(world["p"], world["oix"], world["parents"], bases, offsets, None, None, min_hit_groups=2, thresholds=(0.0, 0.2))
+    for key in ("total_kmers", "num_hits", "num_distinct", "taxon", "classified"):
+        assert np.array_equal(got[key], want[key]), key
+    ho = got["hit_offsets"].astype(np.int64)
+    for i in range(0, len(reads), every):
+        _, hits = orc.classify_read(world["p"], world["oix"], world["parents"], reads[i].tobytes(), None, 2, 0.0)
+        g = got["hits"][ho[i]:ho[i + 1]]
+        assert [(int(t), int(c)) for t, c in zip(g["taxon"], g["count"])] == hits, (i, len(reads[i]))
+    saved = os.environ.get("SLK_SEG_MIN_LEN")
+    os.environ["SLK_SEG_MIN_LEN"] = "0"
+    try:
+        wave = world["st"].classify_batch(bases, offsets, thresholds=(0.0, 0.2), with_hits=True)
+    finally:
+        os.environ["SLK_SEG_MIN_LEN"] = saved
+    assert np.array_equal(wave["hit_offsets"], got["hit_offsets"]) and np.array_equal(wave["hits"], got["hits"])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SLK_SEG_SEEDS", 4))))   # (SLK_SEG_SEEDS: soak runs)
+def test_hit_lists_from_the_segment_kernel(orc, world, seed):
+    rng = np.random.default_rng(900 + seed)
+    reads = [long_read(world["lib"], rng, int(rng.integers(1001, 4200))) for _ in range(60)]
+    reads += [long_read(world["lib"], rng, int(rng.integers(4200, 30000))) for _ in range(15)]
+    reads += synth.make_reads(world["lib"], 100, rng, vary_length=True)
+    order = rng.permutation(len(reads))
+    check_hits(orc, world, [reads[i] for i in order])
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SLK_SEG_SEEDS", 4))))   # (SLK_SEG_SEEDS: soak runs)
 def test_long_reads_with_cut_spans(orc, world, seed):
     rng = np.random.default_rng(500 + seed)
@@ -135,12 +169,14 @@ def test_segment_borders_one_by_one(orc, world):
     reads.append(np.tile(np.frombuffer(b"ACGGT", np.uint8), 1000))    # one minimizer value throughout
     reads.append(np.full(3000, ord("A"), np.uint8))
     check(orc, world, reads, thresholds=(0.0, 0.3))
+    check_hits(orc, world, reads)       # spans cut by one border, by sixty-three, N runs slid across a border: one hit each
 
 
 def test_very_long_read(orc, world):
     rng = np.random.default_rng(3)
     reads = [long_read(world["lib"], rng, 400_000), long_read(world["lib"], rng, 70_000)]
     check(orc, world, reads)
+    check_hits(orc, world, reads)
 
 
 def test_default_threshold_splits_the_work_between_the_two_kernels(orc, world, monkeypatch):
@@ -214,9 +250,9 @@ def test_hand_on_lists_longer_than_the_grids(orc, world, monkeypatch, route):
 
 @pytest.mark.parametrize("paired", [False, True])
 def test_hit_lists_of_long_reads_with_ambiguous_runs(orc, world, paired):
-    """Hit lists of long fragments come from the wave kernel, which takes a mate holding characters outside ACGTU run by run
-    (valid runs on the 64-lane path, other runs of >= k characters as one ambiguous span each): per-read results and the
-    un-merged hit lists against the oracle, single and paired."""
+    """Hit lists of long PAIRED fragments come from the wave kernel, which takes a mate holding characters outside ACGTU run by run
+    (valid runs on the 64-lane path, other runs of >= k characters as one ambiguous span each); unpaired ones from the segment
+    kernel: per-read results and the un-merged hit lists against the oracle."""
     rng = np.random.default_rng(40 + paired)
     reads = [long_read(world["lib"], rng, int(rng.integers(1001, 9000))) for _ in range(80)]
     reads += [np.full(2000, ord("N"), np.uint8), np.concatenate([np.full(40, ord("N"), np.uint8), world["lib"].genomes[0][:1500]])]
