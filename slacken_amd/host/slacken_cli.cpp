@@ -448,7 +448,8 @@ struct DeviceIndex {
 // handed to f (shared ownership: output formatting keeps them alive on its own threads).
 template <class F>
 static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &files, bool paired, int min_hits,
-                            const std::vector<double> &thresholds, bool want_spans, bool want_hits, F f, RepeatedTitles *rep = nullptr) {
+                            const std::vector<double> &thresholds, bool want_spans, bool want_hits, F f, RepeatedTitles *rep = nullptr,
+                            const std::function<void(const FragmentBatch &)> &pre = nullptr) {
   // Several input files (or pairs) are read side by side, each on its own threads (a gzip file on the cores' share of it, pargz.hpp), and
   // their batches are taken in turn: the order of the output is deterministic, though interleaved between files at batch
   // granularity (the reference's output order is whatever Spark's partitions give).
@@ -524,6 +525,7 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
         const FragmentBatch &fb = *b->frags;
         const size_t n = fb.size();
         total += n;
+        if (pre) pre(fb);   // (on the worker's own time, not under the output's lock)
         b->taxon.resize((size_t)C * n); b->classified.resize((size_t)C * n); nd.resize(n); tk.resize(n);
         b->hit_offs.resize(n + 1);
         const size_t cap = fb.bases.size() + fb.mate_bases.size() + n + 1;
@@ -590,6 +592,7 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
           const FragmentBatch &fb = *b->frags;
           const size_t n = fb.size();
           total += n;
+          if (pre) pre(fb);
           b->taxon.resize((size_t)C * n); b->classified.resize((size_t)C * n); nds[g].resize(n); tks[g].resize(n);
           b->hit_offs.resize(n + 1);
           const size_t cap = fb.bases.size() + fb.mate_bases.size() + n + 1;
@@ -714,16 +717,28 @@ static std::vector<RepeatResult> classify_fragments(DeviceIndex &dev, const std:
   return out;
 }
 
-static void resolve_repeated_titles(DeviceIndex &dev, const IndexParams &ip, const ClassifyOpts &o, OutputSink &sink) {
-  Timer t("Regroup repeated titles");
-  const FlatHashSet<0> D = sink.repeated().to_set();
-  const size_t unit = o.paired ? 2 : 1;
+// What the regrouping yields: per title that occurs more than once, the merged hit list and its classification per threshold
+struct Regrouped {
+  std::vector<std::string> titles;
+  std::vector<uint64_t> moffs{0};
+  std::vector<slk_hit> mhits;
+  std::vector<int32_t> mtaxon;     // [C][titles]
+  std::vector<uint8_t> mcls;
+};
+
+// D: hashes of the titles seen more than once.  uncount(title, result) is called for every fragment the FIRST pass made of such a
+// title (its row and its count are what the merged row replaces).
+template <class Uncount>
+static Regrouped regroup_repeated_titles(DeviceIndex &dev, const std::vector<std::string> &files, bool is_paired, int min_hits,
+                                         const std::vector<double> &thresholds, const FlatHashSet<0> &D, Uncount uncount) {
+  Regrouped out;
+  const size_t unit = is_paired ? 2 : 1;
   std::vector<RepeatFragment> joined;   // the fragments of the reference's reader for these titles
   std::vector<RepeatFragment> first;    // paired: the fragments the first pass made of them (its rows are what gets replaced)
   std::string_view h, sq;
-  for (size_t u = 0; u + unit <= o.files.size(); u += unit) {
-    if (!o.paired) {
-      AsyncRecordStream rs(o.files[u]);
+  for (size_t u = 0; u + unit <= files.size(); u += unit) {
+    if (!is_paired) {
+      AsyncRecordStream rs(files[u]);
       while (rs.next(h, sq)) if (D.contains(title_hash(h))) joined.push_back({std::string(h), std::string(sq), std::string()});
       continue;
     }
@@ -731,7 +746,7 @@ static void resolve_repeated_titles(DeviceIndex &dev, const IndexParams &ip, con
     std::vector<std::string> order;
     std::unordered_map<std::string, std::pair<std::vector<std::string>, std::vector<std::string>>> lists;
     {
-      AsyncRecordStream r1(o.files[u]);
+      AsyncRecordStream r1(files[u]);
       while (r1.next(h, sq)) {
         h = remove_suffix(h, "/1");
         if (!D.contains(title_hash(h))) continue;
@@ -739,7 +754,7 @@ static void resolve_repeated_titles(DeviceIndex &dev, const IndexParams &ip, con
         if (it->second.first.empty()) order.push_back(it->first);
         it->second.first.emplace_back(sq);
       }
-      AsyncRecordStream r2(o.files[u + 1]);
+      AsyncRecordStream r2(files[u + 1]);
       while (r2.next(h, sq)) {
         h = remove_suffix(h, "/2");
         if (!D.contains(title_hash(h))) continue;
@@ -751,7 +766,7 @@ static void resolve_repeated_titles(DeviceIndex &dev, const IndexParams &ip, con
       auto &l = lists[title];
       for (const std::string &s1 : l.first) for (const std::string &s2 : l.second) joined.push_back({title, s1, s2});
     }
-    FragmentSource src({o.files[u], o.files[u + 1]}, true);
+    FragmentSource src({files[u], files[u + 1]}, true);
     for (;;) {
       FragmentBatchPtr bp;
       if (!src.fill(bp, (size_t)1 << 17, (size_t)512 << 20)) break;
@@ -775,18 +790,12 @@ static void resolve_repeated_titles(DeviceIndex &dev, const IndexParams &ip, con
     merged_titles.push_back(title);
     pick.insert(pick.end(), g.begin(), g.end());
   }
-  if (merged_titles.empty()) return;
+  if (merged_titles.empty()) return out;
   std::cerr << merged_titles.size() << " read titles occur more than once (" << pick.size() << " fragments): their hits are regrouped by title" << std::endl;
-  const int C = (int)o.thresholds.size();
-  std::vector<RepeatResult> res = classify_fragments(dev, joined, pick, o.paired, o.min_hits, o.thresholds, true);
+  const int C = (int)thresholds.size();
+  std::vector<RepeatResult> res = classify_fragments(dev, joined, pick, is_paired, min_hits, thresholds, true);
   // what the first pass counted (and wrote) for these titles
-  auto uncount = [&](const std::string &title, const RepeatResult &r) {
-    if (r.hits.empty()) return;  // no span, no row
-    const std::string sample = sink.sample_of(title);
-    for (int c = 0; c < C; c++)
-      if (r.classified[c] || o.with_unclassified) sink.adjust_count(c, sample, r.taxon[c], -1);
-  };
-  if (!o.paired) {
+  if (!is_paired) {
     for (size_t i = 0; i < pick.size(); i++) uncount(joined[pick[i]].title, res[i]);
   } else {
     std::vector<size_t> pick1;
@@ -794,12 +803,10 @@ static void resolve_repeated_titles(DeviceIndex &dev, const IndexParams &ip, con
       auto it = groups.find(first[i].title);
       if (it != groups.end() && it->second.size() >= 2) pick1.push_back(i);
     }
-    std::vector<RepeatResult> res1 = classify_fragments(dev, first, pick1, true, o.min_hits, o.thresholds, false);
+    std::vector<RepeatResult> res1 = classify_fragments(dev, first, pick1, true, min_hits, thresholds, false);
     for (size_t i = 0; i < pick1.size(); i++) uncount(first[pick1[i]].title, res1[i]);
   }
   // merged hit lists: concatenation in input order, stable sort by ordinal (Classifier.scala:136)
-  std::vector<uint64_t> moffs(1, 0);
-  std::vector<slk_hit> mhits;
   std::vector<uint8_t> mdistinct;
   {
     size_t at = 0;
@@ -812,43 +819,59 @@ static void resolve_repeated_titles(DeviceIndex &dev, const IndexParams &ip, con
         for (size_t j = 0; j < res[at + m].hits.size(); j++) refs.push_back({(uint32_t)j, (uint32_t)m});
       std::stable_sort(refs.begin(), refs.end(), [](const Ref &a, const Ref &b) { return a.ordinal < b.ordinal; });
       for (const Ref &r : refs) {
-        mhits.push_back(res[at + r.member].hits[r.ordinal]);
+        out.mhits.push_back(res[at + r.member].hits[r.ordinal]);
         mdistinct.push_back(res[at + r.member].distinct[r.ordinal]);
       }
-      moffs.push_back(mhits.size());
+      out.moffs.push_back(out.mhits.size());
+      out.titles.emplace_back(title);
       at += gn;
     }
   }
   const size_t R = merged_titles.size();
-  std::vector<int32_t> mtaxon((size_t)C * R);
-  std::vector<uint8_t> mcls((size_t)C * R);
+  out.mtaxon.resize((size_t)C * R);
+  out.mcls.resize((size_t)C * R);
   for (size_t r0 = 0; r0 < R;) {   // (bounded calls: a merged list per title, a few million hits per call)
     size_t r1 = r0 + 1;
-    while (r1 < R && r1 - r0 < ((size_t)1 << 18) && moffs[r1 + 1] - moffs[r0] < ((size_t)1 << 23)) r1++;
+    while (r1 < R && r1 - r0 < ((size_t)1 << 18) && out.moffs[r1 + 1] - out.moffs[r0] < ((size_t)1 << 23)) r1++;
     const size_t n = r1 - r0;
     std::vector<int32_t> tx((size_t)C * n);
     std::vector<uint8_t> cl((size_t)C * n);
-    SLK_CALL(slk_classify_hits(dev.ix, dev.st, n, moffs.data() + r0, mhits.data(), mdistinct.data(), o.min_hits, o.thresholds.data(), C,
+    SLK_CALL(slk_classify_hits(dev.ix, dev.st, n, out.moffs.data() + r0, out.mhits.data(), mdistinct.data(), min_hits, thresholds.data(), C,
                                tx.data(), cl.data(), nullptr, nullptr));
     for (int c = 0; c < C; c++)
-      for (size_t i = 0; i < n; i++) { mtaxon[(size_t)c * R + r0 + i] = tx[(size_t)c * n + i]; mcls[(size_t)c * R + r0 + i] = cl[(size_t)c * n + i]; }
+      for (size_t i = 0; i < n; i++) { out.mtaxon[(size_t)c * R + r0 + i] = tx[(size_t)c * n + i]; out.mcls[(size_t)c * R + r0 + i] = cl[(size_t)c * n + i]; }
     r0 = r1;
   }
+  return out;
+}
+
+static void resolve_repeated_titles(DeviceIndex &dev, const IndexParams &ip, const ClassifyOpts &o, OutputSink &sink) {
+  Timer t("Regroup repeated titles");
+  const FlatHashSet<0> D = sink.repeated().to_set();
+  const int C = (int)o.thresholds.size();
+  const Regrouped g = regroup_repeated_titles(dev, o.files, o.paired, o.min_hits, o.thresholds, D, [&](const std::string &title, const RepeatResult &r) {
+    if (r.hits.empty()) return;  // no span, no row
+    const std::string sample = sink.sample_of(title);
+    for (int c = 0; c < C; c++)
+      if (r.classified[c] || o.with_unclassified) sink.adjust_count(c, sample, r.taxon[c], -1);
+  });
+  const size_t R = g.titles.size();
+  if (R == 0) return;
   std::map<std::pair<int, std::string>, std::string> extra;
   for (size_t r = 0; r < R; r++) {
-    const size_t n = moffs[r + 1] - moffs[r];
+    const size_t n = g.moffs[r + 1] - g.moffs[r];
     if (n == 0) continue;   // none of the fragments had a span: no row
-    const std::string sample = sink.sample_of(merged_titles[r]);
+    const std::string sample = sink.sample_of(g.titles[r]);
     for (int c = 0; c < C; c++) {
-      const bool classified = mcls[(size_t)c * R + r] != 0;
+      const bool classified = g.mcls[(size_t)c * R + r] != 0;
       if (!classified && !o.with_unclassified) continue;
-      const int32_t tx = mtaxon[(size_t)c * R + r];
+      const int32_t tx = g.mtaxon[(size_t)c * R + r];
       sink.adjust_count(c, sample, tx, +1);
-      if (o.detailed) OutputSink::append_output_line(extra[{c, sample}], classified, merged_titles[r], tx, mhits.data() + moffs[r], n, ip.k, true);
+      if (o.detailed) OutputSink::append_output_line(extra[{c, sample}], classified, g.titles[r], tx, g.mhits.data() + g.moffs[r], n, ip.k, true);
     }
   }
   std::unordered_map<std::string_view, bool> drop;
-  for (std::string_view title : merged_titles) drop[title] = true;
+  for (const std::string &title : g.titles) drop[title] = true;
   sink.replace_rows([&](std::string_view title) { return drop.count(title) != 0; }, extra);
 }
 
@@ -989,11 +1012,30 @@ static int cmd_classify2(int argc, char **argv) {
         for (auto &pr : pairs) m[pr.first] += 1;
       }
     } else {
-      // ClassifiedReadCount(threshold, confidence): classified reads per taxon (classifiedReadsPerTaxon :133-141)
+      // ClassifiedReadCount(threshold, confidence): classified reads per taxon (classifiedReadsPerTaxon :133-141).  That count goes
+      // through Classifier.classify, which regroups the hits by title (Classifier.scala:92): fragments that share a title are one
+      // read here too -- the titles are tracked on the way, and those that repeat are settled as in the final classification.
+      ConcurrentTitleSet seen;
+      RepeatedTitles rep;
       classify_stream(base, o.files, o.paired, o.min_hits, {o.init_confidence}, false, false, [&](std::shared_ptr<const ClassifiedBatch> b) {
         for (size_t i = 0; i < b->frags->size(); i++)
           if (b->hit_offs[i + 1] > b->hit_offs[i] && b->classified[i]) m[b->taxon[i]] += 1;
+      }, &rep, [&](const FragmentBatch &fb) {
+        std::vector<uint64_t> hs(fb.size()), again;
+        for (size_t i = 0; i < fb.size(); i++) hs[i] = title_hash(fb.title(i));
+        seen.insert_many(hs, again);
+        rep.add(again);
       });
+      rep.settle_unmatched([&](uint64_t h) { return seen.contains(h); });
+      if (!rep.empty()) {
+        const std::vector<double> thr{o.init_confidence};
+        const Regrouped g = regroup_repeated_titles(base, o.files, o.paired, o.min_hits, thr, rep.to_set(), [&](const std::string &, const RepeatResult &r) {
+          if (!r.hits.empty() && r.classified[0]) m[r.taxon[0]] -= 1;
+        });
+        for (size_t r = 0; r < g.titles.size(); r++)
+          if (g.moffs[r + 1] > g.moffs[r] && g.mcls[r]) m[g.mtaxon[r]] += 1;
+        for (auto it = m.begin(); it != m.end();) it = it->second == 0 ? m.erase(it) : std::next(it);
+      }
     }
     counts.assign(m.begin(), m.end());
   }  // the base index leaves HBM here

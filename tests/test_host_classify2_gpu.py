@@ -177,3 +177,77 @@ def test_classify2_minimizer_criteria(tmp_path, orc, flag, criterion, threshold)
     keep, lines, _ = restate(orc, S, criterion, threshold, rank_depth=7)
     assert [int(l) for l in open(f"{out}_taxonSet.txt").read().split()] == keep and keep
     assert read_out(f"{out}_c0.0") == lines[0.0]
+
+
+def test_classify2_repeated_titles_count_once_in_the_detection_pass(tmp_path, orc):
+    """The taxon-set detection counts classified READS per taxon through Classifier.classify (Dynamic.scala:133-141), which regroups
+    the hits by title (Classifier.scala:92): fragments that share a title are ONE read there.  A sample in which eleven fragments of
+    one species' genome carry the same title: counted one by one that species has 30 classified reads, as the reference counts 20.
+    With -R 25 the species is in the taxon set only under the wrong count -- so the set, the dynamic library and every output line
+    depend on the regrouping in the FIRST pass as well as in the final one."""
+    S = setup(tmp_path, orc, seed=13)
+    p, parents, tax = S["p"], S["parents"], S["tax"]
+    rng = np.random.default_rng(5)
+    # a species genome that setup() did not sample gets 30 fragments, eleven of them under one title, placed apart in the file
+    class L:
+        pass
+    import synth as _s
+    reads = list(S["reads"])
+    gi = next(g for g in (2, 3, 5) if hostmodel.depth(tax, S["seq_taxa"][3 * g]) >= 8)
+    sp = S["seq_taxa"][3 * gi]
+    L.genomes = [np.frombuffer(S["seqs"][3 * gi].encode(), np.uint8)[3000:]]   # part 0 of that genome, clear of the shared stretch
+    extra = _s.make_reads(L, 30, rng, frac_random=0.0, short=0.0, n_single=0.0, n_run=0.0, lowercase=0.0)
+    extra = [r.tobytes().decode() for r in extra]
+    dup = [("dup_title", s) for s in extra[:11]]
+    single = [(f"extra_{i}", s) for i, s in enumerate(extra[11:])]
+    reads = reads[:300] + dup[:4] + reads[300:700] + single + dup[4:] + reads[700:]
+    S["reads"] = reads
+    fq = tmp_path / "sample_dup.fq"
+    with open(fq, "w") as f:
+        for t, s in reads:
+            f.write(f"@{t}\n{s}\n+\n{'I' * len(s)}\n")
+    base = orc.Index(1, *S["base"])
+
+    def counts_of(grouped):
+        frags = []
+        for title, s in reads:
+            res, hits = orc.classify_read(p, base, parents, s, None, 2, 0.15)
+            distinct = [sp["distinct"] for sp in orc.spans(p, s)]
+            frags.append((title, hits, distinct, res))
+        counts = {}
+        if not grouped:
+            for _, hits, _, res in frags:
+                if hits and res["classified"]:
+                    counts[res["taxon"]] = counts.get(res["taxon"], 0) + 1
+            return counts
+        for title, hits, distinct in hostmodel.merge_by_title([(t, h, d) for t, h, d, _ in frags]):
+            res = orc.classify_hits(parents, hits, distinct, 2, 0.15)
+            if res["classified"]:
+                counts[res["taxon"]] = counts.get(res["taxon"], 0) + 1
+        return counts
+
+    one_by_one, grouped = counts_of(False), counts_of(True)
+    keep_wrong = hostmodel.count_filter(tax, sorted(one_by_one.items()), 8, 25)
+    keep = hostmodel.count_filter(tax, sorted(grouped.items()), 8, 25)
+    assert one_by_one[sp] == 30 and grouped[sp] == 20 and sp in keep_wrong and sp not in keep
+    out = tmp_path / "dyn"
+    err = run2("-i", S["loc"], "-o", out, "--library", S["lib"], "-R", 25, S["fq"].replace("sample.fq", "sample_dup.fq"))
+    assert "1 read titles occur more than once (11 fragments)" in err
+    assert [int(l) for l in open(f"{out}_taxonSet.txt").read().split()] == keep
+    # the final classification against the dynamic library of THAT set, the repeated title as one row
+    full = hostmodel.with_descendants(tax, keep)
+    sel = [i for i, t in enumerate(S["seq_taxa"]) if t in full]
+    b = np.frombuffer("".join(S["seqs"][i] for i in sel).encode(), np.uint8)
+    o = np.zeros(len(sel) + 1, np.uint64)
+    np.cumsum([len(S["seqs"][i]) for i in sel], out=o[1:])
+    dyn = orc.Index(1, *orc.build_records(p, parents, b, o, [S["seq_taxa"][i] for i in sel]))
+    frags = []
+    for title, s in reads:
+        _, hits = orc.classify_read(p, dyn, parents, s, None, 2, 0.0)
+        frags.append((title, hits, [sp["distinct"] for sp in orc.spans(p, s)]))
+    want = []
+    for title, hits, distinct in hostmodel.merge_by_title(frags):
+        res = orc.classify_hits(parents, hits, distinct, 2, 0.0)
+        want.append(orc.output_line(res["classified"], title, res["taxon"], hits, 35))
+    got = read_out(f"{out}_c0.0")
+    assert sorted(got) == sorted(want) and sum(l.split("\t")[1] == "dup_title" for l in got) == 1
