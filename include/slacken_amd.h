@@ -22,8 +22,8 @@
  *   - an slk_index is immutable after slk_index_finalize() and may be shared by many threads; an slk_stream holds
  *     one HIP stream plus the scratch of ONE in-flight batch: use one per calling thread.
  *   - minimizers of up to 128 nt (id_longs = ceil(m/32) <= 4 key words per record, row-major) are supported by
- *     slk_index_create / append / lookup and the classify entry points; the spans, staged, sharded and library-construction
- *     entry points take one-word keys (m <= 32) and return SLK_E_UNSUPPORTED otherwise.
+ *     slk_index_create / append / lookup / add_sequences / export, slk_spans_batch_wide and the classify entry points; the staged
+ *     device entries and the sharded ones take one-word keys (m <= 32) and return SLK_E_UNSUPPORTED otherwise.
  */
 #ifndef SLACKEN_AMD_H
 #define SLACKEN_AMD_H
@@ -159,8 +159,8 @@ int32_t slk_index_add_sequences_device(slk_index *ix, const uint8_t *d_bases, co
  * cells) so that the fast kernels apply; ids crossing the ABI are unaffected.  Set the taxonomy BEFORE finalizing to get
  * this; it cannot be replaced afterwards on such an index. */
 int32_t slk_index_finalize(slk_index *ix);
-/* The table's records as (key, taxon) arrays -- what KeyValueIndex.writeRecords would persist (KeyValueIndex.scala:125-139).
- * The order is unspecified (a set).  *n_records receives the number of records; if it exceeds capacity only the first
+/* The table's records as (key, taxon) arrays -- what KeyValueIndex.writeRecords would persist (KeyValueIndex.scala:125-139);
+ * keys: id_longs words per record, row-major.  The order is unspecified (a set).  *n_records receives the number of records; if it exceeds capacity only the first
  * `capacity` were written and SLK_E_CAPACITY is returned.  keys/taxa may be NULL with capacity 0 to query the count. */
 int32_t slk_index_export(const slk_index *ix, int64_t *keys, int32_t *taxa, uint64_t capacity, uint64_t *n_records);
 int32_t slk_index_get_info(const slk_index *ix, slk_index_info *out);
@@ -189,6 +189,13 @@ void slk_stream_destroy(slk_stream *st);
 int32_t slk_spans_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, const uint64_t *offsets,
                         const uint8_t *mate_bases, const uint64_t *mate_offsets, uint64_t R,
                         uint64_t *out_span_offsets, slk_span *out_spans, uint64_t spans_capacity);
+
+/* The same for any number of id columns (KeyValueIndex.scala:49: idLongs = ceil(m / 32)): out_keys[spans * id_longs] receives
+ * OrdinalSpan.minimizer row by row (id1..idN, left-aligned words), out_spans[i].key = id1.  With one id column it equals
+ * slk_spans_batch plus the copy of the keys. */
+int32_t slk_spans_batch_wide(slk_index *ix, slk_stream *st, const uint8_t *bases, const uint64_t *offsets,
+                             const uint8_t *mate_bases, const uint64_t *mate_offsets, uint64_t R,
+                             uint64_t *out_span_offsets, slk_span *out_spans, int64_t *out_keys, uint64_t spans_capacity);
 
 /* ---- the hot path: replaces Classifier.classify (S/slacken/Classifier.scala:114-121) =
  * collectHitsBySequence (:70-96: getSpans -> join -> spanToHit -> group) + classifyHits (:124-147) ->

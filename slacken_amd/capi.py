@@ -53,7 +53,7 @@ HIT_DTYPE = np.dtype([("taxon", "<i4"), ("count", "<i4")])
 EXPORTS = ["slk_device_count", "slk_last_error", "slk_version", "slk_host_alloc", "slk_host_register", "slk_host_free", "slk_index_create", "slk_index_append",
            "slk_index_append_device", "slk_index_set_shard", "slk_index_set_taxonomy", "slk_index_finalize", "slk_index_get_info",
            "slk_index_lookup", "slk_index_add_sequences", "slk_index_add_sequences_device", "slk_index_export", "slk_index_destroy", "slk_stream_create", "slk_stream_synchronize",
-           "slk_stream_hip_stream", "slk_stream_destroy", "slk_spans_batch", "slk_classify_batch",
+           "slk_stream_hip_stream", "slk_stream_destroy", "slk_spans_batch", "slk_spans_batch_wide", "slk_classify_batch",
            "slk_classify_batch_device", "slk_classify_hits", "slk_stream_last_stage_ms", "slk_scan_device", "slk_lookup_device",
            "slk_shard_of", "slk_classify_hits_device", "slk_shard_batch_rows", "slk_shard_emit_device", "slk_shard_compact_device",
            "slk_shard_apply_device", "slk_stream_last_deferred", "slk_table_slot", "slk_table_hash_of",
@@ -112,6 +112,7 @@ def lib():
     L.slk_stream_destroy.argtypes = [vp]
     L.slk_stream_destroy.restype = None
     L.slk_spans_batch.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, u64p, vp, C.c_uint64]
+    L.slk_spans_batch_wide.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, u64p, vp, i64p, C.c_uint64]
     L.slk_classify_batch.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_int32, C.POINTER(C.c_double),
                                      C.c_int32, i32p, u8p, i32p, i32p, u64p, vp, C.c_uint64]
     L.slk_classify_batch_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -232,9 +233,13 @@ class Index:
         """(keys, taxa) of every record in the table, sorted by key."""
         n = C.c_uint64(0)
         _check(lib().slk_index_export(self.h, None, None, 0, C.byref(n)))
-        keys, taxa = np.zeros(n.value, np.int64), np.zeros(n.value, np.int32)
+        keys, taxa = np.zeros(n.value * self.W, np.int64), np.zeros(n.value, np.int32)
         if n.value:
             _check(lib().slk_index_export(self.h, _ptr(keys), _ptr(taxa), n.value, C.byref(n)))
+        if self.W > 1:   # rows of W words, sorted as unsigned numbers word by word (the oracle's order)
+            rows = keys.reshape(-1, self.W)
+            order = np.lexsort(rows.view(np.uint64).T[::-1])
+            return rows[order], taxa[order]
         order = np.argsort(keys, kind="stable")
         return keys[order], taxa[order]
 
@@ -366,6 +371,21 @@ class Stream:
         _check(lib().slk_spans_batch(self.index.h, self.h, _ptr(bases), _ptr(offsets), _ptr(mate_bases),
                                      _ptr(mate_offsets), R, _ptr(out_off), _ptr(out), capacity))
         return out_off, out[:int(out_off[R])]
+
+    def spans_batch_wide(self, bases, offsets, mate_bases=None, mate_offsets=None):
+        """-> (span_offsets u64[R+1], spans SPAN_DTYPE, keys int64 [n_spans, id_longs])"""
+        bases, offsets = _np(bases, np.uint8), _np(offsets, np.uint64)
+        R = offsets.size - 1
+        if mate_bases is not None:
+            mate_bases, mate_offsets = _np(mate_bases, np.uint8), _np(mate_offsets, np.uint64)
+        capacity = int(bases.size + (mate_bases.size + R if mate_bases is not None else 0)) + 1
+        out_off = np.zeros(R + 1, np.uint64)
+        out = np.zeros(capacity, SPAN_DTYPE)
+        keys = np.zeros((capacity, self.index.W), np.int64)
+        _check(lib().slk_spans_batch_wide(self.index.h, self.h, _ptr(bases), _ptr(offsets), _ptr(mate_bases), _ptr(mate_offsets), R,
+                                          _ptr(out_off), _ptr(out), _ptr(keys), capacity))
+        n = int(out_off[R])
+        return out_off, out[:n], keys[:n]
 
     def classify_batch(self, bases, offsets, mate_bases=None, mate_offsets=None, min_hit_groups=2,
                        thresholds=(0.0,), with_hits=True, hits_capacity=None, with_num_hits=False, out=None):

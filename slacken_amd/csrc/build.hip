@@ -21,27 +21,6 @@ namespace {
 
 constexpr int BW = 4;  // waves per block
 
-__device__ __forceinline__ int32_t tax_parent(const int32_t *parents, int32_t ntax, int32_t t) {
-  return ((uint32_t)t < (uint32_t)ntax) ? parents[t] : 0;
-}
-
-// LowestCommonAncestor.apply (LowestCommonAncestor.scala:49-78): the first node of b's path to the root that lies on a's
-// path; ROOT when the paths never meet; NONE is the identity.  Computed by levelling the depths (O(depth) loads).
-__device__ int32_t tax_lca(const int32_t *parents, int32_t ntax, int32_t a, int32_t b) {
-  if (a == 0 || b == 0) return b == 0 ? a : b;
-  if (a == b) return a;
-  int da = 0, db = 0;
-  for (int32_t x = a; x != 0; x = tax_parent(parents, ntax, x)) da++;
-  for (int32_t y = b; y != 0; y = tax_parent(parents, ntax, y)) db++;
-  for (; da > db; da--) a = tax_parent(parents, ntax, a);
-  for (; db > da; db--) b = tax_parent(parents, ntax, b);
-  while (a != b && a != 0) {
-    a = tax_parent(parents, ntax, a);
-    b = tax_parent(parents, ntax, b);
-  }
-  return a != 0 ? a : 1;
-}
-
 // Insert (key, taxon) or merge the taxon into the existing record.  Returns 1 if a new record was created, 0 if merged (or
 // the key belongs to another rank's shard of the table), -1 if no cell could be found within the displacement limit.
 __device__ int insert_merge(const TableBuild &t, const int32_t *parents, int32_t ntax, uint64_t key, int32_t taxon, int &max_d) {

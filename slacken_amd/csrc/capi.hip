@@ -371,16 +371,78 @@ int32_t slk_index_set_taxonomy(slk_index *ix, const int32_t *parents, int32_t T)
   return build_tax_nodes(parents, T, 1 << 26, &ix->d_nodes_orig);
 }
 
+// Library construction with several id columns (minimizers of 33..128 nt): the staged kernels of wide.hip.  Groups of about 64 MiB
+// of sequence are cut into chunks of BUILD_CHUNK_WINDOWS k-mer windows (overlapping by k - 1 bases: the same minimizer SET), the
+// chunks are scanned as a batch of fragments, and their SEQUENCE-flag spans are inserted / LCA-merged one lane per span.
+static int32_t add_sequences_wide(slk_index *ix, const uint8_t *bases, const uint64_t *offsets, const int32_t *taxa, uint64_t S, bool bases_on_device) {
+  const uint32_t k = (uint32_t)ix->wp.k, CW = BUILD_CHUNK_WINDOWS;
+  for (uint64_t i = 0; i < S; i++) {
+    if (offsets[i + 1] < offsets[i]) return fail(SLK_E_INVALID, "offsets must be non-decreasing (sequence %llu)", (unsigned long long)i);
+    if (taxa[i] < 0) return fail(SLK_E_INVALID, "sequence %llu: negative taxon %d", (unsigned long long)i, taxa[i]);
+  }
+  std::vector<uint8_t> host_copy;
+  if (bases_on_device && S) {   // (this path stages its chunks on the host)
+    host_copy.resize(offsets[S]);
+    HIPCHK(hipMemcpy(host_copy.data(), bases, offsets[S], hipMemcpyDeviceToHost));
+    bases = host_copy.data();
+  }
+  const uint64_t GROUP = 64ULL << 20;
+  DevBuf d_bases, d_off, d_tax, d_keys, d_meta, d_count;
+  std::vector<uint8_t> cb;
+  std::vector<uint64_t> coff;
+  std::vector<int32_t> ctax;
+  auto flush = [&]() -> int32_t {
+    if (ctax.empty()) return SLK_OK;
+    const uint64_t nc = ctax.size(), total = cb.size();
+    HIPCHK(d_bases.ensure(total + 16));
+    HIPCHK(d_off.ensure((nc + 1) * 8));
+    HIPCHK(d_tax.ensure(nc * 4));
+    HIPCHK(d_keys.ensure((total + 1) * 8 * ix->W));
+    HIPCHK(d_meta.ensure((total + 1) * 4));
+    HIPCHK(d_count.ensure((nc + 1) * 4));
+    int32_t rc = copy_in(&ix->staging, ix->build_stream, d_bases.p, cb.data(), total);
+    if (!rc) rc = copy_in(&ix->staging, ix->build_stream, d_off.p, coff.data(), (nc + 1) * 8);
+    if (!rc) rc = copy_in(&ix->staging, ix->build_stream, d_tax.p, ctax.data(), nc * 4);
+    if (rc) return rc;
+    launch_wide_scan(ix->wp, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), nullptr, nullptr, nc, d_keys.as<uint64_t>(), d_meta.as<int32_t>(),
+                     d_count.as<int32_t>(), ix->build_stream);
+    launch_wide_build_insert(ix->wt, ix->W, ix->d_parents, ix->T, d_off.as<uint64_t>(), nc, d_keys.as<uint64_t>(), d_meta.as<int32_t>(),
+                             d_count.as<int32_t>(), d_tax.as<int32_t>(), ix->d_counters, ix->build_stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ix->build_stream));
+    cb.clear(); coff.assign(1, 0); ctax.clear();
+    return SLK_OK;
+  };
+  coff.assign(1, 0);
+  for (uint64_t q = 0; q < S; q++) {
+    const uint64_t len = offsets[q + 1] - offsets[q];
+    if (taxa[q] == 0 || len < k) continue;
+    const uint64_t windows = len - k + 1;
+    for (uint64_t w0 = 0; w0 < windows; w0 += CW) {
+      const uint64_t nw = std::min<uint64_t>(CW, windows - w0);
+      const uint8_t *src = bases + offsets[q] + w0;
+      cb.insert(cb.end(), src, src + nw + k - 1);
+      coff.push_back(cb.size());
+      ctax.push_back(taxa[q]);
+      if (cb.size() >= GROUP) { int32_t rc = flush(); if (rc) return rc; }
+    }
+  }
+  int32_t rc = flush();
+  if (rc) return rc;
+  d_bases.release(); d_off.release(); d_tax.release(); d_keys.release(); d_meta.release(); d_count.release();
+  return read_build_counters(ix);
+}
+
 // bases_on_device: `bases` is resident on the index's GPU and is scanned where it lies
 static int32_t add_sequences(slk_index *ix, const uint8_t *bases, const uint64_t *offsets, const int32_t *taxa, uint64_t S,
                              bool bases_on_device) {
   if (!ix || (S && (!bases || !offsets || !taxa))) return fail(SLK_E_INVALID, "null argument");
   if (ix->finalized) return fail(SLK_E_STATE, "index is finalized");
-  if (ix->W > 1) return fail(SLK_E_UNSUPPORTED, "library construction supports minimizers of up to 32 nt (one id column)");
   if (!ix->d_parents) return fail(SLK_E_STATE, "slk_index_add_sequences needs the taxonomy (LCA merging): call slk_index_set_taxonomy first");
-  if (ix->sp.w > BUILD_MAX_W) return fail(SLK_E_UNSUPPORTED, "library construction supports windows of up to %d m-mers (k - m + 1 = %d)", BUILD_MAX_W, ix->sp.w);
+  if (ix->W == 1 && ix->sp.w > BUILD_MAX_W) return fail(SLK_E_UNSUPPORTED, "library construction supports windows of up to %d m-mers (k - m + 1 = %d)", BUILD_MAX_W, ix->sp.w);
   int32_t rc = set_device(ix);
   if (rc) return rc;
+  if (ix->W > 1) return add_sequences_wide(ix, bases, offsets, taxa, S, bases_on_device);
   const int32_t max_t = (int32_t)((1LL << ix->taxon_bits) - 1);
   const uint32_t k = (uint32_t)ix->sp.k, CW = BUILD_CHUNK_WINDOWS;
   for (uint64_t i = 0; i < S; i++) {
@@ -450,15 +512,17 @@ int32_t slk_index_add_sequences_device(slk_index *ix, const uint8_t *d_bases, co
 
 int32_t slk_index_export(const slk_index *ix, int64_t *keys, int32_t *taxa, uint64_t capacity, uint64_t *n_records) {
   if (!ix || !n_records || (capacity && (!keys || !taxa))) return fail(SLK_E_INVALID, "null argument");
-  if (ix->W > 1) return fail(SLK_E_UNSUPPORTED, "slk_index_export supports minimizers of up to 32 nt (one id column)");
   (void)hipSetDevice(ix->device);
   DevBuf dk, dt, dc;
-  HIPCHK(dk.ensure(std::max<uint64_t>(capacity, 1) * 8));
+  HIPCHK(dk.ensure(std::max<uint64_t>(capacity, 1) * 8 * ix->W));
   HIPCHK(dt.ensure(std::max<uint64_t>(capacity, 1) * 4));
   HIPCHK(dc.ensure(8));
   HIPCHK(hipMemset(dc.p, 0, 8));
-  TableView v = ix->view();
-  launch_export(v, ix->nbuckets, dk.as<int64_t>(), dt.as<int32_t>(), capacity, dc.as<unsigned long long>(), ix->build_stream);
+  if (ix->W > 1) {
+    launch_wide_export(ix->wt, ix->W, dk.as<int64_t>(), dt.as<int32_t>(), capacity, dc.as<unsigned long long>(), ix->build_stream);
+  } else {
+    launch_export(ix->view(), ix->nbuckets, dk.as<int64_t>(), dt.as<int32_t>(), capacity, dc.as<unsigned long long>(), ix->build_stream);
+  }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ix->build_stream));
   unsigned long long n = 0;
@@ -466,7 +530,7 @@ int32_t slk_index_export(const slk_index *ix, int64_t *keys, int32_t *taxa, uint
   *n_records = n;
   uint64_t got = std::min<uint64_t>(n, capacity);
   if (got) {
-    HIPCHK(hipMemcpy(keys, dk.p, got * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(keys, dk.p, got * 8 * ix->W, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(taxa, dt.p, got * 4, hipMemcpyDeviceToHost));
   }
   dk.release(); dt.release(); dc.release();
@@ -1189,12 +1253,13 @@ int32_t counts_to_offsets(slk_stream *st, const int32_t *d_counts, uint64_t R, u
   return copy_in(st, st->out_offsets.p, out_offsets, (R + 1) * 8);
 }
 
-int32_t slk_spans_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, const uint64_t *offsets,
-                        const uint8_t *mate_bases, const uint64_t *mate_offsets, uint64_t R,
-                        uint64_t *out_span_offsets, slk_span *out_spans, uint64_t spans_capacity) {
+// slk_spans_batch / slk_spans_batch_wide: out_keys (nullable) receives the spans' id1..idW rows
+static int32_t spans_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, const uint64_t *offsets, const uint8_t *mate_bases,
+                           const uint64_t *mate_offsets, uint64_t R, uint64_t *out_span_offsets, slk_span *out_spans, int64_t *out_keys,
+                           uint64_t spans_capacity) {
   int32_t rc = check_ready(ix, st, false);
   if (rc) return rc;
-  if (ix->W > 1) return fail(SLK_E_UNSUPPORTED, "slk_spans_batch returns one key word per span: minimizers of up to 32 nt (one id column)");
+  if (ix->W > 1 && !out_keys) return fail(SLK_E_UNSUPPORTED, "slk_spans_batch returns one key word per span: minimizers of up to 32 nt (one id column); use slk_spans_batch_wide");
   if (!offsets || !out_span_offsets || (R && !bases)) return fail(SLK_E_INVALID, "null argument");
   if ((mate_bases == nullptr) != (mate_offsets == nullptr))
     return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
@@ -1210,7 +1275,10 @@ int32_t slk_spans_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, con
   if (rc) return rc;
   const uint64_t *d_off = st->offsets.as<uint64_t>();
   const uint64_t *d_moff = paired ? st->mate_offsets.as<uint64_t>() : nullptr;
-  if (use_fused(ix)) {
+  if (ix->W > 1) {
+    launch_wide_scan(ix->wp, st->bases.as<uint8_t>(), d_off, paired ? st->mate_bases.as<uint8_t>() : nullptr, d_moff, R,
+                     st->span_keys.as<uint64_t>(), st->span_meta.as<int32_t>(), st->span_count.as<int32_t>(), st->s);
+  } else if (use_fused(ix)) {
     FusedArgs A{};
     A.P = ix->sp; A.bases = st->bases.as<uint8_t>(); A.offsets = d_off;
     A.mate_bases = paired ? st->mate_bases.as<uint8_t>() : nullptr; A.mate_offsets = d_moff; A.R = R;
@@ -1228,14 +1296,36 @@ int32_t slk_spans_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, con
   if (n) {
     if (!out_spans) return fail(SLK_E_INVALID, "out_spans is null");
     HIPCHK(st->out_items.ensure(n * sizeof(slk_span)));
-    launch_gather_spans(d_off, d_moff, R, st->span_keys.as<uint64_t>(), st->span_meta.as<int32_t>(),
-                        st->out_offsets.as<uint64_t>(), st->out_items.p, st->s);
+    if (ix->W > 1) {
+      HIPCHK(st->out_taxon.ensure(n * 8 * ix->W));   // (free here: this entry classifies nothing)
+      launch_wide_gather_spans(ix->W, d_off, d_moff, R, st->span_keys.as<uint64_t>(), st->span_meta.as<int32_t>(), st->out_offsets.as<uint64_t>(),
+                               st->out_items.p, st->out_taxon.as<int64_t>(), st->s);
+    } else {
+      launch_gather_spans(d_off, d_moff, R, st->span_keys.as<uint64_t>(), st->span_meta.as<int32_t>(),
+                          st->out_offsets.as<uint64_t>(), st->out_items.p, st->s);
+    }
     HIPCHK(hipGetLastError());
     rc = copy_out(st, out_spans, st->out_items.p, n * sizeof(slk_span));
+    if (!rc && ix->W > 1) rc = copy_out(st, out_keys, st->out_taxon.p, n * 8 * ix->W);
     if (rc) return rc;
+    if (ix->W == 1 && out_keys)
+      for (uint64_t i = 0; i < n; i++) out_keys[i] = out_spans[i].key;
   }
   HIPCHK(hipStreamSynchronize(st->s));
   return SLK_OK;
+}
+
+int32_t slk_spans_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, const uint64_t *offsets,
+                        const uint8_t *mate_bases, const uint64_t *mate_offsets, uint64_t R,
+                        uint64_t *out_span_offsets, slk_span *out_spans, uint64_t spans_capacity) {
+  return spans_batch(ix, st, bases, offsets, mate_bases, mate_offsets, R, out_span_offsets, out_spans, nullptr, spans_capacity);
+}
+
+int32_t slk_spans_batch_wide(slk_index *ix, slk_stream *st, const uint8_t *bases, const uint64_t *offsets,
+                             const uint8_t *mate_bases, const uint64_t *mate_offsets, uint64_t R,
+                             uint64_t *out_span_offsets, slk_span *out_spans, int64_t *out_keys, uint64_t spans_capacity) {
+  if (!out_keys && spans_capacity) return fail(SLK_E_INVALID, "out_keys is null");
+  return spans_batch(ix, st, bases, offsets, mate_bases, mate_offsets, R, out_span_offsets, out_spans, out_keys, spans_capacity);
 }
 
 int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, const uint64_t *offsets,

@@ -36,6 +36,12 @@ void launch_wide_lookup(const WideTable &t, int W, const int64_t *keys, uint64_t
 void launch_wide_scan(const WideParams &P, const uint8_t *bases, const uint64_t *offsets, const uint8_t *mate_bases,
                       const uint64_t *mate_offsets, uint64_t R, uint64_t *span_keys, int32_t *span_meta, int32_t *span_count,
                       hipStream_t s);
+void launch_wide_build_insert(const WideTable &t, int W, const int32_t *parents, int32_t ntax, const uint64_t *offsets, uint64_t R,
+                              const uint64_t *span_keys, const int32_t *span_meta, const int32_t *span_count, const int32_t *chunk_taxon,
+                              unsigned long long *counters, hipStream_t s);
+void launch_wide_export(const WideTable &t, int W, int64_t *keys, int32_t *taxa, uint64_t capacity, unsigned long long *counter, hipStream_t s);
+void launch_wide_gather_spans(int W, const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, const uint64_t *span_keys,
+                              const int32_t *span_meta, const uint64_t *out_offsets, void *out, int64_t *out_keys, hipStream_t s);
 void launch_wide_probe(const WideTable &t, int W, const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R,
                        const uint64_t *span_keys, const int32_t *span_meta, const int32_t *span_count, int32_t *span_taxon,
                        hipStream_t s);
@@ -108,6 +114,27 @@ __host__ __device__ inline uint64_t fmix64(uint64_t x) {
   x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
   x ^= x >> 33;
   return x;
+}
+
+__device__ __forceinline__ int32_t tax_parent(const int32_t *parents, int32_t ntax, int32_t t) {
+  return ((uint32_t)t < (uint32_t)ntax) ? parents[t] : 0;
+}
+
+// LowestCommonAncestor.apply (LowestCommonAncestor.scala:49-78): the first node of b's path to the root that lies on a's
+// path; ROOT when the paths never meet; NONE is the identity.  Computed by levelling the depths (O(depth) loads).
+__device__ inline int32_t tax_lca(const int32_t *parents, int32_t ntax, int32_t a, int32_t b) {
+  if (a == 0 || b == 0) return b == 0 ? a : b;
+  if (a == b) return a;
+  int da = 0, db = 0;
+  for (int32_t x = a; x != 0; x = tax_parent(parents, ntax, x)) da++;
+  for (int32_t y = b; y != 0; y = tax_parent(parents, ntax, y)) db++;
+  for (; da > db; da--) a = tax_parent(parents, ntax, a);
+  for (; db > da; db--) b = tax_parent(parents, ntax, b);
+  while (a != b && a != 0) {
+    a = tax_parent(parents, ntax, a);
+    b = tax_parent(parents, ntax, b);
+  }
+  return a != 0 ? a : 1;
 }
 
 // span_meta packing: kmers (signed) << 4 | flag << 1 | distinct

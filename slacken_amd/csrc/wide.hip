@@ -254,6 +254,114 @@ __global__ void __launch_bounds__(256) wide_probe_kernel(WideTable t, const uint
   }
 }
 
+// ---- library construction with W-word keys (slk_index_add_sequences; KeyValueIndex.makeRecords, KeyValueIndex.scala:85-93) ----
+// The SEQUENCE-flag spans of the scanned chunks are the super-mers' minimizers (SplitterMinimizers.find, Minimizers.scala:43-76:
+// library sequences are split around anything that is not a nucleotide, which is what the scan's run splitting does; runs it
+// flags as ambiguous carry no minimizer).  One lane per span inserts (key, taxon) or merges the taxon into the record that is there
+// by LCA (TaxonLCA, LowestCommonAncestor.scala:152-170).  A slot is claimed by its taxon word: 0 -> CLAIMED, key words written,
+// then the taxon published; a lane that meets a CLAIMED slot comes back to it in its next round -- nobody waits inside a round, so
+// lanes of one wave cannot hold each other up.
+constexpr int32_t WIDE_CLAIMED = -1;
+template <int W>
+__global__ void __launch_bounds__(256) wide_build_insert_kernel(WideTable t, const int32_t *__restrict__ parents, int32_t ntax,
+                                                                const uint64_t *__restrict__ offsets, uint64_t R,
+                                                                const uint64_t *__restrict__ span_keys, const int32_t *__restrict__ span_meta,
+                                                                const int32_t *__restrict__ span_count, const int32_t *__restrict__ chunk_taxon,
+                                                                unsigned long long *__restrict__ counters) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  int created = 0, failed = 0;
+  for (uint64_t r = wave; r < R; r += nwaves) {
+    const uint64_t base = offsets[r];
+    const int32_t n = span_count[r], taxon = chunk_taxon[r];
+    for (int32_t j0 = 0; j0 < n; j0 += 64) {
+      const int32_t j = j0 + (int32_t)lane;
+      bool todo = j < n && meta_flag(span_meta[base + j]) == 1;
+      uint64_t k[W];
+#pragma unroll
+      for (int i = 0; i < W; i++) k[i] = todo ? span_keys[(base + j) * W + i] : 0;
+      uint64_t slot = key_hash<W>(k) & t.mask, steps = 0;
+      while (__ballot(todo) != 0) {
+        if (todo) {
+          int32_t cur = __hip_atomic_load(&t.taxa[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          if (cur == 0) {
+            if (atomicCAS((int *)&t.taxa[slot], 0, WIDE_CLAIMED) == 0) {
+#pragma unroll
+              for (int i = 0; i < W; i++) t.keys[slot * W + i] = k[i];
+              __hip_atomic_store(&t.taxa[slot], taxon, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+              created++;
+              todo = false;
+            }                              // (lost the race: look at the slot again next round)
+          } else if (cur != WIDE_CLAIMED) {
+            bool eq = true;
+#pragma unroll
+            for (int i = 0; i < W; i++) eq = eq && __hip_atomic_load(&t.keys[slot * W + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k[i];
+            if (eq) {
+              for (;;) {                   // (the word holds a published taxon from here on: only LCA merges change it)
+                const int32_t merged = tax_lca(parents, ntax, cur, taxon);
+                if (merged == cur) break;
+                const int32_t prev = atomicCAS((int *)&t.taxa[slot], cur, merged);
+                if (prev == cur) break;
+                cur = prev;
+              }
+              todo = false;
+            } else {
+              slot = (slot + 1) & t.mask;
+              if (++steps > t.mask) { failed++; todo = false; }
+            }
+          }
+        }
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { created += __shfl_xor(created, o); failed += __shfl_xor(failed, o); }
+  if (lane == 0) {
+    if (created) atomicAdd(&counters[0], (unsigned long long)created);
+    if (failed) atomicAdd(&counters[2], (unsigned long long)failed);
+  }
+}
+
+// the table's records as (W key words, taxon) rows (slk_index_export)
+template <int W>
+__global__ void __launch_bounds__(256) wide_export_kernel(WideTable t, int64_t *__restrict__ keys, int32_t *__restrict__ taxa, uint64_t capacity,
+                                                          unsigned long long *__restrict__ counter) {
+  const uint64_t nslots = t.mask + 1;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (uint64_t)gridDim.x * blockDim.x) {
+    const int32_t taxon = t.taxa[i];
+    if (taxon == 0) continue;
+    const unsigned long long at = atomicAdd(counter, 1ULL);
+    if (at < capacity) {
+#pragma unroll
+      for (int j = 0; j < W; j++) keys[at * W + j] = (int64_t)t.keys[i * W + j];
+      taxa[at] = taxon;
+    }
+  }
+}
+
+// span slots -> the caller's dense arrays (slk_spans_batch_wide): the slk_span records (key = id1) and the key rows beside them
+struct WideSpanOut { int64_t key; int32_t kmers; int8_t flag; uint8_t distinct; uint16_t pad; };
+template <int W>
+__global__ void __launch_bounds__(256) wide_gather_spans_kernel(const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ mate_offsets,
+                                                                uint64_t R, const uint64_t *__restrict__ span_keys,
+                                                                const int32_t *__restrict__ span_meta, const uint64_t *__restrict__ out_offsets,
+                                                                WideSpanOut *__restrict__ out, int64_t *__restrict__ out_keys) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (uint64_t r = wave; r < R; r += nwaves) {
+    const uint64_t base = span_region(offsets, mate_offsets, r), o = out_offsets[r];
+    const uint64_t n = out_offsets[r + 1] - o;
+    for (uint64_t j = lane; j < n; j += 64) {
+      const int32_t m = span_meta[base + j];
+      WideSpanOut s;
+      s.key = (int64_t)span_keys[(base + j) * W];
+      s.kmers = meta_kmers(m); s.flag = (int8_t)meta_flag(m); s.distinct = (uint8_t)meta_distinct(m); s.pad = 0;
+      out[o + j] = s;
+#pragma unroll
+      for (int i = 0; i < W; i++) out_keys[(o + j) * W + i] = (int64_t)span_keys[(base + j) * W + i];
+    }
+  }
+}
+
 }  // namespace
 
 #define WIDE_DISPATCH(W, CALL) \
@@ -293,4 +401,26 @@ void launch_wide_probe(const WideTable &t, int W, const uint64_t *offsets, const
                                       span_keys, span_meta, span_count, span_taxon));
 }
 
+}  // namespace slk
+
+namespace slk {
+void launch_wide_build_insert(const WideTable &t, int W, const int32_t *parents, int32_t ntax, const uint64_t *offsets, uint64_t R,
+                              const uint64_t *span_keys, const int32_t *span_meta, const int32_t *span_count, const int32_t *chunk_taxon,
+                              unsigned long long *counters, hipStream_t s) {
+  if (R == 0) return;
+  uint64_t blocks = std::min<uint64_t>((R + 3) / 4, 256 * 32);
+  WIDE_DISPATCH(W, hipLaunchKernelGGL(wide_build_insert_kernel<WW>, dim3((unsigned)blocks), dim3(256), 0, s, t, parents, ntax, offsets, R,
+                                      span_keys, span_meta, span_count, chunk_taxon, counters));
+}
+void launch_wide_export(const WideTable &t, int W, int64_t *keys, int32_t *taxa, uint64_t capacity, unsigned long long *counter, hipStream_t s) {
+  uint64_t blocks = std::min<uint64_t>((t.mask + 256) / 256, 256 * 32);
+  WIDE_DISPATCH(W, hipLaunchKernelGGL(wide_export_kernel<WW>, dim3((unsigned)blocks), dim3(256), 0, s, t, keys, taxa, capacity, counter));
+}
+void launch_wide_gather_spans(int W, const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, const uint64_t *span_keys,
+                              const int32_t *span_meta, const uint64_t *out_offsets, void *out, int64_t *out_keys, hipStream_t s) {
+  if (R == 0) return;
+  uint64_t blocks = std::min<uint64_t>((R + 3) / 4, 8192);
+  WIDE_DISPATCH(W, hipLaunchKernelGGL(wide_gather_spans_kernel<WW>, dim3((unsigned)blocks), dim3(256), 0, s, offsets, mate_offsets, R,
+                                      span_keys, span_meta, out_offsets, (WideSpanOut *)out, out_keys));
+}
 }  // namespace slk

@@ -96,11 +96,74 @@ def test_wide_limits(orc):
     assert e.value.code == slacken_amd.capi.E_UNSUPPORTED
     ix = slacken_amd.Index(k=50, m=40, expected_records=16, max_taxon=7)
     ix.set_taxonomy(np.array([0, 0, 1, 1], np.int32))
-    with pytest.raises(slacken_amd.SlackenError):            # library construction is one-column only
-        ix.add_sequences(np.frombuffer(b"ACGT" * 20, np.uint8), np.array([0, 80], np.uint64), [2])
     ix.finalize()
-    with pytest.raises(slacken_amd.SlackenError):
+    with pytest.raises(slacken_amd.SlackenError):            # one key word per span: the wide entry is slk_spans_batch_wide
         ix.stream().spans_batch(np.frombuffer(b"ACGT" * 20, np.uint8), np.array([0, 80], np.uint64))
+    with pytest.raises(slacken_amd.SlackenError):            # the sharded entries are one-column only
+        slacken_amd.Index(k=50, m=40, expected_records=16, max_taxon=7).set_shard(0, 2)
+
+
+@pytest.mark.parametrize("k,m,spaces,canonical", [(45, 40, 7, True), (70, 63, 10, True), (80, 65, 16, False), (110, 100, 20, True), (158, 128, 64, True)])
+def test_wide_library_construction_spans_and_export(orc, k, m, spaces, canonical):
+    """The rest of the reference's surface for idLongs > 1 (KeyValueIndex.scala:49 carries the id columns everywhere): library
+    construction from taxon-labelled sequences (makeRecords: minimizers of the sequences split around non-nucleotides, LCA per
+    minimizer), the records back out of the table, and getSpans with all key words -- against the oracle's multi-word arithmetic."""
+    import slacken_amd
+    rng = np.random.default_rng(7 * k + m)
+    p, W, parents, genomes, keys, tx = build_world(orc, k, m, spaces, canonical, rng, n_genomes=5, genome_len=3000)
+    taxa = np.array(taxgen.defined_taxa(parents))
+    leaves = np.setdiff1d(taxa, parents[taxa])
+    g_taxa = rng.choice(leaves[leaves != 1], len(genomes), replace=False).astype(np.int32)
+    seqs = []
+    for g in genomes:                       # Ns, a run of them, lower case: the sequences are split there
+        s = g.copy()
+        s[rng.integers(0, len(s), 3)] = ord("N")
+        a = int(rng.integers(100, len(s) - 200))
+        s[a:a + 50] = ord("N")
+        seqs.append(np.frombuffer(s.tobytes().lower(), np.uint8) if rng.random() < 0.3 else s)
+    seqs.append(synth.random_dna(k - 1, rng))      # shorter than k: nothing
+    seq_taxa = list(g_taxa) + [int(g_taxa[0])]
+    recs = {}
+    for s, t in zip(seqs, seq_taxa):
+        for sp in orc.spans(p, s.tobytes()):
+            if sp["flag"] == 1:
+                key = tuple(sp["key"][:W])
+                recs[key] = orc.lca(parents, recs.get(key, 0), int(t))
+    want_keys = np.array(sorted(recs), dtype=np.uint64).reshape(-1, W)
+    want_tx = np.array([recs[tuple(int(x) for x in row)] for row in want_keys], np.int32)
+    bases, offsets = synth.pack(seqs)
+    for split in (len(seqs), 2):            # one call, and the sequences over several calls (same records)
+        ix = slacken_amd.Index(k=k, m=m, spaces=spaces, canonical=canonical, expected_records=len(want_tx) + 64, max_taxon=len(parents) - 1)
+        ix.set_taxonomy(parents)
+        for a in range(0, len(seqs), split):
+            b = min(len(seqs), a + split)
+            ix.add_sequences(bases[int(offsets[a]):int(offsets[b])], offsets[a:b + 1] - offsets[a], seq_taxa[a:b])
+        ix.finalize()
+        gk, gt = ix.export()
+        assert ix.info().records == len(want_tx)
+        assert np.array_equal(gk.view(np.uint64), want_keys) and np.array_equal(gt, want_tx)
+        assert np.array_equal(ix.lookup(want_keys.view(np.int64)), want_tx)
+    # getSpans with every key word, single and paired
+    class L:
+        pass
+    L.genomes = genomes
+    reads = synth.make_reads(L, 150, rng, length=2 * k, vary_length=True, n_single=0.2, n_run=0.1)
+    mates = synth.make_reads(L, 150, rng, length=k + 30, vary_length=True, short=0.1)
+    st = ix.stream()
+    for mb_mo in (None, synth.pack(mates)):
+        rb, ro = synth.pack(reads)
+        mb, mo = mb_mo if mb_mo else (None, None)
+        so, spans, skeys = st.spans_batch_wide(rb, ro, mb, mo)
+        so = so.astype(np.int64)
+        for i in range(len(reads)):
+            want = orc.spans(p, reads[i].tobytes(), None if mb is None else mates[i].tobytes())
+            got = spans[so[i]:so[i + 1]]
+            assert len(got) == len(want)
+            for j, w in enumerate(want):
+                assert (int(got["kmers"][j]), int(got["flag"][j]), bool(got["distinct"][j])) == (w["kmers"], w["flag"], w["distinct"])
+                if w["flag"] == 1:
+                    assert tuple(int(x) for x in skeys[so[i] + j].view(np.uint64)) == tuple(w["key"][:W])
+                    assert int(got["key"][j]) == int(skeys[so[i] + j][0])
 
 
 def test_wide_library_through_the_cli(orc, tmp_path):
