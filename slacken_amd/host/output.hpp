@@ -368,11 +368,13 @@ class OutputSink {
       FILE *out = fopen(tmp.c_str(), "wb");
       if (!out) throw std::runtime_error("cannot write under " + dir);
       std::string text;
+      bool wrote_any = false;
       auto flush = [&](bool all) {
         if (text.empty() || (!all && text.size() < ((size_t)8 << 20))) return;
         std::string gz = gzip_member(text);
         if (fwrite(gz.data(), 1, gz.size(), out) != gz.size()) throw std::runtime_error("write failed");
         text.clear();
+        wrote_any = true;
       };
       if (std::filesystem::exists(path)) {
         gzFile in = gzopen(path.c_str(), "rb");
@@ -396,9 +398,19 @@ class OutputSink {
       }
       auto ex = extra.find(key);
       if (ex != extra.end()) text.append(ex->second);
+      const bool any_text = wrote_any || !text.empty();
       flush(true);
-      fclose(out);
-      std::filesystem::rename(tmp, path);
+      if (fclose(out) != 0) { std::filesystem::remove(tmp); throw std::runtime_error("write failed: " + tmp); }   // (the old part file stays)
+      if (any_text) {
+        std::filesystem::rename(tmp, path);
+      } else {
+        // every row of this sample went and none came: the reference would have no such file (and a 0-byte .gz is not a gzip file)
+        std::error_code ec;
+        std::filesystem::remove(tmp, ec);
+        std::filesystem::remove(path, ec);
+        const auto dir = std::filesystem::path(path).parent_path();
+        if (std::filesystem::is_empty(dir, ec)) std::filesystem::remove(dir, ec);
+      }
     }
   }
 

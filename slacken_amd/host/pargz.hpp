@@ -52,6 +52,7 @@ namespace slk {
 namespace pargz {
 
 struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+struct ReserveError : std::runtime_error { using std::runtime_error::runtime_error; };   // region mode: no address space (not the file's fault)
 
 // ---- bits -------------------------------------------------------------------------------------------------------------------
 struct BitReader {
@@ -880,12 +881,13 @@ class Reader {
     if (region_mode_) {
       info_.resize(nchunks_);
       // deflate expands at most 1032-fold; the reservation costs address space only
-      size_t want = std::min<size_t>((size_t)8 << 40, n_ * 1032 + ((size_t)64 << 20));
-      for (; want >= n_ * 8 + ((size_t)64 << 20); want /= 4) {
-        void *m = mmap(nullptr, want, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-        if (m != MAP_FAILED) { region_ = (uint8_t *)m; region_cap_ = want; break; }
-      }
-      if (!region_) { if (p_) munmap((void *)p_, n_); ::close(fd_); throw std::runtime_error("cannot reserve address space to inflate " + path); }
+      // (all of it or nothing: a smaller stretch would turn a valid file that inflates beyond it into an error half way through;
+      //  the caller reads the file through zlib instead when this throws.  SLK_GZ_RESERVE_LIMIT: a cap in bytes, for tests.)
+      const size_t want = std::min<size_t>((size_t)8 << 40, n_ * 1032 + ((size_t)64 << 20));
+      const char *lim = getenv("SLK_GZ_RESERVE_LIMIT");
+      void *m = (lim && (size_t)atoll(lim) < want) ? MAP_FAILED : mmap(nullptr, want, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+      if (m != MAP_FAILED) { region_ = (uint8_t *)m; region_cap_ = want; }
+      if (!region_) { if (p_) munmap((void *)p_, n_); ::close(fd_); throw ReserveError("cannot reserve address space to inflate " + path); }
     }
     nthreads_ = std::min<size_t>((size_t)threads, std::max<size_t>(1, nchunks_));
     th_.reserve(nthreads_);

@@ -688,8 +688,14 @@ class AsyncRecordStream {
 
   explicit AsyncRecordStream(const std::string &file) {
     if (regular_file(file) && !ends_with(file, ".bz2") && ByteSource::gzip_file_worth_threads(file, gz_chunk_bytes()) && gz_threads() >= 1) {
+      try {
+        gz_ = std::make_unique<slk::pargz::Reader>(file, gz_threads(), gz_chunk_bytes(), true);
+      } catch (const slk::pargz::ReserveError &) {
+        // the address space for the inflated file could not be reserved (ulimit -v, overcommit = 2): zlib reads the file as well
+        th_.emplace_back([this, file] { run_serial(file); });
+        return;
+      }
       parallel_ = true;
-      gz_ = std::make_unique<slk::pargz::Reader>(file, gz_threads(), gz_chunk_bytes(), true);
       gz_group_ = gz_group();
       gz_->set_consumer_span(gz_group_);
       nseg_ = (gz_->segments() + gz_group_ - 1) / gz_group_;

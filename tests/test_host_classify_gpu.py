@@ -442,6 +442,38 @@ def test_cli_devices_share_the_reads(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_sample_whose_only_row_is_merged_away(tmp_path):
+    """A sample whose only read is a title that occurs twice: one fragment classifies on its own, the other is all misses; merged
+    (Classifier.scala:92) the read is unclassified -- its k-mer total has grown, its clade has not.  With --nounclassified the
+    reference would write nothing for that sample: no part file (certainly not a 0-byte .gz, which is no gzip file), no
+    directory, no report; with unclassified rows on, the one merged U row."""
+    g, loc, tax, reads = make_library(tmp_path)
+    rng = np.random.default_rng(8)
+    fq = tmp_path / "reads.fq"
+    probe = tmp_path / "probe.fq"
+    with open(probe, "w") as f:
+        for t, s in reads[:200]:
+            f.write(f"@s1_{t}\n{s}\n+\n{'I' * len(s)}\n")
+    classify("-i", loc, "-o", tmp_path / "probe", "-c", "0.5", "--sample-regex", "^(s[0-9]+)_", probe)
+    first_c = next(l.split("\t")[1] for l in read_out(f"{tmp_path / 'probe'}_c0.5", "s1") if l.startswith("C"))
+    seq_c = dict((f"s1_{t}", s) for t, s in reads[:200])[first_c]
+    noise = "".join("ACGT"[i] for i in rng.integers(0, 4, 600))
+    with open(fq, "w") as f:
+        for t, s in reads[:200]:
+            f.write(f"@s1_{t}\n{s}\n+\n{'I' * len(s)}\n")
+        f.write(f"@s7_dup\n{seq_c}\n+\n{'I' * len(seq_c)}\n")
+        f.write(f"@s7_dup\n{noise}\n+\n{'I' * len(noise)}\n")
+    off, on = tmp_path / "off", tmp_path / "on"
+    classify("-i", loc, "-o", off, "-c", "0.5", "--sample-regex", "^(s[0-9]+)_", "--nounclassified", fq)
+    classify("-i", loc, "-o", on, "-c", "0.5", "--sample-regex", "^(s[0-9]+)_", fq)
+    assert not os.path.exists(f"{off}_c0.5/sample=s7") and not os.path.exists(f"{off}_c0.5/s7_kreport.txt")
+    assert os.path.exists(f"{off}_c0.5/sample=s1/part-00000.txt.gz") and not glob.glob(f"{off}_c0.5/sample=*/*.tmp")
+    rows = read_out(f"{on}_c0.5", "s7")
+    assert len(rows) == 1 and rows[0].startswith("U\ts7_dup\t0\t")
+    assert read_out(f"{on}_c0.5", "s1") and all(l.startswith("C") for l in read_out(f"{off}_c0.5", "s1"))
+
+
+@pytest.mark.gpu
 def test_cli_shard_table_gives_the_same_files(tmp_path):
     """--shard-table: the library is SPREAD over the devices of --devices (each keeps the records whose minimizer falls to it) and
     the batches are classified in rounds through slk_shardset_classify -- minimizers to their owners, taxa back.  Per-read files

@@ -247,3 +247,23 @@ def test_random_streams(tmp_path, seed):
         chunk = max(64, os.path.getsize(path) // 3)
     got = gunzip(path, threads=int(rng.integers(1, 9)), chunk=chunk)
     assert got == data, (seed, len(got), len(data), chunk)
+
+
+def test_no_address_space_for_the_region_falls_back_to_zlib(tmp_path):
+    """The in-place route reserves address space for the whole inflated file up front (1032 x the compressed size: all or nothing).
+    Where that is refused -- ulimit -v, vm.overcommit_memory = 2; here SLK_GZ_RESERVE_LIMIT stands in -- the records must still be
+    read, through zlib: a valid .gz is never an error because of the process's address-space limits."""
+    import gzip as gz
+    rng = np.random.default_rng(31)
+    text = fastq_text(rng, 6000)
+    path = str(tmp_path / "reads.fq.gz")
+    open(path, "wb").write(gz.compress(text, 6))
+    outs = []
+    for limit in (None, "1000"):
+        env = dict(os.environ, SLK_GZ_THREADS="4", SLK_GZ_CHUNK="40000", SLK_PARSE_THREADS="3")
+        if limit:
+            env["SLK_GZ_RESERVE_LIMIT"] = limit
+        p = subprocess.run([CLI, "parse", path], env=env, capture_output=True, timeout=300)
+        assert p.returncode == 0, p.stderr.decode()
+        outs.append(p.stdout)
+    assert outs[0] == outs[1] and outs[0].count(b"\n") == 6000
