@@ -54,7 +54,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 K, M, SPACES = 35, 31, 7
 READ_LEN = 150
 TAX_EXTENT = 3080008  # README.md:374 of the reference (NCBI taxonomy array extent)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
 
 
 def log(*a):
@@ -564,11 +564,11 @@ def main():
         same = (tj.get("reads_per_launch") == n_reads and tj.get("records") == int(args.records)
                 and tj.get("genomes") == [G, args.genome_len])
         if same and tj.get("kernel_source_hash") == kernel_source_hash():
-            traffic, traffic_note = tj["hbm_bytes_per_launch"], "profiles/r02_traffic.json (same kernel sources, same workload)"
+            traffic, traffic_note = tj["hbm_bytes_per_launch"], "profiles/r03_traffic.json (same kernel sources, same workload)"
             if tj.get("tcc_miss_x64_bytes"):
                 miss_requests = tj["tcc_miss_x64_bytes"] // 64
         else:
-            traffic_note = "profiles/r02_traffic.json is for other kernel sources or another workload: not quoted"
+            traffic_note = "profiles/r03_traffic.json is for other kernel sources or another workload: not quoted"
 
     out = {
         "metric": "classify_throughput_150bp_standard224scale",

@@ -21,4 +21,4 @@ for PMC in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD S
 done
 python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
-python3 tools/make_traffic.py $OUT $OUT/bench_trace.json > $OUT/traffic.log 2>&1 && cp profiles/r02_traffic.json $OUT/ || tail -3 $OUT/traffic.log
+python3 tools/make_traffic.py $OUT $OUT/bench_trace.json > $OUT/traffic.log 2>&1 && cp profiles/r03_traffic.json $OUT/ || tail -3 $OUT/traffic.log
