@@ -219,3 +219,38 @@ def test_rccl_leg_runs_with_one_member(tmp_path):
     script.write_text(RCCL_SCRIPT.format(root=root))
     p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=240)
     assert p.returncode == 0 and "RCCL-OK" in p.stdout, p.stderr[-3000:]
+
+
+def test_splitter_outside_the_lane_kernels_range_takes_the_staged_round(orc):
+    """A window of 40 m-mers (k = 70, m = 31): neither the lane kernel nor the wave kernel take it -- every fragment of every member
+    goes through the staged round (scan kernel, keys collected by owner, exchange, unbounded classify kernel)."""
+    import slacken_amd
+    from slacken_amd import capi
+    rng = np.random.default_rng(21)
+    parents = taxgen.taxonomy(8 * 16, rng)
+    p = orc.params(k=70, m=31, spaces=5)
+    lib = synth.Library(orc, p, parents, n_genomes=6, genome_len=6000, pad_records=5000)
+    members = []
+    for g in range(2):
+        ix = slacken_amd.Index(k=70, m=31, spaces=5, expected_records=len(lib.keys), max_taxon=len(parents) - 1)
+        ix.set_shard(g, 2)
+        ix.append(lib.keys, lib.taxa)
+        ix.set_taxonomy(parents)
+        ix.finalize()
+        members.append(ix)
+    sset = capi.ShardSet(members)
+    oix = orc.Index(1, lib.keys, lib.taxa)
+    batches, wants, all_reads = [], [], []
+    for g in range(2):
+        reads = synth.make_reads(lib, 300, rng, length=200, vary_length=True, n_single=0.1, n_run=0.05)
+        bases, offsets = synth.pack(reads)
+        batches.append((bases, offsets))
+        all_reads.append(reads)
+        wants.append(orc.classify_batch(p, oix, parents, bases, offsets, thresholds=(0.0, 0.1)))
+    outs = sset.classify(batches, thresholds=(0.0, 0.1))
+    world = dict(p=p, oix=oix, parents=parents)
+    for g in range(2):
+        same(outs[g], wants[g])
+        same_hits(orc, world, outs[g], all_reads[g], step=9)
+    assert wants[0]["classified"][0].mean() > 0.3
+    sset.close()
