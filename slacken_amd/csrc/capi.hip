@@ -163,11 +163,12 @@ int32_t slk_index_create(const slk_params *p, const slk_table_config *cfg, int32
   const uint64_t cells_needed = (uint64_t)((double)expected / lf) + CELLS;
   Shape sh = shape_of((cells_needed + CELLS - 1) / CELLS);
   while (sh.disp < DISP_MIN && sh.nb < (1ULL << 33)) sh = shape_of(grow(sh.nb));
-  // With the default load factor, a table whose cells leave a short displacement field (mid-size tables under wide taxon ids) is
-  // made larger until either the field or the load is comfortable: filled to 0.7, a record of a table with 4 displacement bits
-  // can find no cell within reach (one in ~800 random tables of a soak did, loudly: SLK_E_CAPACITY).
-  if (default_lf)
-    while (sh.disp < (CELLS == 16 ? 5 : 6) && sh.nb < (1ULL << 32) && (double)expected / ((double)sh.nb * CELLS) > 0.45) sh = shape_of(grow(sh.nb));
+  // A table whose cells leave a short displacement field (mid-size tables under wide taxon ids) is made larger until the field is
+  // long enough for the load the table will then have: the chains of full buckets grow with the load (measured maxima at 1e5..1e10
+  // records: load 0.55: 14 buckets, 0.70: 32, 0.80: over 63), and a record that finds no cell within reach is an error
+  // (SLK_E_CAPACITY; a soak of random tables at given loads of 0.70-0.80 with 4-bit fields hit it in 7 of 200).
+  auto need_bits = [](double load) { return load <= 0.50 ? 4 : load <= 0.62 ? 5 : load <= 0.72 ? 6 : load <= 0.80 ? 7 : 8; };
+  while (sh.nb < (1ULL << 32) && sh.disp < std::max(DISP_MIN, need_bits((double)expected / ((double)sh.nb * CELLS)))) sh = shape_of(grow(sh.nb));
   if (sh.nb > (1ULL << 32) || sh.disp < DISP_MIN) { delete ix; return fail(SLK_E_CAPACITY, "a table of %llu buckets is too large", (unsigned long long)sh.nb); }
   ix->bucket_bits = sh.q;
   ix->taxon_bits = tb;
@@ -857,7 +858,12 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
       const int long_max = std::min(long_env ? atoi(long_env) : 4999, 8191);
       const char *seg_env = getenv("SLK_SEG_MIN_LEN");
       const int seg_min = seg_env ? atoi(seg_env) : 5000;
-      const bool seg_on = !paired && ix->sp.w == 5 && seg_min > 0;
+      // (hit lists: the segment kernel can put them together -- SLK_SEG_HITS=1 --, but its spans reach memory one 8-byte entry at a
+      //  time, and measured 32-47 Gbp/s against the wave kernel's 43-75 on the same reads: profiles/r03_long_hits_*.json; so per-read
+      //  lines of long reads keep the wave kernel unless asked otherwise)
+      const char *seg_hits_env = getenv("SLK_SEG_HITS");
+      const bool seg_hits = seg_hits_env != nullptr && seg_hits_env[0] == '1';
+      const bool seg_on = (!want_hits || seg_hits) && !paired && ix->sp.w == 5 && seg_min > 0;
       A.long_max = long_max > 1000 ? (uint32_t)long_max : 0;
       if (A.long_max) {  // class borders: a geometric ladder from 1000 to the limit (a tile's lanes then differ by at most ~1.5x)
         const double ratio = pow((double)A.long_max / 1000.0, 0.25);

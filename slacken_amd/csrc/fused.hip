@@ -991,13 +991,17 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
         if (lane >= d) incl += up;
       }
       const uint32_t off = incl - mine;
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");     // the scratch entries of the whole wave are written
+      // (the scratch entries were written by other lanes of THIS wave: workgroup scope -- an agent-scope fence writes the XCD's L2
+      //  back, twice per fragment: measured at 4x the kernel's time)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       for (uint32_t i = (uint32_t)merged; i < lcount; i++) {
         const uint2 e = prov[w0 + i];
         A.span_taxon[o + off + i - (uint32_t)merged] = (int32_t)e.x;
         A.span_meta[o + off + i - (uint32_t)merged] = (int32_t)e.y;
       }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       wave_sync();
       if (merged) atomicAdd(&A.span_meta[o + off - 1], meta_kmers((int32_t)prov[w0].y) << 4);   // (engine.h pack_meta: k-mers << 4)
       if (lane == 0) A.span_count[r] = n_out;

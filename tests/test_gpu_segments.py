@@ -2,8 +2,8 @@
 lane cannot see -- whether its first super-mer equals the last one before it, whether a super-mer or an ambiguous span was cut
 by a segment border -- is settled at the end.  Reads built to hit those borders, against the oracle: taxon, classified,
 distinct hit groups, k-mer total and the number of spans -- and the un-merged hit lists in ordinal order, which the segment kernel
-puts together from its lanes' stretches once the borders are settled (a span cut by a border is ONE hit with the k-mers of both
-parts)."""
+can put together from its lanes' stretches once the borders are settled (a span cut by a border is ONE hit with the k-mers of both
+parts; SLK_SEG_HITS=1: by default the hit lists of long reads stay with the wave kernel, the faster route for them)."""
 import os
 
 import numpy as np
@@ -22,6 +22,8 @@ def segments_from_1001_bases(monkeypatch):
     # borders many
     monkeypatch.setenv("SLK_SEG_MIN_LEN", "1001")
     monkeypatch.setenv("SLK_LANE_LONG_MAX", "0")
+    # hit lists too come from the segment kernel here (the engine's default keeps them on the wave kernel, which measured faster)
+    monkeypatch.setenv("SLK_SEG_HITS", "1")
 
 
 @pytest.fixture(scope="module")

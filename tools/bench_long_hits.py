@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Long unpaired reads WITH hit lists (per-read output lines): kernel time of the host entry's launches (the engine's own events,
-slk_stream_last_stage_ms) by read length.  Run twice -- SLK_SEG_MIN_LEN=0 (hit lists from the wave-per-fragment kernel, the only
-route before round 3) and default (from 5000 bases: the lane-per-segment kernel) -- to compare the two routes."""
+slk_stream_last_stage_ms) by read length.  Run twice -- default (hit lists from the wave-per-fragment kernel) and SLK_SEG_HITS=1 (from
+5000 bases: the lane-per-segment kernel) -- to compare the two routes."""
 import json
 import os
 import sys
@@ -28,7 +28,7 @@ def main():
     ix.add_sequences(bases, np.arange(G + 1, dtype=np.uint64) * np.uint64(L), rng.choice(taxa[len(taxa) // 2:], G).astype(np.int32))
     ix.finalize()
     st = ix.stream()
-    out = dict(seg_min_len=os.environ.get("SLK_SEG_MIN_LEN", "default"))
+    out = dict(seg_min_len=os.environ.get("SLK_SEG_MIN_LEN", "default"), seg_hits=os.environ.get("SLK_SEG_HITS", "0"))
     for L_read in (5000, 10000, 30000, 100000):
         R = max(64, 200_000_000 // L_read)
         starts = rng.integers(0, G * L - L_read, R)
