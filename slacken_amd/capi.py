@@ -236,7 +236,7 @@ class Index:
         keys, taxa = np.zeros(n.value * self.W, np.int64), np.zeros(n.value, np.int32)
         if n.value:
             _check(lib().slk_index_export(self.h, _ptr(keys), _ptr(taxa), n.value, C.byref(n)))
-        if self.W > 1:   # rows of W words, sorted as unsigned numbers word by word (the oracle's order)
+        if self.W > 1:   # rows of W words, sorted as unsigned numbers, word by word
             rows = keys.reshape(-1, self.W)
             order = np.lexsort(rows.view(np.uint64).T[::-1])
             return rows[order], taxa[order]
