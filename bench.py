@@ -341,14 +341,16 @@ def table_sharded(args, rank, world, local_rank):
             dist.barrier()
         torch.cuda.synchronize()
 
-    outs = sc.classify_many([batch] * max(1, args.warmup), thresholds=(0.0,), min_hit_groups=2)
+    fused = not args.separate_lookup
+    outs = sc.classify_many([batch] * max(1, args.warmup), thresholds=(0.0,), min_hit_groups=2, fused_lookup=fused)
     if outs is None:
         raise SystemExit("the fast sharded route does not take this splitter")
     barrier()
     t_start = time.perf_counter()
-    outs = sc.classify_many([batch] * args.steps, thresholds=(0.0,), min_hit_groups=2, profile=True)   # K steps = K batches in the pipeline
+    outs = sc.classify_many([batch] * args.steps, thresholds=(0.0,), min_hit_groups=2, profile=True, fused_lookup=fused)   # K steps = K batches in the pipeline
     barrier()
     elapsed = time.perf_counter() - t_start
+    alone = sc.stage_times_alone(batch) if world == 1 and not args.collectives_at_one_rank else None   # (after the timed region)
     elapsed = sdist.max_over_ranks(elapsed, dist, None if args.rehearse_on_one_gpu else device)
     ms_per_step = elapsed / args.steps * 1e3
     reads_per_s = world * n_reads / (elapsed / args.steps)
@@ -359,7 +361,10 @@ def table_sharded(args, rank, world, local_rank):
     classified = float(o["classified"][:n_reads].float().mean().item())
     x_ms = stage.get("exchange_keys", 0.0)
     per_link = (remote / max(1, world - 1)) * 8 / (x_ms * 1e-3) / 1e9 if world > 1 and x_ms > 0 else None
-    lookup_ms = stage.get("lookup", 0.0)
+    # the owner's lookups ride inside the scan of a later batch ("emit+lookup"; only the first and last batches' run as a kernel of
+    # their own): their rate is taken over that fused stage
+    fused_ms = stage.get("emit+lookup", 0.0)
+    lookup_ms = fused_ms if fused_ms > 0 else stage.get("lookup", 0.0)
     lookup_rate = looked_up / (lookup_ms * 1e-3) / 1e9 if lookup_ms > 0 else None
     # algorithmic bytes of a step on one rank (SURVEY 8d's B(r), with the probes served by whichever rank owns them) against the
     # WHOLE pipeline's time per step: the path has four kernels here, and none of them is "the" kernel
@@ -374,21 +379,22 @@ def table_sharded(args, rank, world, local_rank):
         "config": {
             "workload": "oversized custom library, hash-sharded over the GPUs (k=35,m=31,s=7), synthetic 150 bp single-end reads; "
                         "minimizers to their owners and taxa back by all-to-all (BASELINE.json configs[3])",
-            "parallelism": f"table-sharded x{world}", "records_per_rank": int(info.records), "records_all_ranks": int(info.records) * world,
+            "parallelism": f"table-sharded x{world}", "lookups": "inside the scan of batch t + 2" if fused else "a kernel of their own", "records_per_rank": int(info.records), "records_all_ranks": int(info.records) * world,
             "table_GiB_per_rank": round(info.table_bytes / 2**30, 1), "table_GB_all_ranks": round(info.table_bytes * world / 1e9, 1),
             "exceeds_one_gpu_288GB": bool(info.table_bytes * world > 288e9),
             "bucket_bytes": int(info.bucket_cells) * 8, "table_load": round(info.records / (info.buckets * info.bucket_cells), 3),
             "genomes": G, "genome_len": args.genome_len, "reads_per_gpu_per_step": n_reads, "read_len": READ_LEN,
             "classified_fraction": round(classified, 4), "deferred_to_staged_route": int(o.get("deferred", 0)),
             "stage_ms_in_pipeline": {k: round(v, 3) for k, v in stage.items()},
+            **({"stage_ms_alone": alone} if alone else {}),
             "keys_per_read": round(keys_per_batch / n_reads, 3),
             "exchanged_bytes_per_read": round(12.0 * keys_per_batch / n_reads, 1),     # 8-byte key out, 4-byte taxon back
             "remote_bytes_per_read": round(12.0 * remote / n_reads, 1),
             "xgmi_link_GBps_keys": None if per_link is None else round(per_link, 1), "xgmi_link_peak_GBps": XGMI_LINK_GBPS,
             "xgmi_link_frac": None if per_link is None else round(per_link / XGMI_LINK_GBPS, 3),
         },
-        "roofline": {"bound": "hbm", "kernel": "the sharded pipeline: lane_kernel<EMIT>, list compaction, lookup_coop_kernel, lane_kernel<APPLY> "
-                                               "on two streams, beside the exchange", "achieved": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9, 1),
+        "roofline": {"bound": "hbm", "kernel": "the sharded pipeline: lane_kernel<EMIT> with the owner's lookups of an earlier batch riding along, list compaction, "
+                                               "lane_kernel<APPLY> on two streams, beside the exchange", "achieved": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9, 1),
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                      "traffic": None, "algorithmic_bytes_per_launch": bytes_per_step, "kernel_ms": round(ms_per_step, 3),
                      "lookup_stage_Grequests_per_s": None if lookup_rate is None else round(lookup_rate, 2),
@@ -415,6 +421,8 @@ def main():
     ap.add_argument("--table-sharded", action="store_true",
                     help="BASELINE configs[3]: every rank holds 1/N of the table, minimizers and taxa cross the links (RCCL all-to-all)")
     ap.add_argument("--records-per-rank", type=float, default=5.0e9, help="--table-sharded: records of one rank's shard")
+    ap.add_argument("--separate-lookup", action="store_true",
+                    help="--table-sharded: the owner's lookups as a kernel of their own beside the scans (round 2's pipeline), for A/B")
     ap.add_argument("--collectives-at-one-rank", action="store_true",
                     help="--table-sharded with ONE rank: the keys and taxa go through the RCCL all-to-all all the same (the rank sends to "
                          "itself), so that the `nccl` process group and its device collectives run on a one-GPU box")

@@ -290,6 +290,20 @@ int32_t slk_shard_emit_device(slk_index *ix, slk_stream *st, const uint8_t *d_ba
                               uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys, uint32_t *d_send_meta,
                               uint64_t capacity_per_sublist, uint64_t *d_send_counts, uint32_t *d_batch_base,
                               uint32_t *d_tile_rows, int32_t *d_read_info, int32_t *d_defer);
+/* slk_shard_emit_device with the OWNER's side of an earlier batch riding along: whenever a wavefront has sent off 64 of its own keys
+ * it also answers 64 of the keys this rank received (d_side_keys[0 .. side_n), answers to d_side_taxa in the same order), so the
+ * lookups' latency hides behind the scan as the probes of slk_classify_batch_device do, instead of a lookup kernel running beside
+ * the scan.  The 64-key batches are dealt out to the scan's tiles (64 fragments each): tile t owns batches [t * side_per_tile,
+ * (t + 1) * side_per_tile) -- side_per_tile * ceil(R / 64) * 64 >= side_n --, and d_side_done[ceil(R / 64)] (zeroed by the call)
+ * receives how many of its batches each tile got to; slk_lookup_rest_device answers the rest -- usually little or nothing. */
+int32_t slk_shard_emit_lookup_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
+                                     const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
+                                     uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys, uint32_t *d_send_meta,
+                                     uint64_t capacity_per_sublist, uint64_t *d_send_counts, uint32_t *d_batch_base,
+                                     uint32_t *d_tile_rows, int32_t *d_read_info, int32_t *d_defer, const int64_t *d_side_keys,
+                                     uint64_t side_n, uint32_t side_per_tile, uint32_t *d_side_done, int32_t *d_side_taxa);
+int32_t slk_lookup_rest_device(slk_index *ix, slk_stream *st, const int64_t *d_keys, uint64_t n, uint32_t side_per_tile, uint64_t tiles,
+                               const uint32_t *d_side_done, int32_t *d_out_taxa);
 int32_t slk_shard_compact_device(slk_index *ix, slk_stream *st, const int64_t *d_send_keys, uint32_t n_shards, uint32_t n_sublists,
                                  uint64_t capacity_per_sublist, const uint64_t *d_send_counts, int64_t *d_out_keys,
                                  uint64_t *d_list_offsets, uint64_t *d_owner_counts);

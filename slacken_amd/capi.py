@@ -55,7 +55,8 @@ EXPORTS = ["slk_device_count", "slk_last_error", "slk_version", "slk_host_alloc"
            "slk_index_lookup", "slk_index_add_sequences", "slk_index_add_sequences_device", "slk_index_export", "slk_index_destroy", "slk_stream_create", "slk_stream_synchronize",
            "slk_stream_hip_stream", "slk_stream_destroy", "slk_spans_batch", "slk_spans_batch_wide", "slk_classify_batch",
            "slk_classify_batch_device", "slk_classify_hits", "slk_stream_last_stage_ms", "slk_scan_device", "slk_lookup_device",
-           "slk_shard_of", "slk_classify_hits_device", "slk_shard_batch_rows", "slk_shard_emit_device", "slk_shard_compact_device",
+           "slk_shard_of", "slk_classify_hits_device", "slk_shard_batch_rows", "slk_shard_emit_device", "slk_shard_emit_lookup_device",
+           "slk_lookup_rest_device", "slk_shard_compact_device",
            "slk_shard_apply_device", "slk_stream_last_deferred", "slk_table_slot", "slk_table_hash_of",
            "slk_shardset_create", "slk_shardset_classify", "slk_shardset_exchange_mode", "slk_shardset_destroy"]
 
@@ -130,6 +131,9 @@ def lib():
     L.slk_shard_batch_rows.restype = C.c_uint64
     L.slk_shard_emit_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_uint32, i64p, vp, C.c_uint64, u64p, vp,
                                         vp, i32p, i32p]
+    L.slk_shard_emit_lookup_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_uint32, i64p, vp, C.c_uint64, u64p, vp,
+                                               vp, i32p, i32p, i64p, C.c_uint64, C.c_uint32, vp, i32p]
+    L.slk_lookup_rest_device.argtypes = [vp, vp, i64p, C.c_uint64, C.c_uint32, C.c_uint64, vp, i32p]
     L.slk_shard_compact_device.argtypes = [vp, vp, i64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, i64p, u64p, u64p]
     L.slk_stream_last_deferred.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.slk_shard_apply_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, i32p, u64p, vp, vp,
@@ -462,10 +466,21 @@ class Stream:
         _check(lib().slk_lookup_device(self.index.h, self.h, d_keys, n, d_out_taxa))
 
     def shard_emit_device(self, d_bases, d_offsets, R, n_shards, n_sublists, d_send_keys, d_send_meta, capacity_per_sublist,
-                          d_send_counts, d_batch_base, d_tile_rows, d_read_info, d_defer, d_mate_bases=None, d_mate_offsets=None):
+                          d_send_counts, d_batch_base, d_tile_rows, d_read_info, d_defer, d_mate_bases=None, d_mate_offsets=None,
+                          side=None):
+        """side: (d_side_keys, side_n, side_per_tile, d_side_done, d_side_taxa) -- an earlier batch's lookups ride along
+        (slk_shard_emit_lookup_device)"""
+        if side is not None:
+            _check(lib().slk_shard_emit_lookup_device(self.index.h, self.h, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, n_shards,
+                                                      n_sublists, d_send_keys, d_send_meta, capacity_per_sublist, d_send_counts, d_batch_base,
+                                                      d_tile_rows, d_read_info, d_defer, side[0], side[1], side[2], side[3], side[4]))
+            return
         _check(lib().slk_shard_emit_device(self.index.h, self.h, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, n_shards,
                                            n_sublists, d_send_keys, d_send_meta, capacity_per_sublist, d_send_counts, d_batch_base,
                                            d_tile_rows, d_read_info, d_defer))
+
+    def lookup_rest_device(self, d_keys, n, side_per_tile, tiles, d_side_done, d_out_taxa):
+        _check(lib().slk_lookup_rest_device(self.index.h, self.h, d_keys, n, side_per_tile, tiles, d_side_done, d_out_taxa))
 
     def shard_compact_device(self, d_send_keys, n_shards, n_sublists, capacity_per_sublist, d_send_counts, d_out_keys,
                              d_list_offsets, d_owner_counts):

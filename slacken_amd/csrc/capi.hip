@@ -1006,11 +1006,12 @@ uint64_t slk_shard_batch_rows(uint64_t total_bases, uint64_t total_mate_bases, u
   return (span_slots(total_bases, total_mate_bases, R, paired != 0) >> 6) + (R + 63) / 64 + 2;
 }
 
-int32_t slk_shard_emit_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
-                              const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
-                              uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys, uint32_t *d_send_meta,
-                              uint64_t capacity_per_sublist, uint64_t *d_send_counts, uint32_t *d_batch_base,
-                              uint32_t *d_tile_rows, int32_t *d_read_info, int32_t *d_defer) {
+static int32_t shard_emit(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
+                          const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
+                          uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys, uint32_t *d_send_meta,
+                          uint64_t capacity_per_sublist, uint64_t *d_send_counts, uint32_t *d_batch_base,
+                          uint32_t *d_tile_rows, int32_t *d_read_info, int32_t *d_defer, const int64_t *d_side_keys, uint64_t side_n,
+                          uint32_t side_per_tile, uint32_t *d_side_done, int32_t *d_side_taxa) {
   int32_t rc = check_ready(ix, st, false);
   if (rc) return rc;
   if (!lane_path_ok(ix)) return fail(SLK_E_UNSUPPORTED, "splitter outside the fused kernel's range: use the staged calls");
@@ -1021,20 +1022,58 @@ int32_t slk_shard_emit_device(slk_index *ix, slk_stream *st, const uint8_t *d_ba
   if (capacity_per_sublist >= (1ull << 25)) return fail(SLK_E_INVALID, "capacity_per_sublist must be below 2^25 (use more sub-lists)");
   if ((d_mate_bases == nullptr) != (d_mate_offsets == nullptr))
     return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
+  if (side_n && (!d_side_keys || !d_side_done || !d_side_taxa)) return fail(SLK_E_INVALID, "null argument (side lookups)");
+  if (side_n && (uint64_t)side_per_tile * ((R + 63) / 64) * 64 < side_n)
+    return fail(SLK_E_INVALID, "side_per_tile = %u batches for each of the %llu tiles do not cover %llu keys", side_per_tile, (unsigned long long)((R + 63) / 64), (unsigned long long)side_n);
   rc = set_device(ix);
   if (rc) return rc;
   HIPCHK(hipMemsetAsync(d_send_counts, 0, (size_t)n_shards * n_sublists * sizeof(uint64_t), st->s));
   HIPCHK(hipMemsetAsync(d_defer, 0, (R ? R : 1) * sizeof(int32_t), st->s));
+  if (side_n) HIPCHK(hipMemsetAsync(d_side_done, 0, ((R + 63) / 64) * sizeof(uint32_t), st->s));
   FusedArgs A{};
   A.P = ix->sp; A.bases = d_bases; A.offsets = d_offsets; A.mate_bases = d_mate_bases; A.mate_offsets = d_mate_offsets; A.R = R;
   A.status = st->d_status;
+  if (side_n) A.T = ix->view();
   ShardIO S{};
   S.n_shards = (int32_t)n_shards; S.n_sub = (int32_t)n_sublists; S.cap = capacity_per_sublist; S.send_keys = d_send_keys;
   S.send_counts = (unsigned long long *)d_send_counts; S.batch_base = d_batch_base; S.send_meta = d_send_meta;
   S.tile_rows = d_tile_rows; S.read_info = (int2 *)d_read_info;
+  S.side_keys = d_side_keys; S.side_n = side_n; S.side_per_tile = side_n ? side_per_tile : 0; S.side_done = d_side_done; S.side_out = d_side_taxa;
   st->queued.emplace_back();  // (not re-runnable: an overflow of this call is reported as an error)
   launch_lane_sharded(LANE_EMIT, A, S, d_defer, 1000, st->s);
   HIPCHK(hipMemcpyAsync(st->h_status, st->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st->s));
+  HIPCHK(hipGetLastError());
+  return SLK_OK;
+}
+
+int32_t slk_shard_emit_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
+                              const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
+                              uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys, uint32_t *d_send_meta,
+                              uint64_t capacity_per_sublist, uint64_t *d_send_counts, uint32_t *d_batch_base,
+                              uint32_t *d_tile_rows, int32_t *d_read_info, int32_t *d_defer) {
+  return shard_emit(ix, st, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, n_shards, n_sublists, d_send_keys, d_send_meta, capacity_per_sublist,
+                    d_send_counts, d_batch_base, d_tile_rows, d_read_info, d_defer, nullptr, 0, 0, nullptr, nullptr);
+}
+
+int32_t slk_shard_emit_lookup_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
+                                     const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
+                                     uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys, uint32_t *d_send_meta,
+                                     uint64_t capacity_per_sublist, uint64_t *d_send_counts, uint32_t *d_batch_base,
+                                     uint32_t *d_tile_rows, int32_t *d_read_info, int32_t *d_defer, const int64_t *d_side_keys, uint64_t side_n,
+                                     uint32_t side_per_tile, uint32_t *d_side_done, int32_t *d_side_taxa) {
+  return shard_emit(ix, st, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, n_shards, n_sublists, d_send_keys, d_send_meta, capacity_per_sublist,
+                    d_send_counts, d_batch_base, d_tile_rows, d_read_info, d_defer, d_side_keys, R ? side_n : 0, side_per_tile, d_side_done, d_side_taxa);
+}
+
+int32_t slk_lookup_rest_device(slk_index *ix, slk_stream *st, const int64_t *d_keys, uint64_t n, uint32_t side_per_tile, uint64_t tiles,
+                               const uint32_t *d_side_done, int32_t *d_out_taxa) {
+  int32_t rc = check_ready(ix, st, false);
+  if (rc) return rc;
+  if (ix->W > 1) return fail(SLK_E_UNSUPPORTED, "the staged and sharded entry points support minimizers of up to 32 nt (one id column)");
+  if (!d_side_done || (n && (!d_keys || !d_out_taxa))) return fail(SLK_E_INVALID, "null argument");
+  rc = set_device(ix);
+  if (rc) return rc;
+  launch_lookup_coop_rest(ix->view(), d_keys, n, side_per_tile, tiles, d_side_done, d_out_taxa, st->s);
   HIPCHK(hipGetLastError());
   return SLK_OK;
 }

@@ -251,11 +251,25 @@ struct ShardIO {
   const int32_t *taxa;               // LANE_APPLY: the owners' answers, in the compacted order of the keys
   const int32_t *to_dense;           // LANE_APPLY: caller's id -> the table's dense id (nullptr: ids as given)
   int32_t n_to_dense;
+  // LANE_EMIT, optional: the owner's side of an EARLIER batch rides along.  Whenever a wave has sent off a batch of 64 of its own
+  // keys it also probes 64 of the keys this rank RECEIVED (side_keys[0 .. side_n)) with the local kernel's cooperative access shape,
+  // answers to side_out: the lookups' latency hides behind the scan exactly as the local kernel's probes do, instead of running as
+  // a kernel of their own beside it.  The 64-key batches are dealt out statically -- tile t owns batches [t * side_per_tile,
+  // (t + 1) * side_per_tile) (a shared cursor would be one atomic address for six million draws: measured, 73 ms) -- and a tile that
+  // sends off fewer batches than it owns says how far it got in side_done[t]: launch_lookup_coop_rest answers the rest.
+  const int64_t *side_keys;
+  uint64_t side_n;
+  uint32_t side_per_tile;
+  uint32_t *side_done;               // [tiles]
+  int32_t *side_out;
 };
 enum { LANE_LOCAL = 0, LANE_EMIT = 1, LANE_APPLY = 2 };
 void launch_lane_sharded(int mode, const FusedArgs &A, const ShardIO &S, int32_t *defer, uint32_t max_len, hipStream_t s);
 // cooperative point lookups (4 lanes x 16 B per bucket) and the scatter of returned taxa to their slots (shard.hip)
 void launch_lookup_coop(const TableView &t, const int64_t *keys, uint64_t n, int32_t *out, hipStream_t s);
+// what a LANE_EMIT launch with a side job left over: of every tile's batches [t * per_tile, (t + 1) * per_tile) those from done[t] on
+void launch_lookup_coop_rest(const TableView &t, const int64_t *keys, uint64_t n, uint32_t per_tile, uint64_t tiles, const uint32_t *done,
+                             int32_t *out, hipStream_t s);
 // The send lists as one contiguous array in (owner, sub-list) order: list_off[n_lists + 1] = exclusive prefix of the list
 // lengths, owner_counts[n_shards] = keys per owner (the all-to-all's split sizes), out_keys = the lists back to back.
 void launch_compact_lists(const int64_t *send_keys, const unsigned long long *send_counts, uint32_t n_shards, uint32_t n_sub,

@@ -233,9 +233,82 @@ __device__ __forceinline__ uint32_t shard_owner(uint64_t key, uint32_t ns) {  //
 }
 // LANE_EMIT: append the batch's minimizers to their owners' send lists (one atomic per owner per batch); the span metadata the
 // second pass needs (owner lane, distinct, k-mers) goes to a list of the same shape, which stays on this rank
+// One key of an earlier batch's lookups per lane, loaded a batch ahead of its use (engine.h: ShardIO.side_*)
+__device__ __forceinline__ uint64_t side_load(const ShardIO &S, uint64_t batch, int lane) {
+  const uint64_t i = batch * 64 + (uint64_t)lane;
+  return i < S.side_n ? (uint64_t)S.side_keys[i] : 0;
+}
+// LANE_EMIT with a side job: 64 of the keys this rank received for an earlier batch, probed with probe_batch's access shape (LPB
+// lanes per bucket, all of the batch's loads in flight before the first compare); a key whose bucket is full, flagged and does
+// not hold it goes on alone (as in shard.hip's lookup_coop_kernel).  `key` was loaded a batch ago (side_load).
+__device__ __forceinline__ void side_probe(LaneLds *L, const TableView &T, const ShardIO &S, int lane, uint64_t batch, uint64_t key) {
+  const uint64_t base = batch * 64;
+  if (base >= S.side_n) return;
+  const uint64_t i = base + (uint64_t)lane;
+  const bool in = i < S.side_n;
+  const uint64_t h = fmix64(key);
+  uint32_t home;
+  uint64_t rem_hi;
+  table_slot(T.g, h, home, rem_hi);
+  const uint64_t tag = in ? rem_hi : ~0ULL;
+  uint4 st;
+  st.x = home; st.y = 0; st.z = (uint32_t)tag; st.w = (uint32_t)(tag >> 32);
+  ((uint4 *)L->stash)[lane] = st;
+  L->found[lane] = 0;
+  lane_wave_sync();
+  const int g = lane / LPB, c = lane % LPB;
+  const uint64_t tmask = (1ULL << T.g.taxon_bits) - 1;
+  const char *cellbase = (const char *)T.cells + c * 16;
+  ulonglong2 cell[LPB];
+#pragma unroll
+  for (int s = 0; s < LPB; s++) cell[s] = SLK_PROBE_LOAD((const ulonglong2 *)(cellbase + ((uint64_t)((const uint4 *)L->stash)[s * PG + g].x << BUCKET_SHIFT)));
+  uint32_t unresolved = 0;
+#pragma unroll
+  for (int s = 0; s < LPB; s++) {
+    const uint2 tg = *(const uint2 *)&((const uint4 *)L->stash)[s * PG + g].z;
+    const uint64_t want = ((uint64_t)tg.y << 32) | tg.x;
+    const bool act = want != ~0ULL;
+    const bool e0 = cell[s].x == 0, e1 = cell[s].y == 0;
+    const bool m0 = act && !e0 && cell_tag(T.g, cell[s].x) == want;
+    const bool m1 = act && !e1 && cell_tag(T.g, cell[s].y) == want;
+    if (m0 || m1) L->found[s * PG + g] = (uint32_t)((m0 ? cell[s].x : cell[s].y) & tmask);
+    const bool closed = T.g.flag != 0 && c == 0 && (cell[s].x & T.g.flag) == 0;
+    const uint64_t B = __ballot(m0 || m1 || e0 || e1 || !act || closed);
+    if (((B >> (g * LPB)) & ((1u << LPB) - 1)) == 0) unresolved |= 1u << s;
+  }
+  lane_wave_sync();
+  int32_t taxon = (int32_t)L->found[lane];
+  const uint32_t ur = (uint32_t)__shfl((int)unresolved, (lane % PG) * LPB);   // entry `lane` was group lane % PG of step lane / PG
+  if (in && ((ur >> (lane / PG)) & 1)) {
+    for (int d = 1; d <= T.max_disp; d++) {
+      const ulonglong2 *b = (const ulonglong2 *)(T.cells + ((uint64_t)table_bucket(T.g, home, (uint32_t)d) * CELLS));
+      const uint64_t want = rem_hi | (uint64_t)d;
+      bool has_empty = false, closed = false;
+      int32_t hit = 0;
+#pragma unroll
+      for (int q = 0; q < LPB; q++) {
+        const ulonglong2 v = b[q];
+        has_empty |= (v.x == 0) | (v.y == 0);
+        if (q == 0) closed = T.g.flag != 0 && (v.x & T.g.flag) == 0;
+        if (v.x != 0 && cell_tag(T.g, v.x) == want) hit = (int32_t)(v.x & tmask);
+        if (v.y != 0 && cell_tag(T.g, v.y) == want) hit = (int32_t)(v.y & tmask);
+      }
+      if (hit) { taxon = hit; break; }
+      if (has_empty || closed) break;
+    }
+  }
+  if (in) S.side_out[i] = ext_taxon(T, taxon);
+  lane_wave_sync();
+}
+
+// LANE_EMIT: the batch's minimizers go to their owners' send lists, the span metadata the second pass needs (owner lane, distinct,
+// k-mers) to a list of the same shape, which stays on this rank.  ONE atomic instruction per batch whatever the number of owners:
+// lane sh bumps owner sh's cursor by the number of the batch's keys that owner gets, and every key's lane picks its owner's answer
+// up (a loop of one atomic per owner was a memory round trip per owner and batch).  Between the atomic and the use of its answer
+// runs the batch's side job, if there is one: the cursor's round trip and the lookups' share one wait.
 template <bool HITS>
-__device__ __forceinline__ void emit_batch(LaneLds *L, const ShardIO &S, int32_t *status, int qhead, int cnt, int lane, uint32_t sub,
-                                           uint64_t row) {
+__device__ __forceinline__ void emit_batch(LaneLds *L, const FusedArgs &A, const ShardIO &S, int qhead, int cnt, int lane, uint32_t sub,
+                                           uint64_t row, uint64_t tile, uint32_t &side_j, uint64_t &side_key) {
   const bool in = lane < cnt;
   const int qi = (qhead + lane) & (QCAP - 1);
   const uint64_t key = L->q_key[qi];
@@ -244,29 +317,33 @@ __device__ __forceinline__ void emit_batch(LaneLds *L, const ShardIO &S, int32_t
   const uint32_t meta = L->q_meta[qi] | (HITS ? (uint32_t)L->q_ord[qi] << 20 : 0u);
   const uint32_t ns = (uint32_t)S.n_shards;
   const uint32_t g = shard_owner(key, ns);
+  uint32_t mycount = 0, rank = 0;
   for (uint32_t sh = 0; sh < ns; sh++) {
-    const bool mine = in && g == sh;
-    const uint64_t m = __ballot(mine);
-    if (m == 0) {
-      if (lane == 0) S.batch_base[row * ns + sh] = 0;   // (no key of this batch goes to this owner)
-      continue;
-    }
-    const int leader = __ffsll((long long)m) - 1;
-    unsigned long long base = 0;
-    const uint64_t list = (uint64_t)sh * (uint32_t)S.n_sub + sub;
-    if (lane == leader) {
-      base = atomicAdd(&S.send_counts[list], (unsigned long long)__popcll(m));
-      S.batch_base[row * ns + sh] = ((uint32_t)base << 7) | (uint32_t)__popcll(m);   // (cap < 2^25, checked by the host side)
-    }
-    base = lane_readlane64(base, leader);
-    if (mine) {
-      const uint64_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-      if (pos < S.cap) {
-        S.send_keys[list * S.cap + pos] = (int64_t)key;
-        S.send_meta[list * S.cap + pos] = meta;
-      } else {
-        atomicOr(status, 2);
-      }
+    const uint64_t m = __ballot(in && g == sh);
+    if ((uint32_t)lane == sh) mycount = (uint32_t)__popcll(m);
+    if (g == sh) rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+  }
+  unsigned long long base = 0;
+  if ((uint32_t)lane < ns) {
+    if (mycount) base = atomicAdd(&S.send_counts[(uint64_t)lane * (uint32_t)S.n_sub + sub], (unsigned long long)mycount);
+  }
+  if (side_j < S.side_per_tile) {   // the owner's side of an earlier batch: one batch of its lookups per batch of keys sent off
+    const uint64_t batch = tile * S.side_per_tile + side_j;
+    const uint64_t k_now = side_key;
+    side_j++;
+    if (side_j < S.side_per_tile) side_key = side_load(S, batch + 1, lane);   // (in flight while this batch is probed)
+    side_probe(L, A.T, S, lane, batch, k_now);
+  }
+  if ((uint32_t)lane < ns) S.batch_base[row * ns + (uint32_t)lane] = mycount ? (((uint32_t)base << 7) | mycount) : 0u;   // (cap < 2^25, checked by the host side)
+  const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)base, (int)g), bhi = (uint32_t)__shfl((int)(uint32_t)(base >> 32), (int)g);
+  if (in) {
+    const uint64_t pos = (((uint64_t)bhi << 32) | blo) + rank;
+    const uint64_t list = (uint64_t)g * (uint32_t)S.n_sub + sub;
+    if (pos < S.cap) {
+      S.send_keys[list * S.cap + pos] = (int64_t)key;
+      S.send_meta[list * S.cap + pos] = meta;
+    } else {
+      atomicOr(A.status, 2);
     }
   }
   lane_wave_sync();
@@ -349,7 +426,9 @@ __device__ __forceinline__ uint4 stream_refill(LaneLds *L, int lane, const uint8
 #if SLK_LANE_WPS > 0
 #define LANE_BOUNDS __launch_bounds__(LW * 64, SLK_LANE_WPS)
 #else
-#define LANE_BOUNDS __launch_bounds__(LW * 64)
+// (at least four waves per SIMD -- what the LDS footprint allows anyway --, i.e. at most 128 VGPRs: the emit variant with its side
+//  job came out at 129 and lost a quarter of its resident waves)
+#define LANE_BOUNDS __launch_bounds__(LW * 64) __attribute__((amdgpu_waves_per_eu(4)))
 #endif
 
 // A wave of the first pass (or of the long variant) hands fragments on: straight into the hand-on list of the kernel that takes such
@@ -487,6 +566,8 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     bool first = true, have_last = false;
     uint64_t last_key = 0;
     int32_t total = 0, np = 0, nhits = 0;
+    uint32_t side_j = (MODE == LANE_EMIT && S.side_n != 0) ? 0u : 0xFFFFFFFFu;   // batches of the side job done by this tile (wave-uniform)
+    uint64_t side_key = (MODE == LANE_EMIT && S.side_n != 0 && S.side_per_tile != 0) ? side_load(S, tile * S.side_per_tile, lane) : 0;
     int qn = 0;       // queue fill (wave-uniform)
     int qhead = 0;    // ring position of the oldest queued entry (wave-uniform)
     int tphase = 0;   // generic window: step mod w (wave-uniform)
@@ -637,7 +718,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
         while (qn >= 64) {
           lane_wave_sync();
           int back = 0;
-          if (MODE == LANE_EMIT) emit_batch<HITS>(L, S, A.status, qhead, 64, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++);
+          if (MODE == LANE_EMIT) emit_batch<HITS>(L, A, S, qhead, 64, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++, tile, side_j, side_key);
           else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS, LONG>(L, ocnt, A.T, qhead, qn, 64, lane, dbg, A.span_meta, A.span_taxon);
           qhead = (qhead + 64) & (QCAP - 1);
           qn += back - 64;
@@ -648,7 +729,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       lane_wave_sync();
       const int cnt = min(qn, 64);
       int back = 0;
-      if (MODE == LANE_EMIT) emit_batch<HITS>(L, S, A.status, qhead, cnt, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++);
+      if (MODE == LANE_EMIT) emit_batch<HITS>(L, A, S, qhead, cnt, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++, tile, side_j, side_key);
       else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS, LONG>(L, ocnt, A.T, qhead, qn, cnt, lane, dbg, A.span_meta, A.span_taxon);
       qhead = (qhead + cnt) & (QCAP - 1);
       qn += back - cnt;
@@ -657,6 +738,18 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     if (MODE == LANE_EMIT) {   // what the second pass cannot recompute without scanning again
       if (have) S.read_info[r] = make_int2(total, nhits);
       if (lane == 0) S.tile_rows[tile] = (uint32_t)(row - ((span_region(A.offsets, A.mate_offsets, tile * 64) >> 6) + tile));
+      if (S.side_n != 0) {
+        // a tile that sent off fewer batches than it owns of the side job answers the rest of its share now (a few at most:
+        // the shares are dealt out by the batch's average)
+        while (side_j < S.side_per_tile) {
+          const uint64_t batch = tile * S.side_per_tile + side_j;
+          const uint64_t k_now = side_key;
+          side_j++;
+          if (side_j < S.side_per_tile) side_key = side_load(S, batch + 1, lane);
+          side_probe(L, A.T, S, lane, batch, k_now);
+        }
+        if (lane == 0) S.side_done[tile] = side_j;
+      }
     }
 
     // ---- per-read classification (one lane per read) ------------------------------------------------------------------

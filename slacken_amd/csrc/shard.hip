@@ -24,7 +24,8 @@ __device__ __forceinline__ void wsync() {
 // wave instruction, LPB instructions in flight -- the access shape of the classify kernel's probe.  A key whose home bucket
 // is full without holding it, and has overflowed (its flag), continues alone in the next buckets.
 __global__ void __launch_bounds__(SW * 64) lookup_coop_kernel(TableView T, const int64_t *__restrict__ keys, uint64_t n,
-                                                              int32_t *__restrict__ out) {
+                                                              int32_t *__restrict__ out, uint32_t per_tile, uint64_t tiles,
+                                                              const uint32_t *__restrict__ done) {
   constexpr int PG = 64 / LPB;
   __shared__ __attribute__((aligned(16))) uint4 stash_all[SW][64];
   const int lane = threadIdx.x & 63;
@@ -34,7 +35,13 @@ __global__ void __launch_bounds__(SW * 64) lookup_coop_kernel(TableView T, const
   const uint64_t tmask = (1ULL << T.g.taxon_bits) - 1;
   const int g = lane / LPB, c = lane % LPB;
   const char *cellbase = (const char *)T.cells + c * 16;
-  for (uint64_t base = ((uint64_t)blockIdx.x * SW + wib) * 64; base < n; base += nwaves * 64) {
+  // done == nullptr: all keys, 64 per wave iteration.  Otherwise what an emit launch's side job left over (engine.h ShardIO.side_*):
+  // a wave iteration is a TILE of that launch, and of the tile's batches those from done[tile] on are answered
+  const uint64_t units = done ? tiles : (n + 63) / 64;
+  for (uint64_t unit = (uint64_t)blockIdx.x * SW + wib; unit < units; unit += nwaves)
+  for (uint64_t j = done ? done[unit] : 0, j1 = done ? per_tile : 1; j < j1; j++) {
+    const uint64_t base = (done ? unit * per_tile + j : unit) * 64;
+    if (base >= n) break;
     const uint64_t i = base + lane;
     const bool in = i < n;
     const uint64_t key = in ? (uint64_t)keys[i] : 0;
@@ -140,11 +147,20 @@ __global__ void __launch_bounds__(256) list_copy_kernel(const int64_t *__restric
 
 void launch_lookup_coop(const TableView &t, const int64_t *keys, uint64_t n, int32_t *out, hipStream_t s) {
   if (n == 0) return;
-  // The kernel is bound by HBM requests, not by instruction issue: a few resident waves per SIMD keep enough probes in flight
-  // (64 per wave), and what they leave free is where the emit / apply scans of the neighbouring batches run (sharded.py).
-  static const int bpc = getenv("SLK_LOOKUP_BLOCKS_PER_CU") ? std::max(1, atoi(getenv("SLK_LOOKUP_BLOCKS_PER_CU"))) : 2;  // (measured: 2 = 8 waves per CU is as fast as 16 alone, and 20 % faster in the pipeline)
+  // The kernel is bound by the memory system's request rate and, per wave, by two dependent round trips (the key, then its bucket):
+  // it wants every wave slot it can get (64 waves per CU: 12.8 ms per 3.9e8 keys with 8 waves per CU, alone, against a 68 GiB table).
+  // Round 2 ran it BESIDE the scans of the next batch with 8 waves per CU (SLK_LOOKUP_BLOCKS_PER_CU=2), which was best against a
+  // table small enough for the Infinity Cache; now the stages of the sharded pipeline follow each other on one stream.
+  static const int bpc = getenv("SLK_LOOKUP_BLOCKS_PER_CU") ? std::max(1, atoi(getenv("SLK_LOOKUP_BLOCKS_PER_CU"))) : 16;
   uint64_t blocks = std::min<uint64_t>((n + SW * 64 - 1) / (SW * 64), (uint64_t)256 * bpc);
-  hipLaunchKernelGGL(lookup_coop_kernel, dim3((unsigned)blocks), dim3(SW * 64), 0, s, t, keys, n, out);
+  hipLaunchKernelGGL(lookup_coop_kernel, dim3((unsigned)blocks), dim3(SW * 64), 0, s, t, keys, n, out, 0u, (uint64_t)0, (const uint32_t *)nullptr);
+}
+void launch_lookup_coop_rest(const TableView &t, const int64_t *keys, uint64_t n, uint32_t per_tile, uint64_t tiles, const uint32_t *done,
+                             int32_t *out, hipStream_t s) {
+  if (n == 0 || tiles == 0) return;
+  // (how much is left is only known on the device: usually little or nothing)
+  const uint64_t blocks = std::min<uint64_t>((tiles + SW - 1) / SW, 256 * 4);
+  hipLaunchKernelGGL(lookup_coop_kernel, dim3((unsigned)blocks), dim3(SW * 64), 0, s, t, keys, n, out, per_tile, tiles, done);
 }
 void launch_compact_lists(const int64_t *send_keys, const unsigned long long *send_counts, uint32_t n_shards, uint32_t n_sub,
                           uint64_t cap, int64_t *out_keys, uint64_t *list_off, uint64_t *owner_counts, hipStream_t s) {

@@ -174,12 +174,24 @@ class ShardedClassifier:
             self._mem = (mem, torch.cuda.ExternalStream(mem.hip_stream, device=self.device))
         return self._scan, self._mem
 
+    def _compute(self):
+        """(engine stream, torch view of it) the memory-bound stages -- compaction, lookups, apply -- are launched on: the memory
+        stream beside the scans (round 2's pipeline), or the scan stream itself, one kernel after the other (the fused pipeline: on a
+        table of HBM size kernels side by side cost more than they hide)"""
+        scan, mem = self._two_streams()
+        return scan if getattr(self, "_serial_compute", False) else mem
+
+    def _xstream(self):
+        """the stream the exchanges are issued on: the memory stream (beside the compute stream in the fused pipeline)"""
+        return self._two_streams()[1][1]
+
     def _ev(self, b, name, ext):
         """(profile) an event pair around a stage of batch b on stream ext: a context manager"""
         return _StageSpan(self.torch, b["prof"] if b is not None else None, name, ext)
 
-    def _fast_emit(self, batch, cap_scale=1, profile=False):
-        """stage 1 (scan stream, asynchronous): scan + send lists.  None if this index's splitter only has the staged route."""
+    def _fast_emit(self, batch, cap_scale=1, profile=False, side=None):
+        """stage 1 (scan stream, asynchronous): scan + send lists.  None if this index's splitter only has the staged route.
+        side: the state of an EARLIER batch whose received keys are answered on the way (slk_shard_emit_lookup_device)."""
         import slacken_amd
         from slacken_amd import capi
         torch, dev, W = self.torch, self.device, self.world
@@ -200,6 +212,14 @@ class ShardedClassifier:
         if cur != torch.cuda.default_stream(self.device):     # (the caller's tensors were produced on ITS stream)
             ext.wait_stream(cur)
         b = dict(R=R, SUB=SUB, cap=cap, mkw=mkw, batch=batch, prof=[] if profile else None)
+        side_args = None
+        if side is not None and side["looked_up"] and R:
+            ext.wait_event(side["keys_here"])         # (its keys have arrived)
+            # the keys' batches of 64 are dealt out to this scan's tiles; what a tile does not get to is on file in side["done"]
+            side["per_tile"], side["tiles"] = -(-(-(-side["looked_up"] // 64)) // tiles), tiles
+            with torch.cuda.stream(ext):
+                side["done"] = torch.empty(tiles, dtype=torch.int32, device=dev)
+            side_args = (side["recv_keys"].data_ptr(), side["looked_up"], side["per_tile"], side["done"].data_ptr(), side["found"].data_ptr())
         with torch.cuda.stream(ext):
             defer = torch.empty(max(R, 1), dtype=torch.int32, device=dev)
             batch_base = torch.empty(rows * W, dtype=torch.int32, device=dev)
@@ -209,10 +229,10 @@ class ShardedClassifier:
             tile_rows = torch.empty(tiles + 1, dtype=torch.int32, device=dev)
             read_info = torch.empty(2 * max(R, 1), dtype=torch.int32, device=dev)
             try:
-                with self._ev(b, "emit", ext):
+                with self._ev(b, "emit+lookup" if side_args else "emit", ext):
                     st.shard_emit_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, W, SUB, send_keys.data_ptr(), send_meta.data_ptr(), cap,
                                          counts.data_ptr(), batch_base.data_ptr(), tile_rows.data_ptr(), read_info.data_ptr(),
-                                         defer.data_ptr(), **mkw)
+                                         defer.data_ptr(), side=side_args, **mkw)
             except slacken_amd.SlackenError as e:
                 if e.code != capi.E_UNSUPPORTED:
                     raise
@@ -224,9 +244,9 @@ class ShardedClassifier:
         return b
 
     def _fast_compact(self, b):
-        """stage 2 (memory stream, asynchronous): the send lists back to back; the split sizes on their way to the host"""
+        """stage 2 (asynchronous): the send lists back to back; the split sizes on their way to the host"""
         torch, dev, W = self.torch, self.device, self.world
-        _, (st, ext) = self._two_streams()
+        st, ext = self._compute()
         with torch.cuda.stream(ext):
             ext.wait_event(b["emitted"])
             b["out_keys"] = torch.empty_like(b["send_keys"])   # (room for every list at its capacity; the used prefix is what is sent)
@@ -240,34 +260,73 @@ class ShardedClassifier:
             b["ready"] = torch.cuda.Event()
             b["ready"].record(ext)
 
-    def _fast_exchange(self, b, send_counts, recv_counts):
-        """stage 3 (memory stream): keys to their owners, lookup, taxa back"""
+    def _exchange_keys(self, b, send_counts, recv_counts):
+        """stage 3a (exchange stream): keys to their owners"""
         torch = self.torch
-        _, (st, ext) = self._two_streams()
+        ext = self._xstream()
         n_send, n_recv = sum(send_counts), sum(recv_counts)
+        cext = self._compute()[1]
         with torch.cuda.stream(ext):
+            ext.wait_event(b["ready"])
+            b["out_keys"].record_stream(ext)      # (made on the compute stream, read here: the allocator must not hand it out before)
             with self._ev(b, "exchange_keys", ext):
                 recv_keys = self.ex.all_to_all(b["out_keys"][:n_send], send_counts, recv_counts)
-            found = torch.empty(max(n_recv, 1), dtype=torch.int32, device=self.device)
-            if n_recv:
-                recv_keys = recv_keys.contiguous()
-                with self._ev(b, "lookup", ext):
-                    st.lookup_device(recv_keys.data_ptr(), n_recv, found.data_ptr())
-            with self._ev(b, "exchange_taxa", ext):
-                back = self.ex.all_to_all(found[:n_recv], recv_counts, send_counts)
-            b["taxa"] = back.contiguous() if back.numel() else torch.zeros(1, dtype=torch.int32, device=self.device)
+            b["recv_keys"] = recv_keys.contiguous() if n_recv else torch.zeros(1, dtype=torch.int64, device=self.device)
+            b["found"] = torch.empty(max(n_recv, 1), dtype=torch.int32, device=self.device)
+            for tns in (b["recv_keys"], b["found"]):   # (made here, used by the lookups on the compute stream -- and the scan's side job)
+                tns.record_stream(cext)
+                tns.record_stream(self._two_streams()[0][1])
+            b["keys_here"] = torch.cuda.Event()
+            b["keys_here"].record(ext)
         b["exchanged"], b["looked_up"] = n_send, n_recv
+        b["send_counts"], b["recv_counts"] = send_counts, recv_counts
         b["sent_remote"] = n_send - send_counts[self.rank]
         del b["send_keys"], b["out_keys"]
+
+    def _lookup_and_return(self, b, after=None):
+        """stage 3b: the keys a scan's side job has not answered (all of them if none ran) on the compute stream, then the taxa back
+        on the exchange stream.  after: the event of the emit launch that carried the side job."""
+        torch = self.torch
+        st, ext = self._compute()
+        xs = self._xstream()
+        n_recv = b["looked_up"]
+        with torch.cuda.stream(ext):
+            ext.wait_event(b["keys_here"])
+            if after is not None:
+                ext.wait_event(after)
+            if n_recv and "done" in b:      # a later scan answered most of them: the rest
+                with self._ev(b, "lookup_rest", ext):
+                    st.lookup_rest_device(b["recv_keys"].data_ptr(), n_recv, b["per_tile"], b["tiles"], b["done"].data_ptr(), b["found"].data_ptr())
+            elif n_recv:
+                with self._ev(b, "lookup", ext):
+                    st.lookup_device(b["recv_keys"].data_ptr(), n_recv, b["found"].data_ptr())
+            looked = torch.cuda.Event()
+            looked.record(ext)
+        with torch.cuda.stream(xs):
+            xs.wait_event(looked)
+            with self._ev(b, "exchange_taxa", xs):
+                back = self.ex.all_to_all(b["found"][:n_recv], b["recv_counts"], b["send_counts"])
+            b["taxa"] = back.contiguous() if back.numel() else torch.zeros(1, dtype=torch.int32, device=self.device)
+            b["taxa"].record_stream(ext)          # (read by the apply on the compute stream)
+            b["taxa_here"] = torch.cuda.Event()
+            b["taxa_here"].record(xs)
+        for k in ("recv_keys", "found", "done"):
+            b.pop(k, None)
+
+    def _fast_exchange(self, b, send_counts, recv_counts):
+        """stage 3 (memory stream): keys to their owners, lookup, taxa back"""
+        self._exchange_keys(b, send_counts, recv_counts)
+        self._lookup_and_return(b)
 
     def _fast_apply(self, b, thresholds, min_hit_groups):
         """stage 4 (memory stream, behind the lookup; asynchronous): the batches of probes are replayed from the emit's log and
         folded with the owners' answers -- no second scan.  The result tensors are valid once that stream has been synchronised."""
         torch, dev, R, W = self.torch, self.device, b["R"], self.world
-        _, (st, ext) = self._two_streams()
+        st, ext = self._compute()
         d_bases, d_offsets = b["batch"][0], b["batch"][1]
         C = len(thresholds)
         with torch.cuda.stream(ext):
+            ext.wait_event(b["taxa_here"])
             out = dict(taxon=torch.zeros(C * max(R, 1), dtype=torch.int32, device=dev),
                        classified=torch.zeros(C * max(R, 1), dtype=torch.uint8, device=dev),
                        num_distinct=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
@@ -289,14 +348,18 @@ class ShardedClassifier:
         outs = self.classify_many([(d_bases, d_offsets, R, total_bases, mates)], thresholds, min_hit_groups)
         return None if outs is None else outs[0]
 
-    def classify_many(self, batches, thresholds=(0.0,), min_hit_groups=2, profile=False):
+    def classify_many(self, batches, thresholds=(0.0,), min_hit_groups=2, profile=False, fused_lookup=True):
         """The fast route over several batches [(d_bases, d_offsets, R, total_bases, mates or None)], two in flight (see above).
+        fused_lookup (the default): the keys a rank RECEIVES for batch t - 2 are answered inside the scan of batch t
+        (_classify_many_fused); False: by a lookup kernel of their own beside the scan of batch t + 1, as in round 2.
         Every rank must pass the same number of batches.  Returns the list of result dicts, or None if the splitter only has the
         staged route.  profile: self.stage_ms = {stage: mean device ms per batch} from events around every stage (the stages of
         neighbouring batches overlap on the two streams: these are their durations IN the pipeline, not alone)."""
         import slacken_amd
         from slacken_amd import capi
         torch = self.torch
+        if fused_lookup:
+            return self._classify_many_fused(batches, thresholds, min_hit_groups, profile)
         states, outs = [], []
         overflowed = False
         _, (_, mem_ext) = self._two_streams()
@@ -355,6 +418,119 @@ class ShardedClassifier:
             d_bases, d_offsets, R, total_bases, mates = batch
             outs[i] = self._finish_deferred(outs[i], b, d_bases, d_offsets, R, thresholds, min_hit_groups, mates)
         return outs
+
+    def _classify_many_fused(self, batches, thresholds, min_hit_groups, profile):
+        """Kernels side by side cost more than they hide on a table of HBM size: the scan and a lookup kernel share one request rate
+        and the wave slots (lookup 8-13 ms alone, 14 beside the scan, the scan 6.5 alone and 8-10 beside it).  The local
+        kernel does not have that problem -- its probes hide behind its own scan -- so the sharded scan takes the owner's lookups
+        along the same way: the scan of batch t answers the keys this rank received for batch t - 2 (their exchange ran during the
+        scan of batch t - 1), and the other stages follow it on the SAME stream, one kernel after the other.  Per iteration t:
+          compute stream   emit(t) + lookups(t - 2) | what is left of lookups(t - 2) | compact(t) | apply(t - 2)
+          host             waits for the split sizes of batch t - 1 (while emit(t) runs)
+          exchange stream  keys(t - 1) to their owners (beside emit(t)) | taxa(t - 2) back (beside compact(t))
+        Results come out two batches late; the last two batches' lookups run as a kernel of their own."""
+        import slacken_amd
+        from slacken_amd import capi
+        torch = self.torch
+        n = len(batches)
+        states, outs = [None] * n, [None] * n
+        _, (_, mem_ext) = self._two_streams()
+        self._serial_compute = True
+        try:
+            return self._fused_loop(batches, thresholds, min_hit_groups, profile, states, outs, mem_ext)
+        finally:
+            self._serial_compute = False
+
+    def _fused_loop(self, batches, thresholds, min_hit_groups, profile, states, outs, mem_ext):
+        import slacken_amd
+        from slacken_amd import capi
+        torch = self.torch
+        n = len(batches)
+        overflowed = False
+
+        def settle(j):   # batch j: the host's wait for its split sizes, then its keys travel
+            nonlocal overflowed
+            b, scale = states[j], 1
+            while True:
+                b["ready"].synchronize()
+                send_counts = [int(v) for v in b["h_counts"][:self.world].tolist()]
+                with torch.cuda.stream(mem_ext):
+                    recv_counts, over = self.ex.split_sizes(send_counts, int(b["h_counts"][self.world]) != 0)
+                if not over:
+                    break
+                overflowed = True                      # (rare: a send list overflowed somewhere -- every rank emits again, without a side job)
+                scale *= 2
+                b = states[j] = self._fast_emit(batches[j], scale, profile)
+                self._fast_compact(b)
+            self._exchange_keys(b, send_counts, recv_counts)
+
+        for t in range(n + 2):
+            if t < n:
+                b = self._fast_emit(batches[t], 1, profile, side=states[t - 2] if t >= 2 else None)
+                if t == 0 and self._any_rank(b is None):
+                    return None
+                states[t] = b
+            if 1 <= t <= n:
+                settle(t - 1)
+            if t >= 2:
+                self._lookup_and_return(states[t - 2], after=states[t]["emitted"] if t < n else None)
+            if t < n:
+                self._fast_compact(states[t])                 # (beside the taxa's way back)
+            if t >= 2:
+                outs[t - 2] = self._fast_apply(states[t - 2], thresholds, min_hit_groups)
+            for sb in states:   # batches whose apply has run give their device memory back
+                if sb is not None and "applied" in sb and "taxa" in sb and sb["applied"].query():
+                    for k in ("taxa", "batch_base", "list_off", "counts", "send_meta", "tile_rows", "read_info"):
+                        sb.pop(k, None)
+        (scan_st, _), (mem_st, _) = self._two_streams()
+        for st in (scan_st, mem_st):
+            try:
+                st.synchronize()
+            except slacken_amd.SlackenError as e:
+                if not (overflowed and e.code == capi.E_CAPACITY):
+                    raise
+        if profile:
+            acc = {}
+            for sb in states:
+                for name, e0, e1 in sb["prof"]:
+                    acc.setdefault(name, []).append(e0.elapsed_time(e1))
+            self.stage_ms = {k: float(np.mean(v)) for k, v in acc.items()}
+        for i, (b, batch) in enumerate(zip(states, batches)):
+            for k in ("taxa", "batch_base", "list_off", "counts", "send_meta", "tile_rows", "read_info"):
+                b.pop(k, None)
+            d_bases, d_offsets, R, total_bases, mates = batch
+            outs[i] = self._finish_deferred(outs[i], b, d_bases, d_offsets, R, thresholds, min_hit_groups, mates)
+        return outs
+
+    def stage_times_alone(self, batch, thresholds=(0.0,), min_hit_groups=2):
+        """Every stage of one batch run ALONE (a synchronisation between stages; world = 1 only): what the stages cost without
+        each other's company, next to their times in the pipeline (classify_many(profile=True)).  -> {stage: ms}"""
+        import time
+        torch = self.torch
+        assert self.ex.single
+        (scan_st, _), (mem_st, mem_ext) = self._two_streams()
+
+        def timed(f):
+            torch.cuda.synchronize(); scan_st.synchronize(); mem_st.synchronize()
+            t0 = time.perf_counter()
+            r = f()
+            scan_st.synchronize(); mem_st.synchronize(); torch.cuda.synchronize()
+            return r, (time.perf_counter() - t0) * 1e3
+
+        out = {}
+        b0, out["emit"] = timed(lambda: self._fast_emit(batch))
+        _, out["compact"] = timed(lambda: self._fast_compact(b0))
+        counts = [int(v) for v in b0["h_counts"][:1].tolist()]
+        self._exchange_keys(b0, counts, counts)
+        b1, out["emit+lookup"] = timed(lambda: self._fast_emit(batch, side=b0))
+        self._fast_compact(b1)
+        self._exchange_keys(b1, counts, counts)
+        _, out["lookup_rest"] = timed(lambda: self._lookup_and_return(b0))
+        _, out["apply"] = timed(lambda: self._fast_apply(b0, thresholds, min_hit_groups))
+        _, out["lookup"] = timed(lambda: self._lookup_and_return(b1))
+        self._fast_apply(b1, thresholds, min_hit_groups)
+        scan_st.synchronize(); mem_st.synchronize()
+        return {k: round(v, 3) for k, v in out.items()}
 
     def _finish_deferred(self, out, b, d_bases, d_offsets, R, thresholds, min_hit_groups, mates):
         """fragments the fused kernel does not take: a compacted batch through the staged route (all ranks, also with none)"""

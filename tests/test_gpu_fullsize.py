@@ -228,7 +228,7 @@ def test_bench_table_sharded_two_ranks_rehearsal():
     assert cfg["records_per_rank"] == 100_000_000 and cfg["reads_per_gpu_per_step"] == 1_000_000
     assert 30 < cfg["keys_per_read"] < 45 and 0.3 < cfg["remote_bytes_per_read"] / cfg["exchanged_bytes_per_read"] < 0.7
     assert cfg["classified_fraction"] > 0.5         # the other rank's half of the genome records answers too
-    for stage in ("emit", "compact", "exchange_keys", "lookup", "exchange_taxa", "apply"):
+    for stage in ("emit", "emit+lookup", "compact", "exchange_keys", "lookup", "exchange_taxa", "apply"):
         assert cfg["stage_ms_in_pipeline"][stage] > 0
     assert abs(line["value"] - 2 * 1.0 / (line["ms_per_step"] * 1e-3)) < 0.01 * line["value"]
 

@@ -163,3 +163,68 @@ def test_single_rank_paired(orc):
             assert np.array_equal(out[k].cpu().numpy()[:R], want[k]), (k, fast)
         if fast:
             assert out["deferred"] >= 1
+
+
+def _rank_many(rank, world, port, payload, outdir):
+    """several batches through classify_many, with the owner's lookups inside the scans of later batches and as a kernel of their own"""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    keys, taxa, parents, batches = payload
+    ix = slacken_amd.Index(expected_records=len(keys), max_taxon=len(parents) - 1)
+    ix.set_shard(rank, world)               # (fed everything, keeps its share)
+    ix.append(keys, taxa)
+    ix.set_taxonomy(parents)
+    ix.finalize()
+    dev = torch.device("cuda", 0)
+    mine = [b for i, b in enumerate(batches) if i % world == rank]
+    dbs = [(torch.from_numpy(b).to(dev), torch.from_numpy(o.astype(np.int64)).to(dev), len(o) - 1, int(o[-1]), None) for b, o in mine]
+    sc = sharded.ShardedClassifier(ix, rank, world, dist, dev, exchange_on_cpu=True)
+    res = {}
+    for fused in (True, False):
+        outs = sc.classify_many(dbs, thresholds=(0.0, 0.2), fused_lookup=fused)
+        for j, o in enumerate(outs):
+            for k in ("taxon", "classified", "num_distinct", "total_kmers", "num_hits"):
+                res[f"{'f' if fused else 's'}_{j}_{k}"] = o[k].cpu().numpy()
+    np.savez(os.path.join(outdir, f"many{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_many_batches_with_the_lookups_inside_later_scans(orc, tmp_path, world):
+    """classify_many over five batches per rank (uneven sizes, one of a single fragment, one with fragments the lane kernel hands
+    back): the keys a rank receives for batch t are answered inside the scan of batch t + 2 -- the first batches' side jobs find
+    nothing to do, the last two batches' lookups run as a kernel of their own, a scan shorter than the keys waiting for it leaves
+    the rest to that kernel too -- and, for comparison, by the separate lookup kernel throughout.  Every batch against the oracle."""
+    import torch.multiprocessing as mp
+    import synth
+    import taxgen
+    rng = np.random.default_rng(57)
+    parents = taxgen.taxonomy(8 * 32, rng)
+    p = orc.params()
+    lib = synth.Library(orc, p, parents, n_genomes=8, genome_len=10000, pad_records=20000)
+    sizes = [1500, 1, 2200, 90, 1700, 2600, 300, 1200, 64, 2000][:5 * world]
+    batches, wants = [], []
+    for i, n in enumerate(sizes):
+        reads = synth.make_reads(lib, n, rng, n_single=0.1, n_run=0.05, vary_length=True)
+        if i == 2:
+            reads += synth.make_reads(lib, 12, rng, length=1600, short=0)
+        bases, offsets = synth.pack(reads)
+        batches.append((bases, offsets))
+        wants.append(orc.classify_batch(p, orc.Index(1, lib.keys, lib.taxa), parents, bases, offsets, thresholds=(0.0, 0.2)))
+    if world == 1:
+        _rank_many(0, 1, _free_port(), (lib.keys, lib.taxa, parents, batches), str(tmp_path))
+    else:
+        mp.spawn(_rank_many, args=(world, _free_port(), (lib.keys, lib.taxa, parents, batches), str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        z = np.load(os.path.join(str(tmp_path), f"many{rank}.npz"))
+        mine = [i for i in range(len(batches)) if i % world == rank]
+        for j, i in enumerate(mine):
+            R = len(batches[i][1]) - 1
+            for tag in ("f", "s"):
+                assert np.array_equal(z[f"{tag}_{j}_taxon"].reshape(2, -1)[:, :R], wants[i]["taxon"]), (tag, i)
+                assert np.array_equal(z[f"{tag}_{j}_classified"].reshape(2, -1)[:, :R], wants[i]["classified"]), (tag, i)
+                for k in ("num_distinct", "total_kmers", "num_hits"):
+                    assert np.array_equal(z[f"{tag}_{j}_{k}"][:R], wants[i][k]), (tag, i, k)
