@@ -420,6 +420,53 @@ __device__ __forceinline__ uint4 stream_refill(LaneLds *L, int lane, const uint8
   return v[0];
 }
 
+// ---- the read stream as whole 128-byte lines (SLK_PACKED_STREAM) ----------------------------------------------------------------
+// The lanes of a tile read 64 fragments that lie back to back in the caller's buffer.  Fetched lane by lane (stream_refill) those
+// bytes reach the memory system as one 64-byte request per sector a lane touches: 2.3e7 of the 4.2e8 requests of a 10 M x 150 bp
+// launch, each at the price of a table probe (the part serves requests, not bytes: DESIGN.md 4).  A tile whose fragments span at most
+// PACK_MAX_SPAN bytes (64 fragments of up to 170 bases) is instead fetched by the whole wave at once -- 16 bytes per lane, 1 KiB per
+// instruction, whole lines, half the requests -- and kept for the length of the scan in the LDS slots of the lane-wise stream, which
+// it fits as 3 bits per base: 2-bit codes (BitRepresentation.charToTwobit, BitRepresentation.scala:127-135) and a validity bit, 16
+// bases per word.  A lane then takes 16 bases per refill from the two words its position straddles; the step body reads a code
+// and a validity bit where the lane-wise stream decodes a character.  Longer tiles, pairs and the long variant keep the lane-wise
+// stream.
+#ifndef SLK_PACKED_STREAM
+#define SLK_PACKED_STREAM 1
+#endif
+#ifndef SLK_PACK_ROUNDS
+#define SLK_PACK_ROUNDS 2
+#endif
+constexpr uint32_t PACK_MAX_SPAN = 10880;                       // bytes of a tile that can be staged (680 words of 16 bases)
+constexpr uint32_t PACK_WORDS = PACK_MAX_SPAN / 16 + 1;         // + one word of padding: a refill reads two words
+constexpr int PACK_LOADS = (PACK_MAX_SPAN + 1023) / 1024;       // wave-wide 1 KiB loads per tile, at most
+static_assert((size_t)PACK_WORDS * 6 <= (size_t)(SBLK - 1) * 64 * 16, "the packed tile lives in the lane-wise stream's LDS slots");
+// 16 characters -> (2-bit codes, char i in bits 2i..2i+1; validity bits, char i in bit i)
+__device__ __forceinline__ void pack16(const uint4 v, uint32_t &codes, uint32_t &valid) {
+  const uint32_t VM = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20) | (1u << 21);  // A C G T U, either case
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  codes = 0; valid = 0;
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    uint32_t t = (w[d] >> 1) & 0x03030303u;       // A,C,T/U,G -> 0,1,2,3 per byte
+    t ^= (t >> 1) & 0x01010101u;                  // -> A=0 C=1 G=2 T=3 (BitRepresentation.scala:35-39)
+    t = (t | (t >> 6) | (t >> 12) | (t >> 18)) & 0xFFu;
+    codes |= t << (8 * d);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const uint32_t c = (w[d] >> (8 * b)) & 0xFFu;
+      const uint32_t ok = (((c & 0xC0u) == 0x40u) ? 1u : 0u) & (VM >> (c & 31u));   // BitRepresentation.isValid :140-143
+      valid |= (ok & 1u) << (4 * d + b);
+    }
+  }
+}
+// the 16 bases from position s of the packed tile on: codes in .x, validity bits in .y
+__device__ __forceinline__ uint2 packed_take(const uint32_t *pcodes, const uint16_t *pvalid, uint32_t s) {
+  const uint32_t wi = s >> 4, bo = s & 15u;
+  const uint64_t c64 = (uint64_t)pcodes[wi] | ((uint64_t)pcodes[wi + 1] << 32);
+  const uint32_t v32 = (uint32_t)pvalid[wi] | ((uint32_t)pvalid[wi + 1] << 16);
+  return make_uint2((uint32_t)(c64 >> (2 * bo)), (v32 >> bo) & 0xFFFFu);
+}
+
 #ifndef SLK_LANE_WPS
 #define SLK_LANE_WPS 0
 #endif
@@ -552,9 +599,53 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     int mate = 0;
     uint32_t cur = 0, b1 = 0, b2 = 0, b3 = 0;  // 16 buffered characters
     int sb = 1;  // next staged sub-block (SBLK: none left, fetch)
+    // a short unpaired tile is fetched by the whole wave and staged as codes (above); `cur` then holds 16 codes, `b1` 16 validity bits
+    bool packed = false;
+    uint32_t s0 = 0;   // packed: where this lane's fragment starts in the tile
+    uint32_t *const pcodes = (uint32_t *)L->sbuf;
+    uint16_t *const pvalid = (uint16_t *)(pcodes + PACK_WORDS);
+    constexpr bool CAN_PACK = SLK_PACKED_STREAM && !LONG && MODE == LANE_LOCAL;   // (the sharded scan has no registers to spare for a second stream)
+    if (CAN_PACK && !paired) {
+      const uint64_t t0 = tile * 64, t1 = min(A.R, t0 + 64);
+      const uint64_t span_o = A.offsets[t0], span = A.offsets[t1] - span_o;   // (wave-uniform loads)
+      if (span <= PACK_MAX_SPAN && __ballot(!fin) != 0) {
+        packed = true;
+        s0 = have ? (uint32_t)(A.offsets[r] - span_o) : 0;
+        const uint8_t *tb = A.bases + span_o;
+        const uint32_t troom = clamp_room(bases_end - span_o), sp = (uint32_t)span;
+        // (in SLK_PACK_ROUNDS rounds of loads: all eleven in flight at once cost the kernel 44 registers it does not have)
+        constexpr int PG0 = (PACK_LOADS + SLK_PACK_ROUNDS - 1) / SLK_PACK_ROUNDS;
+#pragma unroll
+        for (int j0 = 0; j0 < PACK_LOADS; j0 += PG0) {
+          uint4 v[PG0];
+#pragma unroll
+          for (int j = 0; j < PG0; j++) {
+            const uint32_t cb = (uint32_t)(j0 + j) * 1024u + (uint32_t)lane * 16u;
+            v[j] = make_uint4(0, 0, 0, 0);
+            if (j0 + j < PACK_LOADS && cb < sp) v[j] = load_block16(tb + cb, troom - cb);
+          }
+#pragma unroll
+          for (int j = 0; j < PG0; j++) {
+            const uint32_t cb = (uint32_t)(j0 + j) * 1024u + (uint32_t)lane * 16u;
+            if (j0 + j < PACK_LOADS && cb < sp + 16u) {       // (and the word behind the last one: a refill reads two)
+              uint32_t cw, vw;
+              pack16(v[j], cw, vw);
+              pcodes[cb >> 4] = cw;
+              pvalid[cb >> 4] = (uint16_t)vw;
+            }
+          }
+        }
+        lane_wave_sync();
+      }
+    }
     if (!fin && n > 0) {
-      uint4 v = stream_refill(L, lane, seq, 0, n, room);
-      cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
+      if (CAN_PACK && packed) {
+        const uint2 pk = packed_take(pcodes, pvalid, s0);
+        cur = pk.x; b1 = pk.y;
+      } else {
+        uint4 v = stream_refill(L, lane, seq, 0, n, room);
+        cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
+      }
     }
     int run_class = 0;
     uint32_t run_len = 0, nvalid = 0;
@@ -586,10 +677,17 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       if (!W5 && tphase == 0) pre = ~0ULL;  // a new w-block starts: empty prefix
       const bool act = !fin;
       const bool is_end = pos >= n;
-      const uint32_t c = cur & 0xFF;
-      const bool okc = ((c & 0xC0) == 0x40) && ((VM >> (c & 31)) & 1);  // BitRepresentation.isValid :140-143
-      uint32_t t = (c >> 1) & 3;  // A,C,T/U,G -> 0,1,2,3
-      t ^= t >> 1;                // -> A=0 C=1 G=2 T=3 (BitRepresentation.scala:35-39)
+      bool okc;
+      uint32_t t;
+      if (CAN_PACK && packed) {   // (wave-uniform) the tile was staged as codes and validity bits
+        t = cur & 3u;
+        okc = (b1 & 1u) != 0;
+      } else {
+        const uint32_t c = cur & 0xFF;
+        okc = ((c & 0xC0) == 0x40) && ((VM >> (c & 31)) & 1);  // BitRepresentation.isValid :140-143
+        t = (c >> 1) & 3;  // A,C,T/U,G -> 0,1,2,3
+        t ^= t >> 1;       // -> A=0 C=1 G=2 T=3 (BitRepresentation.scala:35-39)
+      }
       const int cls = is_end ? -1 : (okc ? 1 : 0);
       // -- does the current run end here?
       const bool run_end = act && run_len > 0 && cls != run_class;
@@ -647,18 +745,29 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       cur_run = (start || change) ? 1 : (same ? cur_run + 1 : cur_run);
       // -- advance the character stream
       pos += proc ? 1u : 0u;
-      const bool nextdw = proc && (pos & 3) == 0;
-      cur = nextdw ? b1 : (proc ? (cur >> 8) : cur);
-      b1 = nextdw ? b2 : b1;
-      b2 = nextdw ? b3 : b2;
       const bool refill = proc && (pos & 15) == 0;
-      if (__ballot(refill) != 0) {
-        if (refill) {
-          if (pos < n) {
-            uint4 v;
-            if (sb < SBLK) { v = L->sbuf[(sb - 1) * 64 + lane]; sb++; }
-            else { v = stream_refill(L, lane, seq, pos, n, room); sb = 1; }
-            cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
+      if (CAN_PACK && packed) {
+        cur = proc ? (cur >> 2) : cur;
+        b1 = proc ? (b1 >> 1) : b1;
+        if (__ballot(refill) != 0) {
+          if (refill && pos < n) {
+            const uint2 pk = packed_take(pcodes, pvalid, s0 + pos);
+            cur = pk.x; b1 = pk.y;
+          }
+        }
+      } else {
+        const bool nextdw = proc && (pos & 3) == 0;
+        cur = nextdw ? b1 : (proc ? (cur >> 8) : cur);
+        b1 = nextdw ? b2 : b1;
+        b2 = nextdw ? b3 : b2;
+        if (__ballot(refill) != 0) {
+          if (refill) {
+            if (pos < n) {
+              uint4 v;
+              if (sb < SBLK) { v = L->sbuf[(sb - 1) * 64 + lane]; sb++; }
+              else { v = stream_refill(L, lane, seq, pos, n, room); sb = 1; }
+              cur = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
+            }
           }
         }
       }
