@@ -503,3 +503,40 @@ def test_mixed_lengths_take_the_length_bucketed_tile_order(orc, world):
     assert world["st"].last_deferred() >= 50
     mates = synth.make_reads(world["lib"], n, rng, vary_length=True, short=0.1)
     check_classify(orc, world, reads, mates, thresholds=(0.0,))
+
+
+def test_tiles_staged_by_the_whole_wave(orc, world):
+    """The hot kernel fetches a tile of 64 short fragments with wave-wide loads and scans it from 2-bit codes + validity bits in LDS
+    when the tile spans at most 10 880 bytes (lane.hip: SLK_PACKED_STREAM), and lane by lane otherwise.  Tiles right at that border
+    (10 879 / 10 880 / 10 881 bytes), tiles of empty fragments, every byte value but the line breaks as a character (only ACGTU in
+    either case are nucleotides: BitRepresentation.scala:127-143), a last tile of fewer than 64 fragments that ends with the buffer, fragments that
+    start at every offset within a 16-byte word: without hit lists (the hot path) and with them, against the oracle."""
+    rng = np.random.default_rng(170)
+    lib = world["lib"]
+
+    def tile_of(span):   # 64 fragments whose lengths sum to `span`
+        lens = rng.integers(100, 240, 64)
+        lens = np.maximum(1, (lens * (span / lens.sum())).astype(np.int64))
+        lens[-1] += span - lens.sum()
+        assert lens.sum() == span and lens.min() >= 1
+        return synth.make_reads(lib, 64, rng, short=0.0)[:0] + [synth.make_reads(lib, 1, rng, length=int(L), short=0.0)[0] for L in lens]
+
+    reads = []
+    for span in (10879, 10880, 10881, 10880, 9600, 64):
+        reads += tile_of(span)
+    reads += [np.zeros(0, np.uint8)] * 64                                        # a tile of empty fragments
+    odd = synth.make_reads(lib, 64, rng, length=150, short=0.0)
+    allbytes = np.arange(256, dtype=np.uint8)
+    allbytes[[10, 13]] = ord("N")      # (line breaks inside a read are outside the contract: getSpans takes whitespace-free reads, KeyValueIndex.scala:162)
+    for i in range(0, 64, 4):                                                    # every (other) byte value inside genome-derived reads
+        odd[i] = np.concatenate([odd[i][:60], allbytes[(i * 4) % 256:(i * 4) % 256 + 16], odd[i][60:]])
+    odd[1] = np.frombuffer(b"acgtuACGTU" * 15, np.uint8)
+    odd[2] = np.frombuffer(b"N" * 150, np.uint8)
+    odd[3] = np.frombuffer(b"-" * 40 + b"ACGT" * 30, np.uint8)
+    reads += odd
+    reads += synth.make_reads(lib, 37, rng, vary_length=True, n_single=0.3, n_run=0.2)   # the last tile: 37 fragments, then the buffer ends
+    got = check_classify(orc, world, reads, thresholds=(0.0, 0.2))
+    assert got["classified"][0].mean() > 0.5
+    # the same fragments shifted through the tiles: every alignment of a fragment's start within a word, tiles that mix the two routes
+    for shift in (1, 7, 33):
+        check_classify(orc, world, reads[shift:] + reads[:shift], thresholds=(0.0,))
