@@ -842,7 +842,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
       st->last_used_lane = true;
       // Hot path: one lane per fragment.  What that kernel does not take -- fragments over 1000 bases, taxon maps that overflow --
       // it appends to the hand-on list of the kernel that does (engine.h: FusedArgs.hand_*): four length classes for its own long
-      // variant (1001 .. 4999 bases), the lane-per-segment kernel (unpaired, from 5000 bases, w = 5), the
+      // variant (1001 .. 4999 bases), the lane-per-segment kernel (unpaired, from 16 000 bases, w = 5), the
       // wave-per-fragment kernel (the rest, and what the long variant hands on in turn).  The passes run behind it on this stream;
       // the segment pass, which depends on nothing but the first pass, on a second stream beside the other two.
       const size_t hdr_bytes = 16 * sizeof(uint64_t);
@@ -852,15 +852,17 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
       A.hand_lists = (uint32_t *)((char *)st->defer_list.p + hdr_bytes);
       A.hand_stride = R;
       // SLK_LANE_LONG_MAX moves the long variant's limit (at most 8191: queue entries carry 13-bit k-mer counts; 0: no such pass),
-      // SLK_SEG_MIN_LEN the segment kernel's (5000: below that, too few of the 64 lanes have a segment of a useful length; 0: wave
-      // kernel only).  Read per call, so that tests can move them.
+      // SLK_SEG_MIN_LEN the segment kernel's (16 000: the wave kernel is the faster one up to there -- 104 against 90 Gbp/s at
+      // 5 kbp, level at 15-20 kbp, 79 against 92 at 100 kbp, 55 against 74 at 300 kbp, profiles/r03_long_routes.txt; it was 5 000
+      // until round 3, when both kernels were last measured side by side below 10 kbp; 0: wave kernel only).  Read per call, so
+      // that tests can move them.
       const char *long_env = getenv("SLK_LANE_LONG_MAX");
       const int long_max = std::min(long_env ? atoi(long_env) : 4999, 8191);
       const char *seg_env = getenv("SLK_SEG_MIN_LEN");
-      const int seg_min = seg_env ? atoi(seg_env) : 5000;
-      // (hit lists: the segment kernel can put them together -- SLK_SEG_HITS=1 --, but its spans reach memory one 8-byte entry at a
-      //  time, and measured 32-47 Gbp/s against the wave kernel's 43-75 on the same reads: profiles/r03_long_hits_*.json; so per-read
-      //  lines of long reads keep the wave kernel unless asked otherwise)
+      const int seg_min = seg_env ? atoi(seg_env) : 16000;
+      // (hit lists: the segment kernel can put them together -- SLK_SEG_HITS=1 --, but the queues that take its spans to memory
+      //  in order cost it half its resident waves, and it measured 51-53 Gbp/s against the wave kernel's 68-79 on the same reads:
+      //  profiles/r03_long_hits_*.json; so per-read lines of long reads keep the wave kernel unless asked otherwise)
       const char *seg_hits_env = getenv("SLK_SEG_HITS");
       const bool seg_hits = seg_hits_env != nullptr && seg_hits_env[0] == '1';
       const bool seg_on = (!want_hits || seg_hits) && !paired && ix->sp.w == 5 && seg_min > 0;

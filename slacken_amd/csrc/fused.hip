@@ -742,9 +742,22 @@ struct __attribute__((aligned(16))) SegLds {
   uint4 sbuf[(SEG_SBLK - 1) * 64];
   uint64_t first_key[64], last_key[64];
   uint32_t flags[64];
-  uint32_t span_dst[SPAN_CAP];   // HITS: where in the fragment's span region the buffered span belongs (w0 of its lane + its number there)
 };
 enum { SEGF_HAS = 1, SEGF_ENDS_OPEN = 2, SEGF_END_AMB = 4 };
+// HITS: a lane's spans get their taxa in the wave's probe chunks, out of any order a memory system would like -- consecutive entries
+// of a chunk belong to different lanes, i.e. to places of the span region far apart: written where they belong one by one they were
+// four scattered requests per span, and the hit lists came out at 32-47 Gbp/s where the wave kernel's run at 43-75.  So every lane
+// collects ITS entries (taxon, meta: 8 bytes) in a queue of its own in LDS, in span order, and writes them to its stretch of the
+// scratch region eight at a time: 64 contiguous bytes.  A lane that gets more than the queue holds within one chunk (one segment
+// producing nearly all spans of a stretch of the fragment) has the surplus written directly, and empties its queue after the chunk.
+constexpr int SEG_QL = 8;
+template <bool HITS> struct SegHitLds {};
+template <> struct __attribute__((aligned(16))) SegHitLds<true> {
+  uint2 q[SEG_QL][64];        // [entry number mod SEG_QL][lane]
+  uint32_t span_dst[SPAN_CAP];  // whose the buffered span is (lane << 24) and its number among that lane's spans
+  uint32_t delivered[64];     // entries of the lane that have their taxon (they arrive in order)
+  uint32_t flushed[64];       // entries of the lane that are in the scratch region
+};
 
 // (room: bytes from seq to the end of the caller's buffer -- the buffer's last block is assembled from byte loads)
 __device__ __forceinline__ uint4 seg_refill(SegLds *G, int lane, const uint8_t *seq, uint32_t p, uint32_t n, uint32_t room) {
@@ -759,14 +772,46 @@ __device__ __forceinline__ uint4 seg_refill(SegLds *G, int lane, const uint8_t *
   return v[0];
 }
 
+// A lane writes the entries of its queue that have arrived to its stretch of the scratch region (`mine`): whole groups of SEG_QG
+// consecutive entries (32 contiguous bytes) as long as the queue did not overflow in the last chunk; everything, entry by entry, when
+// it did (the surplus is in the region already) or at the end (ALL).
+constexpr uint32_t SEG_QG = 4;
+template <bool ALL>
+__device__ __forceinline__ void seg_flush_queue(SegHitLds<true> *Q, uint2 *mine, int lane) {
+  const uint32_t D = Q->delivered[lane];
+  uint32_t F = Q->flushed[lane];
+  if (ALL || D > F + (uint32_t)SEG_QL) {
+    const uint32_t upto = D < F + (uint32_t)SEG_QL ? D : F + (uint32_t)SEG_QL;
+    for (uint32_t j = F; j < upto; j++) mine[j] = Q->q[j % SEG_QL][lane];
+    F = D;
+  } else {
+    while (D - F >= SEG_QG) {
+      uint2 e[SEG_QG];
+#pragma unroll
+      for (uint32_t j = 0; j < SEG_QG; j++) e[j] = Q->q[(F + j) % SEG_QL][lane];
+#pragma unroll
+      for (uint32_t j = 0; j < SEG_QG; j += 2) *(uint4 *)&mine[F + j] = make_uint4(e[j].x, e[j].y, e[j + 1].x, e[j + 1].y);
+      F += SEG_QG;
+    }
+  }
+  Q->flushed[lane] = F;
+}
+template <bool ALL>
+__device__ __forceinline__ void seg_flush_queue(SegHitLds<false> *, uint2 *, int) {}
+
 template <bool HITS>
 __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
   __shared__ WaveLds lds[FW];
   __shared__ SegLds seg[FW];
+  __shared__ SegHitLds<HITS> hitq[FW];
+  // (four blocks per CU at 37 888 bytes; at 39 936 -- four times that is still under 160 KB -- the part held three, and the kernel
+  //  lost 12 %: what only the hit lists need lives in SegHitLds)
+  static_assert(HITS || FW * (sizeof(WaveLds) + sizeof(SegLds)) <= 37888, "the plain variant's LDS block grew: four blocks per CU no longer fit");
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   WaveLds *L = &lds[wib];
   SegLds *G = &seg[wib];
+  SegHitLds<HITS> *Q = &hitq[wib];
   const ScanParams P = A.P;
   const int k = P.k, m = P.m;
   const uint64_t nwaves = (uint64_t)gridDim.x * FW;
@@ -789,6 +834,7 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
     const uint32_t room = clamp_room(bases_end - o - (exists ? w0 : 0));  // bytes from seq to the end of the caller's buffer
     uint2 *const prov = HITS ? (uint2 *)A.span_keys + o : nullptr;        // (unpaired: the fragment's span region starts at offsets[r])
     uint32_t lcount = 0;                                                   // spans of this lane so far
+    if constexpr (HITS) { Q->delivered[lane] = 0; Q->flushed[lane] = 0; }
     // ---- wave state (as fused_kernel) ----
     int nbuf = 0, n_out = 0;
     int32_t nd = 0, np = 0, t0 = 0;
@@ -836,10 +882,9 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
         const bool seqrun = run_class == 1 && nvalid >= (uint32_t)k;
         const bool seq_close = run_end && seqrun;
         const bool amb_close = run_end && !seqrun && run_len >= (uint32_t)k;
-        total += amb_close ? (int32_t)run_len - (k - 1) : 0;
+        const int32_t amb_kmers = (int32_t)run_len - (k - 1);
+        total += amb_close ? amb_kmers : 0;
         namb += amb_close ? 1 : 0;
-        if (HITS && amb_close) prov[w0 + lcount] = make_uint2((uint32_t)-1, (uint32_t)pack_meta((int32_t)run_len - (k - 1), 2, 0));  // spanToHit: AMBIGUOUS_SPAN
-        lcount += amb_close ? 1u : 0u;
         first_run_amb = (run_end && !first_run_done) ? amb_close : first_run_amb;
         first_run_done = first_run_done || run_end;
         ends_open = (act && is_end) ? seq_close : ends_open;
@@ -894,15 +939,19 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
         last_key = emit ? ekey : last_key;
         have_last = have_last || emit;
         total += emit ? ekmers : 0;
-        const uint64_t E = __ballot(emit);
+        // (HITS: the ambiguous spans take their place in the buffer too -- the hit list is in span order, and a lane's entries reach
+        //  its queue in the order of the buffer; probe_chunk gives them their special taxon, nothing else looks at them)
+        const bool push = emit || (HITS && amb_close);
+        const uint64_t E = __ballot(push);
         if (E != 0) {
-          if (emit) {
+          if (push) {
             const int slot = nbuf + lanes_below(E);
-            put_span(L, slot, ekey, ekmers, 1, distinct);
-            if (HITS) G->span_dst[slot] = w0 + lcount;
+            if (emit) put_span(L, slot, ekey, ekmers, 1, distinct);
+            else put_span(L, slot, 0, amb_kmers, 2, false);
+            if constexpr (HITS) Q->span_dst[slot] = ((uint32_t)lane << 24) | lcount;     // whose span, and its number there
             if (is_first && lane > 0) first_slot = slot;
           }
-          lcount += emit ? 1u : 0u;
+          lcount += push ? 1u : 0u;
           nbuf += __popcll(E);
         }
       }
@@ -917,7 +966,18 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
         const int32_t taxon = probe_chunk(L, A.T, s0, cnt, lane, meta);
         const int32_t count = meta_kmers(meta);
         const bool real = in && taxon >= 0;
-        if (HITS && in) prov[G->span_dst[s0 + lane]] = make_uint2((uint32_t)ext_taxon(A.T, taxon), (uint32_t)meta);
+        if constexpr (HITS) {
+          if (in) {   // the entry to its lane's queue (or, beyond what the queue holds, straight to its place)
+            const uint32_t dst = Q->span_dst[s0 + lane], p = dst >> 24, i = dst & 0xFFFFFFu;
+            const uint2 e = make_uint2((uint32_t)ext_taxon(A.T, taxon), (uint32_t)meta);
+            if (i < Q->flushed[p] + (uint32_t)SEG_QL) Q->q[i % SEG_QL][p] = e;
+            else prov[(uint64_t)p * S + i] = e;
+            atomicMax(&Q->delivered[p], i + 1);
+          }
+          wave_sync();
+          seg_flush_queue<false>(Q, prov + w0, lane);
+          wave_sync();
+        }
         nd += __popcll(__ballot(in && meta_distinct(meta) && taxon != 0));
         np += __popcll(__ballot(real));
         {  // the lanes whose first super-mer is in this chunk learn its taxon
@@ -952,9 +1012,9 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
       const int rest = nbuf - nflush;
       if (nflush > 0 && rest > 0) {
         uint64_t kk = 0; int32_t mm = 0; uint32_t dd = 0;
-        if (lane < rest) { kk = L->span_key[nflush + lane]; mm = L->span_meta[nflush + lane]; if (HITS) dd = G->span_dst[nflush + lane]; }
+        if (lane < rest) { kk = L->span_key[nflush + lane]; mm = L->span_meta[nflush + lane]; if constexpr (HITS) dd = Q->span_dst[nflush + lane]; }
         wave_sync();
-        if (lane < rest) { L->span_key[lane] = kk; L->span_meta[lane] = mm; if (HITS) G->span_dst[lane] = dd; }
+        if (lane < rest) { L->span_key[lane] = kk; L->span_meta[lane] = mm; if constexpr (HITS) Q->span_dst[lane] = dd; }
         if (first_slot >= 0) first_slot -= nflush;
         wave_sync();
       }
@@ -979,9 +1039,9 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
       if ((fp & SEGF_END_AMB) && first_run_amb) merged = 1;                                      // one ambiguous span, cut
     }
     nd -= __popcll(__ballot(undo_distinct));
-    n_out += wave_sum(namb) - wave_sum(merged);
+    n_out += (HITS ? 0 : wave_sum(namb)) - wave_sum(merged);   // (HITS: the ambiguous spans went through the buffer and are counted)
     total = wave_sum(total);
-    if (HITS) {
+    if constexpr (HITS) {
       // the hit list in ordinal order: lane j's entries start where the earlier lanes' end
       const uint32_t mine = lcount - (uint32_t)merged;        // (merged implies lcount >= 1: the cut span is this lane's first)
       uint32_t incl = mine;
@@ -991,14 +1051,27 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
         if (lane >= d) incl += up;
       }
       const uint32_t off = incl - mine;
+      seg_flush_queue<true>(Q, prov + w0, lane);              // what is left in the queues
+      wave_sync();
+      Q->delivered[lane] = incl;                               // (the queues are done with: where each lane's entries end in the list,
+      Q->flushed[lane] = (uint32_t)merged;                     //  and whether its first one went into the lane before)
       // (the scratch entries were written by other lanes of THIS wave: workgroup scope -- an agent-scope fence writes the XCD's L2
       //  back, twice per fragment: measured at 4x the kernel's time)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      for (uint32_t i = (uint32_t)merged; i < lcount; i++) {
-        const uint2 e = prov[w0 + i];
-        A.span_taxon[o + off + i - (uint32_t)merged] = (int32_t)e.x;
-        A.span_meta[o + off + i - (uint32_t)merged] = (int32_t)e.y;
+      wave_sync();
+      // the copy by the whole wave, 64 consecutive places of the list at a time (whole lines written, and the reads run along the
+      // lanes' stretches): a lane finds whose entry belongs at its place by bisection over the 64 ends.  (A lane copying its own
+      // stretch writes 64 places far apart with every store: three scattered requests per entry, 9 ms per Gbp.)
+      const uint32_t n_list = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      for (uint32_t t = lane; t < n_list; t += 64) {
+        int j = 0;
+#pragma unroll
+        for (int b = 32; b > 0; b >>= 1) j += (Q->delivered[j + b - 1] <= t) ? b : 0;   // the first lane whose end lies beyond t
+        const uint32_t begin = j > 0 ? Q->delivered[j - 1] : 0u;
+        const uint2 e = prov[(uint64_t)j * S + Q->flushed[j] + (t - begin)];
+        A.span_taxon[o + t] = (int32_t)e.x;
+        A.span_meta[o + t] = (int32_t)e.y;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

@@ -24,7 +24,8 @@ def main():
     acgt = np.frombuffer(b"ACGT", np.uint8)
     bases = acgt[rng.integers(0, 4, G * L, dtype=np.uint8)]
     kms = [int(x) for x in os.environ.get("KMS", "35,31,7").split(",")]   # k, m, spaces of the splitter
-    ix = slacken_amd.Index(k=kms[0], m=kms[1], spaces=kms[2], expected_records=G * L // 2, max_taxon=len(parents) - 1)
+    ix = slacken_amd.Index(k=kms[0], m=kms[1], spaces=kms[2], expected_records=int(os.environ.get('EXPECTED', G * L // 2)), max_taxon=len(parents) - 1,
+                           load_factor=float(os.environ.get('LOAD', 0)))   # (EXPECTED=134217722 LOAD=0.5: a power of two of buckets)
     ix.set_taxonomy(parents)
     ix.add_sequences(bases, np.arange(G + 1, dtype=np.uint64) * np.uint64(L), rng.choice(taxa[len(taxa) // 2:], G).astype(np.int32))
     ix.finalize()

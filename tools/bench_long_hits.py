@@ -29,16 +29,21 @@ def main():
     ix.finalize()
     st = ix.stream()
     out = dict(seg_min_len=os.environ.get("SLK_SEG_MIN_LEN", "default"), seg_hits=os.environ.get("SLK_SEG_HITS", "0"))
-    for L_read in (5000, 10000, 30000, 100000):
-        R = max(64, 200_000_000 // L_read)
+    with_hits = os.environ.get("SLK_BENCH_NO_HITS", "0") != "1"     # (=1: the same reads without hit lists, for the cost of the lists)
+    out["with_hits"] = with_hits
+    for L_read in [int(x) for x in os.environ.get('LENGTHS', '5000,10000,30000,100000').split(',')]:
+        R = max(64, int(float(os.environ.get('SLK_BENCH_BASES', '2e8'))) // L_read)
         starts = rng.integers(0, G * L - L_read, R)
         rb = bases[(starts[:, None] + np.arange(L_read)[None, :]).reshape(-1)].copy()
         rb[np.arange(0, R, 100) * L_read + L_read // 3] = ord("N")      # one N in one read of a hundred
         ro = np.arange(0, (R + 1) * L_read, L_read, dtype=np.uint64)
         ms = []
         for _ in range(3):
-            res = st.classify_batch(rb, ro, thresholds=(0.0,), with_hits=True)
+            res = st.classify_batch(rb, ro, thresholds=(0.0,), with_hits=with_hits)
             ms.append(sum(st.last_stage_ms()))
+        if not with_hits:
+            out[f"{L_read}bp"] = dict(reads=R, kernel_ms=round(min(ms), 2), Gbp_per_s=round(R * L_read / min(ms) / 1e6, 1))
+            continue
         out[f"{L_read}bp"] = dict(reads=R, kernel_ms=round(min(ms), 2), Gbp_per_s=round(R * L_read / min(ms) / 1e6, 1),
                                   hits=int(res["hit_offsets"][-1]), classified=round(float(res["classified"][0].mean()), 3),
                                   taxon_sum=int(res["taxon"].astype(np.int64).sum()), hit_sum=int(res["hits"]["count"].astype(np.int64).sum()))
