@@ -754,7 +754,7 @@ constexpr int SEG_QL = 8;
 template <bool HITS> struct SegHitLds {};
 template <> struct __attribute__((aligned(16))) SegHitLds<true> {
   uint2 q[SEG_QL][64];        // [entry number mod SEG_QL][lane]
-  uint32_t span_dst[SPAN_CAP];  // whose the buffered span is (lane << 24) and its number among that lane's spans
+  uint32_t span_dst[SPAN_CAP];  // whose the buffered span is (lane << 26) and its number among that lane's spans
   uint32_t delivered[64];     // entries of the lane that have their taxon (they arrive in order)
   uint32_t flushed[64];       // entries of the lane that are in the scratch region
 };
@@ -948,7 +948,7 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
             const int slot = nbuf + lanes_below(E);
             if (emit) put_span(L, slot, ekey, ekmers, 1, distinct);
             else put_span(L, slot, 0, amb_kmers, 2, false);
-            if constexpr (HITS) Q->span_dst[slot] = ((uint32_t)lane << 24) | lcount;     // whose span, and its number there
+            if constexpr (HITS) Q->span_dst[slot] = ((uint32_t)lane << 26) | lcount;     // whose span, and its number there (a lane has fewer than 2^25 windows)
             if (is_first && lane > 0) first_slot = slot;
           }
           lcount += push ? 1u : 0u;
@@ -968,7 +968,7 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
         const bool real = in && taxon >= 0;
         if constexpr (HITS) {
           if (in) {   // the entry to its lane's queue (or, beyond what the queue holds, straight to its place)
-            const uint32_t dst = Q->span_dst[s0 + lane], p = dst >> 24, i = dst & 0xFFFFFFu;
+            const uint32_t dst = Q->span_dst[s0 + lane], p = dst >> 26, i = dst & 0x3FFFFFFu;
             const uint2 e = make_uint2((uint32_t)ext_taxon(A.T, taxon), (uint32_t)meta);
             if (i < Q->flushed[p] + (uint32_t)SEG_QL) Q->q[i % SEG_QL][p] = e;
             else prov[(uint64_t)p * S + i] = e;
