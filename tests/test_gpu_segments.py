@@ -174,6 +174,30 @@ def test_segment_borders_one_by_one(orc, world):
     check_hits(orc, world, reads)       # spans cut by one border, by sixty-three, N runs slid across a border: one hit each
 
 
+def test_hit_lists_when_few_lanes_hold_all_the_sequence(orc, world):
+    """The hit-list variant queues a lane's entries in LDS, eight at a time; a chunk of 64 spans that comes from two or three lanes
+    -- islands of sequence in a sea of Ns, or one lane's stretch of a long fragment with a new minimizer in every window while its
+    neighbours sit in a repeat -- overruns the queues, and the surplus goes straight to its place."""
+    rng = np.random.default_rng(41)
+    lib = world["lib"]
+    reads = []
+    for n_islands, island, sea in ((1, 120, 3000), (2, 90, 2500), (3, 200, 4000), (1, 64 + 34, 6000), (5, 70, 900)):
+        parts = [np.full(sea, ord("N"), np.uint8)]
+        for _ in range(n_islands):
+            g = lib.genomes[rng.integers(0, len(lib.genomes))]
+            a = int(rng.integers(0, len(g) - island))
+            parts += [g[a:a + island].copy(), np.full(int(rng.integers(sea // 2, sea)), ord("N"), np.uint8)]
+        reads.append(np.concatenate(parts))
+    # repeats (one span per hundreds of bases) around a stretch of genome (a span every few bases)
+    for unit_len, mid in ((2, 300), (5, 150), (3, 1000)):
+        unit = synth.random_dna(unit_len, rng)
+        g = lib.genomes[rng.integers(0, len(lib.genomes))]
+        a = int(rng.integers(0, len(g) - mid))
+        reads.append(np.concatenate([np.tile(unit, 4000 // unit_len), g[a:a + mid], np.tile(unit, 5000 // unit_len)]))
+    check(orc, world, reads)
+    check_hits(orc, world, reads)
+
+
 def test_very_long_read(orc, world):
     rng = np.random.default_rng(3)
     reads = [long_read(world["lib"], rng, 400_000), long_read(world["lib"], rng, 70_000)]
