@@ -8,6 +8,7 @@ and ONE comparison with the oracle itself at full size: a sample of the reads (t
 oracle against a mini-index that holds, for exactly the sample's minimizers, what POINT LOOKUPS of the big table returned (a different
 kernel from the classify kernels' probe) -- so bucket addressing at 2^31 buckets / 128 GiB offsets is checked against the oracle too."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -22,6 +23,9 @@ def big():
     import slacken_amd
     full = os.environ.get("SLK_FULLSIZE", "1") == "1"
     n_records, n_reads = (int(1e10), int(1e7)) if full else (1 << 30, 2_000_000)
+    # (SLK_FULLSIZE_RECORDS=2e10: the largest table the bench has a line for -- 213 GiB, 3.6e9 buckets, load 0.70, chains of 32
+    #  buckets; run once per round as a soak, gpurun_out/fullsize_2e10.log)
+    n_records = int(float(os.environ.get("SLK_FULLSIZE_RECORDS", n_records)))
     dev = torch.device("cuda", 0)
     parents, taxa, leaves = bench.build_taxonomy()
     rng = np.random.default_rng(224)
@@ -46,6 +50,8 @@ def big():
         ix.append_device(keys.data_ptr(), tx.data_ptr(), n)
         del keys, tx
     ix.finalize()
+    info = ix.info()
+    print(f"[fullsize] {info.records} records, {info.table_bytes / 2**30:.1f} GiB, max displacement {info.max_displacement}", file=sys.stderr)
     bases, offsets = bench.make_reads_device(torch, genome_cat, GL, G, n_reads, 150, dev)
     return dict(torch=torch, ix=ix, st=ix.stream(), bases=bases, offsets=offsets, R=n_reads, dev=dev,
                 ntax=bench.TAX_EXTENT, parents=parents)
