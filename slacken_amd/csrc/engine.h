@@ -50,8 +50,9 @@ void launch_wide_probe(const WideTable &t, int W, const uint64_t *offsets, const
 // 64-byte buckets, one HBM access granule, four lanes x 16 B per probe.  16: 128-byte buckets, one L2 line, eight lanes per probe
 // -- a gather microbenchmark serves random requests of either size at the same rate, but the classify kernel with 128-byte
 // buckets measured 3-4 % SLOWER at every load factor (twice the load instructions and bytes per probe for a tenth of the
-// second-bucket probes; profiles/r03_bucket_geometry.txt), so that variant is a build option kept for the record.  The number of buckets is ANY number (not a power of two: a 1.2e10-record library must not cost
-// twice the memory of a 1.0e10-record one), chosen by a multiply-shift range reduction of the hash's top q bits:
+// second-bucket probes; profiles/r03_bucket_geometry.txt), so that variant is a build option kept for the record.
+// The number of buckets is ANY number (not a power of two: a 1.2e10-record library must not cost twice the memory of a
+// 1.0e10-record one), chosen by a multiply-shift range reduction of the hash's top q bits:
 //   h      = fmix64(key)                       (bijective, so (home bucket, remainder) identifies the key: lossless)
 //   x      = h >> (64 - q),  q = ceil(log2(nbuckets))
 //   home   = (x * nbuckets) >> q               (at most two consecutive x share a home bucket, since 2^(q-1) < nbuckets <= 2^q)
@@ -80,7 +81,9 @@ struct TableGeom {
 };
 // home bucket of hash h and the remainder field of its cells, already shifted past the displacement field
 __host__ __device__ __forceinline__ void table_slot(const TableGeom &g, uint64_t h, uint32_t &home, uint64_t &rem_hi) {
-  const uint64_t prod = (h >> (64 - g.q)) * g.nbuckets;                // (both factors below 2^32 + 1)
+  // (q <= 32, so x is a 32-bit number; nbuckets is one too unless it is 2^32 itself: one 32 x 32 -> 64 multiply)
+  const uint32_t x = (uint32_t)(h >> (64 - g.q));
+  const uint64_t prod = (g.nbuckets >> 32) != 0 ? (uint64_t)x << 32 : (uint64_t)x * (uint32_t)g.nbuckets;
   home = (uint32_t)(prod >> g.q);
   const uint64_t extra = (prod & ((1ULL << g.q) - 1)) >= g.nbuckets ? 1 : 0;
   rem_hi = ((h & g.rem_mask) | (extra << (64 - g.q))) << g.disp_bits;
