@@ -3,5 +3,3 @@
 export SLK_FUZZ_SEEDS=${SLK_FUZZ_SEEDS:-400} SLK_SEG_SEEDS=${SLK_SEG_SEEDS:-80} SLK_DEEP_SEEDS=${SLK_DEEP_SEEDS:-100} SLK_TITLE_SEEDS=${SLK_TITLE_SEEDS:-12}
 timeout -k 10 1000 python -m pytest tests -m gpu -x -q --deselect tests/test_gpu_fullsize.py -p no:cacheprovider > gpurun_out/soak_r03.log 2>&1; echo "soak rc=$?"; tail -4 gpurun_out/soak_r03.log
 timeout -k 10 300 python tools/soak_sizing.py > gpurun_out/soak_sizing_r03.log 2>&1; echo "sizing rc=$?"; tail -3 gpurun_out/soak_sizing_r03.log
-SLK_SEG_MIN_LEN=0 timeout -k 10 300 python tools/bench_long_hits.py > gpurun_out/r03_long_hits_wave.json 2> gpurun_out/r03_long_hits_wave.err; echo "rc=$?"; cat gpurun_out/r03_long_hits_wave.json
-timeout -k 10 300 python tools/bench_long_hits.py > gpurun_out/r03_long_hits_segment.json 2> gpurun_out/r03_long_hits_segment.err; echo "rc=$?"; cat gpurun_out/r03_long_hits_segment.json
