@@ -656,16 +656,19 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
             if (nz != 0) {
               if (t0 == 0) t0 = __builtin_amdgcn_readlane(taxon, __builtin_ctzll(nz));
               if (__ballot(real && taxon != 0 && taxon != t0) != 0) {
-                map_mode = true;   // a second taxon: the others go to the LDS map from here on
+                // a second taxon: move the single-taxon summary into the LDS map and continue there
+                int32_t c0 = wave_sum(acc_t0), cn = wave_sum(acc_none);
+                if (lane == 0 && c0 != 0) map_insert(L, t0, c0, A.status);
+                if (lane == 1 && cn != 0) map_insert(L, 0, cn, A.status);
+                map_mode = true;
               }
             }
           }
-          // (the first taxon and NONE stay in the lanes' registers in map mode too: they are most of a read's hits, and 64 lanes
-          //  adding to one LDS word are 64 atomics in a row; they join the map once, before it is resolved)
-          if (real) {
-            if (taxon == 0) acc_none += count;
-            else if (taxon == t0) acc_t0 += count;
-            else map_insert(L, taxon, count, A.status);
+          if (map_mode) {
+            if (real) map_insert(L, taxon, count, A.status);
+          } else if (real) {
+            if (taxon != 0) acc_t0 += count;
+            else acc_none += count;
           }
           if (MODE == MODE_HITS && in) {
             A.span_meta[base + n_out + lane] = meta;
@@ -686,12 +689,6 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
 
     // ---- per-read classification -------------------------------------------------------------------------------------
     if (map_mode) {
-      {
-        const int32_t c0 = wave_sum(acc_t0), cn = wave_sum(acc_none);
-        if (lane == 0 && c0 != 0) map_insert(L, t0, c0, A.status);
-        if (lane == 1 && cn != 0) map_insert(L, 0, cn, A.status);
-        wave_sync();
-      }
       resolve_map(L, A, r, lane, total, nd);
     } else {
       // Every non-NONE hit names t0 (or there is none): resolveTree's first loop yields t0; lifting it changes nothing
@@ -994,14 +991,18 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
           if (nz != 0) {
             if (t0 == 0) t0 = __builtin_amdgcn_readlane(taxon, __builtin_ctzll(nz));
             if (__ballot(real && taxon != 0 && taxon != t0) != 0) {
+              int32_t c0 = wave_sum(acc_t0), cn = wave_sum(acc_none);
+              if (lane == 0 && c0 != 0) map_insert(L, t0, c0, A.status);
+              if (lane == 1 && cn != 0) map_insert(L, 0, cn, A.status);
               map_mode = true;
             }
           }
         }
-        if (real) {   // (as fused_kernel: the first taxon and NONE in registers, the others into the map)
-          if (taxon == 0) acc_none += count;
-          else if (taxon == t0) acc_t0 += count;
-          else map_insert(L, taxon, count, A.status);
+        if (map_mode) {
+          if (real) map_insert(L, taxon, count, A.status);
+        } else if (real) {
+          if (taxon != 0) acc_t0 += count;
+          else acc_none += count;
         }
         n_out += cnt;
       }
@@ -1081,12 +1082,6 @@ __global__ void FUSED_BOUNDS segment_kernel(FusedArgs A) {
 
     // ---- per-read classification (as fused_kernel) ----
     if (map_mode) {
-      {
-        const int32_t c0 = wave_sum(acc_t0), cn = wave_sum(acc_none);
-        if (lane == 0 && c0 != 0) map_insert(L, t0, c0, A.status);
-        if (lane == 1 && cn != 0) map_insert(L, 0, cn, A.status);
-        wave_sync();
-      }
       resolve_map(L, A, r, lane, total, nd);
     } else {
       bool need_count = false;
