@@ -26,7 +26,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
             cnt[(name, r.get("Counter_Name", ""))] += 1
         print("== pmc:", os.path.relpath(f, out))
         for name, ctrs in acc.items():
-            if "lane" not in name and "fused" not in name and "probe" not in name and "scan" not in name and "classify" not in name:
+            if "lane" not in name and "fused" not in name and "segment" not in name and "probe" not in name and "scan" not in name and "classify" not in name:
                 continue
             for c, v in sorted(ctrs.items()):
                 n = cnt[(name, c)]
