@@ -742,36 +742,56 @@ static Regrouped regroup_repeated_titles(DeviceIndex &dev, const std::vector<std
       while (rs.next(h, sq)) if (D.contains(title_hash(h))) joined.push_back({std::string(h), std::string(sq), std::string()});
       continue;
     }
-    // PairedInputReader.getFragments: every record of file 1 with every record of file 2 of the same header
+    // PairedInputReader.getFragments: every record of file 1 with every record of file 2 of the same header.  Three readers at
+    // once -- file 1, file 2, and the pairing walk of the first pass (whose fragments are what the merged rows replace) --, each
+    // with its own stream: one pass of wall time over the pair, not three one after the other.
     std::vector<std::string> order;
     std::unordered_map<std::string, std::pair<std::vector<std::string>, std::vector<std::string>>> lists;
-    {
-      AsyncRecordStream r1(files[u]);
-      while (r1.next(h, sq)) {
-        h = remove_suffix(h, "/1");
-        if (!D.contains(title_hash(h))) continue;
-        auto it = lists.try_emplace(std::string(h)).first;
-        if (it->second.first.empty()) order.push_back(it->first);
-        it->second.first.emplace_back(sq);
+    std::unordered_map<std::string, std::vector<std::string>> second;
+    std::exception_ptr err1, err2;
+    std::thread t1([&] {
+      try {
+        std::string_view h1, s1;
+        AsyncRecordStream r1(files[u]);
+        while (r1.next(h1, s1)) {
+          h1 = remove_suffix(h1, "/1");
+          if (!D.contains(title_hash(h1))) continue;
+          auto it = lists.try_emplace(std::string(h1)).first;
+          if (it->second.first.empty()) order.push_back(it->first);
+          it->second.first.emplace_back(s1);
+        }
+      } catch (...) { err1 = std::current_exception(); }
+    });
+    std::thread t2([&] {
+      try {
+        std::string_view h2, s2;
+        AsyncRecordStream r2(files[u + 1]);
+        while (r2.next(h2, s2)) {
+          h2 = remove_suffix(h2, "/2");
+          if (D.contains(title_hash(h2))) second[std::string(h2)].emplace_back(s2);
+        }
+      } catch (...) { err2 = std::current_exception(); }
+    });
+    std::exception_ptr err0;
+    try {
+      FragmentSource src({files[u], files[u + 1]}, true);
+      for (;;) {
+        FragmentBatchPtr bp;
+        if (!src.fill(bp, (size_t)1 << 17, (size_t)512 << 20)) break;
+        for (size_t i = 0; i < bp->size(); i++)
+          if (D.contains(title_hash(bp->title(i)))) first.push_back({std::string(bp->title(i)), std::string(bp->seq(i)), std::string(bp->mate(i))});
       }
-      AsyncRecordStream r2(files[u + 1]);
-      while (r2.next(h, sq)) {
-        h = remove_suffix(h, "/2");
-        if (!D.contains(title_hash(h))) continue;
-        auto it = lists.find(std::string(h));
-        if (it != lists.end()) it->second.second.emplace_back(sq);
-      }
+    } catch (...) { err0 = std::current_exception(); }
+    t1.join();
+    t2.join();
+    for (std::exception_ptr e : {err0, err1, err2}) if (e) std::rethrow_exception(e);
+    for (auto &kv : second) {   // (a header of file 2 alone joins nothing)
+      auto it = lists.find(kv.first);
+      if (it != lists.end()) it->second.second = std::move(kv.second);
     }
     for (const std::string &title : order) {
       auto &l = lists[title];
       for (const std::string &s1 : l.first) for (const std::string &s2 : l.second) joined.push_back({title, s1, s2});
-    }
-    FragmentSource src({files[u], files[u + 1]}, true);
-    for (;;) {
-      FragmentBatchPtr bp;
-      if (!src.fill(bp, (size_t)1 << 17, (size_t)512 << 20)) break;
-      for (size_t i = 0; i < bp->size(); i++)
-        if (D.contains(title_hash(bp->title(i)))) first.push_back({std::string(bp->title(i)), std::string(bp->seq(i)), std::string(bp->mate(i))});
     }
   }
   // titles (compared as strings) with more than one fragment
