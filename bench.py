@@ -410,8 +410,8 @@ def table_sharded(args, rank, world, local_rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--records", type=float, default=1.0e10, help="library records (standard-224-scale)")
     ap.add_argument("--reads", type=float, default=1.0e7, help="150 bp reads per GPU per step")
     ap.add_argument("--genomes", type=int, default=8192)
