@@ -11,7 +11,14 @@ LIB := slacken_amd/lib/libslacken_amd.so
 
 CLI := slacken_amd/bin/slacken-amd
 
-all: $(LIB) $(CLI) oracle
+GATHER := slacken_amd/lib/libslk_gather.so
+
+all: $(LIB) $(CLI) $(GATHER) oracle
+
+# measurement helper of bench.py (the part's random-request rate, measured in the bench run): not linked or loaded by the product
+$(GATHER): tools/gather_rate.hip
+	@mkdir -p slacken_amd/lib
+	$(HIPCC) -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -shared -o $@ tools/gather_rate.hip
 
 $(LIB): $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/build.hip $(CSRC)/shard.hip $(CSRC)/wide.hip $(CSRC)/capi.hip $(CSRC)/shardset.hip $(CSRC)/engine.h $(CSRC)/hostside.h include/slacken_amd.h
 	@mkdir -p slacken_amd/lib
@@ -38,7 +45,7 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(LIB)
+	rm -f $(LIB) $(GATHER)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

@@ -48,17 +48,82 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-# random 64-byte requests/s this part sustains against a 128 GiB table (tools/gather_bench2.hip, profiles/r02_gather_experiments.txt)
+# random 64-byte requests/s this part sustains against a 128 GiB table (tools/gather_bench2.hip, profiles/r02_gather_experiments.txt):
+# the FALLBACK only -- a run measures the rate itself after its timed region (measure_request_ceiling) and says which it quotes
 GATHER_CEILING_GLPS = 48.4
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 K, M, SPACES = 35, 31, 7
 READ_LEN = 150
 TAX_EXTENT = 3080008  # README.md:374 of the reference (NCBI taxonomy array extent)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", os.environ.get("SLK_TRAFFIC_FILE", "r04_traffic.json"))
 
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
+    progress(" ".join(str(x) for x in a)[:120])
+
+
+# ---- watchdog: a rank that makes no progress for WATCHDOG_S seconds says where it is and exits non-zero (never a re-exec) ----
+WATCHDOG_S = float(os.environ.get("SLK_BENCH_WATCHDOG_S", "300"))
+_progress = {"stage": "start", "t": time.monotonic(), "armed": False}
+
+
+def progress(stage):
+    """called at every milestone (every log line is one): the stage a hung rank would be reported in"""
+    _progress["stage"], _progress["t"] = stage, time.monotonic()
+
+
+def arm_watchdog(rank):
+    import threading
+    if _progress["armed"] or WATCHDOG_S <= 0:
+        return
+    _progress["armed"] = True
+
+    def watch():
+        while True:
+            time.sleep(min(5.0, max(0.05, WATCHDOG_S / 4)))
+            idle = time.monotonic() - _progress["t"]
+            if idle > WATCHDOG_S:
+                print(f"[bench] rank {rank}: WATCHDOG: no progress for {idle:.0f} s in stage: {_progress['stage']} -- giving up",
+                      file=sys.stderr, flush=True)
+                os._exit(3)
+
+    threading.Thread(target=watch, name="bench-watchdog", daemon=True).start()
+
+
+def measure_request_ceiling(torch, device, table_bytes):
+    """The part's random-request rate measured in THIS run, on this box (boxes differ by ~5 %): uniformly random aligned 64-byte
+    and 128-byte requests with the probe's access shape over a buffer of the table's size (tools/gather_rate.hip ->
+    slacken_amd/lib/libslk_gather.so, built by `make all`).  Call after the index has been closed.  -> dict or None."""
+    import ctypes
+    path = os.path.join(ROOT, "slacken_amd", "lib", "libslk_gather.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        G = ctypes.CDLL(path)
+        G.slk_gather_rate.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
+                                      ctypes.POINTER(ctypes.c_float)]
+        G.slk_gather_rate.restype = ctypes.c_int
+        torch.cuda.empty_cache()
+        nbytes = min(int(table_bytes), 128 << 30) // 4096 * 4096
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)   # (contents irrelevant)
+        torch.cuda.synchronize()
+        out = {"bytes": nbytes}
+        for lanes, name in ((4, "64B"), (8, "128B")):
+            g, ms = ctypes.c_double(0), ctypes.c_float(0)
+            best = 0.0
+            for _ in range(2):
+                rc = G.slk_gather_rate(buf.data_ptr(), nbytes, lanes, 1500.0, ctypes.byref(g), ctypes.byref(ms))
+                if rc != 0:
+                    return None
+                best = max(best, g.value)
+            out[name] = round(best, 2)
+        del buf
+        torch.cuda.empty_cache()
+        return out
+    except Exception as e:   # (a measurement aid: the bench line says so instead of failing)
+        log("request-rate ceiling not measured:", repr(e))
+        return None
 
 
 def kernel_source_hash():
@@ -170,6 +235,10 @@ def dry_run(args, rank, world):
 
     for _ in range(args.warmup):
         x = x * np.uint64(3) + np.uint64(1)
+    if os.environ.get("SLK_BENCH_TEST_HANG_RANK") == str(rank):   # (tests/test_dist_cpu.py: what the watchdog does about a stuck rank)
+        progress("test hang before the first barrier")
+        time.sleep(3600)
+    progress("dry run: barrier before the timed steps")
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -414,10 +483,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--records", type=float, default=1.0e10, help="library records (standard-224-scale)")
     ap.add_argument("--reads", type=float, default=1.0e7, help="150 bp reads per GPU per step")
+    ap.add_argument("--reads-total", type=float, default=0.0,
+                    help="150 bp reads per step over ALL GPUs (overrides --reads: each rank takes reads_total / N; BASELINE.json "
+                         "configs[2] as written is --gpus 8 --reads-total 1e8 = 12.5 M per GPU)")
     ap.add_argument("--genomes", type=int, default=8192)
     ap.add_argument("--genome-len", type=int, default=1 << 20)
     ap.add_argument("--load-factor", type=float, default=0.0, help="cells-used fraction of the table (0: the engine's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ceiling", action="store_true", help="do not measure the random-request rate after the timed region")
     ap.add_argument("--table-sharded", action="store_true",
                     help="BASELINE configs[3]: every rank holds 1/N of the table, minimizers and taxa cross the links (RCCL all-to-all)")
     ap.add_argument("--records-per-rank", type=float, default=5.0e9, help="--table-sharded: records of one rank's shard")
@@ -441,6 +514,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}; start it as `python bench.py --gpus N` or "
                          f"under torch.distributed.run with --nproc-per-node equal to --gpus")
+    arm_watchdog(rank)
+    if args.reads_total > 0:
+        args.reads = float(int(args.reads_total) // world)
     if args.dry_run:
         return dry_run_sharded(args, rank, world) if args.table_sharded else dry_run(args, rank, world)
     if args.table_sharded:
@@ -572,11 +648,31 @@ def main():
         same = (tj.get("reads_per_launch") == n_reads and tj.get("records") == int(args.records)
                 and tj.get("genomes") == [G, args.genome_len])
         if same and tj.get("kernel_source_hash") == kernel_source_hash():
-            traffic, traffic_note = tj["hbm_bytes_per_launch"], "profiles/r03_traffic.json (same kernel sources, same workload)"
+            traffic, traffic_note = tj["hbm_bytes_per_launch"], f"profiles/{os.path.basename(TRAFFIC_FILE)} (same kernel sources, same workload)"
             if tj.get("tcc_miss_x64_bytes"):
                 miss_requests = tj["tcc_miss_x64_bytes"] // 64
         else:
-            traffic_note = "profiles/r03_traffic.json is for other kernel sources or another workload: not quoted"
+            traffic_note = f"profiles/{os.path.basename(TRAFFIC_FILE)} is for other kernel sources or another workload: not quoted"
+
+    # ---- after the timed region: the CPU baseline, then the part's random-request rate on THIS box (the index is closed for it)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        progress("cpu baseline")
+        cpu = cpu_baseline(torch, slacken_amd, args, parents, genome_cat, genome_taxa, G, device)
+    deferred = st.last_deferred()
+    ceiling, ceiling_src, ceil_meas = GATHER_CEILING_GLPS, "constant of round 2 (FALLBACK: not measured in this run)", None
+    if rank == 0 and not args.no_ceiling:
+        progress("request-rate ceiling")
+        table_bytes = int(info.table_bytes)
+        del d_bases, d_offsets, genome_cat
+        st.close()
+        ix.close()
+        ceil_meas = measure_request_ceiling(torch, device, table_bytes)
+        if ceil_meas:
+            ceiling = ceil_meas["64B"]
+            ceiling_src = (f"measured in this run: uniformly random 64-byte requests (4 lanes x 16 B) over {ceil_meas['bytes'] / 2**30:.0f} GiB, "
+                           f"tools/gather_rate.hip")
+    log(f"rank {rank}: request-rate ceiling {ceiling} G/s ({ceiling_src})")
 
     out = {
         "metric": "classify_throughput_150bp_standard224scale",
@@ -591,6 +687,7 @@ def main():
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
+        "reads_total": world * n_reads,
         **({"rehearsal": "all ranks on GPU 0: not a measurement"} if args.rehearse_on_one_gpu else {}),
         "config": {
             "workload": "standard-224-scale synthetic library (k=35,m=31,s=7), synthetic 150 bp single-end reads, "
@@ -598,9 +695,13 @@ def main():
             "records": int(info.records), "table_GiB": round(info.table_bytes / 2**30, 1), "bucket_bytes": int(info.bucket_cells) * 8,
             "table_load": round(info.records / (info.buckets * info.bucket_cells), 3), "max_displacement": int(info.max_displacement),
             "genomes": G, "genome_len": args.genome_len, "genome_records": n_genome_records,
-            "reads_per_gpu_per_step": n_reads, "read_len": READ_LEN, "parallelism": f"read-sharded x{world}, table replicated",
+            "reads_per_gpu_per_step": n_reads, "reads_total_per_step": world * n_reads, "read_len": READ_LEN,
+            "parallelism": f"read-sharded x{world}, table replicated",
+            "scaling_note": (f"weak: every rank classifies its own {n_reads} reads per step, value = {world} x {n_reads} reads / the slowest rank's time"
+                             + ("; --reads-total given: the step's reads are BASELINE.json configs[2]'s total cut into equal shares" if args.reads_total > 0
+                                else "; BASELINE.json configs[2] as written (100 M reads over 8 GPUs) is --gpus 8 --reads-total 1e8")),
             "probes_per_read": round(probes / n_reads, 3), "classified_fraction": round(classified, 4),
-            "deferred_to_wave_kernel": st.last_deferred(),
+            "deferred_to_wave_kernel": deferred,
             "stage_ms": ({"fused_last_step": round(float(stage_ms[0]), 3), "step_device_ms_min": round(float(step_dev_ms.min()), 3),
                           "step_device_ms_max": round(float(step_dev_ms.max()), 3)} if fused else
                          {"scan": round(float(stage_ms[0]), 3), "probe": round(float(stage_ms[1]), 3),
@@ -612,20 +713,21 @@ def main():
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                      "traffic_source": traffic_note,
                      "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": round(dom_ms, 3),
-                     # the part's measured rate of random 64-byte requests on a 128 GiB table (tools/gather_bench2.hip,
-                     # profiles/r02_gather_experiments.txt): what a hash-table probe can reach, as opposed to the streaming peak
-                     "random_line_ceiling_Glines_per_s": GATHER_CEILING_GLPS,
+                     # the part's rate of random 64-byte requests over a buffer of the table's size: what a hash-table probe can
+                     # reach, as opposed to the streaming peak
+                     "random_line_ceiling_Glines_per_s": ceiling,
+                     "random_line_ceiling_source": ceiling_src,
+                     "random_128B_request_ceiling_G_per_s": ceil_meas["128B"] if ceil_meas else None,
                      "probe_lines_per_s_G": round(probes / (dom_ms * 1e-3) / 1e9, 2),
-                     "frac_of_random_line_ceiling": round(probes / (dom_ms * 1e-3) / 1e9 / GATHER_CEILING_GLPS, 3),
+                     "frac_of_random_line_ceiling": round(probes / (dom_ms * 1e-3) / 1e9 / ceiling, 3),
                      # every L2 miss of the kernel (probes, second-bucket probes, the read stream's lines, outputs; TCC_MISS_sum of the
-                     # same counter file) against the same ceiling: the request rate is what bounds the path
+                     # counter file) against the same ceiling: the request rate is what bounds the path
                      "l2_miss_requests_per_launch": miss_requests,
-                     "frac_of_request_rate_ceiling": (round(miss_requests / (dom_ms * 1e-3) / 1e9 / GATHER_CEILING_GLPS, 3)
+                     "frac_of_request_rate_ceiling": (round(miss_requests / (dom_ms * 1e-3) / 1e9 / ceiling, 3)
                                                       if miss_requests else None)},
     }
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(torch, slacken_amd, args, parents, genome_cat, genome_taxa, G, device)
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -135,3 +135,59 @@ def test_exchange_three_ranks(tmp_path):
     out = str(tmp_path / "ok.npy")
     mp.spawn(_exchange_worker, args=(3, _free_port(), out), nprocs=3, join=True)
     assert os.path.exists(out)
+
+
+def test_bench_watchdog_names_the_stage_of_a_stuck_rank():
+    """A rank that stops making progress (here: rank 1 sleeps before the first barrier, so rank 0 hangs IN the barrier) is not
+    waited for forever: every rank's watchdog prints the stage it is in and exits non-zero; nothing is re-executed."""
+    p, lines = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "1000", "--dry-run",
+                      env={"SLK_BENCH_WATCHDOG_S": "10", "SLK_BENCH_TEST_HANG_RANK": "1"})
+    assert p.returncode != 0 and not lines
+    assert "WATCHDOG: no progress" in p.stderr
+    # (the launcher ends the other rank as soon as the first one has given up: one of the two lines is certain, usually both)
+    assert ("stage: test hang before the first barrier" in p.stderr            # the stuck rank
+            or "stage: dry run: barrier before the timed steps" in p.stderr)   # the rank that waits for it
+
+
+def test_bench_reads_total_is_cut_into_equal_shares():
+    """BASELINE.json configs[2] is a TOTAL (100 M reads over 8 GPUs): --reads-total N gives every rank N / world reads."""
+    p, lines = _bench("--gpus", "4", "--steps", "2", "--warmup", "1", "--reads-total", "10000", "--dry-run")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert lines[0]["n_gpus"] == 4 and lines[0]["config"]["reads_all_ranks_per_step"] == 10000
+
+
+def test_bench_table_sharded_dry_eight_ranks():
+    """The table-sharded exchange protocol at the node's real world size (8 gloo ranks on CPU): every answer checked."""
+    p, lines = _bench("--gpus", "8", "--table-sharded", "--steps", "2", "--warmup", "1", "--reads", "3000", "--dry-run")
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 8 and lines[0]["config"]["parallelism"] == "table-sharded x8"
+    assert lines[0]["config"]["reads_all_ranks_per_step"] == 8 * 3000
+
+
+def _zero_split_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from slacken_amd import sharded
+    ex = sharded.Exchange(rank, world, dist, torch.device("cpu"))
+    # rank r sends NOTHING to rank (r + 1) % world and to itself, 5 + r items to the others; rank 2 sends nothing at all
+    send_counts = [0 if (d == rank or d == (rank + 1) % world or rank == 2) else 5 + rank for d in range(world)]
+    send = torch.cat([torch.full((c,), 100 * rank + d, dtype=torch.int64) for d, c in enumerate(send_counts)] or [torch.zeros(0, dtype=torch.int64)])
+    recv_counts, _ = ex.split_sizes(send_counts)
+    want_counts = [0 if (rank == s or rank == (s + 1) % world or s == 2) else 5 + s for s in range(world)]
+    assert recv_counts == want_counts
+    got = ex.all_to_all(send, send_counts, recv_counts)
+    want = torch.cat([torch.full((c,), 100 * s + rank, dtype=torch.int64) for s, c in enumerate(want_counts)])
+    assert torch.equal(got, want)
+    back = ex.all_to_all((got + 1).to(torch.int32), recv_counts, send_counts)
+    assert torch.equal(back.long(), send + 1)
+    if rank == 0:
+        np.save(out, np.array([1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_with_zero_length_splits(tmp_path):
+    """Peers that get nothing (and a rank that sends nothing at all): the all-to-all(v) with zero-length splits in both directions."""
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_zero_split_worker, args=(4, _free_port(), out), nprocs=4, join=True)
+    assert os.path.exists(out)
