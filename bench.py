@@ -26,7 +26,7 @@ baseline, not the target.
 --table-sharded (BASELINE.json configs[3]): the library is larger than one GPU's HBM, so rank g holds only the records whose key
 falls to it (fmix64(key) mod N; slk_index_set_shard) -- by default 5.0e9 records per rank, 4.0e10 at N = 8 (> 288 GB of table) --
 and a step is one 10 M-read batch per rank through scan -> keys to their owners (all-to-all over RCCL / xGMI) -> lookup -> taxa
-back -> per-read LCA (slacken_amd/sharded.py).  The K timed steps are K batches in the two-stream pipeline.  The line carries the
+back -> per-read LCA (slacken_amd/sharded.py).  The K timed steps are K batches in the pipeline (K + 4 kernel launches).  The line carries the
 stages' device times, the bytes exchanged per read, the per-link rate against the 153 GB/s xGMI link and the lookup stage's share
 of the part's random-request rate.
 
@@ -410,16 +410,19 @@ def table_sharded(args, rank, world, local_rank):
             dist.barrier()
         torch.cuda.synchronize()
 
-    fused = not args.separate_lookup
-    outs = sc.classify_many([batch] * max(1, args.warmup), thresholds=(0.0,), min_hit_groups=2, fused_lookup=fused)
+    progress("table-sharded: warm-up batches")
+    outs = sc.classify_many([batch] * max(1, args.warmup), thresholds=(0.0,), min_hit_groups=2)
     if outs is None:
         raise SystemExit("the fast sharded route does not take this splitter")
     barrier()
+    progress("table-sharded: timed batches")
     t_start = time.perf_counter()
-    outs = sc.classify_many([batch] * args.steps, thresholds=(0.0,), min_hit_groups=2, profile=True, fused_lookup=fused)   # K steps = K batches in the pipeline
+    outs = sc.classify_many([batch] * args.steps, thresholds=(0.0,), min_hit_groups=2, profile=True)   # K steps = K batches in the pipeline
     barrier()
     elapsed = time.perf_counter() - t_start
-    alone = sc.stage_times_alone(batch) if world == 1 and not args.collectives_at_one_rank else None   # (after the timed region)
+    progress("table-sharded: jobs alone")
+    step_ms = list(getattr(sc, "step_ms", []))
+    alone = sc.jobs_alone(batch) if world == 1 and not args.collectives_at_one_rank else None   # (after the timed region)
     elapsed = sdist.max_over_ranks(elapsed, dist, None if args.rehearse_on_one_gpu else device)
     ms_per_step = elapsed / args.steps * 1e3
     reads_per_s = world * n_reads / (elapsed / args.steps)
@@ -428,16 +431,29 @@ def table_sharded(args, rank, world, local_rank):
     keys_per_batch, remote = int(o["exchanged_keys"]), int(o["sent_remote_keys"])
     looked_up = int(o["looked_up_keys"])
     classified = float(o["classified"][:n_reads].float().mean().item())
+    n_deferred = int(o.get("deferred", 0))
     x_ms = stage.get("exchange_keys", 0.0)
     per_link = (remote / max(1, world - 1)) * 8 / (x_ms * 1e-3) / 1e9 if world > 1 and x_ms > 0 else None
-    # the owner's lookups ride inside the scan of a later batch ("emit+lookup"; only the first and last batches' run as a kernel of
-    # their own): their rate is taken over that fused stage
-    fused_ms = stage.get("emit+lookup", 0.0)
-    lookup_ms = fused_ms if fused_ms > 0 else stage.get("lookup", 0.0)
-    lookup_rate = looked_up / (lookup_ms * 1e-3) / 1e9 if lookup_ms > 0 else None
+    # the owner's lookups ride inside the step kernel: their rate is taken over a steady-state step (one that carries all three jobs:
+    # steps 4 .. K - 1 of the K + 4 of a run)
+    steady = step_ms[4:args.steps] if len(step_ms) >= args.steps and args.steps > 4 else step_ms
+    steady_ms = float(np.median(steady)) if steady else 0.0
+    lookup_rate = looked_up / (steady_ms * 1e-3) / 1e9 if steady_ms > 0 else None
     # algorithmic bytes of a step on one rank (SURVEY 8d's B(r), with the probes served by whichever rank owns them) against the
-    # WHOLE pipeline's time per step: the path has four kernels here, and none of them is "the" kernel
+    # WHOLE pipeline's time per step
     bytes_per_step = total_bases + 64 * looked_up + 8 * n_reads
+    # the part's random-request rate on THIS box, measured now that the timed region is over (the shard is closed for it)
+    ceiling, ceiling_src, ceil_meas = GATHER_CEILING_GLPS, "constant of round 2 (FALLBACK: not measured in this run)", None
+    if rank == 0 and not args.no_ceiling and not args.rehearse_on_one_gpu:
+        progress("request-rate ceiling")
+        table_bytes = int(info.table_bytes)
+        del outs, o, batch, d_bases, d_offsets
+        sc.close()
+        ix.close()
+        ceil_meas = measure_request_ceiling(torch, device, table_bytes)
+        if ceil_meas:
+            ceiling = ceil_meas["64B"]
+            ceiling_src = f"measured in this run: uniformly random 64-byte requests over {ceil_meas['bytes'] / 2**30:.0f} GiB, tools/gather_rate.hip"
     out = {
         "metric": "classify_throughput_150bp_standard224scale", "value": round(reads_per_s / 1e6, 3), "unit": "M reads/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -448,27 +464,28 @@ def table_sharded(args, rank, world, local_rank):
         "config": {
             "workload": "oversized custom library, hash-sharded over the GPUs (k=35,m=31,s=7), synthetic 150 bp single-end reads; "
                         "minimizers to their owners and taxa back by all-to-all (BASELINE.json configs[3])",
-            "parallelism": f"table-sharded x{world}", "lookups": "inside the scan of batch t + 2" if fused else "a kernel of their own", "records_per_rank": int(info.records), "records_all_ranks": int(info.records) * world,
+            "parallelism": f"table-sharded x{world}", "pipeline": "step t = one kernel: EMIT(t) + LOOKUP(t - 2) + APPLY(t - 4); exchanges of t - 1 and t - 3 beside it", "records_per_rank": int(info.records), "records_all_ranks": int(info.records) * world,
             "table_GiB_per_rank": round(info.table_bytes / 2**30, 1), "table_GB_all_ranks": round(info.table_bytes * world / 1e9, 1),
             "exceeds_one_gpu_288GB": bool(info.table_bytes * world > 288e9),
             "bucket_bytes": int(info.bucket_cells) * 8, "table_load": round(info.records / (info.buckets * info.bucket_cells), 3),
             "genomes": G, "genome_len": args.genome_len, "reads_per_gpu_per_step": n_reads, "read_len": READ_LEN,
-            "classified_fraction": round(classified, 4), "deferred_to_staged_route": int(o.get("deferred", 0)),
+            "classified_fraction": round(classified, 4), "deferred_to_staged_route": n_deferred,
             "stage_ms_in_pipeline": {k: round(v, 3) for k, v in stage.items()},
-            **({"stage_ms_alone": alone} if alone else {}),
+            "steady_state_step_ms": round(steady_ms, 3), "step_ms_all": [round(v, 2) for v in step_ms],
+            **({"job_ms_alone": alone} if alone else {}),
             "keys_per_read": round(keys_per_batch / n_reads, 3),
             "exchanged_bytes_per_read": round(12.0 * keys_per_batch / n_reads, 1),     # 8-byte key out, 4-byte taxon back
             "remote_bytes_per_read": round(12.0 * remote / n_reads, 1),
             "xgmi_link_GBps_keys": None if per_link is None else round(per_link, 1), "xgmi_link_peak_GBps": XGMI_LINK_GBPS,
             "xgmi_link_frac": None if per_link is None else round(per_link / XGMI_LINK_GBPS, 3),
         },
-        "roofline": {"bound": "hbm", "kernel": "the sharded pipeline: lane_kernel<EMIT> with the owner's lookups of an earlier batch riding along, list compaction, "
-                                               "lane_kernel<APPLY> on two streams, beside the exchange", "achieved": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9, 1),
+        "roofline": {"bound": "hbm", "kernel": "the sharded pipeline: lane_step_kernel (EMIT of batch t, LOOKUP of batch t - 2 and APPLY of batch t - 4 in one launch) "
+                                               "beside the exchanges; K batches take K + 4 steps", "achieved": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9, 1),
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                      "traffic": None, "algorithmic_bytes_per_launch": bytes_per_step, "kernel_ms": round(ms_per_step, 3),
                      "lookup_stage_Grequests_per_s": None if lookup_rate is None else round(lookup_rate, 2),
-                     "random_line_ceiling_Glines_per_s": GATHER_CEILING_GLPS,
-                     "lookup_stage_frac_of_request_rate_ceiling": None if lookup_rate is None else round(lookup_rate / GATHER_CEILING_GLPS, 3)},
+                     "random_line_ceiling_Glines_per_s": ceiling, "random_line_ceiling_source": ceiling_src,
+                     "lookup_stage_frac_of_request_rate_ceiling": None if lookup_rate is None else round(lookup_rate / ceiling, 3)},
     }
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -494,8 +511,6 @@ def main():
     ap.add_argument("--table-sharded", action="store_true",
                     help="BASELINE configs[3]: every rank holds 1/N of the table, minimizers and taxa cross the links (RCCL all-to-all)")
     ap.add_argument("--records-per-rank", type=float, default=5.0e9, help="--table-sharded: records of one rank's shard")
-    ap.add_argument("--separate-lookup", action="store_true",
-                    help="--table-sharded: the owner's lookups as a kernel of their own beside the scans (round 2's pipeline), for A/B")
     ap.add_argument("--collectives-at-one-rank", action="store_true",
                     help="--table-sharded with ONE rank: the keys and taxa go through the RCCL all-to-all all the same (the rank sends to "
                          "itself), so that the `nccl` process group and its device collectives run on a one-GPU box")

@@ -260,61 +260,69 @@ int32_t slk_lookup_device(slk_index *ix, slk_stream *st, const int64_t *d_keys, 
 /* Which rank owns a minimizer in table-sharded mode: fmix64(key) mod n_shards (host helper; the device side of the
  * Python host uses the same bijective mixer) */
 uint32_t slk_shard_of(int64_t key, uint32_t n_shards);
-/* The fast form of the table-sharded path for fragments of up to 1000 bases (both mates together): ONE scan, and nothing but
- * 8-byte keys and 4-byte taxa on the links -- no span arrays in HBM, no per-probe return addresses.
- *   slk_shard_emit_device    scans the fragments and appends every minimizer to a send list of its owner (slk_shard_of).
- *                            Every owner has n_sublists lists (a power of two; 256 is a good value: the appending wavefronts
- *                            spread over them, so the list cursors do not serialise on one address): d_send_keys is
- *                            [n_shards][n_sublists][capacity_per_sublist] (capacity < 2^25), d_send_counts[n_shards][n_sublists]
- *                            receives the list lengths (zeroed by the call).  What the second pass needs stays on this rank:
- *                            d_send_meta (same shape as d_send_keys, 4 bytes each: the span behind every key), d_batch_base
- *                            (uint32 [slk_shard_batch_rows(..)][n_shards]: per batch of 64 probes, where each owner's keys went
- *                            and how many), d_tile_rows (uint32 [(R + 63) / 64]) and d_read_info (int32 [R][2]: k-mers and spans
- *                            of a fragment).  Lists that overflow their capacity are reported by slk_shard_compact_device.
- *   slk_shard_compact_device the lists back to back in (owner, sub-list) order in d_out_keys (room for the sum of the list
- *                            lengths, at most n_shards * n_sublists * capacity), d_list_offsets[n_shards * n_sublists + 1]
- *                            = where each list starts there, d_owner_counts[n_shards + 1] = keys per owner (the all-to-all's
- *                            split sizes) and, last, the number of lists that overflowed their capacity (emit again with
- *                            longer lists if it is not zero).
- *   (all-to-all of keys, slk_lookup_device on the owners, all-to-all of taxa back, in the same order: the caller's, e.g. RCCL)
- *   slk_shard_apply_device   replays the batches from the log -- no second scan: d_bases may be NULL --, takes each probe's taxon
- *                            from d_taxa (the answers, in the order of d_out_keys) and classifies: same outputs as
- *                            slk_classify_batch_device.
- * d_defer[R] (zeroed by slk_shard_emit_device) is set to 1 for fragments this path does not take (longer than 1000 bases,
- * or more than 12 distinct taxa): classify those with the staged calls above.  SLK_E_UNSUPPORTED if the index's splitter
- * is outside the fused kernel's range (window wider than 32 m-mers, or taxon ids beyond 22 bits that slk_index_finalize could
- * not renumber): use the staged calls. */
+/* The fast form of the table-sharded path for fragments of up to 1000 bases (both mates together): ONE scan per batch, and nothing
+ * but 8-byte keys and 4-byte taxa on the links -- no span arrays in HBM, no per-probe return addresses, no compaction of the lists.
+ * It replaces the shuffle behind the reference's join (S/slacken/Classifier.scala:84-95).  A batch passes through three JOBS, and one
+ * slk_shard_step_device call launches up to three jobs of three different batches as ONE kernel, so that the latency-bound ones hide
+ * behind the scan the way the probes of slk_classify_batch_device do:
+ *   EMIT    scans the batch's fragments and appends every minimizer to the send region of its owner (slk_shard_of): d_send_keys is
+ *           [n_shards][capacity_per_owner], filled from the front without holes -- what travels to owner g is
+ *           d_send_keys[g * capacity .. + d_cursors[g]) as it stands (d_cursors[0 .. n_shards) after the step; a multiple of
+ *           slk_shard_chunk(n_shards): the last few entries are zero keys whose answers nobody reads).  A cursor beyond the capacity
+ *           means the region was too small: slk_stream_synchronize reports SLK_E_CAPACITY, emit the batch again with larger regions.
+ *           What the APPLY of the same batch needs stays on this rank, in the other arrays of slk_shard_lists.
+ *   LOOKUP  the OWNER's side: taxon or NONE for the n keys this rank received (any batch, any ranks), as slk_lookup_device.
+ *   APPLY   replays the batch's probe log -- no second scan --, takes each probe's taxon from d_taxa ([n_shards][capacity_per_owner]:
+ *           the owners' answers at the positions the keys had) and classifies: the outputs of slk_classify_batch_device.
+ * (between the jobs: all-to-all of keys, all-to-all of taxa back into the same positions -- the caller's, e.g. RCCL.)
+ * Any of emit / lookup / apply may be NULL.  A step without an EMIT runs the other jobs as kernels of their own.
+ * d_defer[R] of a batch (zeroed by its EMIT) is 1 after its APPLY for the fragments this path does not take (longer than 1000
+ * bases, more than 12 distinct taxa): classify those with the staged calls above.  SLK_E_UNSUPPORTED if the index's splitter is
+ * outside the fused kernel's range (window wider than 32 m-mers, or taxon ids beyond 22 bits that slk_index_finalize could not
+ * renumber): use the staged calls. */
+typedef struct {
+  const uint8_t *d_bases;       /* the batch (EMIT only; the APPLY reads d_offsets / d_mate_offsets when hit lists are written) */
+  const uint64_t *d_offsets;
+  const uint8_t *d_mate_bases;  /* nullable */
+  const uint64_t *d_mate_offsets;
+  uint64_t R;
+  uint64_t total_bases;         /* d_offsets[R] / d_mate_offsets[R]: the caller knows them (spares a copy back to the host) */
+  uint64_t total_mate_bases;
+  uint32_t n_shards;
+  uint32_t reserved;
+  uint64_t capacity_per_owner;  /* entries of each owner's region: a multiple of slk_shard_chunk(n_shards), below 2^32 */
+  int64_t *d_send_keys;         /* [n_shards][capacity_per_owner] */
+  uint32_t *d_send_meta;        /* [n_shards][capacity_per_owner]: the span behind every key */
+  uint64_t *d_cursors;          /* [n_shards + 3] (zeroed by the EMIT): [g] = entries to send to owner g; [n_shards + 2] = after the
+                                   APPLY, the number of fragments flagged in d_defer */
+  uint32_t *d_batch_log;        /* [slk_shard_batch_rows(..)][n_shards][4]: per batch of 64 probes, where each owner's keys went */
+  uint32_t *d_tile_rows;        /* [ceil(R / 64)][2] */
+  int32_t *d_read_info;         /* [R][2]: k-mers and spans of a fragment */
+  int32_t *d_defer;             /* [R] */
+  int32_t *d_span_meta;         /* hit lists (all three or none; span slots as for slk_scan_device): the EMIT writes the flagged spans, */
+  int32_t *d_span_taxon;        /* the APPLY the hits; gather them with d_span_count[r] entries per fragment */
+  int32_t *d_span_count;
+} slk_shard_lists;
+typedef struct {
+  const int64_t *d_keys;
+  uint64_t n;
+  int32_t *d_out_taxa;
+} slk_shard_lookup;
+typedef struct {
+  const int32_t *d_taxa;        /* [n_shards][capacity_per_owner] of the batch's lists */
+  int32_t min_hit_groups;
+  int32_t C;
+  const double *thresholds;     /* host, [C] */
+  int32_t *d_out_taxon;         /* [C * R] threshold-major */
+  uint8_t *d_out_classified;
+  int32_t *d_out_num_distinct;  /* nullable */
+  int32_t *d_out_total_kmers;   /* nullable */
+  int32_t *d_out_num_hits;      /* nullable: spans per fragment (0 => no row) */
+} slk_shard_results;
+uint32_t slk_shard_chunk(uint32_t n_shards);
 uint64_t slk_shard_batch_rows(uint64_t total_bases, uint64_t total_mate_bases, uint64_t R, int32_t paired);
-int32_t slk_shard_emit_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
-                              const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
-                              uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys, uint32_t *d_send_meta,
-                              uint64_t capacity_per_sublist, uint64_t *d_send_counts, uint32_t *d_batch_base,
-                              uint32_t *d_tile_rows, int32_t *d_read_info, int32_t *d_defer);
-/* slk_shard_emit_device with the OWNER's side of an earlier batch riding along: whenever a wavefront has sent off 64 of its own keys
- * it also answers 64 of the keys this rank received (d_side_keys[0 .. side_n), answers to d_side_taxa in the same order), so the
- * lookups' latency hides behind the scan as the probes of slk_classify_batch_device do, instead of a lookup kernel running beside
- * the scan.  The 64-key batches are dealt out to the scan's tiles (64 fragments each): tile t owns batches [t * side_per_tile,
- * (t + 1) * side_per_tile) -- side_per_tile * ceil(R / 64) * 64 >= side_n --, and d_side_done[ceil(R / 64)] (zeroed by the call)
- * receives how many of its batches each tile got to; slk_lookup_rest_device answers the rest -- usually little or nothing. */
-int32_t slk_shard_emit_lookup_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
-                                     const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
-                                     uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys, uint32_t *d_send_meta,
-                                     uint64_t capacity_per_sublist, uint64_t *d_send_counts, uint32_t *d_batch_base,
-                                     uint32_t *d_tile_rows, int32_t *d_read_info, int32_t *d_defer, const int64_t *d_side_keys,
-                                     uint64_t side_n, uint32_t side_per_tile, uint32_t *d_side_done, int32_t *d_side_taxa);
-int32_t slk_lookup_rest_device(slk_index *ix, slk_stream *st, const int64_t *d_keys, uint64_t n, uint32_t side_per_tile, uint64_t tiles,
-                               const uint32_t *d_side_done, int32_t *d_out_taxa);
-int32_t slk_shard_compact_device(slk_index *ix, slk_stream *st, const int64_t *d_send_keys, uint32_t n_shards, uint32_t n_sublists,
-                                 uint64_t capacity_per_sublist, const uint64_t *d_send_counts, int64_t *d_out_keys,
-                                 uint64_t *d_list_offsets, uint64_t *d_owner_counts);
-int32_t slk_shard_apply_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
-                               const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
-                               uint32_t n_shards, uint32_t n_sublists, uint64_t capacity_per_sublist, const int32_t *d_taxa,
-                               const uint64_t *d_list_offsets, const uint32_t *d_send_meta, const uint32_t *d_batch_base,
-                               const uint32_t *d_tile_rows, const int32_t *d_read_info, int32_t min_hit_groups,
-                               const double *thresholds, int32_t C, int32_t *d_out_taxon, uint8_t *d_out_classified,
-                               int32_t *d_out_num_distinct, int32_t *d_out_total_kmers, int32_t *d_out_num_hits,
-                               int32_t *d_defer);
+int32_t slk_shard_step_device(slk_index *ix, slk_stream *st, const slk_shard_lists *emit, const slk_shard_lookup *lookup,
+                              const slk_shard_lists *apply_lists, const slk_shard_results *apply);
 /* classifyHits (Classifier.scala:124-147, 439-454) over span slots whose taxa have been filled in (d_span_taxon: record
  * taxon / NONE for SEQUENCE spans; AMBIGUOUS and MATE_PAIR_BORDER spans are recognised from d_span_meta).  d_scratch:
  * as many 8-byte entries as span slots. */
@@ -356,6 +364,13 @@ typedef struct {
 int32_t slk_shardset_create(slk_index *const *members, int32_t n_members, int32_t exchange, slk_shardset **out);
 int32_t slk_shardset_classify(slk_shardset *set, slk_shard_batch *batches /* [n_members] */, int32_t min_hit_groups,
                               const double *thresholds, int32_t C);
+/* n_rounds rounds in one call, batches[round * n_members + member], PIPELINED: per step every member launches one kernel that scans
+ * round t, answers the keys it received for round t - 2 and classifies round t - 4, while the keys of round t - 1 and the taxa of
+ * round t - 3 travel on the members' exchange streams; the host's only wait per step is for the split sizes of the round emitted a
+ * step earlier.  Results as n_rounds calls of slk_shardset_classify.  device_resident != 0: every pointer of the batches is a DEVICE
+ * pointer on its member's GPU (reads and results stay in HBM; no hit lists: out_hit_offsets / out_hits must be NULL). */
+int32_t slk_shardset_classify_rounds(slk_shardset *set, slk_shard_batch *batches /* [n_rounds][n_members] */, int32_t n_rounds,
+                                     int32_t device_resident, int32_t min_hit_groups, const double *thresholds, int32_t C);
 int32_t slk_shardset_exchange_mode(const slk_shardset *set); /* SLK_EXCHANGE_RCCL or SLK_EXCHANGE_COPY: what AUTO chose */
 void slk_shardset_destroy(slk_shardset *set);
 

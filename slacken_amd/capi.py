@@ -45,6 +45,26 @@ class _ShardBatch(C.Structure):
                 ("hits_capacity", C.c_uint64)]
 
 
+class ShardLists(C.Structure):
+    """slk_shard_lists: a batch and the lists its EMIT job leaves on its rank (all device addresses)"""
+    _fields_ = [("d_bases", C.c_void_p), ("d_offsets", C.c_void_p), ("d_mate_bases", C.c_void_p), ("d_mate_offsets", C.c_void_p),
+                ("R", C.c_uint64), ("total_bases", C.c_uint64), ("total_mate_bases", C.c_uint64), ("n_shards", C.c_uint32),
+                ("reserved", C.c_uint32), ("capacity_per_owner", C.c_uint64),
+                ("d_send_keys", C.c_void_p), ("d_send_meta", C.c_void_p), ("d_cursors", C.c_void_p), ("d_batch_log", C.c_void_p),
+                ("d_tile_rows", C.c_void_p), ("d_read_info", C.c_void_p), ("d_defer", C.c_void_p), ("d_span_meta", C.c_void_p),
+                ("d_span_taxon", C.c_void_p), ("d_span_count", C.c_void_p)]
+
+
+class ShardLookup(C.Structure):
+    _fields_ = [("d_keys", C.c_void_p), ("n", C.c_uint64), ("d_out_taxa", C.c_void_p)]
+
+
+class ShardResults(C.Structure):
+    _fields_ = [("d_taxa", C.c_void_p), ("min_hit_groups", C.c_int32), ("C", C.c_int32), ("thresholds", C.POINTER(C.c_double)),
+                ("d_out_taxon", C.c_void_p), ("d_out_classified", C.c_void_p), ("d_out_num_distinct", C.c_void_p),
+                ("d_out_total_kmers", C.c_void_p), ("d_out_num_hits", C.c_void_p)]
+
+
 EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_COPY = 0, 1, 2
 SPAN_DTYPE = np.dtype([("key", "<i8"), ("kmers", "<i4"), ("flag", "i1"), ("distinct", "u1"), ("pad", "<u2")])
 HIT_DTYPE = np.dtype([("taxon", "<i4"), ("count", "<i4")])
@@ -55,10 +75,9 @@ EXPORTS = ["slk_device_count", "slk_last_error", "slk_version", "slk_host_alloc"
            "slk_index_lookup", "slk_index_add_sequences", "slk_index_add_sequences_device", "slk_index_export", "slk_index_destroy", "slk_stream_create", "slk_stream_synchronize",
            "slk_stream_hip_stream", "slk_stream_destroy", "slk_spans_batch", "slk_spans_batch_wide", "slk_classify_batch",
            "slk_classify_batch_device", "slk_classify_hits", "slk_stream_last_stage_ms", "slk_scan_device", "slk_lookup_device",
-           "slk_shard_of", "slk_classify_hits_device", "slk_shard_batch_rows", "slk_shard_emit_device", "slk_shard_emit_lookup_device",
-           "slk_lookup_rest_device", "slk_shard_compact_device",
-           "slk_shard_apply_device", "slk_stream_last_deferred", "slk_table_slot", "slk_table_hash_of",
-           "slk_shardset_create", "slk_shardset_classify", "slk_shardset_exchange_mode", "slk_shardset_destroy"]
+           "slk_shard_of", "slk_classify_hits_device", "slk_shard_batch_rows", "slk_shard_chunk", "slk_shard_step_device",
+           "slk_stream_last_deferred", "slk_table_slot", "slk_table_hash_of",
+           "slk_shardset_create", "slk_shardset_classify", "slk_shardset_classify_rounds", "slk_shardset_exchange_mode", "slk_shardset_destroy"]
 
 
 def lib_path():
@@ -94,6 +113,7 @@ def lib():
     L.slk_table_hash_of.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
     L.slk_shardset_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.POINTER(vp)]
     L.slk_shardset_classify.argtypes = [vp, C.POINTER(_ShardBatch), C.c_int32, C.POINTER(C.c_double), C.c_int32]
+    L.slk_shardset_classify_rounds.argtypes = [vp, C.POINTER(_ShardBatch), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_int32]
     L.slk_shardset_exchange_mode.argtypes = [vp]
     L.slk_shardset_destroy.argtypes = [vp]
     L.slk_shardset_destroy.restype = None
@@ -129,15 +149,10 @@ def lib():
                                            C.POINTER(C.c_double), C.c_int32, i32p, u8p, i32p, i32p, i32p]
     L.slk_shard_batch_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32]
     L.slk_shard_batch_rows.restype = C.c_uint64
-    L.slk_shard_emit_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_uint32, i64p, vp, C.c_uint64, u64p, vp,
-                                        vp, i32p, i32p]
-    L.slk_shard_emit_lookup_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_uint32, i64p, vp, C.c_uint64, u64p, vp,
-                                               vp, i32p, i32p, i64p, C.c_uint64, C.c_uint32, vp, i32p]
-    L.slk_lookup_rest_device.argtypes = [vp, vp, i64p, C.c_uint64, C.c_uint32, C.c_uint64, vp, i32p]
-    L.slk_shard_compact_device.argtypes = [vp, vp, i64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, i64p, u64p, u64p]
+    L.slk_shard_chunk.argtypes = [C.c_uint32]
+    L.slk_shard_chunk.restype = C.c_uint32
+    L.slk_shard_step_device.argtypes = [vp, vp, C.POINTER(ShardLists), C.POINTER(ShardLookup), C.POINTER(ShardLists), C.POINTER(ShardResults)]
     L.slk_stream_last_deferred.argtypes = [vp, C.POINTER(C.c_uint64)]
-    L.slk_shard_apply_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, i32p, u64p, vp, vp,
-                                         vp, i32p, C.c_int32, C.POINTER(C.c_double), C.c_int32, i32p, u8p, i32p, i32p, i32p, i32p]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is C.c_int:  # default: int32 status
@@ -331,6 +346,68 @@ class ShardSet:
                 o["num_hits"] = np.diff(hit_off.astype(np.int64)).astype(np.int32)
         return outs
 
+    def classify_rounds_device(self, rounds, min_hit_groups=2, thresholds=(0.0,)):
+        """Pipelined rounds over DEVICE-resident batches (slk_shardset_classify_rounds, device_resident = 1): rounds[r][g] is a dict of
+        raw device addresses on member g's GPU -- bases, offsets, R, out_taxon, out_classified and optionally mate_bases,
+        mate_offsets, out_num_distinct, out_total_kmers -- or None.  Synchronous: returns when every round is done."""
+        n = len(self.members)
+        Cn = len(thresholds)
+        thr = (C.c_double * Cn)(*thresholds)
+        arr = (_ShardBatch * (n * len(rounds)))()
+        for r, rnd in enumerate(rounds):
+            assert len(rnd) == n
+            for g, b in enumerate(rnd):
+                if b is None:
+                    continue
+                arr[r * n + g] = _ShardBatch(b["bases"], b["offsets"], b.get("mate_bases"), b.get("mate_offsets"), b["R"], b["out_taxon"],
+                                             b["out_classified"], b.get("out_num_distinct"), b.get("out_total_kmers"), None, None, 0)
+        _check(lib().slk_shardset_classify_rounds(self.h, arr, len(rounds), 1, min_hit_groups, thr, Cn))
+
+    def classify_rounds(self, rounds, min_hit_groups=2, thresholds=(0.0,), with_hits=True):
+        """Several rounds of classify() in ONE pipelined call (slk_shardset_classify_rounds, host pointers): rounds[r][g] as
+        classify()'s batches[g].  -> list (per round) of lists (per member) of result dicts."""
+        n = len(self.members)
+        Cn = len(thresholds)
+        thr = (C.c_double * Cn)(*thresholds)
+        arr = (_ShardBatch * (n * len(rounds)))()
+        keep, outs = [], []
+        for r, rnd in enumerate(rounds):
+            assert len(rnd) == n
+            row = []
+            for g, b in enumerate(rnd):
+                if b is None:
+                    row.append(None)
+                    continue
+                bases, offsets = _np(b[0], np.uint8), _np(b[1], np.uint64)
+                mb = mo = None
+                if len(b) > 2 and b[2] is not None:
+                    mb, mo = _np(b[2], np.uint8), _np(b[3], np.uint64)
+                R = offsets.size - 1
+                o = dict(taxon=np.zeros((Cn, R), np.int32), classified=np.zeros((Cn, R), np.uint8), num_distinct=np.zeros(R, np.int32),
+                         total_kmers=np.zeros(R, np.int32))
+                hit_off = hits = None
+                cap = 0
+                if with_hits:
+                    cap = int(bases.size + (mb.size + R if mb is not None else 0)) + 1
+                    hit_off, hits = np.zeros(R + 1, np.uint64), np.zeros(cap, HIT_DTYPE)
+                keep.append((bases, offsets, mb, mo, hit_off, hits))
+                arr[r * n + g] = _ShardBatch(_ptr(bases), _ptr(offsets), _ptr(mb), _ptr(mo), R, _ptr(o["taxon"]), _ptr(o["classified"]),
+                                             _ptr(o["num_distinct"]), _ptr(o["total_kmers"]), _ptr(hit_off), _ptr(hits), cap)
+                o["_hit"] = (hit_off, hits)
+                row.append(o)
+            outs.append(row)
+        _check(lib().slk_shardset_classify_rounds(self.h, arr, len(rounds), 0, min_hit_groups, thr, Cn))
+        for row in outs:
+            for o in row:
+                if o is None:
+                    continue
+                hit_off, hits = o.pop("_hit")
+                if hit_off is not None:
+                    o["hit_offsets"] = hit_off
+                    o["hits"] = hits[:int(hit_off[-1])]
+                    o["num_hits"] = np.diff(hit_off.astype(np.int64)).astype(np.int32)
+        return outs
+
     def close(self):
         if getattr(self, "h", None):
             lib().slk_shardset_destroy(self.h)
@@ -343,12 +420,30 @@ class ShardSet:
             pass
 
 
+_deferred_streams = []   # engine streams whose destruction was put off because torch still held a view of them (Stream.close)
+
+
 class Stream:
     def __init__(self, index):
         self.index = index
         h = C.c_void_p()
         _check(lib().slk_stream_create(index.h, C.byref(h)))
         self.h = h
+        self._views = []     # weak references to the torch ExternalStream wrappers handed out
+
+    def external_stream(self, torch, device):
+        """The torch view of this stream (torch.cuda.ExternalStream).  torch's caching allocator ties every block to the stream it was
+        allocated on and records events on the streams a tensor was used on when the tensor dies -- on a stream that no longer
+        exists that is a crash -- so the engine stream is NOT destroyed while a view of it is alive: close() puts the destruction
+        off (see below), and whoever hands views out drops them, after torch.cuda.empty_cache(), before it closes the stream
+        (slacken_amd.sharded.ShardedClassifier.close)."""
+        import weakref
+        ext = torch.cuda.ExternalStream(self.hip_stream, device=device)
+        self._views.append(weakref.ref(ext))
+        return ext
+
+    def views_alive(self):
+        return any(r() is not None for r in self._views)
 
     @property
     def hip_stream(self):
@@ -465,38 +560,13 @@ class Stream:
     def lookup_device(self, d_keys, n, d_out_taxa):
         _check(lib().slk_lookup_device(self.index.h, self.h, d_keys, n, d_out_taxa))
 
-    def shard_emit_device(self, d_bases, d_offsets, R, n_shards, n_sublists, d_send_keys, d_send_meta, capacity_per_sublist,
-                          d_send_counts, d_batch_base, d_tile_rows, d_read_info, d_defer, d_mate_bases=None, d_mate_offsets=None,
-                          side=None):
-        """side: (d_side_keys, side_n, side_per_tile, d_side_done, d_side_taxa) -- an earlier batch's lookups ride along
-        (slk_shard_emit_lookup_device)"""
-        if side is not None:
-            _check(lib().slk_shard_emit_lookup_device(self.index.h, self.h, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, n_shards,
-                                                      n_sublists, d_send_keys, d_send_meta, capacity_per_sublist, d_send_counts, d_batch_base,
-                                                      d_tile_rows, d_read_info, d_defer, side[0], side[1], side[2], side[3], side[4]))
-            return
-        _check(lib().slk_shard_emit_device(self.index.h, self.h, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, n_shards,
-                                           n_sublists, d_send_keys, d_send_meta, capacity_per_sublist, d_send_counts, d_batch_base,
-                                           d_tile_rows, d_read_info, d_defer))
-
-    def lookup_rest_device(self, d_keys, n, side_per_tile, tiles, d_side_done, d_out_taxa):
-        _check(lib().slk_lookup_rest_device(self.index.h, self.h, d_keys, n, side_per_tile, tiles, d_side_done, d_out_taxa))
-
-    def shard_compact_device(self, d_send_keys, n_shards, n_sublists, capacity_per_sublist, d_send_counts, d_out_keys,
-                             d_list_offsets, d_owner_counts):
-        _check(lib().slk_shard_compact_device(self.index.h, self.h, d_send_keys, n_shards, n_sublists, capacity_per_sublist,
-                                              d_send_counts, d_out_keys, d_list_offsets, d_owner_counts))
-
-    def shard_apply_device(self, d_bases, d_offsets, R, n_shards, n_sublists, capacity_per_sublist, d_taxa, d_list_offsets,
-                           d_send_meta, d_batch_base, d_tile_rows, d_read_info, d_out_taxon, d_out_classified, d_defer,
-                           d_out_num_distinct=None, d_out_total_kmers=None, d_out_num_hits=None, d_mate_bases=None,
-                           d_mate_offsets=None, min_hit_groups=2, thresholds=(0.0,)):
-        Cn = len(thresholds)
-        thr = (C.c_double * Cn)(*thresholds)
-        _check(lib().slk_shard_apply_device(self.index.h, self.h, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, n_shards,
-                                            n_sublists, capacity_per_sublist, d_taxa, d_list_offsets, d_send_meta, d_batch_base,
-                                            d_tile_rows, d_read_info, min_hit_groups, thr, Cn, d_out_taxon, d_out_classified,
-                                            d_out_num_distinct, d_out_total_kmers, d_out_num_hits, d_defer))
+    def shard_step(self, emit=None, lookup=None, apply_lists=None, apply=None):
+        """One pipeline step of the table-sharded mode (slk_shard_step_device): emit / apply_lists: ShardLists, lookup: ShardLookup,
+        apply: ShardResults -- any may be None.  Asynchronous on this stream."""
+        _check(lib().slk_shard_step_device(self.index.h, self.h, C.byref(emit) if emit is not None else None,
+                                           C.byref(lookup) if lookup is not None else None,
+                                           C.byref(apply_lists) if apply_lists is not None else None,
+                                           C.byref(apply) if apply is not None else None))
 
     def classify_hits_device(self, d_offsets, R, d_span_meta, d_span_taxon, d_span_count, d_scratch, d_out_taxon,
                              d_out_classified, d_out_num_distinct=None, d_out_total_kmers=None, d_out_num_hits=None,
@@ -514,7 +584,13 @@ class Stream:
         return list(out)
 
     def close(self):
+        """Destroys the engine stream -- unless torch still holds a view of it (external_stream): then the handle is parked in
+        capi._deferred_streams, alive, and release_deferred_streams() destroys it once the views are gone."""
         if getattr(self, "h", None):
+            if self.views_alive():
+                _deferred_streams.append((self.h, list(self._views), self.index))
+                self.h = None
+                return
             lib().slk_stream_destroy(self.h)
             self.h = None
 
@@ -523,3 +599,15 @@ class Stream:
             self.close()
         except Exception:
             pass
+
+
+def release_deferred_streams():
+    """Destroys the parked streams whose torch views have all died; -> how many are still parked."""
+    keep = []
+    for h, views, index in _deferred_streams:
+        if any(r() is not None for r in views):
+            keep.append((h, views, index))
+        else:
+            lib().slk_stream_destroy(h)
+    _deferred_streams[:] = keep
+    return len(keep)

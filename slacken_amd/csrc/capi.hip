@@ -780,7 +780,7 @@ int32_t check_status(slk_stream *st) {  // call after the stream has been synchr
       }
       return SLK_OK;
     }
-    if (v & 2) return fail(SLK_E_CAPACITY, "a send list of slk_shard_emit_device overflowed its capacity_per_sublist");
+    if (v & 2) return fail(SLK_E_CAPACITY, "a send region of slk_shard_step_device's EMIT job overflowed its capacity_per_owner");
     if (v & 1) return fail(SLK_E_CAPACITY, "a fragment hit more than %d distinct taxa; the per-read taxon map overflowed", 128);
     return fail(SLK_E_HIP, "device status %d", v);
   }
@@ -1008,135 +1008,118 @@ uint64_t slk_shard_batch_rows(uint64_t total_bases, uint64_t total_mate_bases, u
   return (span_slots(total_bases, total_mate_bases, R, paired != 0) >> 6) + (R + 63) / 64 + 2;
 }
 
-static int32_t shard_emit(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
-                          const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
-                          uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys, uint32_t *d_send_meta,
-                          uint64_t capacity_per_sublist, uint64_t *d_send_counts, uint32_t *d_batch_base,
-                          uint32_t *d_tile_rows, int32_t *d_read_info, int32_t *d_defer, const int64_t *d_side_keys, uint64_t side_n,
-                          uint32_t side_per_tile, uint32_t *d_side_done, int32_t *d_side_taxa) {
-  int32_t rc = check_ready(ix, st, false);
-  if (rc) return rc;
-  if (!lane_path_ok(ix)) return fail(SLK_E_UNSUPPORTED, "splitter outside the fused kernel's range: use the staged calls");
-  if (n_sublists < 1 || n_sublists > 4096 || (n_sublists & (n_sublists - 1))) return fail(SLK_E_INVALID, "n_sublists must be a power of two <= 4096");
-  if (n_shards < 1 || n_shards > 64 || !d_send_counts || !d_defer ||
-      (R && (!d_bases || !d_offsets || !d_send_keys || !d_send_meta || !d_batch_base || !d_tile_rows || !d_read_info)))
-    return fail(SLK_E_INVALID, "bad argument");
-  if (capacity_per_sublist >= (1ull << 25)) return fail(SLK_E_INVALID, "capacity_per_sublist must be below 2^25 (use more sub-lists)");
-  if ((d_mate_bases == nullptr) != (d_mate_offsets == nullptr))
-    return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
-  if (side_n && (!d_side_keys || !d_side_done || !d_side_taxa)) return fail(SLK_E_INVALID, "null argument (side lookups)");
-  if (side_n && (uint64_t)side_per_tile * ((R + 63) / 64) * 64 < side_n)
-    return fail(SLK_E_INVALID, "side_per_tile = %u batches for each of the %llu tiles do not cover %llu keys", side_per_tile, (unsigned long long)((R + 63) / 64), (unsigned long long)side_n);
-  rc = set_device(ix);
-  if (rc) return rc;
-  HIPCHK(hipMemsetAsync(d_send_counts, 0, (size_t)n_shards * n_sublists * sizeof(uint64_t), st->s));
-  HIPCHK(hipMemsetAsync(d_defer, 0, (R ? R : 1) * sizeof(int32_t), st->s));
-  if (side_n) HIPCHK(hipMemsetAsync(d_side_done, 0, ((R + 63) / 64) * sizeof(uint32_t), st->s));
-  FusedArgs A{};
-  A.P = ix->sp; A.bases = d_bases; A.offsets = d_offsets; A.mate_bases = d_mate_bases; A.mate_offsets = d_mate_offsets; A.R = R;
+// entries a wave reserves at a time in an owner's send region (engine.h: ShardIO.chunk): one atomic per chunk and owner on ONE
+// address per owner, so the fewer owners the larger the chunk (an owner's keys come 1 / n_shards as fast); what stays unwritten at
+// the end of a launch is half a chunk per wave and owner -- 2 M entries of the 390 M of a 10 M-read batch whatever n_shards is
+uint32_t slk_shard_chunk(uint32_t n_shards) {
+  uint32_t c = 1024;
+  while (c > 64 && c * n_shards > 1024) c >>= 1;
+  return c;
+}
+
+// FusedArgs / ShardIO of a batch's EMIT job from its lists
+static void fill_emit(const slk_index *ix, slk_stream *st, const slk_shard_lists &E, FusedArgs &A, ShardIO &S) {
+  A.P = ix->sp; A.T = ix->view();
+  A.bases = E.d_bases; A.offsets = E.d_offsets; A.mate_bases = E.d_mate_bases; A.mate_offsets = E.d_mate_offsets; A.R = E.R;
+  A.span_meta = E.d_span_meta; A.span_taxon = E.d_span_taxon; A.span_count = E.d_span_count;
   A.status = st->d_status;
-  if (side_n) A.T = ix->view();
-  ShardIO S{};
-  S.n_shards = (int32_t)n_shards; S.n_sub = (int32_t)n_sublists; S.cap = capacity_per_sublist; S.send_keys = d_send_keys;
-  S.send_counts = (unsigned long long *)d_send_counts; S.batch_base = d_batch_base; S.send_meta = d_send_meta;
-  S.tile_rows = d_tile_rows; S.read_info = (int2 *)d_read_info;
-  S.side_keys = d_side_keys; S.side_n = side_n; S.side_per_tile = side_n ? side_per_tile : 0; S.side_done = d_side_done; S.side_out = d_side_taxa;
-  st->queued.emplace_back();  // (not re-runnable: an overflow of this call is reported as an error)
-  launch_lane_sharded(LANE_EMIT, A, S, d_defer, 1000, st->s);
-  HIPCHK(hipMemcpyAsync(st->h_status, st->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st->s));
-  HIPCHK(hipGetLastError());
+  S.n_shards = (int32_t)E.n_shards; S.chunk = slk_shard_chunk(E.n_shards); S.cap = E.capacity_per_owner;
+  S.send_keys = E.d_send_keys; S.cursors = (unsigned long long *)E.d_cursors; S.send_meta = E.d_send_meta;
+  S.batch_log = (uint4 *)E.d_batch_log; S.tile_rows = (uint2 *)E.d_tile_rows; S.read_info = (int2 *)E.d_read_info;
+}
+static int32_t check_lists(const slk_shard_lists &E, const char *what) {
+  if (E.n_shards < 1 || E.n_shards > 64) return fail(SLK_E_INVALID, "%s: n_shards %u outside 1..64", what, E.n_shards);
+  const uint32_t chunk = slk_shard_chunk(E.n_shards);
+  if (E.capacity_per_owner < chunk || E.capacity_per_owner % chunk != 0 || E.capacity_per_owner >= (1ull << 32))
+    return fail(SLK_E_INVALID, "%s: capacity_per_owner must be a multiple of slk_shard_chunk(n_shards) = %u below 2^32", what, chunk);
+  if (!E.d_cursors || !E.d_defer || (E.R && (!E.d_offsets || !E.d_send_keys || !E.d_send_meta || !E.d_batch_log || !E.d_tile_rows || !E.d_read_info)))
+    return fail(SLK_E_INVALID, "%s: null argument", what);
+  if ((E.d_mate_bases == nullptr) != (E.d_mate_offsets == nullptr)) return fail(SLK_E_INVALID, "%s: mate_bases and mate_offsets must be given together", what);
+  if ((E.d_span_meta == nullptr) != (E.d_span_taxon == nullptr) || (E.d_span_meta == nullptr) != (E.d_span_count == nullptr))
+    return fail(SLK_E_INVALID, "%s: the span arrays of the hit lists must be given together", what);
+  if (E.R >= 0xFFFFFFFFull) return fail(SLK_E_INVALID, "%s: a batch holds fewer than 2^32 fragments", what);
   return SLK_OK;
 }
 
-int32_t slk_shard_emit_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
-                              const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
-                              uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys, uint32_t *d_send_meta,
-                              uint64_t capacity_per_sublist, uint64_t *d_send_counts, uint32_t *d_batch_base,
-                              uint32_t *d_tile_rows, int32_t *d_read_info, int32_t *d_defer) {
-  return shard_emit(ix, st, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, n_shards, n_sublists, d_send_keys, d_send_meta, capacity_per_sublist,
-                    d_send_counts, d_batch_base, d_tile_rows, d_read_info, d_defer, nullptr, 0, 0, nullptr, nullptr);
-}
-
-int32_t slk_shard_emit_lookup_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
-                                     const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
-                                     uint32_t n_shards, uint32_t n_sublists, int64_t *d_send_keys, uint32_t *d_send_meta,
-                                     uint64_t capacity_per_sublist, uint64_t *d_send_counts, uint32_t *d_batch_base,
-                                     uint32_t *d_tile_rows, int32_t *d_read_info, int32_t *d_defer, const int64_t *d_side_keys, uint64_t side_n,
-                                     uint32_t side_per_tile, uint32_t *d_side_done, int32_t *d_side_taxa) {
-  return shard_emit(ix, st, d_bases, d_offsets, d_mate_bases, d_mate_offsets, R, n_shards, n_sublists, d_send_keys, d_send_meta, capacity_per_sublist,
-                    d_send_counts, d_batch_base, d_tile_rows, d_read_info, d_defer, d_side_keys, R ? side_n : 0, side_per_tile, d_side_done, d_side_taxa);
-}
-
-int32_t slk_lookup_rest_device(slk_index *ix, slk_stream *st, const int64_t *d_keys, uint64_t n, uint32_t side_per_tile, uint64_t tiles,
-                               const uint32_t *d_side_done, int32_t *d_out_taxa) {
-  int32_t rc = check_ready(ix, st, false);
+// One pipeline step of the table-sharded mode (engine.h: ShardIO): up to three jobs of three different batches in ONE kernel.
+int32_t slk_shard_step_device(slk_index *ix, slk_stream *st, const slk_shard_lists *emit, const slk_shard_lookup *lookup,
+                              const slk_shard_lists *apply_lists, const slk_shard_results *apply) {
+  int32_t rc = check_ready(ix, st, apply != nullptr);
   if (rc) return rc;
   if (ix->W > 1) return fail(SLK_E_UNSUPPORTED, "the staged and sharded entry points support minimizers of up to 32 nt (one id column)");
-  if (!d_side_done || (n && (!d_keys || !d_out_taxa))) return fail(SLK_E_INVALID, "null argument");
-  rc = set_device(ix);
-  if (rc) return rc;
-  launch_lookup_coop_rest(ix->view(), d_keys, n, side_per_tile, tiles, d_side_done, d_out_taxa, st->s);
-  HIPCHK(hipGetLastError());
-  return SLK_OK;
-}
-
-int32_t slk_shard_compact_device(slk_index *ix, slk_stream *st, const int64_t *d_send_keys, uint32_t n_shards, uint32_t n_sublists,
-                                 uint64_t capacity_per_sublist, const uint64_t *d_send_counts, int64_t *d_out_keys,
-                                 uint64_t *d_list_offsets, uint64_t *d_owner_counts) {
-  int32_t rc = check_ready(ix, st, false);
-  if (rc) return rc;
-  if (n_sublists < 1 || n_sublists > 4096 || n_shards < 1 || n_shards > 64 || !d_send_keys || !d_send_counts || !d_out_keys ||
-      !d_list_offsets || !d_owner_counts)
-    return fail(SLK_E_INVALID, "bad argument");
-  rc = set_device(ix);
-  if (rc) return rc;
-  launch_compact_lists(d_send_keys, (const unsigned long long *)d_send_counts, n_shards, n_sublists, capacity_per_sublist, d_out_keys,
-                       d_list_offsets, d_owner_counts, st->s);
-  HIPCHK(hipGetLastError());
-  return SLK_OK;
-}
-
-int32_t slk_shard_apply_device(slk_index *ix, slk_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets,
-                               const uint8_t *d_mate_bases, const uint64_t *d_mate_offsets, uint64_t R,
-                               uint32_t n_shards, uint32_t n_sublists, uint64_t capacity_per_sublist, const int32_t *d_taxa,
-                               const uint64_t *d_list_offsets, const uint32_t *d_send_meta, const uint32_t *d_batch_base,
-                               const uint32_t *d_tile_rows, const int32_t *d_read_info, int32_t min_hit_groups,
-                               const double *thresholds, int32_t C,
-                               int32_t *d_out_taxon, uint8_t *d_out_classified, int32_t *d_out_num_distinct,
-                               int32_t *d_out_total_kmers, int32_t *d_out_num_hits, int32_t *d_defer) {
-  int32_t rc = check_ready(ix, st, true);
-  if (rc) return rc;
   if (!lane_path_ok(ix)) return fail(SLK_E_UNSUPPORTED, "splitter outside the fused kernel's range: use the staged calls");
-  if (C < 1 || C > MAX_THRESHOLDS || !thresholds) return fail(SLK_E_INVALID, "need 1..%d thresholds", MAX_THRESHOLDS);
-  if (n_sublists < 1 || n_sublists > 4096 || (n_sublists & (n_sublists - 1)) || n_shards < 1 || n_shards > 64)
-    return fail(SLK_E_INVALID, "bad n_shards / n_sublists");
-  if (!d_defer || (R && (!d_offsets || !d_taxa || !d_list_offsets || !d_send_meta || !d_batch_base || !d_tile_rows || !d_read_info ||
-                         !d_out_taxon || !d_out_classified)))
-    return fail(SLK_E_INVALID, "null argument");
-  if ((d_mate_bases == nullptr) != (d_mate_offsets == nullptr))
-    return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
+  if ((apply_lists == nullptr) != (apply == nullptr)) return fail(SLK_E_INVALID, "apply_lists and apply must be given together");
+  if (emit && (rc = check_lists(*emit, "emit"))) return rc;
+  if (emit && emit->R && !emit->d_bases) return fail(SLK_E_INVALID, "emit: null argument");
+  if (apply_lists && (rc = check_lists(*apply_lists, "apply"))) return rc;
+  if (lookup && lookup->n && (!lookup->d_keys || !lookup->d_out_taxa)) return fail(SLK_E_INVALID, "lookup: null argument");
+  if (apply) {
+    if (apply->C < 1 || apply->C > MAX_THRESHOLDS || !apply->thresholds) return fail(SLK_E_INVALID, "need 1..%d thresholds", MAX_THRESHOLDS);
+    if (apply_lists->R && (!apply->d_taxa || !apply->d_out_taxon || !apply->d_out_classified)) return fail(SLK_E_INVALID, "apply: null argument");
+    if (emit && emit->R && (apply_lists->d_span_meta == nullptr) != (emit->d_span_meta == nullptr))
+      return fail(SLK_E_INVALID, "the batches of one step write hit lists or none does");
+  }
   rc = set_device(ix);
   if (rc) return rc;
-  Thresholds thr{};
-  memcpy(thr.v, thresholds, C * sizeof(double));
+  const bool scans = emit && emit->R != 0;
   FusedArgs A{};
-  A.P = ix->sp; A.T = ix->view(); A.parents = ix->kernel_parents(); A.ntax = ix->kernel_ntax(); A.nodes = ix->kernel_nodes();   // (A.T: for to_orig only)
-  A.bases = d_bases; A.offsets = d_offsets; A.mate_bases = d_mate_bases; A.mate_offsets = d_mate_offsets; A.R = R;
-  A.out_stride = R;
-  A.min_hit_groups = min_hit_groups; A.thr = thr; A.C = C;
-  A.out_taxon = d_out_taxon; A.out_classified = d_out_classified;
-  A.out_nd = d_out_num_distinct; A.out_tk = d_out_total_kmers; A.out_nh = d_out_num_hits;
-  A.status = st->d_status;
   ShardIO S{};
-  S.n_shards = (int32_t)n_shards; S.n_sub = (int32_t)n_sublists;
-  S.cap = capacity_per_sublist;
-  S.batch_base = const_cast<uint32_t *>(d_batch_base); S.list_off = d_list_offsets; S.taxa = d_taxa;
-  S.send_meta = const_cast<uint32_t *>(d_send_meta); S.tile_rows = const_cast<uint32_t *>(d_tile_rows);
-  S.read_info = (int2 *)const_cast<int32_t *>(d_read_info);
-  S.to_dense = ix->d_to_dense; S.n_to_dense = ix->T;
-  st->queued.emplace_back();
-  launch_lane_sharded(LANE_APPLY, A, S, d_defer, 1000, st->s);
-  HIPCHK(hipGetLastError());
+  A.P = ix->sp; A.status = st->d_status;
+  if (scans) {
+    fill_emit(ix, st, *emit, A, S);
+    HIPCHK(hipMemsetAsync(emit->d_cursors, 0, ((size_t)emit->n_shards + 3) * sizeof(uint64_t), st->s));
+    HIPCHK(hipMemsetAsync(emit->d_defer, 0, emit->R * sizeof(int32_t), st->s));
+  } else if (emit) {
+    HIPCHK(hipMemsetAsync(emit->d_cursors, 0, ((size_t)emit->n_shards + 3) * sizeof(uint64_t), st->s));
+  }
+  uint64_t *draw = scans ? emit->d_cursors + emit->n_shards : nullptr;
+  if (lookup && lookup->n) {
+    // The lookups ride in the scan, their 64-key batches dealt out to its tiles -- unless the scan is far too short for them (a
+    // tile sends off about 2 / (w + 1) keys per base; a tile handed several times as many lookups as that would finish them alone,
+    // at its end, with the rest of the part idle): then they run as a kernel of their own, like those of a step without a scan.
+    const uint64_t tiles = scans ? (emit->R + 63) / 64 : 0, batches = (lookup->n + 63) / 64;
+    const double own = scans ? 2.0 / (ix->sp.w + 1) * (double)(emit->total_bases + emit->total_mate_bases) / 64.0 / (double)tiles : 0;
+    const uint64_t per_tile = scans ? (batches + tiles - 1) / tiles : 0;
+    if (scans && (double)per_tile <= 3.0 * own + 8.0) {
+      S.side_keys = lookup->d_keys; S.side_n = lookup->n; S.side_out = lookup->d_out_taxa;
+      S.side_per_tile = (uint32_t)per_tile;
+    } else {
+      launch_lookup_coop(ix->view(), lookup->d_keys, lookup->n, lookup->d_out_taxa, st->s);
+      HIPCHK(hipGetLastError());
+    }
+  }
+  ApplyJob J{};
+  const bool applies = apply && apply_lists->R != 0;
+  if (applies) {
+    Thresholds thr{};
+    memcpy(thr.v, apply->thresholds, apply->C * sizeof(double));
+    FusedArgs &B = J.A;
+    B.P = ix->sp; B.T = ix->view(); B.parents = ix->kernel_parents(); B.ntax = ix->kernel_ntax(); B.nodes = ix->kernel_nodes();
+    B.offsets = apply_lists->d_offsets; B.mate_offsets = apply_lists->d_mate_offsets; B.R = apply_lists->R; B.out_stride = apply_lists->R;
+    B.min_hit_groups = apply->min_hit_groups; B.thr = thr; B.C = apply->C;
+    B.out_taxon = apply->d_out_taxon; B.out_classified = apply->d_out_classified; B.out_nd = apply->d_out_num_distinct;
+    B.out_tk = apply->d_out_total_kmers; B.out_nh = apply->d_out_num_hits;
+    B.span_meta = apply_lists->d_span_meta; B.span_taxon = apply_lists->d_span_taxon; B.span_count = apply_lists->d_span_count;
+    B.status = st->d_status;
+    J.n_shards = (int32_t)apply_lists->n_shards; J.cap = apply_lists->capacity_per_owner;
+    J.send_meta = apply_lists->d_send_meta; J.batch_log = (const uint4 *)apply_lists->d_batch_log;
+    J.tile_rows = (const uint2 *)apply_lists->d_tile_rows; J.read_info = (const int2 *)apply_lists->d_read_info;
+    J.taxa = apply->d_taxa; J.to_dense = ix->d_to_dense; J.n_to_dense = ix->T; J.defer = apply_lists->d_defer;
+    J.n_deferred = (unsigned long long *)(apply_lists->d_cursors + apply_lists->n_shards + 2);
+    if (!scans) {   // a step without a scan: the replay's waves draw their tiles from a counter of its own (the batch's spare word)
+      draw = apply_lists->d_cursors + apply_lists->n_shards + 1;
+      HIPCHK(hipMemsetAsync(draw, 0, sizeof(uint64_t), st->s));
+      S.n_shards = 0;
+    }
+  }
+  if (scans || applies) {
+    // (S.cursors[S.n_shards] is the tile draw: with a scan the batch's own word behind its cursors, else the word chosen above)
+    if (!scans) S.cursors = (unsigned long long *)draw;
+    st->queued.emplace_back();   // (not re-runnable: a map overflow of the replay defers the fragment, a full region is an error)
+    launch_lane_step(A, S, J, scans ? emit->d_defer : nullptr, 1000, st->s);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(st->h_status, st->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st->s));
+  }
   return SLK_OK;
 }
 

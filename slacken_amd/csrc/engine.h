@@ -235,48 +235,60 @@ struct FusedArgs {
   unsigned long long *work_draw;
 };
 
-// Table-sharded classification (BASELINE configs[3]): the lane kernel runs twice per batch.  LANE_EMIT scans the
-// fragments and, instead of probing, appends every minimizer to the send list of the rank that owns it
-// (fmix64(key) mod n_shards), logging per probe batch where each owner's group of keys went; LANE_APPLY scans again, forms
-// the same batches, and takes each probe's taxon from the owners' answers at the logged list positions.
+// APPLY job of the table-sharded step kernel: the lists and the log an EARLIER batch's EMIT left on this rank, the owners' answers,
+// and where that batch's results go (A: R, outputs, thresholds, taxonomy; offsets only when hit lists are written).  A.R == 0: no job.
+struct ApplyJob {
+  FusedArgs A;
+  int32_t n_shards;
+  uint64_t cap;
+  const uint32_t *send_meta;
+  const uint4 *batch_log;
+  const uint2 *tile_rows;
+  const int2 *read_info;
+  const int32_t *taxa;               // [n_shards][cap]: the owners' answers at the positions of the keys (the caller's ids)
+  const int32_t *to_dense;           // caller's id -> the table's dense id (nullptr: ids as given)
+  int32_t n_to_dense;
+  int32_t *defer;                    // [R] in: 1 = the EMIT did not take the fragment (too long); out: also map overflows
+  unsigned long long *n_deferred;    // += the fragments flagged in defer[] (one atomic per wave that has any)
+};
+
+// Table-sharded classification (BASELINE configs[3]).  A batch takes three jobs, each of them riding in the ONE kernel
+// launched per pipeline step (lane_step_kernel, lane.hip) beside the jobs of its neighbours:
+//   EMIT    (step t)      scans the fragments and, instead of probing, appends every minimizer to the send region of the rank that
+//                         owns it (fmix64(key) mod n_shards), logging per probe batch where each owner's group of keys went;
+//   LOOKUP  (step t + 2)  the OWNER's side: the keys this rank received are answered with the local kernel's cooperative probe,
+//                         64 of them whenever a wave has sent off 64 keys of its own;
+//   APPLY   (step t + 4)  no second scan: the tile's probe batches are replayed from the log, each probe's taxon is read from the
+//                         owners' answers at the logged position, folded into the fragment's map and resolved as the local kernel does.
+// Send regions: ONE contiguous region per owner, [n_shards][cap] -- what the exchange sends is region[0 .. cursor) as it stands, no
+// compaction pass.  A wave reserves `chunk` entries of an owner's region at a time (one atomic per chunk: a cursor per owner bumped
+// once per probe batch serialised the appends, 73 ms per 10 M reads) and keeps the chunk it is filling from tile to tile (the
+// kernel's waves are persistent and draw tiles from a counter), so the only entries never written are the tails of the chunks the
+// waves hold when the kernel ends (zeroed there: they travel and are answered like keys, nobody reads their answers).
 struct ShardIO {
   int32_t n_shards;
-  int32_t n_sub;                     // sub-lists per shard (power of two): waves append to sub-list (tile index mod n_sub), so that
-                                     // the cursor atomics spread over n_sub addresses per shard instead of serialising on one
-  uint64_t cap;                      // capacity of each sub-list
-  int64_t *send_keys;                // LANE_EMIT: [n_shards][n_sub][cap]
-  unsigned long long *send_counts;   // LANE_EMIT: [n_shards][n_sub] cursors; a cursor beyond cap raises status bit 2
-  uint32_t *send_meta;               // [n_shards][n_sub][cap]: the keys' span metadata (owner lane | distinct | k-mers); stays on this rank
-  uint32_t *batch_base;              // [rows][n_shards]: (where a probe batch's keys for an owner start in its sub-list) << 7 | how many
-  uint32_t *tile_rows;               // [tiles]: rows of the log the tile used
+  uint32_t chunk;                    // entries a wave reserves at a time (a power of two >= 64)
+  uint64_t cap;                      // entries per owner region (a multiple of chunk, < 2^32)
+  int64_t *send_keys;                // [n_shards][cap]
+  unsigned long long *cursors;       // [n_shards + 1]: entries reserved per owner (multiples of chunk; beyond cap: status bit 2);
+                                     // [n_shards]: tile draw of the launch
+  uint32_t *send_meta;               // [n_shards][cap]: the keys' span metadata (owner lane | distinct | k-mers | ordinal); stays on this rank
+  uint4 *batch_log;                  // [rows][n_shards]: {position of the owner's group, start of a freshly reserved chunk, keys, room left
+                                     // at the position}: key i of the group sits at position + i while i < room, else at fresh + i - room
+  uint2 *tile_rows;                  // [tiles]: {first row of the tile in the log, rows it used}
   int2 *read_info;                   // [R]: total k-mers, spans of a fragment (TaxonCounts.totalKmers; the "no span, no row" test)
-  const uint64_t *list_off;          // LANE_APPLY: [n_shards * n_sub + 1] start of every sub-list in the compacted order
-  const int32_t *taxa;               // LANE_APPLY: the owners' answers, in the compacted order of the keys
-  const int32_t *to_dense;           // LANE_APPLY: caller's id -> the table's dense id (nullptr: ids as given)
-  int32_t n_to_dense;
-  // LANE_EMIT, optional: the owner's side of an EARLIER batch rides along.  Whenever a wave has sent off a batch of 64 of its own
-  // keys it also probes 64 of the keys this rank RECEIVED (side_keys[0 .. side_n)) with the local kernel's cooperative access shape,
-  // answers to side_out: the lookups' latency hides behind the scan exactly as the local kernel's probes do, instead of running as
-  // a kernel of their own beside it.  The 64-key batches are dealt out statically -- tile t owns batches [t * side_per_tile,
-  // (t + 1) * side_per_tile) (a shared cursor would be one atomic address for six million draws: measured, 73 ms) -- and a tile that
-  // sends off fewer batches than it owns says how far it got in side_done[t]: launch_lookup_coop_rest answers the rest.
+  // LOOKUP job (optional: side_n != 0).  The 64-key batches of side_keys[0 .. side_n) are dealt out statically -- tile t of the scan
+  // owns batches [t * side_per_tile, (t + 1) * side_per_tile) (a shared cursor would be one atomic address for six million draws:
+  // measured, 73 ms) -- and a tile that sends off fewer batches than it owns finishes its share at its end.
   const int64_t *side_keys;
   uint64_t side_n;
   uint32_t side_per_tile;
-  uint32_t *side_done;               // [tiles]
   int32_t *side_out;
 };
-enum { LANE_LOCAL = 0, LANE_EMIT = 1, LANE_APPLY = 2 };
-void launch_lane_sharded(int mode, const FusedArgs &A, const ShardIO &S, int32_t *defer, uint32_t max_len, hipStream_t s);
+enum { LANE_LOCAL = 0, LANE_EMIT = 1 };
+void launch_lane_step(const FusedArgs &A, const ShardIO &S, const ApplyJob &J, int32_t *defer, uint32_t max_len, hipStream_t s);
 // cooperative point lookups (4 lanes x 16 B per bucket) and the scatter of returned taxa to their slots (shard.hip)
 void launch_lookup_coop(const TableView &t, const int64_t *keys, uint64_t n, int32_t *out, hipStream_t s);
-// what a LANE_EMIT launch with a side job left over: of every tile's batches [t * per_tile, (t + 1) * per_tile) those from done[t] on
-void launch_lookup_coop_rest(const TableView &t, const int64_t *keys, uint64_t n, uint32_t per_tile, uint64_t tiles, const uint32_t *done,
-                             int32_t *out, hipStream_t s);
-// The send lists as one contiguous array in (owner, sub-list) order: list_off[n_lists + 1] = exclusive prefix of the list
-// lengths, owner_counts[n_shards] = keys per owner (the all-to-all's split sizes), out_keys = the lists back to back.
-void launch_compact_lists(const int64_t *send_keys, const unsigned long long *send_counts, uint32_t n_shards, uint32_t n_sub,
-                          uint64_t cap, int64_t *out_keys, uint64_t *list_off, uint64_t *owner_counts, hipStream_t s);
 // cells' taxon field -> to_dense[taxon]; *undefined counts the cells whose taxon has no dense id; apply = false: count only
 void launch_remap_cells(uint64_t *cells, uint64_t ncells, int32_t taxon_bits, const int32_t *to_dense, int32_t n_to_dense,
                         unsigned long long *undefined, bool apply, hipStream_t s);

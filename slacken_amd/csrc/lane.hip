@@ -27,6 +27,7 @@
 // (TaxonHit per span, ordinal order) into the fragments' span regions, the layout fused.hip's MODE_HITS uses.
 #include "engine.h"
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -217,12 +218,10 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, uint32_t *ocnt, const Tab
   return requeued;
 }
 
-// ---- table-sharded mode (engine.h: ShardIO) ------------------------------------------------------------------------------
-// Both modes run the same scan, so they form the same probe batches in the same order.  LANE_EMIT appends a batch's keys to
-// the send lists of their owners (one cursor bump per owner per batch) and logs where each owner's group went
-// (batch_base[row][owner]); LANE_APPLY finds the same keys in its queue again, recomputes owner and rank inside the group,
-// and reads the taxon the owner returned for that list position.  Nothing but 8-byte keys, 4-byte taxa and the 4-byte log
-// entries touches HBM: no per-probe slot addresses, no scatter of the answers.
+// ---- table-sharded mode (engine.h: ShardIO, ApplyJob) -------------------------------------------------------------------
+// The step kernel runs the local kernel's scan, so it forms the same probe batches in the same order; instead of probing them it
+// appends a batch's keys to the send regions of their owners and logs where each owner's group went.  Nothing but 8-byte keys,
+// 4-byte taxa and the log touches HBM: no per-probe slot addresses, no scatter of the answers, no compaction of the lists.
 __device__ __forceinline__ uint64_t lane_readlane64(uint64_t v, int src) {
   uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src);
   return ((uint64_t)hi << 32) | lo;
@@ -231,16 +230,14 @@ __device__ __forceinline__ uint32_t shard_owner(uint64_t key, uint32_t ns) {  //
   const uint64_t h = fmix64(key);
   return (ns & (ns - 1)) == 0 ? (uint32_t)(h & (ns - 1)) : (uint32_t)(h % ns);
 }
-// LANE_EMIT: append the batch's minimizers to their owners' send lists (one atomic per owner per batch); the span metadata the
-// second pass needs (owner lane, distinct, k-mers) goes to a list of the same shape, which stays on this rank
 // One key of an earlier batch's lookups per lane, loaded a batch ahead of its use (engine.h: ShardIO.side_*)
 __device__ __forceinline__ uint64_t side_load(const ShardIO &S, uint64_t batch, int lane) {
   const uint64_t i = batch * 64 + (uint64_t)lane;
   return i < S.side_n ? (uint64_t)S.side_keys[i] : 0;
 }
-// LANE_EMIT with a side job: 64 of the keys this rank received for an earlier batch, probed with probe_batch's access shape (LPB
-// lanes per bucket, all of the batch's loads in flight before the first compare); a key whose bucket is full, flagged and does
-// not hold it goes on alone (as in shard.hip's lookup_coop_kernel).  `key` was loaded a batch ago (side_load).
+// LOOKUP job: 64 of the keys this rank received for an earlier batch, probed with probe_batch's access shape (LPB lanes per bucket,
+// all of the batch's loads in flight before the first compare); a key whose bucket is full, flagged and does not hold it goes on
+// alone (as in shard.hip's lookup_coop_kernel).  `key` was loaded a batch ago (side_load).
 __device__ __forceinline__ void side_probe(LaneLds *L, const TableView &T, const ShardIO &S, int lane, uint64_t batch, uint64_t key) {
   const uint64_t base = batch * 64;
   if (base >= S.side_n) return;
@@ -301,19 +298,57 @@ __device__ __forceinline__ void side_probe(LaneLds *L, const TableView &T, const
   lane_wave_sync();
 }
 
-// LANE_EMIT: the batch's minimizers go to their owners' send lists, the span metadata the second pass needs (owner lane, distinct,
-// k-mers) to a list of the same shape, which stays on this rank.  ONE atomic instruction per batch whatever the number of owners:
-// lane sh bumps owner sh's cursor by the number of the batch's keys that owner gets, and every key's lane picks its owner's answer
-// up (a loop of one atomic per owner was a memory round trip per owner and batch).  Between the atomic and the use of its answer
-// runs the batch's side job, if there is one: the cursor's round trip and the lookups' share one wait.
+// APPLY job, one row of the log: lane i takes the i-th entry of a logged probe batch in (owner, rank) order, reads its span
+// metadata from this rank's meta region and its taxon from the owners' answers (which lie where the keys lay), and folds it into the
+// owner lane's map exactly as the local kernel does.
 template <bool HITS>
-__device__ __forceinline__ void emit_batch(LaneLds *L, const FusedArgs &A, const ShardIO &S, int qhead, int cnt, int lane, uint32_t sub,
-                                           uint64_t row, uint64_t tile, uint32_t &side_j, uint64_t &side_key) {
+__device__ __forceinline__ void apply_row(LaneLds *L, const ApplyJob &J, int lane, uint64_t row) {
+  const uint32_t ns = (uint32_t)J.n_shards;
+  uint32_t off = 0;
+  bool in = false;
+  uint64_t at = 0;
+  for (uint32_t sh = 0; sh < ns; sh++) {
+    const uint4 e = J.batch_log[row * ns + sh];                        // (wave-uniform loads)
+    const uint32_t cnt = e.z;
+    if (cnt == 0) continue;
+    if ((uint32_t)lane >= off && (uint32_t)lane < off + cnt) {
+      in = true;
+      const uint32_t i = (uint32_t)lane - off;
+      at = (uint64_t)sh * J.cap + (i < e.w ? e.x + i : e.y + (i - e.w));
+    }
+    off += cnt;
+  }
+  uint32_t meta = 0;
+  int32_t taxon = 0;
+  if (in) {
+    meta = J.send_meta[at];
+    taxon = J.taxa[at];
+    if (HITS) {   // the un-merged hit list, as probe_batch writes it (the owners answer in the caller's ids)
+      const uint64_t hat = L->rb[meta & 63] + (meta >> 20);
+      J.A.span_taxon[hat] = taxon;
+      J.A.span_meta[hat] = pack_meta((int32_t)((meta >> 7) & 0x1FFF), 1, (meta >> 6) & 1);
+    }
+    if (J.to_dense != nullptr && taxon > 0) taxon = taxon < J.n_to_dense ? J.to_dense[taxon] : 0;  // (owners answer in the caller's ids)
+  }
+  fold_hit<false>(L, nullptr, in, meta, taxon);
+  lane_wave_sync();
+}
+
+// EMIT job, one probe batch: its minimizers go to their owners' send regions, the span metadata the APPLY needs (owner lane,
+// distinct, k-mers) to a region of the same shape, which stays on this rank.  Lane sh keeps the chunk of owner sh's region this wave
+// is filling (ch_pos .. ch_end); a batch whose keys for that owner do not fit what is left of it takes the rest of the chunk AND the
+// head of a freshly reserved one (one atomic per chunk and owner), so the regions have no holes but the chunk tails at the kernel's
+// end.  Between the atomic and the use of its answer run the batch's side jobs -- 64 lookups of an earlier batch, one row of a yet
+// earlier batch's log -- so the cursor's round trip, the lookups' and the replay's loads share one wait.
+template <bool HITS>
+__device__ __forceinline__ void emit_batch(LaneLds *L, const FusedArgs &A, const ShardIO &S, const ApplyJob &J, int qhead, int cnt, int lane,
+                                           uint64_t row, uint64_t tile, uint32_t &ch_pos, uint32_t &ch_end, uint32_t &side_j, uint64_t &side_key,
+                                           uint32_t &ap_done, uint32_t ap_rows, uint64_t ap_row0) {
   const bool in = lane < cnt;
   const int qi = (qhead + lane) & (QCAP - 1);
   const uint64_t key = L->q_key[qi];
   // (nothing is re-queued in this mode, so the displacement field of the entry is free: with hit lists it carries the span's
-  //  ordinal -- a fragment this kernel takes has fewer than 1000 spans -- for the second pass to write the hit where it belongs)
+  //  ordinal -- a fragment this kernel takes has fewer than 1000 spans -- for the APPLY to write the hit where it belongs)
   const uint32_t meta = L->q_meta[qi] | (HITS ? (uint32_t)L->q_ord[qi] << 20 : 0u);
   const uint32_t ns = (uint32_t)S.n_shards;
   const uint32_t g = shard_owner(key, ns);
@@ -323,66 +358,37 @@ __device__ __forceinline__ void emit_batch(LaneLds *L, const FusedArgs &A, const
     if ((uint32_t)lane == sh) mycount = (uint32_t)__popcll(m);
     if (g == sh) rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
   }
-  unsigned long long base = 0;
-  if ((uint32_t)lane < ns) {
-    if (mycount) base = atomicAdd(&S.send_counts[(uint64_t)lane * (uint32_t)S.n_sub + sub], (unsigned long long)mycount);
-  }
-  if (side_j < S.side_per_tile) {   // the owner's side of an earlier batch: one batch of its lookups per batch of keys sent off
+  const uint32_t pos = ch_pos, room = ch_end - ch_pos;   // (lanes < ns: this wave's chunk of owner `lane`)
+  const bool need = (uint32_t)lane < ns && mycount > room;
+  unsigned long long got = 0;
+  if (need) got = atomicAdd(&S.cursors[lane], (unsigned long long)S.chunk);
+  if (side_j < S.side_per_tile) {   // LOOKUP job: one batch of an earlier batch's lookups per batch of keys sent off
     const uint64_t batch = tile * S.side_per_tile + side_j;
     const uint64_t k_now = side_key;
     side_j++;
     if (side_j < S.side_per_tile) side_key = side_load(S, batch + 1, lane);   // (in flight while this batch is probed)
     side_probe(L, A.T, S, lane, batch, k_now);
   }
-  if ((uint32_t)lane < ns) S.batch_base[row * ns + (uint32_t)lane] = mycount ? (((uint32_t)base << 7) | mycount) : 0u;   // (cap < 2^25, checked by the host side)
-  const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)base, (int)g), bhi = (uint32_t)__shfl((int)(uint32_t)(base >> 32), (int)g);
+  if (ap_done < ap_rows) { apply_row<HITS>(L, J, lane, ap_row0 + ap_done); ap_done++; }   // APPLY job: one row of the log
+  uint32_t fresh = 0xFFFFFFFFu;
+  if (need) {
+    if (got + S.chunk <= S.cap) fresh = (uint32_t)got;
+    else atomicOr(A.status, 2);                       // the region is full: the host emits the batch again with larger regions
+  }
+  if ((uint32_t)lane < ns) {
+    S.batch_log[row * ns + (uint32_t)lane] = make_uint4(pos, fresh, mycount, room);
+    if (need) { ch_pos = fresh == 0xFFFFFFFFu ? 0u : fresh + (mycount - room); ch_end = fresh == 0xFFFFFFFFu ? 0u : fresh + S.chunk; }
+    else ch_pos = pos + mycount;
+  }
+  const uint32_t gpos = (uint32_t)__shfl((int)pos, (int)g), groom = (uint32_t)__shfl((int)room, (int)g), gfresh = (uint32_t)__shfl((int)fresh, (int)g);
   if (in) {
-    const uint64_t pos = (((uint64_t)bhi << 32) | blo) + rank;
-    const uint64_t list = (uint64_t)g * (uint32_t)S.n_sub + sub;
-    if (pos < S.cap) {
-      S.send_keys[list * S.cap + pos] = (int64_t)key;
-      S.send_meta[list * S.cap + pos] = meta;
-    } else {
-      atomicOr(A.status, 2);
+    const bool tail = rank >= groom;                  // beyond what the old chunk had left: the fresh one
+    if (!tail || gfresh != 0xFFFFFFFFu) {
+      const uint64_t at = (uint64_t)g * S.cap + (tail ? gfresh + (rank - groom) : gpos + rank);
+      S.send_keys[at] = (int64_t)key;
+      S.send_meta[at] = meta;
     }
   }
-  lane_wave_sync();
-}
-// LANE_APPLY: no second scan.  The tile's probe batches are replayed from the log: lane i takes the i-th entry of a batch in
-// (owner, rank) order, reads its span metadata from this rank's meta list and its taxon from the owners' answers (which arrive
-// list by list in the order the keys were sent), and folds it into the owner lane's map exactly as the local kernel does.
-template <bool HITS>
-__device__ __forceinline__ void apply_row(LaneLds *L, const ShardIO &S, int lane, uint32_t sub, uint64_t row, int32_t *hit_meta, int32_t *hit_taxon) {
-  const uint32_t ns = (uint32_t)S.n_shards;
-  uint32_t off = 0;
-  bool in = false;
-  uint64_t meta_at = 0, taxon_at = 0;
-  for (uint32_t sh = 0; sh < ns; sh++) {
-    const uint32_t e = S.batch_base[row * ns + sh];                    // (wave-uniform loads)
-    const uint32_t cnt = e & 127u;
-    if (cnt == 0) continue;
-    const uint64_t list = (uint64_t)sh * (uint32_t)S.n_sub + sub;
-    if ((uint32_t)lane >= off && (uint32_t)lane < off + cnt) {
-      in = true;
-      const uint64_t at = (uint64_t)(e >> 7) + ((uint32_t)lane - off);
-      meta_at = list * S.cap + at;
-      taxon_at = S.list_off[list] + at;
-    }
-    off += cnt;
-  }
-  uint32_t meta = 0;
-  int32_t taxon = 0;
-  if (in) {
-    meta = S.send_meta[meta_at];
-    taxon = S.taxa[taxon_at];
-    if (HITS) {   // the un-merged hit list, as probe_batch writes it (the owners answer in the caller's ids)
-      const uint64_t at = L->rb[meta & 63] + (meta >> 20);
-      hit_taxon[at] = taxon;
-      hit_meta[at] = pack_meta((int32_t)((meta >> 7) & 0x1FFF), 1, (meta >> 6) & 1);
-    }
-    if (S.to_dense != nullptr && taxon > 0) taxon = taxon < S.n_to_dense ? S.to_dense[taxon] : 0;  // (owners answer in the caller's ids)
-  }
-  fold_hit<false>(L, nullptr, in, meta, taxon);
   lane_wave_sync();
 }
 
@@ -504,11 +510,134 @@ __device__ __attribute__((noinline)) void hand_on(unsigned long long *hdr, uint3
   }
 }
 
+// Per-read classification, one lane per read: the map the probe batches (or the APPLY job's replay) folded for the lane's fragment
+// -> TaxonCounts / resolveTree / the minHitGroups test -> the fragment's output rows.  oflags = the lane's o_flags word.
+template <bool HITS, bool LONG>
+__device__ __forceinline__ void resolve_lane(LaneLds *L, uint32_t *ocnt, const FusedArgs &A, int lane, uint64_t r, uint32_t oflags, int32_t total,
+                                             int32_t nhits, int32_t np, int dbg) {
+  const int32_t nd = (int32_t)oflags;
+  // The map's entries move to the front of the lane's column (their hash order has served its purpose): entry j of D.
+  uint32_t *const ecnt = LONG ? ocnt : L->omap;
+  int D = 0;
+  for (int s = 0; s < OMAP; s++) {
+    const uint32_t e = L->omap[s * 64 + lane];
+    if (e != 0) {
+      if (LONG) ocnt[D * 64 + lane] = ocnt[s * 64 + lane];
+      L->omap[D * 64 + lane] = e;
+      D++;
+    }
+  }
+#define ENT_TAXON(j) (LONG ? (int32_t)L->omap[(j) * 64 + lane] : (int32_t)(L->omap[(j) * 64 + lane] >> OMAP_CNT_BITS))
+#define ENT_COUNT(j) (LONG ? (int32_t)ecnt[(j) * 64 + lane] : (int32_t)(ecnt[(j) * 64 + lane] & OMAP_CNT_MASK))
+  int32_t maxTaxon = D ? ENT_TAXON(0) : 0;  // D <= 1: the single taxon (or NONE)
+  const int32_t c0 = D ? ENT_COUNT(0) : 0;
+  // D >= 2: resolveTree on Euler-tour intervals (engine.h: FusedArgs.nodes).  One 16-byte load per map taxon, issued back
+  // to back, brings its interval; "is a an ancestor-or-self of b" is then two compares, for the root-path scores (step 1)
+  // as for the clade sums of the confidence walk (step 2).  The intervals live in the probe queue's LDS, idle by now.
+  uint32_t *const tin = (uint32_t *)L, *const tout = tin + OMAP * 64;
+  static_assert(offsetof(LaneLds, omap) >= 2 * OMAP * 64 * sizeof(uint32_t), "the intervals alias the queue and the read stream's slots");
+  uint32_t m_in = 0, m_out = 0;   // maxTaxon's interval
+  int32_t sum_all = c0;
+  if (D >= 2 && !SLK_TUNE_ON(16)) {  // (16: timing experiment)
+#pragma unroll
+    for (int j = 0; j < OMAP; j++) {
+      if (j < D) {
+        const uint4 nj = lane_node(A.nodes, A.ntax, ENT_TAXON(j));
+        tin[j * 64 + lane] = nj.y;
+        tout[j * 64 + lane] = nj.z;
+      }
+    }
+    // step 1 (:101-123): the LCA of the taxa with the maximal root-path score -- a taxon's score is the k-mer count of the
+    // map taxa on its root path, i.e. of the entries whose interval holds its tin
+    maxTaxon = 0;
+    sum_all = 0;
+    int32_t best = 0;
+    for (int a = 0; a < D; a++) {
+      const uint32_t ain = tin[a * 64 + lane], aout = tout[a * 64 + lane];
+      int32_t score = 0;
+      for (int b = 0; b < D; b++)
+        score += (tin[b * 64 + lane] <= ain && ain <= tout[b * 64 + lane]) ? ENT_COUNT(b) : 0;
+      sum_all += ENT_COUNT(a);
+      if (score > best) {
+        maxTaxon = ENT_TAXON(a); best = score; m_in = ain; m_out = aout;
+      } else if (score == best) {   // LowestCommonAncestor.apply :49-78 of (maxTaxon, this taxon)
+        if (m_in <= ain && ain <= m_out) {
+          // maxTaxon is an ancestor-or-self of this taxon: it stays
+        } else if (ain <= m_in && m_in <= aout) {
+          maxTaxon = ENT_TAXON(a); m_in = ain; m_out = aout;
+        } else {                   // neither: the first node above maxTaxon whose interval holds this taxon
+          int32_t x = (int32_t)lane_node(A.nodes, A.ntax, maxTaxon).x;
+          uint4 nx = make_uint4(0, 0, 0, 0);
+          while (x != 0) {
+            nx = lane_node(A.nodes, A.ntax, x);
+            if (nx.y <= ain && ain <= nx.z) break;
+            x = (int32_t)nx.x;
+          }
+          if (x == 0) { x = 1; nx = lane_node(A.nodes, A.ntax, 1); }   // no common node: ROOT (:77)
+          maxTaxon = x; m_in = nx.y; m_out = nx.z;
+        }
+      }
+    }
+  }
+  for (int32_t c = 0; c < A.C; c++) {
+    const double required = ceil(__dmul_rn(A.thr.v[c], (double)total));  // Math.ceil(confidence * totalKmers) :94
+    int32_t mt = maxTaxon;
+    if (D < 2 || SLK_TUNE_ON(16)) {
+      // one taxon: its clade sum never grows (NONE is in no clade), so it is the call or there is none (:125-144)
+      if ((double)c0 < required) mt = 0;
+    } else {
+      // step 2 (:125-144): from maxTaxon towards the root until the clade of the candidate holds `required` k-mers of the
+      // map.  The clade sum only changes where the candidate's interval comes to hold another map taxon, and once it holds
+      // them all no ancestor can do better: the walk ends there (the reference goes on to the root and finds nothing).
+      uint32_t cin = m_in, cout = m_out;
+      uint4 cur = make_uint4(0, 0, 0, 0);
+      bool have_cur = false;
+      while (mt != 0) {
+        int32_t ms = 0;
+        bool side = false;          // a map taxon outside the clade that is NOT an ancestor of the candidate
+        int up = -1;                // the nearest map taxon above the candidate
+        uint32_t up_in = 0;
+        for (int j = 0; j < D; j++) {
+          const uint32_t jin = tin[j * 64 + lane], jout = tout[j * 64 + lane];
+          const bool inside = cin <= jin && jin <= cout;
+          ms += inside ? ENT_COUNT(j) : 0;
+          const bool above = !inside && jin <= cin && cin <= jout;
+          side = side || (!inside && !above);
+          if (above && (up < 0 || jin > up_in)) { up = j; up_in = jin; }   // (deeper on one root path = later in the tour)
+        }
+        if ((double)ms >= required) break;
+        if (ms == sum_all) { mt = 0; break; }
+        if (!side) {
+          // everything left lies above the candidate, on its root path: the next clade that differs is the nearest of them
+          mt = ENT_TAXON(up); cin = up_in; cout = tout[up * 64 + lane];
+          have_cur = false;
+        } else {
+          if (!have_cur) cur = lane_node(A.nodes, A.ntax, mt);
+          mt = (int32_t)cur.x;                                           // Taxonomy.parents
+          if (mt != 0) { cur = lane_node(A.nodes, A.ntax, mt); have_cur = true; cin = cur.y; cout = cur.z; }
+        }
+      }
+    }
+    bool classified = (mt != 0) && (nd >= A.min_hit_groups);            // Classifier.scala:445
+    A.out_taxon[(uint64_t)c * A.out_stride + r] = classified ? ext_taxon(A.T, mt) : 0;
+    A.out_classified[(uint64_t)c * A.out_stride + r] = classified ? 1 : 0;
+  }
+#undef ENT_TAXON
+#undef ENT_COUNT
+  if (A.out_nd) A.out_nd[r] = nd;
+  if (A.out_tk) A.out_tk[r] = total;
+  if (A.out_nh) A.out_nh[r] = nhits;
+  if (HITS) A.span_count[r] = nhits;
+  if (A.out_np) A.out_np[r] = np;
+}
+
 // LONG: the second pass, over the fragments of 1 001 .. A.long_max bases that the first one handed on (hand-on lists 0..3, one per
 // length class), with a map of full 32-bit counts (such a fragment has up to 4 965 k-mers for one taxon; the one-word map of the hot
 // variant counts to 1 023).  What overflows its map too goes on to the wave kernel's list.  The hot variant is untouched by it.
+// MODE == LANE_EMIT (lane_step_kernel): the table-sharded step -- the scan sends its minimizers off instead of probing (EMIT job of
+// batch A), and an earlier batch's lookups (S.side_*) and a yet earlier batch's classification (J) ride along (engine.h: ShardIO).
 template <bool W5, int MODE, bool HITS, bool LONG>
-__global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, uint32_t max_len, int dbg) {
+__device__ __forceinline__ void lane_body(const FusedArgs &A, const ShardIO &S, const ApplyJob *Jp, int32_t *defer, uint32_t max_len, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -524,7 +653,8 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
   uint64_t *win = (uint64_t *)((unsigned char *)L + fixed);
   uint32_t *ocnt = LONG ? (uint32_t *)((unsigned char *)L + fixed + win_bytes) : nullptr;   // LONG: k-mer counts of the map's slots
   const bool paired = A.mate_bases != nullptr;
-  const uint64_t bases_end = A.offsets[A.R], mates_end = paired ? A.mate_offsets[A.R] : 0;  // (wave-uniform loads)
+  const bool scans = MODE != LANE_EMIT || A.R != 0;   // (a step may carry side jobs only)
+  const uint64_t bases_end = scans ? A.offsets[A.R] : 0, mates_end = (scans && paired) ? A.mate_offsets[A.R] : 0;  // (wave-uniform loads)
   // LONG: tiles of the four class lists one after the other (a tile never mixes classes); the first pass has finished (same stream)
   uint64_t cls_n[4] = {0, 0, 0, 0}, cls_tiles[4] = {0, 0, 0, 0};
   uint64_t ntiles = (A.R + 63) / 64;
@@ -534,6 +664,12 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     for (int c = 0; c < 4; c++) { cls_n[c] = A.hand_hdr[c]; cls_tiles[c] = (cls_n[c] + 63) / 64; ntiles += cls_tiles[c]; }
   }
   const uint64_t nwaves = (uint64_t)gridDim.x * LW;
+  // EMIT: tiles of the scan and tiles of the APPLY job (an earlier batch: its tile t rides with the scan's tile t; whichever batch
+  // has more tiles, the rest go alone); the chunk of every owner's send region this wave is filling, in lane `owner`
+  const uint64_t etiles = ntiles;
+  const uint64_t atiles = MODE == LANE_EMIT ? (Jp->A.R + 63) / 64 : 0;
+  if (MODE == LANE_EMIT) ntiles = max(etiles, atiles);
+  uint32_t ch_pos = 0, ch_end = 0;
 
   // (The 64 lanes of a wave run in lockstep, so a tile lasts as long as its longest fragment.  Two ways of handing the tiles
   // fragments of similar length were measured in round 2 and dropped, profiles/r02_mixed_lengths.json: sorting a block's 256
@@ -548,6 +684,13 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       if (it) {
         unsigned long long t = 0;
         if (lane == 0) t = atomicAdd(&A.hand_hdr[6], 1ULL);
+        tile = nwaves + lane_readlane64(t, 0);
+      }
+    } else if (MODE == LANE_EMIT) {
+      // persistent waves (they carry their chunks from tile to tile), tiles drawn from a counter as above
+      if (it) {
+        unsigned long long t = 0;
+        if (lane == 0) t = atomicAdd(&S.cursors[S.n_shards], 1ULL);
         tile = nwaves + lane_readlane64(t, 0);
       }
     } else if (it) {
@@ -579,13 +722,24 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       if (paired) n2 = (uint32_t)(A.mate_offsets[r + 1] - A.mate_offsets[r]);  // (the mate's place is read again when the scan gets there)
     }
     bool too_long = have && ((uint64_t)n + n2 > max_len);
-    bool fin = !have || too_long || MODE == LANE_APPLY;   // (the second pass of the sharded mode does not scan)
-    // sharded modes: the tile's first row in the batch log.  A tile's probes number at most its bases, and tile t starts at
-    // row floor(span_region(first fragment of t) / 64) + t: rows of different tiles never overlap (capi.hip: shard_batch_rows)
-    uint64_t row = 0;
-    if (MODE != LANE_LOCAL) row = (span_region(A.offsets, A.mate_offsets, tile * 64) >> 6) + tile;
+    bool fin = !have || too_long;
+    // EMIT: the tile's first row in the batch log.  A tile's probes number at most its bases, and tile t starts at
+    // row floor(span_region(first fragment of t) / 64) + t: rows of different tiles never overlap (capi.hip: slk_shard_batch_rows)
+    uint64_t row = 0, row0 = 0;
+    if (MODE == LANE_EMIT && tile < etiles) row = row0 = (span_region(A.offsets, A.mate_offsets, tile * 64) >> 6) + tile;
     const uint64_t rbase = (HITS && have) ? span_region(A.offsets, A.mate_offsets, r) : 0;
-    if (HITS) L->rb[lane] = rbase;
+    if (HITS && MODE != LANE_EMIT) L->rb[lane] = rbase;
+    // EMIT: the APPLY job's tile of the same number -- its rows of the log, and for hit lists its fragments' span regions
+    uint32_t ap_rows = 0, ap_done = 0;
+    uint64_t ap_row0 = 0;
+    const uint64_t r2 = tile * 64 + lane;
+    bool have2 = false;
+    if (MODE == LANE_EMIT && tile < atiles) {
+      const uint2 tr = Jp->tile_rows[tile];   // (wave-uniform load)
+      ap_row0 = tr.x; ap_rows = tr.y;
+      have2 = r2 < Jp->A.R;
+      if (HITS) L->rb[lane] = have2 ? span_region(Jp->A.offsets, Jp->A.mate_offsets, r2) : 0;
+    }
     // ---- per-lane LDS state ----
 #pragma unroll
     for (int s = 0; s < OMAP; s++) L->omap[s * 64 + lane] = 0;
@@ -657,20 +811,14 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
     bool first = true, have_last = false;
     uint64_t last_key = 0;
     int32_t total = 0, np = 0, nhits = 0;
-    uint32_t side_j = (MODE == LANE_EMIT && S.side_n != 0) ? 0u : 0xFFFFFFFFu;   // batches of the side job done by this tile (wave-uniform)
-    uint64_t side_key = (MODE == LANE_EMIT && S.side_n != 0 && S.side_per_tile != 0) ? side_load(S, tile * S.side_per_tile, lane) : 0;
+    uint32_t side_j = (MODE == LANE_EMIT && S.side_n != 0 && tile < etiles) ? 0u : 0xFFFFFFFFu;   // batches of the LOOKUP job done by this tile (wave-uniform)
+    uint64_t side_key = (MODE == LANE_EMIT && S.side_n != 0 && S.side_per_tile != 0 && tile < etiles) ? side_load(S, tile * S.side_per_tile, lane) : 0;
     int qn = 0;       // queue fill (wave-uniform)
     int qhead = 0;    // ring position of the oldest queued entry (wave-uniform)
     int tphase = 0;   // generic window: step mod w (wave-uniform)
 
     const uint32_t VM = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20) | (1u << 21);  // A C G T U, either case
-    if (MODE == LANE_APPLY) {
-      // the second pass of the table-sharded mode: what the scan of the first pass found is on file
-      const uint32_t nrows = S.tile_rows[tile];
-      lane_wave_sync();
-      for (uint32_t b = 0; b < nrows; b++) apply_row<HITS>(L, S, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row + b, A.span_meta, A.span_taxon);
-      if (have) { total = S.read_info[r].x; nhits = S.read_info[r].y; }
-    }
+    if (MODE == LANE_EMIT) lane_wave_sync();   // (the map's reset above is seen by the APPLY job's atomics)
     while (__ballot(!fin) != 0) {
       // One event per lane per step: a character, or the end of a mate.  Straight-line predicated code: the per-read
       // control flow (Supermers.splitByAmbiguity :150-178, MinSplitter.splitRead :133-172) is data, not branches.
@@ -827,7 +975,7 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
         while (qn >= 64) {
           lane_wave_sync();
           int back = 0;
-          if (MODE == LANE_EMIT) emit_batch<HITS>(L, A, S, qhead, 64, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++, tile, side_j, side_key);
+          if (MODE == LANE_EMIT) emit_batch<HITS>(L, A, S, *Jp, qhead, 64, lane, row++, tile, ch_pos, ch_end, side_j, side_key, ap_done, ap_rows, ap_row0);
           else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS, LONG>(L, ocnt, A.T, qhead, qn, 64, lane, dbg, A.span_meta, A.span_taxon);
           qhead = (qhead + 64) & (QCAP - 1);
           qn += back - 64;
@@ -838,170 +986,85 @@ __global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, 
       lane_wave_sync();
       const int cnt = min(qn, 64);
       int back = 0;
-      if (MODE == LANE_EMIT) emit_batch<HITS>(L, A, S, qhead, cnt, lane, (uint32_t)tile & (uint32_t)(S.n_sub - 1), row++, tile, side_j, side_key);
+      if (MODE == LANE_EMIT) emit_batch<HITS>(L, A, S, *Jp, qhead, cnt, lane, row++, tile, ch_pos, ch_end, side_j, side_key, ap_done, ap_rows, ap_row0);
       else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS, LONG>(L, ocnt, A.T, qhead, qn, cnt, lane, dbg, A.span_meta, A.span_taxon);
       qhead = (qhead + cnt) & (QCAP - 1);
       qn += back - cnt;
     }
     lane_wave_sync();
-    if (MODE == LANE_EMIT) {   // what the second pass cannot recompute without scanning again
-      if (have) S.read_info[r] = make_int2(total, nhits);
-      if (lane == 0) S.tile_rows[tile] = (uint32_t)(row - ((span_region(A.offsets, A.mate_offsets, tile * 64) >> 6) + tile));
-      if (S.side_n != 0) {
-        // a tile that sent off fewer batches than it owns of the side job answers the rest of its share now (a few at most:
-        // the shares are dealt out by the batch's average)
-        while (side_j < S.side_per_tile) {
-          const uint64_t batch = tile * S.side_per_tile + side_j;
-          const uint64_t k_now = side_key;
-          side_j++;
-          if (side_j < S.side_per_tile) side_key = side_load(S, batch + 1, lane);
-          side_probe(L, A.T, S, lane, batch, k_now);
-        }
-        if (lane == 0) S.side_done[tile] = side_j;
+    if (MODE == LANE_EMIT) {
+      if (tile < etiles) {   // what the APPLY cannot recompute without scanning again
+        if (have) S.read_info[r] = make_int2(total, nhits);
+        if (lane == 0) S.tile_rows[tile] = make_uint2((uint32_t)row0, (uint32_t)(row - row0));
       }
+      // a tile that sent off fewer batches than it owns of the LOOKUP job, or than its APPLY twin logged rows, finishes its
+      // share now (a few at most: the shares are dealt out by the batch's average, and neighbouring batches resemble each other)
+      while (side_j < S.side_per_tile) {
+        const uint64_t batch = tile * S.side_per_tile + side_j;
+        const uint64_t k_now = side_key;
+        side_j++;
+        if (side_j < S.side_per_tile) side_key = side_load(S, batch + 1, lane);
+        side_probe(L, A.T, S, lane, batch, k_now);
+      }
+      for (; ap_done < ap_rows; ap_done++) apply_row<HITS>(L, *Jp, lane, ap_row0 + ap_done);
     }
 
     // ---- per-read classification (one lane per read) ------------------------------------------------------------------
-    const uint32_t oflags = have ? L->o_flags[lane] : 0u;
-    const bool dfr = have && (too_long || (oflags & 0x80000000u));  // re-done by the wave-per-read / segment kernels
     if (MODE == LANE_LOCAL) {
+      const uint32_t oflags = have ? L->o_flags[lane] : 0u;
+      const bool dfr = have && (too_long || (oflags & 0x80000000u));  // re-done by the wave-per-read / segment kernels
       if (__ballot(dfr) != 0)   // (rare, and kept out of line: the hot loop's registers and schedule are not to know about it)
         hand_on(A.hand_hdr, A.hand_lists, A.hand_stride, A.long_max, A.long_bound[0], A.long_bound[1], A.long_bound[2], A.seg_min_len,
                 A.offsets, A.mate_offsets, dfr, too_long, r, lane, LONG);
-    } else if (dfr) {
-      defer[r] = 1;  // sharded modes: the caller routes these fragments
-    }
-    if (have) {
-      if (dfr) {
-        // (sharded mode: the caller routes this fragment through the staged kernels; until then it has no spans on file)
-        if (MODE == LANE_APPLY) { if (A.out_nh) A.out_nh[r] = 0; if (HITS) A.span_count[r] = 0; }
-      } else if (MODE != LANE_EMIT) {
-        const int32_t nd = (int32_t)oflags;
-        // The map's entries move to the front of the lane's column (their hash order has served its purpose): entry j of D.
-        uint32_t *const ecnt = LONG ? ocnt : L->omap;
-        int D = 0;
-        for (int s = 0; s < OMAP; s++) {
-          const uint32_t e = L->omap[s * 64 + lane];
-          if (e != 0) {
-            if (LONG) ocnt[D * 64 + lane] = ocnt[s * 64 + lane];
-            L->omap[D * 64 + lane] = e;
-            D++;
-          }
+      if (have && !dfr) resolve_lane<HITS, LONG>(L, ocnt, A, lane, r, oflags, total, nhits, np, dbg);
+    } else {
+      if (have && too_long) defer[r] = 1;   // EMIT job: fragments this kernel does not take (the caller routes them)
+      const bool dfr2 = have2 && (Jp->defer[r2] != 0 || (L->o_flags[lane] & 0x80000000u));   // not taken by its EMIT, or its map overflowed just now
+      const uint64_t DM = __ballot(dfr2);
+      if (DM != 0 && lane == 0) atomicAdd(Jp->n_deferred, (unsigned long long)__popcll(DM));
+      if (have2) {                          // APPLY job: this tile's fragments of the earlier batch
+        const uint32_t oflags = L->o_flags[lane];
+        if (dfr2) {
+          // (the caller routes this fragment through the staged kernels; until then it has no spans on file)
+          Jp->defer[r2] = 1;
+          if (Jp->A.out_nh) Jp->A.out_nh[r2] = 0;
+          if (HITS) Jp->A.span_count[r2] = 0;
+        } else {
+          const int2 ri = Jp->read_info[r2];
+          resolve_lane<HITS, false>(L, nullptr, Jp->A, lane, r2, oflags, ri.x, ri.y, 0, dbg);
         }
-#define ENT_TAXON(j) (LONG ? (int32_t)L->omap[(j) * 64 + lane] : (int32_t)(L->omap[(j) * 64 + lane] >> OMAP_CNT_BITS))
-#define ENT_COUNT(j) (LONG ? (int32_t)ecnt[(j) * 64 + lane] : (int32_t)(ecnt[(j) * 64 + lane] & OMAP_CNT_MASK))
-        int32_t maxTaxon = D ? ENT_TAXON(0) : 0;  // D <= 1: the single taxon (or NONE)
-        const int32_t c0 = D ? ENT_COUNT(0) : 0;
-        // D >= 2: resolveTree on Euler-tour intervals (engine.h: FusedArgs.nodes).  One 16-byte load per map taxon, issued back
-        // to back, brings its interval; "is a an ancestor-or-self of b" is then two compares, for the root-path scores (step 1)
-        // as for the clade sums of the confidence walk (step 2).  The intervals live in the probe queue's LDS, idle by now.
-        uint32_t *const tin = (uint32_t *)L, *const tout = tin + OMAP * 64;
-        static_assert(offsetof(LaneLds, omap) >= 2 * OMAP * 64 * sizeof(uint32_t), "the intervals alias the queue and the read stream's slots");
-        uint32_t m_in = 0, m_out = 0;   // maxTaxon's interval
-        int32_t sum_all = c0;
-        if (D >= 2 && !SLK_TUNE_ON(16)) {  // (16: timing experiment)
-#pragma unroll
-          for (int j = 0; j < OMAP; j++) {
-            if (j < D) {
-              const uint4 nj = lane_node(A.nodes, A.ntax, ENT_TAXON(j));
-              tin[j * 64 + lane] = nj.y;
-              tout[j * 64 + lane] = nj.z;
-            }
-          }
-          // step 1 (:101-123): the LCA of the taxa with the maximal root-path score -- a taxon's score is the k-mer count of the
-          // map taxa on its root path, i.e. of the entries whose interval holds its tin
-          maxTaxon = 0;
-          sum_all = 0;
-          int32_t best = 0;
-          for (int a = 0; a < D; a++) {
-            const uint32_t ain = tin[a * 64 + lane], aout = tout[a * 64 + lane];
-            int32_t score = 0;
-            for (int b = 0; b < D; b++)
-              score += (tin[b * 64 + lane] <= ain && ain <= tout[b * 64 + lane]) ? ENT_COUNT(b) : 0;
-            sum_all += ENT_COUNT(a);
-            if (score > best) {
-              maxTaxon = ENT_TAXON(a); best = score; m_in = ain; m_out = aout;
-            } else if (score == best) {   // LowestCommonAncestor.apply :49-78 of (maxTaxon, this taxon)
-              if (m_in <= ain && ain <= m_out) {
-                // maxTaxon is an ancestor-or-self of this taxon: it stays
-              } else if (ain <= m_in && m_in <= aout) {
-                maxTaxon = ENT_TAXON(a); m_in = ain; m_out = aout;
-              } else {                   // neither: the first node above maxTaxon whose interval holds this taxon
-                int32_t x = (int32_t)lane_node(A.nodes, A.ntax, maxTaxon).x;
-                uint4 nx = make_uint4(0, 0, 0, 0);
-                while (x != 0) {
-                  nx = lane_node(A.nodes, A.ntax, x);
-                  if (nx.y <= ain && ain <= nx.z) break;
-                  x = (int32_t)nx.x;
-                }
-                if (x == 0) { x = 1; nx = lane_node(A.nodes, A.ntax, 1); }   // no common node: ROOT (:77)
-                maxTaxon = x; m_in = nx.y; m_out = nx.z;
-              }
-            }
-          }
-        }
-        for (int32_t c = 0; c < A.C; c++) {
-          const double required = ceil(__dmul_rn(A.thr.v[c], (double)total));  // Math.ceil(confidence * totalKmers) :94
-          int32_t mt = maxTaxon;
-          if (D < 2 || SLK_TUNE_ON(16)) {
-            // one taxon: its clade sum never grows (NONE is in no clade), so it is the call or there is none (:125-144)
-            if ((double)c0 < required) mt = 0;
-          } else {
-            // step 2 (:125-144): from maxTaxon towards the root until the clade of the candidate holds `required` k-mers of the
-            // map.  The clade sum only changes where the candidate's interval comes to hold another map taxon, and once it holds
-            // them all no ancestor can do better: the walk ends there (the reference goes on to the root and finds nothing).
-            uint32_t cin = m_in, cout = m_out;
-            uint4 cur = make_uint4(0, 0, 0, 0);
-            bool have_cur = false;
-            while (mt != 0) {
-              int32_t ms = 0;
-              bool side = false;          // a map taxon outside the clade that is NOT an ancestor of the candidate
-              int up = -1;                // the nearest map taxon above the candidate
-              uint32_t up_in = 0;
-              for (int j = 0; j < D; j++) {
-                const uint32_t jin = tin[j * 64 + lane], jout = tout[j * 64 + lane];
-                const bool inside = cin <= jin && jin <= cout;
-                ms += inside ? ENT_COUNT(j) : 0;
-                const bool above = !inside && jin <= cin && cin <= jout;
-                side = side || (!inside && !above);
-                if (above && (up < 0 || jin > up_in)) { up = j; up_in = jin; }   // (deeper on one root path = later in the tour)
-              }
-              if ((double)ms >= required) break;
-              if (ms == sum_all) { mt = 0; break; }
-              if (!side) {
-                // everything left lies above the candidate, on its root path: the next clade that differs is the nearest of them
-                mt = ENT_TAXON(up); cin = up_in; cout = tout[up * 64 + lane];
-                have_cur = false;
-              } else {
-                if (!have_cur) cur = lane_node(A.nodes, A.ntax, mt);
-                mt = (int32_t)cur.x;                                           // Taxonomy.parents
-                if (mt != 0) { cur = lane_node(A.nodes, A.ntax, mt); have_cur = true; cin = cur.y; cout = cur.z; }
-              }
-            }
-          }
-          bool classified = (mt != 0) && (nd >= A.min_hit_groups);            // Classifier.scala:445
-          A.out_taxon[(uint64_t)c * A.out_stride + r] = classified ? ext_taxon(A.T, mt) : 0;
-          A.out_classified[(uint64_t)c * A.out_stride + r] = classified ? 1 : 0;
-        }
-#undef ENT_TAXON
-#undef ENT_COUNT
-        if (A.out_nd) A.out_nd[r] = nd;
-        if (A.out_tk) A.out_tk[r] = total;
-        if (A.out_nh) A.out_nh[r] = nhits;
-        if (HITS) A.span_count[r] = nhits;
-        if (A.out_np) A.out_np[r] = np;
       }
     }
     lane_wave_sync();
   }
+  if (MODE == LANE_EMIT) {
+    // the tails of the chunks this wave still holds are never written: zero keys (they travel and are answered; nobody reads the answers)
+    for (uint32_t sh = 0; sh < (uint32_t)S.n_shards; sh++) {
+      const uint32_t p0 = __builtin_amdgcn_readlane(ch_pos, sh), p1 = __builtin_amdgcn_readlane(ch_end, sh);
+      for (uint32_t i = p0 + (uint32_t)lane; i < p1; i += 64) S.send_keys[(uint64_t)sh * S.cap + i] = 0;
+    }
+  }
 }
 
-template <int MODE, bool HITS, bool LONG>
-static void launch_lane_mode(const FusedArgs &A, const ShardIO &S, int32_t *defer, uint32_t max_len, hipStream_t s) {
+template <bool W5, int MODE, bool HITS, bool LONG>
+__global__ void LANE_BOUNDS lane_kernel(FusedArgs A, ShardIO S, int32_t *defer, uint32_t max_len, int dbg) {
+  lane_body<W5, MODE, HITS, LONG>(A, S, nullptr, defer, max_len, dbg);
+}
+// the table-sharded step (engine.h: ShardIO): EMIT job of batch A + LOOKUP job (S.side_*) + APPLY job J of earlier batches
+template <bool W5, bool HITS>
+__global__ void LANE_BOUNDS lane_step_kernel(FusedArgs A, ShardIO S, ApplyJob J, int32_t *defer, uint32_t max_len, int dbg) {
+  lane_body<W5, LANE_EMIT, HITS, false>(A, S, &J, defer, max_len, dbg);
+}
+
+static size_t lane_lds_per_wave(bool hits, bool w5, int w, bool lng) {
+  return (hits ? sizeof(LaneLds) : offsetof(LaneLds, rb)) + (w5 ? 0 : (size_t)w * 64 * sizeof(uint64_t)) + (lng ? (size_t)OMAP * 64 * sizeof(uint32_t) : 0);
+}
+
+template <bool HITS, bool LONG>
+static void launch_lane_mode(const FusedArgs &A, int32_t *defer, uint32_t max_len, hipStream_t s) {
   if (A.R == 0) return;
   const bool w5 = A.P.w == 5;
-  size_t per_wave = (HITS ? sizeof(LaneLds) : offsetof(LaneLds, rb)) + (w5 ? 0 : (size_t)A.P.w * 64 * sizeof(uint64_t)) +
-                    (LONG ? (size_t)OMAP * 64 * sizeof(uint32_t) : 0);
+  const size_t per_wave = lane_lds_per_wave(HITS, w5, A.P.w, LONG);
   static const int extra_lds = getenv("SLK_LANE_EXTRA_LDS") ? atoi(getenv("SLK_LANE_EXTRA_LDS")) : 0;  // (occupancy experiment)
   size_t lds = per_wave * LW + (size_t)extra_lds;
   uint64_t tiles = (A.R + 63) / 64;
@@ -1019,28 +1082,54 @@ static void launch_lane_mode(const FusedArgs &A, const ShardIO &S, int32_t *defe
   if (getenv("SLK_DEBUG_OCC") && !occ_printed) {  // (tuning aid)
     occ_printed = true;
     int nb = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, w5 ? (const void *)lane_kernel<true, MODE, HITS, LONG> : (const void *)lane_kernel<false, MODE, HITS, LONG>, LW * 64, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, w5 ? (const void *)lane_kernel<true, LANE_LOCAL, HITS, LONG> : (const void *)lane_kernel<false, LANE_LOCAL, HITS, LONG>, LW * 64, lds);
     fprintf(stderr, "[slk] lane kernel: %zu B LDS per block, %d blocks (%d waves) resident per CU\n", lds, nb, nb * LW);
   }
-  if (w5) hipLaunchKernelGGL((lane_kernel<true, MODE, HITS, LONG>), g, b, lds, s, A, S, defer, max_len, dbg);
-  else hipLaunchKernelGGL((lane_kernel<false, MODE, HITS, LONG>), g, b, lds, s, A, S, defer, max_len, dbg);
+  if (w5) hipLaunchKernelGGL((lane_kernel<true, LANE_LOCAL, HITS, LONG>), g, b, lds, s, A, ShardIO{}, defer, max_len, dbg);
+  else hipLaunchKernelGGL((lane_kernel<false, LANE_LOCAL, HITS, LONG>), g, b, lds, s, A, ShardIO{}, defer, max_len, dbg);
 }
 
 // A.span_taxon set: the hit lists are written too (span_meta / span_taxon / span_count, the layout of MODE_HITS)
 void launch_lane(const FusedArgs &A, int32_t *defer, uint32_t max_len, hipStream_t s) {
-  if (A.span_taxon) launch_lane_mode<LANE_LOCAL, true, false>(A, ShardIO{}, defer, max_len, s);
-  else launch_lane_mode<LANE_LOCAL, false, false>(A, ShardIO{}, defer, max_len, s);
+  if (A.span_taxon) launch_lane_mode<true, false>(A, defer, max_len, s);
+  else launch_lane_mode<false, false>(A, defer, max_len, s);
 }
 // the pass over the first one's hand-ons of 1 001 .. A.long_max bases (hand-on lists 0..3)
 void launch_lane_long(const FusedArgs &A, uint32_t max_len, hipStream_t s) {
-  if (A.span_taxon) launch_lane_mode<LANE_LOCAL, true, true>(A, ShardIO{}, nullptr, max_len, s);
-  else launch_lane_mode<LANE_LOCAL, false, true>(A, ShardIO{}, nullptr, max_len, s);
+  if (A.span_taxon) launch_lane_mode<true, true>(A, nullptr, max_len, s);
+  else launch_lane_mode<false, true>(A, nullptr, max_len, s);
 }
-// A.span_taxon set (both passes): the hit lists are written too -- the flagged spans by the first pass, the hits by the second
-void launch_lane_sharded(int mode, const FusedArgs &A, const ShardIO &S, int32_t *defer, uint32_t max_len, hipStream_t s) {
-  const bool hits = A.span_taxon != nullptr;
-  if (mode == LANE_EMIT) { if (hits) launch_lane_mode<LANE_EMIT, true, false>(A, S, defer, max_len, s); else launch_lane_mode<LANE_EMIT, false, false>(A, S, defer, max_len, s); }
-  else { if (hits) launch_lane_mode<LANE_APPLY, true, false>(A, S, defer, max_len, s); else launch_lane_mode<LANE_APPLY, false, false>(A, S, defer, max_len, s); }
+
+// The table-sharded step: any of the three jobs may be absent (A.R == 0: no scan; S.side_n == 0: no lookups -- they need a scan to ride
+// in; J.A.R == 0: no replay).  Hit lists are written when the batches carry span arrays (A.span_taxon / J.A.span_taxon: the
+// flagged spans by the EMIT, the hits by the APPLY).  The grid is what the part holds at once: the waves are persistent, they keep
+// the chunks of the send regions they are filling from tile to tile and draw their tiles from S.cursors[n_shards] (zero beforehand).
+template <bool W5, bool HITS>
+static void launch_step_mode(const FusedArgs &A, const ShardIO &S, const ApplyJob &J, int32_t *defer, uint32_t max_len, hipStream_t s) {
+  const uint64_t tiles = std::max((A.R + 63) / 64, (J.A.R + 63) / 64);
+  if (tiles == 0) return;
+  const size_t lds = lane_lds_per_wave(HITS, W5, A.P.w, false) * LW;
+  static int resident[2][2] = {{0, 0}, {0, 0}};   // blocks per CU by (W5, HITS) at the default window; other windows: asked every time
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  int nb = W5 ? resident[1][HITS] : 0;
+  if (nb == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)lane_step_kernel<W5, HITS>, LW * 64, lds) != hipSuccess || nb <= 0) nb = 4;
+    if (W5) resident[1][HITS] = nb;
+  }
+  static const int bpc = getenv("SLK_STEP_BLOCKS_PER_CU") ? atoi(getenv("SLK_STEP_BLOCKS_PER_CU")) : 0;  // (tuning experiment)
+  if (bpc > 0) nb = bpc;
+  const uint64_t blocks = std::min<uint64_t>((tiles + LW - 1) / LW, (uint64_t)cus * nb);
+  hipLaunchKernelGGL((lane_step_kernel<W5, HITS>), dim3((unsigned)blocks), dim3(LW * 64), lds, s, A, S, J, defer, max_len, 0);
+}
+void launch_lane_step(const FusedArgs &A, const ShardIO &S, const ApplyJob &J, int32_t *defer, uint32_t max_len, hipStream_t s) {
+  const bool hits = A.R ? A.span_taxon != nullptr : J.A.span_taxon != nullptr;
+  if (A.P.w == 5) { if (hits) launch_step_mode<true, true>(A, S, J, defer, max_len, s); else launch_step_mode<true, false>(A, S, J, defer, max_len, s); }
+  else { if (hits) launch_step_mode<false, true>(A, S, J, defer, max_len, s); else launch_step_mode<false, false>(A, S, J, defer, max_len, s); }
 }
 
 }  // namespace slk

@@ -1,5 +1,6 @@
-// shard.hip -- the owner side of table-sharded classification (BASELINE configs[3]): point lookups of the keys
-// received from the other ranks, and the scatter of the answers a rank got back to the slots its fragments read them from.
+// shard.hip -- the owner side of table-sharded classification (BASELINE configs[3]) as a kernel of its own: point
+// lookups of the keys received from the other ranks, for the steps of the pipeline that have no scan to carry them (its first and
+// last batches; lane.hip's step kernel answers the others inside the scan) and for the staged route.
 // The lookup is the left join + spanToHit's otherwise(NONE) (S/slacken/Classifier.scala:84, KeyValueIndex.scala:176-185) for
 // keys that arrive without their fragment.
 #include <hip/hip_runtime.h>
@@ -24,8 +25,7 @@ __device__ __forceinline__ void wsync() {
 // wave instruction, LPB instructions in flight -- the access shape of the classify kernel's probe.  A key whose home bucket
 // is full without holding it, and has overflowed (its flag), continues alone in the next buckets.
 __global__ void __launch_bounds__(SW * 64) lookup_coop_kernel(TableView T, const int64_t *__restrict__ keys, uint64_t n,
-                                                              int32_t *__restrict__ out, uint32_t per_tile, uint64_t tiles,
-                                                              const uint32_t *__restrict__ done) {
+                                                              int32_t *__restrict__ out) {
   constexpr int PG = 64 / LPB;
   __shared__ __attribute__((aligned(16))) uint4 stash_all[SW][64];
   const int lane = threadIdx.x & 63;
@@ -35,13 +35,9 @@ __global__ void __launch_bounds__(SW * 64) lookup_coop_kernel(TableView T, const
   const uint64_t tmask = (1ULL << T.g.taxon_bits) - 1;
   const int g = lane / LPB, c = lane % LPB;
   const char *cellbase = (const char *)T.cells + c * 16;
-  // done == nullptr: all keys, 64 per wave iteration.  Otherwise what an emit launch's side job left over (engine.h ShardIO.side_*):
-  // a wave iteration is a TILE of that launch, and of the tile's batches those from done[tile] on are answered
-  const uint64_t units = done ? tiles : (n + 63) / 64;
-  for (uint64_t unit = (uint64_t)blockIdx.x * SW + wib; unit < units; unit += nwaves)
-  for (uint64_t j = done ? done[unit] : 0, j1 = done ? per_tile : 1; j < j1; j++) {
-    const uint64_t base = (done ? unit * per_tile + j : unit) * 64;
-    if (base >= n) break;
+  const uint64_t units = (n + 63) / 64;
+  for (uint64_t unit = (uint64_t)blockIdx.x * SW + wib; unit < units; unit += nwaves) {
+    const uint64_t base = unit * 64;
     const uint64_t i = base + lane;
     const bool in = i < n;
     const uint64_t key = in ? (uint64_t)keys[i] : 0;
@@ -101,48 +97,6 @@ __global__ void __launch_bounds__(SW * 64) lookup_coop_kernel(TableView T, const
   }
 }
 
-// exclusive prefix of the sub-list lengths (clamped to the capacity: an overflow has been flagged by the emit kernel)
-__global__ void __launch_bounds__(256) list_prefix_kernel(const unsigned long long *__restrict__ counts, uint32_t n_shards, uint32_t n_sub,
-                                                          uint64_t cap, uint64_t *__restrict__ list_off, uint64_t *__restrict__ owner_counts) {
-  __shared__ uint64_t part[256];
-  const uint32_t n = n_shards * n_sub, t = threadIdx.x;
-  const uint32_t per = (n + 255) / 256;
-  const uint32_t a = min(n, t * per), b = min(n, a + per);
-  uint64_t sum = 0;
-  for (uint32_t i = a; i < b; i++) sum += min((uint64_t)counts[i], cap);
-  part[t] = sum;
-  __syncthreads();
-  if (t == 0) {
-    uint64_t run = 0;
-    for (int i = 0; i < 256; i++) { uint64_t v = part[i]; part[i] = run; run += v; }
-    list_off[n] = run;
-  }
-  __syncthreads();
-  uint64_t run = part[t];
-  for (uint32_t i = a; i < b; i++) { list_off[i] = run; run += min((uint64_t)counts[i], cap); }
-  __syncthreads();
-  __threadfence_block();
-  if (t < n_shards) {  // (n_shards <= 64)
-    uint64_t c = 0;
-    for (uint32_t i = t * n_sub; i < (t + 1) * n_sub; i++) c += min((uint64_t)counts[i], cap);
-    owner_counts[t] = c;
-  }
-  if (t == 64) {  // [n_shards]: how many lists overflowed their capacity (the caller emits again with longer lists)
-    uint64_t over = 0;
-    for (uint32_t i = 0; i < n; i++) over += (uint64_t)counts[i] > cap;
-    owner_counts[n_shards] = over;
-  }
-}
-// one block column per sub-list: its keys move to their place in the contiguous array
-__global__ void __launch_bounds__(256) list_copy_kernel(const int64_t *__restrict__ send_keys, const unsigned long long *__restrict__ counts,
-                                                        uint64_t cap, const uint64_t *__restrict__ list_off, int64_t *__restrict__ out) {
-  const uint64_t list = blockIdx.y;
-  const uint64_t n = min((uint64_t)counts[list], cap);
-  const int64_t *src = send_keys + list * cap;
-  int64_t *dst = out + list_off[list];
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
-}
-
 }  // namespace
 
 void launch_lookup_coop(const TableView &t, const int64_t *keys, uint64_t n, int32_t *out, hipStream_t s) {
@@ -153,21 +107,6 @@ void launch_lookup_coop(const TableView &t, const int64_t *keys, uint64_t n, int
   // table small enough for the Infinity Cache; now the stages of the sharded pipeline follow each other on one stream.
   static const int bpc = getenv("SLK_LOOKUP_BLOCKS_PER_CU") ? std::max(1, atoi(getenv("SLK_LOOKUP_BLOCKS_PER_CU"))) : 16;
   uint64_t blocks = std::min<uint64_t>((n + SW * 64 - 1) / (SW * 64), (uint64_t)256 * bpc);
-  hipLaunchKernelGGL(lookup_coop_kernel, dim3((unsigned)blocks), dim3(SW * 64), 0, s, t, keys, n, out, 0u, (uint64_t)0, (const uint32_t *)nullptr);
+  hipLaunchKernelGGL(lookup_coop_kernel, dim3((unsigned)blocks), dim3(SW * 64), 0, s, t, keys, n, out);
 }
-void launch_lookup_coop_rest(const TableView &t, const int64_t *keys, uint64_t n, uint32_t per_tile, uint64_t tiles, const uint32_t *done,
-                             int32_t *out, hipStream_t s) {
-  if (n == 0 || tiles == 0) return;
-  // (how much is left is only known on the device: usually little or nothing)
-  const uint64_t blocks = std::min<uint64_t>((tiles + SW - 1) / SW, 256 * 4);
-  hipLaunchKernelGGL(lookup_coop_kernel, dim3((unsigned)blocks), dim3(SW * 64), 0, s, t, keys, n, out, per_tile, tiles, done);
-}
-void launch_compact_lists(const int64_t *send_keys, const unsigned long long *send_counts, uint32_t n_shards, uint32_t n_sub,
-                          uint64_t cap, int64_t *out_keys, uint64_t *list_off, uint64_t *owner_counts, hipStream_t s) {
-  hipLaunchKernelGGL(list_prefix_kernel, dim3(1), dim3(256), 0, s, send_counts, n_shards, n_sub, cap, list_off, owner_counts);
-  const uint32_t n_lists = n_shards * n_sub;
-  // (about 8 blocks per list at the usual 2048 lists: the lists are a few MB each)
-  hipLaunchKernelGGL(list_copy_kernel, dim3(8, n_lists), dim3(256), 0, s, send_keys, send_counts, cap, list_off, out_keys);
-}
-
 }  // namespace slk

@@ -431,9 +431,16 @@ struct DeviceIndex {
     for (slk_index *i : ixs) SLK_CALL(slk_index_finalize(i));
     SLK_CALL(slk_stream_create(ix, &st));
     if (sharded) {
+      // Two sets (two host threads whose rounds overlap) where the exchange is copies; ONE where it is RCCL's: several
+      // communicators over the same devices, driven by threads that do not agree on an order, are NCCL / RCCL's documented way
+      // into a deadlock (the library serialises its grouped calls besides), and no multi-device run has measured a gain from two.
       const char *e = getenv("SLK_SHARD_SETS");
-      const size_t n_sets = std::max<size_t>(1, std::min<size_t>(4, e ? (size_t)atol(e) : 2));
-      for (size_t i = 0; i < n_sets; i++) {
+      slk_shardset *first = nullptr;
+      SLK_CALL(slk_shardset_create(ixs.data(), (int32_t)ixs.size(), SLK_EXCHANGE_AUTO, &first));
+      sets.push_back(first);
+      const bool rccl = slk_shardset_exchange_mode(first) == SLK_EXCHANGE_RCCL;
+      const size_t n_sets = std::max<size_t>(1, std::min<size_t>(4, e ? (size_t)atol(e) : (rccl ? 1 : 2)));
+      for (size_t i = 1; i < n_sets; i++) {
         slk_shardset *s = nullptr;
         SLK_CALL(slk_shardset_create(ixs.data(), (int32_t)ixs.size(), SLK_EXCHANGE_AUTO, &s));
         sets.push_back(s);

@@ -6,10 +6,10 @@ join (S/slacken/Classifier.scala:84) for the one case where data must move; with
 mode (no collective at all).
 
 Host plumbing only: torch for device buffers and the collectives, the engine for all compute.  Two routes:
-  fast    slk_shard_emit_device -> slk_shard_compact_device -> all-to-all -> slk_lookup_device -> all-to-all ->
-          slk_shard_apply_device: the fused lane-per-fragment kernel runs on both sides of the exchange, nothing but 8-byte keys
-          and 4-byte taxa moves, and the fragments are scanned once (the apply replays the emit's log); takes fragments of up to 1000
-          bases with at most 12 distinct taxa; classify_many runs the scans on one stream and the memory-bound stages on another;
+  fast    slk_shard_step_device: per pipeline step ONE kernel scans batch t into per-owner send regions (sent as they stand: no
+          compaction), answers the keys received for batch t - 2 and replays + classifies batch t - 4, while the all-to-alls of
+          batches t - 1 (keys) and t - 3 (taxa) run on a second stream; nothing but 8-byte keys and 4-byte taxa moves and the
+          fragments are scanned once; takes fragments of up to 1000 bases with at most 12 distinct taxa;
   staged  slk_scan_device / slk_lookup_device / slk_classify_hits_device with the exchange lists built by torch ops: takes
           everything, and the fragments the fast route hands back (`defer`)."""
 import numpy as np
@@ -52,9 +52,8 @@ def shard_of_numpy(keys, world):
 
 class _StageSpan:
     """with-block that brackets a stage with two timing events on its stream and files them in the batch's profile list (nothing
-    if that is None).  A plain module-level class: the batch's tensors live on the ENGINE's streams, and must die by reference
-    count, before their stream does -- an object that only the cycle collector frees (a class made per call is one) would keep
-    them past it."""
+    if that is None).  A plain module-level class without a per-call type: nothing here may end up in a reference cycle that only the
+    cycle collector frees (see ShardedClassifier.close)."""
     __slots__ = ("torch", "prof", "name", "ext", "e0")
 
     def __init__(self, torch, prof, name, ext):
@@ -77,7 +76,7 @@ class _StageSpan:
 class Exchange:
     """The two all-to-all(v) steps of the table-sharded mode and nothing else: no engine, no GPU needed (bench.py --dry-run and the
     CPU tests run it over gloo).  Keys go to their owners sorted by destination rank, answers come back in the same order.  The
-    split sizes travel first, and with them one flag word per rank (a send list overflowed: emit again) -- so the decision every
+    split sizes travel first, and with them one flag word per rank (a send region overflowed) -- so the decision every
     rank must take alike costs no collective of its own and nothing touches torch's default stream."""
 
     def __init__(self, rank=0, world=1, dist=None, device=None, on_cpu=False, force=False):
@@ -114,6 +113,35 @@ class Exchange:
         self.dist.all_to_all_single(out, src, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts))
         return out.to(self.device)
 
+    def regions_out(self, regions, recv_counts):
+        """regions[d]: the (contiguous) tensor this rank sends to rank d -- views of per-owner send regions, sent as they stand, no
+        packing pass -> what the ranks sent here, one contiguous tensor sorted by source rank."""
+        torch = self.torch
+        if self.single:
+            return regions[0]
+        if self.on_cpu:
+            return self.all_to_all(torch.cat([r.reshape(-1) for r in regions]), [int(r.numel()) for r in regions], recv_counts)
+        out = torch.empty(max(sum(recv_counts), 1), dtype=regions[0].dtype, device=self.device)
+        outs = list(out[:sum(recv_counts)].split(list(recv_counts)))
+        self.dist.all_to_all(outs, [r.contiguous() for r in regions])
+        return out[:sum(recv_counts)]
+
+    def regions_back(self, send, send_counts, regions):
+        """the way back: send (sorted by destination = the order the keys arrived in) is written INTO regions[d] (views of the
+        per-owner answer regions: the answers land at the positions their keys had)."""
+        if self.single:
+            if regions[0].data_ptr() != send.data_ptr():
+                regions[0].copy_(send[:regions[0].numel()])
+            return
+        if self.on_cpu:
+            back = self.all_to_all(send, send_counts, [int(r.numel()) for r in regions])
+            o = 0
+            for r in regions:
+                r.copy_(back[o:o + r.numel()])
+                o += r.numel()
+            return
+        self.dist.all_to_all(list(regions), list(send[:sum(send_counts)].split(list(send_counts))))
+
     def any_rank(self, flag):
         """logical OR of a host flag over all ranks (every rank must take the same sequence of collectives)"""
         if self.single:
@@ -124,7 +152,9 @@ class Exchange:
 
 
 class ShardedClassifier:
-    """index: this rank's slacken_amd.Index holding ONLY the records with shard_of(key) == rank (plus the taxonomy)."""
+    """index: this rank's slacken_amd.Index holding ONLY the records with shard_of(key) == rank (plus the taxonomy).
+    Call close() when done (or use it as a context manager): the batches' device tensors live on the ENGINE's streams, which torch
+    sees as external streams, and must be gone -- with torch's cache of their blocks -- before those streams are destroyed."""
 
     def __init__(self, index, rank=0, world=1, dist=None, device=None, exchange_on_cpu=False, force_collectives=False):
         import torch
@@ -134,6 +164,47 @@ class ShardedClassifier:
         self.on_cpu = exchange_on_cpu
         self.ex = Exchange(rank, world, dist, self.device, exchange_on_cpu, force_collectives)
         self.stage_ms = None   # classify_many(profile=True): per-stage device times of the batches
+        self._xst = None
+        self._ext = self._xext = None
+        self._closed = False
+
+    # ---- lifetime -----------------------------------------------------------------------------------------------------------------
+    def close(self):
+        """Ordered teardown: nothing of a batch is held any more, both streams are drained, torch's caching allocator gives back the
+        blocks it keeps for them (a cached block belongs to the stream it was allocated on), the torch views of the streams go, and
+        only then are the engine's streams destroyed.  Results handed out earlier stay valid: they were allocated on the CALLER's
+        stream, not on the engine's."""
+        if self._closed:
+            return
+        self._closed = True
+        torch = self.torch
+        for st in (self.st, self._xst):
+            if st is not None and getattr(st, "h", None):
+                try:
+                    st.synchronize()
+                except Exception:
+                    pass
+        if torch.cuda.is_available():
+            torch.cuda.synchronize(self.device)
+            torch.cuda.empty_cache()
+        self._ext = self._xext = None     # (the ExternalStream wrappers: Stream.close refuses while one is alive)
+        for st in (self._xst, self.st):
+            if st is not None:
+                st.close()
+        self._xst = self.st = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _all_to_all(self, send, send_counts):
         """send: tensor sorted by destination rank; returns (received tensor, recv_counts list)."""
@@ -145,262 +216,217 @@ class ShardedClassifier:
         """d_bases uint8 [total_bases], d_offsets int64 [R+1] (device tensors); second mates likewise (optional)."""
         mates = (d_mate_bases, d_mate_offsets, total_mate_bases) if d_mate_bases is not None else None
         if fast:
-            out = self._classify_fast(d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups, mates)
-            if out is not None:
-                return out
+            outs = self.classify_many([(d_bases, d_offsets, R, total_bases, mates)], thresholds, min_hit_groups)
+            if outs is not None:
+                return outs[0]
         return self._classify_staged(d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups, mates)
 
     def _any_rank(self, flag):
-        """logical OR of a host flag over all ranks, on the memory stream (never torch's default stream, see _two_streams)"""
+        """logical OR of a host flag over all ranks, on the exchange stream (never torch's default stream, see _streams)"""
         if self.ex.single:
             return bool(flag)
-        _, (_, ext) = self._two_streams()
-        with self.torch.cuda.stream(ext):
+        _, xext = self._streams()
+        with self.torch.cuda.stream(xext):
             return self.ex.any_rank(flag)
 
-    # ---- the fast route, in stages that are interleaved between batches (classify_many) -------------------------------------
-    # The stages of a batch are bound by different things: the scan (emit) by instruction issue, compaction, the owners' lookup and
-    # the replay of the batches (apply) by HBM, the exchange by the links.  So the scans of all batches go to ONE engine stream and
-    # the other stages to ANOTHER, each wrapped as a torch ExternalStream so that torch kernels, collectives and engine kernels are ordered
-    # by the streams themselves, with an event where the memory stream needs the scan's result.  In steady state the scan stream
-    # runs emit(k+1) while the memory stream runs compact(k), lookup(k), apply(k).
-    # (Nothing here touches torch's default stream: the engine's streams are blocking streams, and an event recorded on the legacy
-    # null stream waits for all of them and holds back whatever is issued after it -- measured: it serialised the pipeline.)
-    def _two_streams(self):
-        if not hasattr(self, "_scan"):
+    # ---- the fast route -------------------------------------------------------------------------------------------------------
+    # A batch passes through three jobs -- EMIT (scan, keys into per-owner send regions), LOOKUP (on the owners), APPLY (replay of
+    # the probe log with the owners' answers, classification) -- with an exchange between them, and step t of classify_many launches
+    # ONE kernel on the compute stream that carries EMIT(t), LOOKUP(t - 2) and APPLY(t - 4) (slk_shard_step_device): the lookups'
+    # and the replay's memory latency hides behind the scan the way the local kernel's probes do.  The exchanges of batches t - 1
+    # (keys) and t - 3 (taxa) run beside it on a second stream.  The host's one wait per step is for the cursors of the batch
+    # emitted a step earlier (the exchange's split sizes); by then the next step is queued.
+    # Both streams are the ENGINE's, wrapped as torch ExternalStreams so that torch kernels, collectives and engine kernels are
+    # ordered by the streams themselves.  (Nothing here touches torch's default stream: the engine's streams are blocking streams,
+    # and an event recorded on the legacy null stream waits for all of them and holds back whatever is issued after it.)
+    def _streams(self):
+        if self._ext is None:
             torch = self.torch
-            self._scan = (self.st, torch.cuda.ExternalStream(self.st.hip_stream, device=self.device))
-            mem = self.ix.stream()
-            self._mem = (mem, torch.cuda.ExternalStream(mem.hip_stream, device=self.device))
-        return self._scan, self._mem
-
-    def _compute(self):
-        """(engine stream, torch view of it) the memory-bound stages -- compaction, lookups, apply -- are launched on: the memory
-        stream beside the scans (round 2's pipeline), or the scan stream itself, one kernel after the other (the fused pipeline: on a
-        table of HBM size kernels side by side cost more than they hide)"""
-        scan, mem = self._two_streams()
-        return scan if getattr(self, "_serial_compute", False) else mem
-
-    def _xstream(self):
-        """the stream the exchanges are issued on: the memory stream (beside the compute stream in the fused pipeline)"""
-        return self._two_streams()[1][1]
+            self._ext = self.st.external_stream(torch, self.device)
+            self._xst = self.ix.stream()
+            self._xext = self._xst.external_stream(torch, self.device)
+        return self._ext, self._xext
 
     def _ev(self, b, name, ext):
         """(profile) an event pair around a stage of batch b on stream ext: a context manager"""
         return _StageSpan(self.torch, b["prof"] if b is not None else None, name, ext)
 
-    def _fast_emit(self, batch, cap_scale=1, profile=False, side=None):
-        """stage 1 (scan stream, asynchronous): scan + send lists.  None if this index's splitter only has the staged route.
-        side: the state of an EARLIER batch whose received keys are answered on the way (slk_shard_emit_lookup_device)."""
-        import slacken_amd
+    def _region_capacity(self, total_bases, R):
+        """entries of an owner's send region: the expected super-mers of random sequence (2 / (w + 1) per k-mer window) spread evenly
+        by the hash, a fifth on top, and a chunk per wave that may hold one half filled when the kernel ends"""
+        from slacken_amd import capi
+        W = self.world
+        chunk = int(capi.lib().slk_shard_chunk(W))
+        w = self.ix.k - self.ix.m + 1
+        windows = max(0, total_bases - R * (self.ix.k - 1))
+        expect = 2.0 / (w + 1) * windows + R
+        cap = int(expect / W * 1.2) + 4096 + chunk * min((R + 63) // 64, 8192)
+        cap = -(-cap // chunk) * chunk
+        return min(cap, ((1 << 32) - 1) // chunk * chunk - chunk)
+
+    def _emit_state(self, batch, profile):
+        """device state of a batch for its three jobs (allocated on the compute stream)"""
         from slacken_amd import capi
         torch, dev, W = self.torch, self.device, self.world
-        (st, ext), _ = self._two_streams()
+        ext, _ = self._streams()
         d_bases, d_offsets, R, total_bases, mates = batch
         mb, mo, mtotal = mates if mates is not None else (None, None, 0)
-        mkw = dict(d_mate_bases=mb.data_ptr(), d_mate_offsets=mo.data_ptr()) if mates is not None else {}
-        # about 0.26 probes per base on random sequence, spread evenly by the hash over W owners and by the tile index over SUB
-        # sub-lists per owner (each fed by at least 64 tiles, so that the spread holds): 0.6 / (W * SUB) per base leaves 2x
-        # headroom; a list that overflows all the same is reported by the compaction, and the batch is emitted again with more room
-        tiles = (R + 63) // 64
-        SUB = 1
-        while SUB < 256 and SUB * 2 * 64 <= tiles:
-            SUB *= 2
-        cap = (int((total_bases + mtotal) * 0.6 / (W * SUB)) + (1 << 12)) * cap_scale
+        cap = self._region_capacity(total_bases + mtotal, R)
         rows = int(capi.lib().slk_shard_batch_rows(total_bases, mtotal, R, 1 if mates is not None else 0))
-        cur = torch.cuda.current_stream()
-        if cur != torch.cuda.default_stream(self.device):     # (the caller's tensors were produced on ITS stream)
-            ext.wait_stream(cur)
-        b = dict(R=R, SUB=SUB, cap=cap, mkw=mkw, batch=batch, prof=[] if profile else None)
-        side_args = None
-        if side is not None and side["looked_up"] and R:
-            ext.wait_event(side["keys_here"])         # (its keys have arrived)
-            # the keys' batches of 64 are dealt out to this scan's tiles; what a tile does not get to is on file in side["done"]
-            side["per_tile"], side["tiles"] = -(-(-(-side["looked_up"] // 64)) // tiles), tiles
-            with torch.cuda.stream(ext):
-                side["done"] = torch.empty(tiles, dtype=torch.int32, device=dev)
-            side_args = (side["recv_keys"].data_ptr(), side["looked_up"], side["per_tile"], side["done"].data_ptr(), side["found"].data_ptr())
+        tiles = (R + 63) // 64
         with torch.cuda.stream(ext):
-            defer = torch.empty(max(R, 1), dtype=torch.int32, device=dev)
-            batch_base = torch.empty(rows * W, dtype=torch.int32, device=dev)
-            send_keys = torch.empty(W * SUB * cap, dtype=torch.int64, device=dev)
-            send_meta = torch.empty(W * SUB * cap, dtype=torch.int32, device=dev)
-            counts = torch.empty(W * SUB, dtype=torch.int64, device=dev)
-            tile_rows = torch.empty(tiles + 1, dtype=torch.int32, device=dev)
-            read_info = torch.empty(2 * max(R, 1), dtype=torch.int32, device=dev)
-            try:
-                with self._ev(b, "emit+lookup" if side_args else "emit", ext):
-                    st.shard_emit_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, W, SUB, send_keys.data_ptr(), send_meta.data_ptr(), cap,
-                                         counts.data_ptr(), batch_base.data_ptr(), tile_rows.data_ptr(), read_info.data_ptr(),
-                                         defer.data_ptr(), side=side_args, **mkw)
-            except slacken_amd.SlackenError as e:
-                if e.code != capi.E_UNSUPPORTED:
-                    raise
-                return None
-            emitted = torch.cuda.Event()
-            emitted.record(ext)
-        b.update(defer=defer, batch_base=batch_base, send_keys=send_keys, send_meta=send_meta, counts=counts,
-                 tile_rows=tile_rows, read_info=read_info, emitted=emitted)
-        return b
+            t = dict(send_keys=torch.empty(W * cap, dtype=torch.int64, device=dev),
+                     send_meta=torch.empty(W * cap, dtype=torch.int32, device=dev),
+                     cursors=torch.empty(W + 3, dtype=torch.int64, device=dev),
+                     log=torch.empty(max(rows, 1) * W * 4, dtype=torch.int32, device=dev),
+                     tile_rows=torch.empty(2 * tiles + 2, dtype=torch.int32, device=dev),
+                     read_info=torch.empty(2 * max(R, 1), dtype=torch.int32, device=dev),
+                     defer=torch.zeros(max(R, 1), dtype=torch.int32, device=dev))
+        L = capi.ShardLists(d_bases.data_ptr(), d_offsets.data_ptr(), mb.data_ptr() if mb is not None else None,
+                            mo.data_ptr() if mo is not None else None, R, total_bases, mtotal, W, 0, cap, t["send_keys"].data_ptr(), t["send_meta"].data_ptr(),
+                            t["cursors"].data_ptr(), t["log"].data_ptr(), t["tile_rows"].data_ptr(), t["read_info"].data_ptr(),
+                            t["defer"].data_ptr(), None, None, None)
+        h = torch.empty(W + 3, dtype=torch.int64, pin_memory=True)
+        return dict(R=R, cap=cap, lists=L, h_cursors=h, prof=[] if profile else None, failed=False, batch=batch, **t)
 
-    def _fast_compact(self, b):
-        """stage 2 (asynchronous): the send lists back to back; the split sizes on their way to the host"""
-        torch, dev, W = self.torch, self.device, self.world
-        st, ext = self._compute()
-        with torch.cuda.stream(ext):
-            ext.wait_event(b["emitted"])
-            b["out_keys"] = torch.empty_like(b["send_keys"])   # (room for every list at its capacity; the used prefix is what is sent)
-            b["list_off"] = torch.empty(W * b["SUB"] + 1, dtype=torch.int64, device=dev)
-            owner_counts = torch.empty(W + 1, dtype=torch.int64, device=dev)
-            with self._ev(b, "compact", ext):
-                st.shard_compact_device(b["send_keys"].data_ptr(), W, b["SUB"], b["cap"], b["counts"].data_ptr(), b["out_keys"].data_ptr(),
-                                        b["list_off"].data_ptr(), owner_counts.data_ptr())
-            b["h_counts"] = torch.empty(W + 1, dtype=torch.int64, pin_memory=True)
-            b["h_counts"].copy_(owner_counts, non_blocking=True)
-            b["ready"] = torch.cuda.Event()
-            b["ready"].record(ext)
-
-    def _exchange_keys(self, b, send_counts, recv_counts):
-        """stage 3a (exchange stream): keys to their owners"""
-        torch = self.torch
-        ext = self._xstream()
-        n_send, n_recv = sum(send_counts), sum(recv_counts)
-        cext = self._compute()[1]
-        with torch.cuda.stream(ext):
-            ext.wait_event(b["ready"])
-            b["out_keys"].record_stream(ext)      # (made on the compute stream, read here: the allocator must not hand it out before)
-            with self._ev(b, "exchange_keys", ext):
-                recv_keys = self.ex.all_to_all(b["out_keys"][:n_send], send_counts, recv_counts)
-            b["recv_keys"] = recv_keys.contiguous() if n_recv else torch.zeros(1, dtype=torch.int64, device=self.device)
-            b["found"] = torch.empty(max(n_recv, 1), dtype=torch.int32, device=self.device)
-            for tns in (b["recv_keys"], b["found"]):   # (made here, used by the lookups on the compute stream -- and the scan's side job)
-                tns.record_stream(cext)
-                tns.record_stream(self._two_streams()[0][1])
-            b["keys_here"] = torch.cuda.Event()
-            b["keys_here"].record(ext)
-        b["exchanged"], b["looked_up"] = n_send, n_recv
-        b["send_counts"], b["recv_counts"] = send_counts, recv_counts
-        b["sent_remote"] = n_send - send_counts[self.rank]
-        del b["send_keys"], b["out_keys"]
-
-    def _lookup_and_return(self, b, after=None):
-        """stage 3b: the keys a scan's side job has not answered (all of them if none ran) on the compute stream, then the taxa back
-        on the exchange stream.  after: the event of the emit launch that carried the side job."""
-        torch = self.torch
-        st, ext = self._compute()
-        xs = self._xstream()
-        n_recv = b["looked_up"]
-        with torch.cuda.stream(ext):
-            ext.wait_event(b["keys_here"])
-            if after is not None:
-                ext.wait_event(after)
-            if n_recv and "done" in b:      # a later scan answered most of them: the rest
-                with self._ev(b, "lookup_rest", ext):
-                    st.lookup_rest_device(b["recv_keys"].data_ptr(), n_recv, b["per_tile"], b["tiles"], b["done"].data_ptr(), b["found"].data_ptr())
-            elif n_recv:
-                with self._ev(b, "lookup", ext):
-                    st.lookup_device(b["recv_keys"].data_ptr(), n_recv, b["found"].data_ptr())
-            looked = torch.cuda.Event()
-            looked.record(ext)
-        with torch.cuda.stream(xs):
-            xs.wait_event(looked)
-            with self._ev(b, "exchange_taxa", xs):
-                back = self.ex.all_to_all(b["found"][:n_recv], b["recv_counts"], b["send_counts"])
-            b["taxa"] = back.contiguous() if back.numel() else torch.zeros(1, dtype=torch.int32, device=self.device)
-            b["taxa"].record_stream(ext)          # (read by the apply on the compute stream)
-            b["taxa_here"] = torch.cuda.Event()
-            b["taxa_here"].record(xs)
-        for k in ("recv_keys", "found", "done"):
-            b.pop(k, None)
-
-    def _fast_exchange(self, b, send_counts, recv_counts):
-        """stage 3 (memory stream): keys to their owners, lookup, taxa back"""
-        self._exchange_keys(b, send_counts, recv_counts)
-        self._lookup_and_return(b)
-
-    def _fast_apply(self, b, thresholds, min_hit_groups):
-        """stage 4 (memory stream, behind the lookup; asynchronous): the batches of probes are replayed from the emit's log and
-        folded with the owners' answers -- no second scan.  The result tensors are valid once that stream has been synchronised."""
-        torch, dev, R, W = self.torch, self.device, b["R"], self.world
-        st, ext = self._compute()
-        d_bases, d_offsets = b["batch"][0], b["batch"][1]
-        C = len(thresholds)
-        with torch.cuda.stream(ext):
-            ext.wait_event(b["taxa_here"])
-            out = dict(taxon=torch.zeros(C * max(R, 1), dtype=torch.int32, device=dev),
-                       classified=torch.zeros(C * max(R, 1), dtype=torch.uint8, device=dev),
-                       num_distinct=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
-                       total_kmers=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
-                       num_hits=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
-                       exchanged_keys=b["exchanged"], looked_up_keys=b["looked_up"], sent_remote_keys=b["sent_remote"])
-            with self._ev(b, "apply", ext):
-                st.shard_apply_device(d_bases.data_ptr(), d_offsets.data_ptr(), R, W, b["SUB"], b["cap"], b["taxa"].data_ptr(),
-                                      b["list_off"].data_ptr(), b["send_meta"].data_ptr(), b["batch_base"].data_ptr(),
-                                      b["tile_rows"].data_ptr(), b["read_info"].data_ptr(), out["taxon"].data_ptr(),
-                                      out["classified"].data_ptr(), b["defer"].data_ptr(), out["num_distinct"].data_ptr(),
-                                      out["total_kmers"].data_ptr(), out["num_hits"].data_ptr(), min_hit_groups=min_hit_groups,
-                                      thresholds=thresholds, **b["mkw"])
-            b["applied"] = torch.cuda.Event()
-            b["applied"].record(ext)
-        return out
-
-    def _classify_fast(self, d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups, mates=None):
-        outs = self.classify_many([(d_bases, d_offsets, R, total_bases, mates)], thresholds, min_hit_groups)
-        return None if outs is None else outs[0]
-
-    def classify_many(self, batches, thresholds=(0.0,), min_hit_groups=2, profile=False, fused_lookup=True):
-        """The fast route over several batches [(d_bases, d_offsets, R, total_bases, mates or None)], two in flight (see above).
-        fused_lookup (the default): the keys a rank RECEIVES for batch t - 2 are answered inside the scan of batch t
-        (_classify_many_fused); False: by a lookup kernel of their own beside the scan of batch t + 1, as in round 2.
+    def classify_many(self, batches, thresholds=(0.0,), min_hit_groups=2, profile=False):
+        """The fast route over several batches [(d_bases, d_offsets, R, total_bases, mates or None)], pipelined (see above).
         Every rank must pass the same number of batches.  Returns the list of result dicts, or None if the splitter only has the
-        staged route.  profile: self.stage_ms = {stage: mean device ms per batch} from events around every stage (the stages of
-        neighbouring batches overlap on the two streams: these are their durations IN the pipeline, not alone)."""
+        staged route.  profile: self.stage_ms = {stage: mean device ms per batch} from events around every stage (the step kernel is
+        ONE stage: its three jobs belong to three batches)."""
+        import ctypes as C
         import slacken_amd
         from slacken_amd import capi
-        torch = self.torch
-        if fused_lookup:
-            return self._classify_many_fused(batches, thresholds, min_hit_groups, profile)
-        states, outs = [], []
-        overflowed = False
-        _, (_, mem_ext) = self._two_streams()
+        torch, dev, W = self.torch, self.device, self.world
+        ext, xext = self._streams()
+        n = len(batches)
+        Cn = len(thresholds)
+        thr = (C.c_double * Cn)(*thresholds)
+        cur = torch.cuda.current_stream()
+        # results: on the CALLER's stream (they outlive this call, and must not belong to the engine's streams, see close())
+        outs = []
+        for (_, _, R, _, _) in batches:
+            outs.append(dict(taxon=torch.zeros(Cn * max(R, 1), dtype=torch.int32, device=dev),
+                             classified=torch.zeros(Cn * max(R, 1), dtype=torch.uint8, device=dev),
+                             num_distinct=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
+                             total_kmers=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
+                             num_hits=torch.zeros(max(R, 1), dtype=torch.int32, device=dev),
+                             exchanged_keys=0, looked_up_keys=0, sent_remote_keys=0))
+        ext.wait_stream(cur)      # (the caller's tensors and the results' memory were produced / last used on ITS stream)
+        states = [None] * n
+        steps = []                # (profile) one event pair per step kernel
+        unsupported = False
 
-        def settle(j):   # batch j: its one host wait, then exchange + lookup + apply on the memory stream
-            nonlocal overflowed
-            b, scale = states[j], 1
-            while True:
-                b["ready"].synchronize()
-                send_counts = [int(v) for v in b["h_counts"][:self.world].tolist()]
-                # (the split sizes carry every rank's overflow flag: all ranks take the same branch without a collective of its own)
-                with torch.cuda.stream(mem_ext):
-                    recv_counts, over = self.ex.split_sizes(send_counts, int(b["h_counts"][self.world]) != 0)
-                if not over:
-                    break
-                overflowed = True                      # (rare: a send list overflowed somewhere -- every rank emits again)
-                scale *= 2
-                b = states[j] = self._fast_emit(batches[j], scale, profile)
-                self._fast_compact(b)
-            self._fast_exchange(b, send_counts, recv_counts)
-            outs.append(self._fast_apply(b, thresholds, min_hit_groups))
+        def launch(t):
+            nonlocal unsupported
+            emit = lk = al = ap = None
+            b = None
+            if t < n:
+                b = states[t] = self._emit_state(batches[t], profile)
+                if batches[t][2]:
+                    emit = b["lists"]
+            if 0 <= t - 2 < n:
+                s2 = states[t - 2]
+                ext.wait_event(s2["keys_here"])
+                if s2["looked_up"] and not s2["failed"]:
+                    lk = capi.ShardLookup(s2["recv_keys"].data_ptr(), s2["looked_up"], s2["found"].data_ptr())
+            if 0 <= t - 4 < n:
+                s4 = states[t - 4]
+                ext.wait_event(s4["taxa_here"])
+                if s4["R"] and not s4["failed"]:
+                    o = outs[t - 4]
+                    al = s4["lists"]
+                    ap = capi.ShardResults(s4["taxa"].data_ptr(), min_hit_groups, Cn, thr, o["taxon"].data_ptr(), o["classified"].data_ptr(),
+                                           o["num_distinct"].data_ptr(), o["total_kmers"].data_ptr(), o["num_hits"].data_ptr())
+            with torch.cuda.stream(ext):
+                with _StageSpan(torch, steps if profile else None, "step", ext):
+                    if emit is not None or lk is not None or ap is not None:
+                        try:
+                            self.st.shard_step(emit, lk, al, ap)
+                        except slacken_amd.SlackenError as e:
+                            if e.code != capi.E_UNSUPPORTED or t != 0:
+                                raise
+                            unsupported = True
+                if b is not None:
+                    if emit is None:
+                        b["cursors"].zero_()
+                    b["h_cursors"].copy_(b["cursors"], non_blocking=True)
+                    b["stepped"] = torch.cuda.Event()
+                    b["stepped"].record(ext)
+                if 0 <= t - 2 < n:
+                    states[t - 2]["looked"] = torch.cuda.Event()
+                    states[t - 2]["looked"].record(ext)
+                if 0 <= t - 4 < n:       # the batch is through: its lists go back to the allocator
+                    s4 = states[t - 4]
+                    for k in ("send_meta", "log", "tile_rows", "read_info", "taxa", "cursors"):
+                        s4.pop(k, None)
 
-        def release_finished():   # batches whose apply has run give their device memory back (a long run holds a few, not all)
-            for sb in states:
-                if "applied" in sb and "taxa" in sb and sb["applied"].query():
-                    for k in ("taxa", "batch_base", "list_off", "counts", "send_meta", "tile_rows", "read_info"):
-                        sb.pop(k, None)
+        def exchange_keys(j):
+            """batch j was emitted a step ago: the host's wait for its cursors, then its keys travel (exchange stream)"""
+            b = states[j]
+            b["stepped"].synchronize()
+            hc = [int(v) for v in b["h_cursors"].tolist()]
+            send_counts = hc[:W]
+            over = any(c > b["cap"] for c in send_counts)
+            with torch.cuda.stream(xext):
+                xext.wait_event(b["stepped"])
+                recv_counts, any_over = self.ex.split_sizes([0] * W if over else send_counts, over)
+                if any_over:   # a region was too small somewhere: this batch takes the staged route on every rank
+                    b["failed"] = True
+                    send_counts, recv_counts = [0] * W, [0] * W
+                n_send, n_recv = sum(send_counts), sum(recv_counts)
+                regions = [b["send_keys"][g * b["cap"]:g * b["cap"] + send_counts[g]] for g in range(W)]
+                with self._ev(b, "exchange_keys", xext):
+                    b["recv_keys"] = self.ex.regions_out(regions, recv_counts)
+                if self.ex.single:          # the answers are written where the apply reads them: no copy on the way back
+                    b["taxa"] = torch.empty(W * b["cap"], dtype=torch.int32, device=dev)
+                    b["found"] = b["taxa"]
+                else:
+                    b["found"] = torch.empty(max(n_recv, 1), dtype=torch.int32, device=dev)
+                # (made on one stream, used on the other: the allocator must not hand the blocks out again before that use is over)
+                b["send_keys"].record_stream(xext)
+                for k in ("recv_keys", "found", "taxa"):
+                    if k in b:
+                        b[k].record_stream(ext)
+                b["keys_here"] = torch.cuda.Event()
+                b["keys_here"].record(xext)
+            b["looked_up"], b["send_counts"], b["recv_counts"] = n_recv, send_counts, recv_counts
+            o = outs[j]
+            o["exchanged_keys"], o["looked_up_keys"], o["sent_remote_keys"] = n_send, n_recv, n_send - send_counts[self.rank]
+            if not self.ex.single:
+                b.pop("send_keys", None)
 
-        for i, batch in enumerate(batches):
-            release_finished()
-            b = self._fast_emit(batch, 1, profile)     # scan stream
-            if i == 0 and self._any_rank(b is None):
-                return None
-            states.append(b)
-            if i >= 1:
-                settle(i - 1)                          # lookup(i-1) and apply(i-1) run beside emit(i)
-            self._fast_compact(b)                      # memory stream, behind apply(i-1)
-        if states:
-            settle(len(states) - 1)
-        (scan_st, _), (mem_st, _) = self._two_streams()
-        for st in (scan_st, mem_st):
+        def exchange_taxa(j):
+            """batch j's lookups ran in the step just finished: the taxa go back (exchange stream)"""
+            b = states[j]
+            with torch.cuda.stream(xext):
+                xext.wait_event(b["looked"])
+                if not self.ex.single:
+                    b["taxa"] = torch.empty(W * b["cap"], dtype=torch.int32, device=dev)
+                    regions = [b["taxa"][g * b["cap"]:g * b["cap"] + b["send_counts"][g]] for g in range(W)]
+                    b["taxa"].record_stream(ext)
+                    with self._ev(b, "exchange_taxa", xext):
+                        self.ex.regions_back(b["found"], b["recv_counts"], regions)
+                b["taxa_here"] = torch.cuda.Event()
+                b["taxa_here"].record(xext)
+            for k in ("recv_keys", "found", "send_keys"):
+                b.pop(k, None)
+
+        try:
+            for t in range(n + 4):
+                launch(t)
+                if t == 0 and self._any_rank(unsupported):
+                    states.clear()
+                    return None
+                if 1 <= t <= n:
+                    exchange_keys(t - 1)
+                if 3 <= t <= n + 2:
+                    exchange_taxa(t - 3)
+        except BaseException:
+            states.clear()     # (nothing of a batch may outlive this call: see close())
+            raise
+        overflowed = any(s["failed"] for s in states)
+        for st in (self.st, self._xst):
             try:
                 st.synchronize()
             except slacken_amd.SlackenError as e:
@@ -411,125 +437,59 @@ class ShardedClassifier:
             for sb in states:
                 for name, e0, e1 in sb["prof"]:
                     acc.setdefault(name, []).append(e0.elapsed_time(e1))
+            for name, e0, e1 in steps:
+                acc.setdefault(name, []).append(e0.elapsed_time(e1))
             self.stage_ms = {k: float(np.mean(v)) for k, v in acc.items()}
+            self.step_ms = [e0.elapsed_time(e1) for _, e0, e1 in steps]
+        cur.wait_stream(ext)
         for i, (b, batch) in enumerate(zip(states, batches)):
-            for k in ("taxa", "batch_base", "list_off", "counts", "send_meta", "tile_rows", "read_info"):
-                b.pop(k, None)
             d_bases, d_offsets, R, total_bases, mates = batch
+            if b["failed"]:      # the whole batch through the staged route
+                outs[i] = dict(self._classify_staged(d_bases, d_offsets, R, total_bases, thresholds, min_hit_groups, mates), deferred=R)
+                continue
             outs[i] = self._finish_deferred(outs[i], b, d_bases, d_offsets, R, thresholds, min_hit_groups, mates)
+        states.clear()
         return outs
 
-    def _classify_many_fused(self, batches, thresholds, min_hit_groups, profile):
-        """Kernels side by side cost more than they hide on a table of HBM size: the scan and a lookup kernel share one request rate
-        and the wave slots (lookup 8-13 ms alone, 14 beside the scan, the scan 6.5 alone and 8-10 beside it).  The local
-        kernel does not have that problem -- its probes hide behind its own scan -- so the sharded scan takes the owner's lookups
-        along the same way: the scan of batch t answers the keys this rank received for batch t - 2 (their exchange ran during the
-        scan of batch t - 1), and the other stages follow it on the SAME stream, one kernel after the other.  Per iteration t:
-          compute stream   emit(t) + lookups(t - 2) | what is left of lookups(t - 2) | compact(t) | apply(t - 2)
-          host             waits for the split sizes of batch t - 1 (while emit(t) runs)
-          exchange stream  keys(t - 1) to their owners (beside emit(t)) | taxa(t - 2) back (beside compact(t))
-        Results come out two batches late; the last two batches' lookups run as a kernel of their own."""
-        import slacken_amd
-        from slacken_amd import capi
-        torch = self.torch
-        n = len(batches)
-        states, outs = [None] * n, [None] * n
-        _, (_, mem_ext) = self._two_streams()
-        self._serial_compute = True
-        try:
-            return self._fused_loop(batches, thresholds, min_hit_groups, profile, states, outs, mem_ext)
-        finally:
-            self._serial_compute = False
-
-    def _fused_loop(self, batches, thresholds, min_hit_groups, profile, states, outs, mem_ext):
-        import slacken_amd
-        from slacken_amd import capi
-        torch = self.torch
-        n = len(batches)
-        overflowed = False
-
-        def settle(j):   # batch j: the host's wait for its split sizes, then its keys travel
-            nonlocal overflowed
-            b, scale = states[j], 1
-            while True:
-                b["ready"].synchronize()
-                send_counts = [int(v) for v in b["h_counts"][:self.world].tolist()]
-                with torch.cuda.stream(mem_ext):
-                    recv_counts, over = self.ex.split_sizes(send_counts, int(b["h_counts"][self.world]) != 0)
-                if not over:
-                    break
-                overflowed = True                      # (rare: a send list overflowed somewhere -- every rank emits again, without a side job)
-                scale *= 2
-                b = states[j] = self._fast_emit(batches[j], scale, profile)
-                self._fast_compact(b)
-            self._exchange_keys(b, send_counts, recv_counts)
-
-        for t in range(n + 2):
-            if t < n:
-                b = self._fast_emit(batches[t], 1, profile, side=states[t - 2] if t >= 2 else None)
-                if t == 0 and self._any_rank(b is None):
-                    return None
-                states[t] = b
-            if 1 <= t <= n:
-                settle(t - 1)
-            if t >= 2:
-                self._lookup_and_return(states[t - 2], after=states[t]["emitted"] if t < n else None)
-            if t < n:
-                self._fast_compact(states[t])                 # (beside the taxa's way back)
-            if t >= 2:
-                outs[t - 2] = self._fast_apply(states[t - 2], thresholds, min_hit_groups)
-            for sb in states:   # batches whose apply has run give their device memory back
-                if sb is not None and "applied" in sb and "taxa" in sb and sb["applied"].query():
-                    for k in ("taxa", "batch_base", "list_off", "counts", "send_meta", "tile_rows", "read_info"):
-                        sb.pop(k, None)
-        (scan_st, _), (mem_st, _) = self._two_streams()
-        for st in (scan_st, mem_st):
-            try:
-                st.synchronize()
-            except slacken_amd.SlackenError as e:
-                if not (overflowed and e.code == capi.E_CAPACITY):
-                    raise
-        if profile:
-            acc = {}
-            for sb in states:
-                for name, e0, e1 in sb["prof"]:
-                    acc.setdefault(name, []).append(e0.elapsed_time(e1))
-            self.stage_ms = {k: float(np.mean(v)) for k, v in acc.items()}
-        for i, (b, batch) in enumerate(zip(states, batches)):
-            for k in ("taxa", "batch_base", "list_off", "counts", "send_meta", "tile_rows", "read_info"):
-                b.pop(k, None)
-            d_bases, d_offsets, R, total_bases, mates = batch
-            outs[i] = self._finish_deferred(outs[i], b, d_bases, d_offsets, R, thresholds, min_hit_groups, mates)
-        return outs
-
-    def stage_times_alone(self, batch, thresholds=(0.0,), min_hit_groups=2):
-        """Every stage of one batch run ALONE (a synchronisation between stages; world = 1 only): what the stages cost without
-        each other's company, next to their times in the pipeline (classify_many(profile=True)).  -> {stage: ms}"""
+    def jobs_alone(self, batch, thresholds=(0.0,), min_hit_groups=2):
+        """world = 1 only: the three jobs of one batch each as a step of its own (the host waits in between), and then together in
+        ONE kernel as the pipeline runs them: what riding along buys.  -> {jobs: ms}"""
+        import ctypes as C
         import time
-        torch = self.torch
-        assert self.ex.single
-        (scan_st, _), (mem_st, mem_ext) = self._two_streams()
+        from slacken_amd import capi
+        torch, dev = self.torch, self.device
+        assert self.ex.single and self.world == 1
+        ext, _ = self._streams()
+        Cn = len(thresholds)
+        thr = (C.c_double * Cn)(*thresholds)
+        R = batch[2]
 
         def timed(f):
-            torch.cuda.synchronize(); scan_st.synchronize(); mem_st.synchronize()
+            torch.cuda.synchronize()
+            self.st.synchronize()
             t0 = time.perf_counter()
-            r = f()
-            scan_st.synchronize(); mem_st.synchronize(); torch.cuda.synchronize()
-            return r, (time.perf_counter() - t0) * 1e3
+            f()
+            self.st.synchronize()
+            return (time.perf_counter() - t0) * 1e3
 
         out = {}
-        b0, out["emit"] = timed(lambda: self._fast_emit(batch))
-        _, out["compact"] = timed(lambda: self._fast_compact(b0))
-        counts = [int(v) for v in b0["h_counts"][:1].tolist()]
-        self._exchange_keys(b0, counts, counts)
-        b1, out["emit+lookup"] = timed(lambda: self._fast_emit(batch, side=b0))
-        self._fast_compact(b1)
-        self._exchange_keys(b1, counts, counts)
-        _, out["lookup_rest"] = timed(lambda: self._lookup_and_return(b0))
-        _, out["apply"] = timed(lambda: self._fast_apply(b0, thresholds, min_hit_groups))
-        _, out["lookup"] = timed(lambda: self._lookup_and_return(b1))
-        self._fast_apply(b1, thresholds, min_hit_groups)
-        scan_st.synchronize(); mem_st.synchronize()
+        with torch.cuda.stream(ext):
+            b0 = self._emit_state(batch, False)
+            out["emit"] = timed(lambda: self.st.shard_step(b0["lists"], None, None, None))
+            n = int(b0["cursors"][0].item())
+            taxa0 = torch.empty(b0["cap"], dtype=torch.int32, device=dev)
+            lk = capi.ShardLookup(b0["send_keys"].data_ptr(), n, taxa0.data_ptr())
+            out["lookup"] = timed(lambda: self.st.shard_step(None, lk, None, None))
+            o0 = [torch.zeros(Cn * max(R, 1), dtype=torch.int32, device=dev), torch.zeros(Cn * max(R, 1), dtype=torch.uint8, device=dev)]
+            ap = capi.ShardResults(taxa0.data_ptr(), min_hit_groups, Cn, thr, o0[0].data_ptr(), o0[1].data_ptr(), None, None, None)
+            out["apply"] = timed(lambda: self.st.shard_step(None, None, b0["lists"], ap))
+            b1 = self._emit_state(batch, False)
+            out["emit+lookup"] = timed(lambda: self.st.shard_step(b1["lists"], lk, None, None))
+            b2 = self._emit_state(batch, False)
+            out["emit+apply"] = timed(lambda: self.st.shard_step(b2["lists"], None, b0["lists"], ap))
+            b3 = self._emit_state(batch, False)
+            out["emit+lookup+apply"] = timed(lambda: self.st.shard_step(b3["lists"], lk, b0["lists"], ap))
+            del b0, b1, b2, b3, taxa0, o0
         return {k: round(v, 3) for k, v in out.items()}
 
     def _finish_deferred(self, out, b, d_bases, d_offsets, R, thresholds, min_hit_groups, mates):

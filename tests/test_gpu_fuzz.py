@@ -130,3 +130,4 @@ def test_sharded_routes_differential(orc, seed):
         assert np.array_equal(out["classified"].cpu().numpy()[:2 * n].reshape(2, n), want["classified"]), ctx
         for key in ("num_distinct", "total_kmers", "num_hits"):
             assert np.array_equal(out[key].cpu().numpy()[:n], want[key]), (key, ctx)
+    sc.close()

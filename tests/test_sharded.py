@@ -51,6 +51,8 @@ def _rank(rank, world, port, payload, outdir, fast):
     assert ("deferred" in out) == fast
     np.savez(os.path.join(outdir, f"r{rank}.npz"), lo=lo, hi=hi, **{k: v.cpu().numpy() for k, v in out.items()
                                                                      if hasattr(v, "cpu")})
+    del out
+    sc.close()
     dist.barrier()
     dist.destroy_process_group()
 
@@ -91,7 +93,7 @@ def test_two_ranks_half_table_each(orc, tmp_path, fast):
 @pytest.mark.gpu
 @pytest.mark.parametrize("big_ids", [False, True], ids=["ids<2^22", "dense-ids"])
 def test_single_rank_fast_route_with_deferrals(orc, big_ids):
-    """world = 1: no exchange, but the same emit -> compact -> lookup -> apply pipeline, incl. fragments the fused kernel
+    """world = 1: no exchange, but the same EMIT -> LOOKUP -> APPLY jobs of the step kernel, incl. fragments the fused kernel
     hands back (longer than 1000 bases; more than 12 distinct taxa) and empty / vanishing fragments.  With taxon ids beyond
     22 bits the table holds dense internal ids: the owners' answers (caller's ids) are translated by the apply kernel."""
     import synth
@@ -127,6 +129,7 @@ def test_single_rank_fast_route_with_deferrals(orc, big_ids):
             assert np.array_equal(out[k].cpu().numpy()[:R], want[k]), (k, fast)
         if fast:
             assert out["deferred"] >= 35
+    sc.close()
 
 
 @pytest.mark.gpu
@@ -163,10 +166,12 @@ def test_single_rank_paired(orc):
             assert np.array_equal(out[k].cpu().numpy()[:R], want[k]), (k, fast)
         if fast:
             assert out["deferred"] >= 1
+    sc.close()
 
 
 def _rank_many(rank, world, port, payload, outdir):
-    """several batches through classify_many, with the owner's lookups inside the scans of later batches and as a kernel of their own"""
+    """several batches through classify_many: the step kernel carries the scan of batch t, the lookups of batch t - 2 and the replay
+    of batch t - 4; twice over (the second pass runs on the buffers torch has cached from the first)"""
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -181,12 +186,14 @@ def _rank_many(rank, world, port, payload, outdir):
     dbs = [(torch.from_numpy(b).to(dev), torch.from_numpy(o.astype(np.int64)).to(dev), len(o) - 1, int(o[-1]), None) for b, o in mine]
     sc = sharded.ShardedClassifier(ix, rank, world, dist, dev, exchange_on_cpu=True)
     res = {}
-    for fused in (True, False):
-        outs = sc.classify_many(dbs, thresholds=(0.0, 0.2), fused_lookup=fused)
+    for tag in ("f", "s"):
+        outs = sc.classify_many(dbs, thresholds=(0.0, 0.2))
         for j, o in enumerate(outs):
             for k in ("taxon", "classified", "num_distinct", "total_kmers", "num_hits"):
-                res[f"{'f' if fused else 's'}_{j}_{k}"] = o[k].cpu().numpy()
+                res[f"{tag}_{j}_{k}"] = o[k].cpu().numpy()
     np.savez(os.path.join(outdir, f"many{rank}.npz"), **res)
+    del outs
+    sc.close()
     dist.barrier()
     dist.destroy_process_group()
 
@@ -195,9 +202,10 @@ def _rank_many(rank, world, port, payload, outdir):
 @pytest.mark.parametrize("world", [1, 2])
 def test_many_batches_with_the_lookups_inside_later_scans(orc, tmp_path, world):
     """classify_many over five batches per rank (uneven sizes, one of a single fragment, one with fragments the lane kernel hands
-    back): the keys a rank receives for batch t are answered inside the scan of batch t + 2 -- the first batches' side jobs find
-    nothing to do, the last two batches' lookups run as a kernel of their own, a scan shorter than the keys waiting for it leaves
-    the rest to that kernel too -- and, for comparison, by the separate lookup kernel throughout.  Every batch against the oracle."""
+    back): the keys a rank receives for batch t are answered inside the scan of batch t + 2 and batch t is replayed and classified
+    inside the scan of batch t + 4 -- the first steps' side jobs find nothing to do, the last batches' lookups and replays run in
+    steps without a scan, a scan with fewer tiles than the batch it carries leaves the rest to tiles without fragments.  Every batch
+    against the oracle."""
     import torch.multiprocessing as mp
     import synth
     import taxgen
@@ -228,3 +236,53 @@ def test_many_batches_with_the_lookups_inside_later_scans(orc, tmp_path, world):
                 assert np.array_equal(z[f"{tag}_{j}_classified"].reshape(2, -1)[:, :R], wants[i]["classified"]), (tag, i)
                 for k in ("num_distinct", "total_kmers", "num_hits"):
                     assert np.array_equal(z[f"{tag}_{j}_{k}"][:R], wants[i][k]), (tag, i, k)
+
+
+@pytest.mark.gpu
+def test_results_held_by_a_reference_cycle_outlive_the_classifier(tmp_path):
+    """Round 3's segfault: tensors of the sharded pipeline, allocated on torch ExternalStreams that wrap the ENGINE's streams, were
+    kept by a reference cycle until the cycle collector ran -- after the streams had been destroyed.  Now the results are
+    allocated on the caller's stream, nothing of a batch outlives classify_many, close() drains, empties torch's cache and drops
+    the stream views BEFORE it destroys the streams, and an engine stream is never destroyed while a torch view of it is alive
+    (capi.Stream.close parks it).  Here: a cycle holds a batch's outputs AND a stream view; the classifier is closed; the
+    collector runs; the process must exit cleanly (run as a child: a crash at interpreter exit would not show in this one)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import gc, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+import numpy as np, torch
+import slacken_amd
+from slacken_amd import sharded, capi
+from oracle import oracle as orc
+import synth, taxgen
+rng = np.random.default_rng(5)
+parents = taxgen.taxonomy(8 * 16, rng)
+p = orc.params()
+lib = synth.Library(orc, p, parents, n_genomes=4, genome_len=6000, pad_records=2000)
+ix = slacken_amd.Index(expected_records=len(lib.keys), max_taxon=len(parents) - 1)
+ix.append(lib.keys, lib.taxa); ix.set_taxonomy(parents); ix.finalize()
+reads = synth.make_reads(lib, 700, rng)
+bases, offsets = synth.pack(reads)
+dev = torch.device('cuda', 0)
+d_b, d_o = torch.from_numpy(bases).to(dev), torch.from_numpy(offsets.astype(np.int64)).to(dev)
+sc = sharded.ShardedClassifier(ix, 0, 1, None, dev)
+outs = sc.classify_many([(d_b, d_o, len(reads), int(offsets[-1]), None)] * 6)
+want = orc.classify_batch(p, orc.Index(1, lib.keys, lib.taxa), parents, bases, offsets)
+assert np.array_equal(outs[3]['taxon'].cpu().numpy()[:len(reads)], want['taxon'][0])
+view = sc.st.external_stream(torch, dev)          # a torch view of the engine's stream that the caller holds on to
+cycle = {{'outs': outs, 'view': view}}
+cycle['self'] = cycle                              # only the cycle collector frees these
+del outs, view
+sc.close()                                         # the stream with the live view is parked, not destroyed
+assert len(capi._deferred_streams) == 1
+del cycle
+gc.collect()
+torch.cuda.synchronize()
+assert capi.release_deferred_streams() == 0        # the view has died: now the stream goes
+ix.close()
+print('clean exit')
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "clean exit" in r.stdout, (r.returncode, r.stderr[-2000:])
