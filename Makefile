@@ -20,7 +20,7 @@ $(GATHER): tools/gather_rate.hip
 	@mkdir -p slacken_amd/lib
 	$(HIPCC) -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -shared -o $@ tools/gather_rate.hip
 
-$(LIB): $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/build.hip $(CSRC)/shard.hip $(CSRC)/wide.hip $(CSRC)/capi.hip $(CSRC)/shardset.hip $(CSRC)/engine.h $(CSRC)/hostside.h include/slacken_amd.h
+$(LIB): $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/build.hip $(CSRC)/shard.hip $(CSRC)/wide.hip $(CSRC)/capi.hip $(CSRC)/shardset.hip $(CSRC)/engine.h $(CSRC)/hostside.h slacken_amd/host/pack.hpp include/slacken_amd.h
 	@mkdir -p slacken_amd/lib
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/lane.hip $(CSRC)/build.hip $(CSRC)/shard.hip $(CSRC)/wide.hip $(CSRC)/capi.hip $(CSRC)/shardset.hip -ldl
 
@@ -37,7 +37,7 @@ slacken_amd/bin/parquet_source.o: slacken_amd/host/parquet_source.cpp slacken_am
 	@mkdir -p slacken_amd/bin
 	g++ -O2 -std=c++20 -Wall $(PQ_CXXFLAGS) -c -o $@ slacken_amd/host/parquet_source.cpp
 
-$(CLI): slacken_amd/bin/parquet_source.o slacken_amd/host/slacken_cli.cpp slacken_amd/host/taxonomy.hpp slacken_amd/host/seqio.hpp slacken_amd/host/pargz.hpp slacken_amd/host/parbz2.hpp slacken_amd/host/titles.hpp slacken_amd/host/output.hpp include/slacken_amd.h $(LIB)
+$(CLI): slacken_amd/bin/parquet_source.o slacken_amd/host/slacken_cli.cpp slacken_amd/host/taxonomy.hpp slacken_amd/host/seqio.hpp slacken_amd/host/pargz.hpp slacken_amd/host/parbz2.hpp slacken_amd/host/titles.hpp slacken_amd/host/output.hpp slacken_amd/host/pack.hpp include/slacken_amd.h $(LIB)
 	@mkdir -p slacken_amd/bin
 	g++ -O2 -std=c++17 -Wall -o $@ slacken_amd/host/slacken_cli.cpp slacken_amd/bin/parquet_source.o $(PQ_LDFLAGS) -Lslacken_amd/lib -lslacken_amd -lz -ldl -lpthread -Wl,-rpath,'$$ORIGIN/../lib'
 

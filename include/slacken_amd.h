@@ -218,6 +218,21 @@ int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, 
                            uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers,
                            uint64_t *out_hit_offsets, slk_hit *out_hits, uint64_t hits_capacity);
 
+/* The same call with the reads in the engine's own 3-bit form -- InputFragment.nucleotides (S/kmers/minimizer/MinSplitter.scala:31-32)
+ * already encoded as BitRepresentation.charToTwobit encodes them (S/kmers/util/BitRepresentation.scala:127-135: A = 0, C = 1, G = 2,
+ * T / U = 3, either case) with the isValid test (:140-143) as one bit per base -- so that a batch costs 6 bytes per 16 bases on the
+ * PCIe link instead of 16: the call a JNI shim makes is bound by that link (slk_classify_batch from pinned memory: 305 M reads/s of
+ * 150 bp against the kernels' 1 100 M).  Base p of the concatenated reads (the p that offsets[] counts) is described by bits
+ * 2 (p % 16) .. 2 (p % 16) + 1 of codes[p / 16] and bit p % 16 of valid[p / 16]; codes of invalid bases are ignored; both arrays
+ * hold ceil(offsets[R] / 16) words (mates likewise).  Results are those of slk_classify_batch on any text with the same codes and
+ * validity.  slk_pack_bases makes the form from text (AVX2 + BMI2 where the CPU has them, several threads for large inputs). */
+int32_t slk_classify_batch_packed(slk_index *ix, slk_stream *st, const uint32_t *codes, const uint16_t *valid, const uint64_t *offsets,
+                                  const uint32_t *mate_codes, const uint16_t *mate_valid, const uint64_t *mate_offsets, uint64_t R,
+                                  int32_t min_hit_groups, const double *thresholds, int32_t C, int32_t *out_taxon,
+                                  uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers,
+                                  uint64_t *out_hit_offsets, slk_hit *out_hits, uint64_t hits_capacity);
+int32_t slk_pack_bases(const uint8_t *bases, uint64_t n, uint32_t *codes, uint16_t *valid);
+
 /* ---- kernel-3-only entry: Classifier.classify (object, S/slacken/Classifier.scala:439-454) on hit lists the caller holds
  * (host pointers; synchronous): TaxonCounts.toMap/totalKmers + resolveTree + the minHitGroups test for R lists of un-merged
  * hits in ordinal order.  This is what the host uses to reproduce the reference's regrouping by TITLE

@@ -74,6 +74,7 @@ EXPORTS = ["slk_device_count", "slk_last_error", "slk_version", "slk_host_alloc"
            "slk_index_append_device", "slk_index_set_shard", "slk_index_set_taxonomy", "slk_index_finalize", "slk_index_get_info",
            "slk_index_lookup", "slk_index_add_sequences", "slk_index_add_sequences_device", "slk_index_export", "slk_index_destroy", "slk_stream_create", "slk_stream_synchronize",
            "slk_stream_hip_stream", "slk_stream_destroy", "slk_spans_batch", "slk_spans_batch_wide", "slk_classify_batch",
+           "slk_classify_batch_packed", "slk_pack_bases",
            "slk_classify_batch_device", "slk_classify_hits", "slk_stream_last_stage_ms", "slk_scan_device", "slk_lookup_device",
            "slk_shard_of", "slk_classify_hits_device", "slk_shard_batch_rows", "slk_shard_chunk", "slk_shard_step_device",
            "slk_stream_last_deferred", "slk_table_slot", "slk_table_hash_of",
@@ -136,6 +137,9 @@ def lib():
     L.slk_spans_batch_wide.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, u64p, vp, i64p, C.c_uint64]
     L.slk_classify_batch.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_int32, C.POINTER(C.c_double),
                                      C.c_int32, i32p, u8p, i32p, i32p, u64p, vp, C.c_uint64]
+    L.slk_classify_batch_packed.argtypes = [vp, vp, vp, vp, u64p, vp, vp, u64p, C.c_uint64, C.c_int32, C.POINTER(C.c_double),
+                                            C.c_int32, i32p, u8p, i32p, i32p, u64p, vp, C.c_uint64]
+    L.slk_pack_bases.argtypes = [u8p, C.c_uint64, vp, vp]
     L.slk_classify_batch_device.argtypes = [vp, vp, u8p, u64p, u8p, u64p, C.c_uint64, C.c_uint64, C.c_uint64,
                                             C.c_int32, C.POINTER(C.c_double), C.c_int32, i32p, u8p, i32p, i32p, i32p, i32p]
     L.slk_classify_hits.argtypes = [vp, vp, C.c_uint64, u64p, vp, u8p, C.c_int32, C.POINTER(C.c_double), C.c_int32, i32p, u8p,
@@ -172,6 +176,16 @@ def _np(a, dtype):
 
 def _ptr(a):
     return a.ctypes.data if a is not None else None
+
+
+def pack_bases(bases, pinned=False):
+    """ASCII bases -> (codes uint32 [ceil(n / 16)], valid uint16 [ceil(n / 16)]): the engine's 3-bit form (slk_pack_bases)"""
+    bases = _np(bases, np.uint8)
+    words = (bases.size + 15) // 16
+    make = (lambda n, dt: pinned_array((n,), dt)) if pinned else (lambda n, dt: np.zeros(n, dt))
+    codes, valid = make(max(words, 1), np.uint32), make(max(words, 1), np.uint16)
+    _check(lib().slk_pack_bases(_ptr(bases), bases.size, _ptr(codes), _ptr(valid)))
+    return codes, valid
 
 
 def pinned_array(shape, dtype):
@@ -487,13 +501,28 @@ class Stream:
         return out_off, out[:n], keys[:n]
 
     def classify_batch(self, bases, offsets, mate_bases=None, mate_offsets=None, min_hit_groups=2,
-                       thresholds=(0.0,), with_hits=True, hits_capacity=None, with_num_hits=False, out=None):
+                       thresholds=(0.0,), with_hits=True, hits_capacity=None, with_num_hits=False, out=None, packed=False):
         """out: optional dict of preallocated result arrays (taxon [C,R] int32, classified [C,R] uint8, num_distinct [R],
-        total_kmers [R]) -- e.g. pinned_array()s, which the library fills by DMA."""
-        bases, offsets = _np(bases, np.uint8), _np(offsets, np.uint64)
+        total_kmers [R]) -- e.g. pinned_array()s, which the library fills by DMA.
+        packed: True = the reads travel in the engine's 3-bit form (packed here by slk_pack_bases; slk_classify_batch_packed), or a
+        tuple (codes, valid[, mate_codes, mate_valid]) of arrays packed beforehand (bases may then be None)."""
+        offsets = _np(offsets, np.uint64)
         R = offsets.size - 1
-        if mate_bases is not None:
-            mate_bases, mate_offsets = _np(mate_bases, np.uint8), _np(mate_offsets, np.uint64)
+        pk = None
+        if packed:
+            if packed is True:
+                pk = pack_bases(bases) + (pack_bases(mate_bases) if mate_bases is not None else (None, None))
+            else:
+                pk = tuple(packed) + (None, None) * (len(packed) == 2)
+            n_bases = int(offsets[R])
+            n_mates = int(_np(mate_offsets, np.uint64)[R]) if mate_offsets is not None else 0
+        else:
+            bases = _np(bases, np.uint8)
+            n_bases, n_mates = bases.size, (np.asarray(mate_bases).size if mate_bases is not None else 0)
+        if mate_offsets is not None:
+            mate_offsets = _np(mate_offsets, np.uint64)
+            if not packed:
+                mate_bases = _np(mate_bases, np.uint8)
         Cn = len(thresholds)
         thr = (C.c_double * Cn)(*thresholds)
         if out is not None:
@@ -508,14 +537,19 @@ class Stream:
         cap = 0
         if with_hits:
             cap = hits_capacity if hits_capacity is not None else \
-                int(bases.size + (mate_bases.size + R if mate_bases is not None else 0)) + 1
+                int(n_bases + (n_mates + R if mate_offsets is not None else 0)) + 1
             hit_off = np.zeros(R + 1, np.uint64)
             hits = np.zeros(cap, HIT_DTYPE)
         elif with_num_hits:   # the number of spans per fragment without the lists: offsets only
             hit_off = np.zeros(R + 1, np.uint64)
-        _check(lib().slk_classify_batch(self.index.h, self.h, _ptr(bases), _ptr(offsets), _ptr(mate_bases),
-                                        _ptr(mate_offsets), R, min_hit_groups, thr, Cn, _ptr(taxon), _ptr(cls),
-                                        _ptr(nd), _ptr(tk), _ptr(hit_off), _ptr(hits), cap))
+        if pk is not None:
+            _check(lib().slk_classify_batch_packed(self.index.h, self.h, _ptr(pk[0]), _ptr(pk[1]), _ptr(offsets), _ptr(pk[2]), _ptr(pk[3]),
+                                                   _ptr(mate_offsets), R, min_hit_groups, thr, Cn, _ptr(taxon), _ptr(cls),
+                                                   _ptr(nd), _ptr(tk), _ptr(hit_off), _ptr(hits), cap))
+        else:
+            _check(lib().slk_classify_batch(self.index.h, self.h, _ptr(bases), _ptr(offsets), _ptr(mate_bases),
+                                            _ptr(mate_offsets), R, min_hit_groups, thr, Cn, _ptr(taxon), _ptr(cls),
+                                            _ptr(nd), _ptr(tk), _ptr(hit_off), _ptr(hits), cap))
         out = dict(taxon=taxon, classified=cls, num_distinct=nd, total_kmers=tk)
         if with_hits:
             out["hit_offsets"] = hit_off

@@ -189,13 +189,13 @@ __host__ __device__ inline uint64_t fmix64_inverse(uint64_t x) {
 
 // Every occupied cell back to its (key, taxon) record: the cell holds the hash remainder and its displacement, the bucket
 // index gives the home bucket, and both the range reduction (engine.h: table_hash_of) and fmix64 are invertible.
-__global__ void __launch_bounds__(256) export_kernel(TableView T, uint64_t ncells, int64_t *__restrict__ keys,
+__global__ void __launch_bounds__(256) export_kernel(TableView T, uint64_t cell0, uint64_t ncells, int64_t *__restrict__ keys,
                                                      int32_t *__restrict__ taxa, uint64_t capacity,
                                                      unsigned long long *__restrict__ counter) {
   uint64_t i;
   const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t tmask = (1ULL << T.g.taxon_bits) - 1, dmask = (1ULL << T.g.disp_bits) - 1;
-  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < ncells; base += step) {  // wave-uniform trip count
+  for (uint64_t base = cell0 + (uint64_t)blockIdx.x * blockDim.x; base < ncells; base += step) {  // wave-uniform trip count
     i = base + threadIdx.x;
     uint64_t cell = i < ncells ? T.cells[i] : 0;
     const bool has = cell != 0;
@@ -235,9 +235,15 @@ void launch_build(const ScanParams &P, const TableBuild &T, const int32_t *paren
 
 void launch_export(const TableView &T, uint64_t nbuckets, int64_t *keys, int32_t *taxa, uint64_t capacity,
                    unsigned long long *counter, hipStream_t s) {
-  uint64_t ncells = nbuckets * CELLS;
-  uint64_t blocks = std::min<uint64_t>((ncells + 255) / 256, 256 * 64);
-  hipLaunchKernelGGL(export_kernel, dim3((unsigned)blocks), dim3(256), 0, s, T, ncells, keys, taxa, capacity, counter);
+  launch_export_range(T, 0, nbuckets, keys, taxa, capacity, counter, s);
+}
+// the records of buckets [bucket0, bucket1) (a table that is being moved to a larger one goes there piece by piece)
+void launch_export_range(const TableView &T, uint64_t bucket0, uint64_t bucket1, int64_t *keys, int32_t *taxa, uint64_t capacity,
+                         unsigned long long *counter, hipStream_t s) {
+  if (bucket1 <= bucket0) return;
+  const uint64_t cell0 = bucket0 * CELLS, ncells = bucket1 * CELLS;
+  uint64_t blocks = std::min<uint64_t>((ncells - cell0 + 255) / 256, 256 * 64);
+  hipLaunchKernelGGL(export_kernel, dim3((unsigned)blocks), dim3(256), 0, s, T, cell0, ncells, keys, taxa, capacity, counter);
 }
 
 }  // namespace slk

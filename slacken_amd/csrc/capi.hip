@@ -2,6 +2,7 @@
 // Host-side only: handle management, HBM table sizing, per-stream scratch, H2D/D2H for the host-pointer entry points.
 // There is NO CPU fallback: without a gfx950 device every compute entry point fails with SLK_E_NO_GPU / SLK_E_HIP.
 #include "hostside.h"
+#include "../host/pack.hpp"
 
 extern "C" {
 
@@ -43,6 +44,36 @@ static int ceil_log2_u64(uint64_t x) {
   int b = 0;
   while (b < 63 && (1ULL << b) < x) b++;
   return b;
+}
+
+// Geometry of the record table.  Any number of buckets (engine.h: the multiply-shift range reduction); a cell holds
+//   [flag] remainder (64 - q, + 1 unless the count is a power of two) | displacement | taxon     in 64 bits,
+// so the displacement field gets what the other fields leave (8 bits at most are used: 255 buckets of linear probing; a table
+// filled to 0.8 has chains of over 63 full buckets), and the buckets' "a record went past" flag exists where a bit is left for it.
+struct TableShape { uint64_t nb; int q, disp; bool flag; };
+static const int DISP_MIN = CELLS == 16 ? 3 : 4;
+static TableShape shape_of(uint64_t nb, int tb) {
+  TableShape sh{std::max<uint64_t>(nb, 32), 0, 0, false};
+  sh.q = ceil_log2_u64(sh.nb);
+  const bool pow2 = sh.nb == (1ULL << sh.q);
+  const int avail = 64 - tb - (64 - sh.q + (pow2 ? 0 : 1));
+  static const bool no_flag = getenv("SLK_NO_BUCKET_FLAG") != nullptr && getenv("SLK_NO_BUCKET_FLAG")[0] == '1';   // (A/B switch)
+  sh.flag = avail - 1 >= DISP_MIN && !no_flag;
+  sh.disp = std::min(8, avail - (sh.flag ? 1 : 0));
+  return sh;
+}
+static uint64_t grow_buckets(uint64_t nb) { const int q = ceil_log2_u64(nb); return nb == (1ULL << q) ? nb * 2 : (1ULL << q); }
+// displacement bits a table filled to `load` needs: the chains of full buckets grow with the load (measured maxima at 1e5..1e10
+// records: load 0.55: 14 buckets, 0.70: 32, 0.80: over 63)
+static int need_disp_bits(double load) { return load <= 0.50 ? 4 : load <= 0.62 ? 5 : load <= 0.72 ? 6 : load <= 0.80 ? 7 : 8; }
+// `records` records in at least `nb` buckets: the table is made larger (to the next power of two: one bit back from the remainder)
+// until its cells leave a displacement field long enough for the load it will then have.  ok = false: no such table below 2^32 buckets.
+static TableShape settle_shape(uint64_t nb, uint64_t records, int tb, bool *ok) {
+  TableShape sh = shape_of(nb, tb);
+  while (sh.disp < DISP_MIN && sh.nb < (1ULL << 33)) sh = shape_of(grow_buckets(sh.nb), tb);
+  while (sh.nb < (1ULL << 32) && sh.disp < std::max(DISP_MIN, need_disp_bits((double)records / ((double)sh.nb * CELLS)))) sh = shape_of(grow_buckets(sh.nb), tb);
+  *ok = !(sh.nb > (1ULL << 32) || sh.disp < DISP_MIN);
+  return sh;
 }
 
 int32_t slk_index_create(const slk_params *p, const slk_table_config *cfg, int32_t device, slk_index **out) {
@@ -141,35 +172,11 @@ int32_t slk_index_create(const slk_params *p, const slk_table_config *cfg, int32
     else lf = std::min(0.85, cell_bytes / (0.80 * t));
   }
   if (lf > 0.95) lf = 0.95;
-  // Geometry.  Any number of buckets (engine.h: the multiply-shift range reduction); a cell holds
-  //   [flag] remainder (64 - q, + 1 unless the count is a power of two) | displacement | taxon     in 64 bits,
-  // so the displacement field gets what the other fields leave (8 bits at most are used: 255 buckets of linear probing; a table
-  // filled to 0.8 has chains of over 63 full buckets), and the
-  // buckets' "a record went past" flag exists where a bit is left for it.  A table whose cells leave fewer than DISP_MIN
-  // displacement bits is made larger (to the next power of two: one bit back from the remainder).
-  const int DISP_MIN = CELLS == 16 ? 3 : 4;
-  struct Shape { uint64_t nb; int q, disp; bool flag; };
-  auto shape_of = [&](uint64_t nb) {
-    Shape sh{std::max<uint64_t>(nb, 32), 0, 0, false};
-    sh.q = ceil_log2_u64(sh.nb);
-    const bool pow2 = sh.nb == (1ULL << sh.q);
-    const int avail = 64 - tb - (64 - sh.q + (pow2 ? 0 : 1));
-    static const bool no_flag = getenv("SLK_NO_BUCKET_FLAG") != nullptr && getenv("SLK_NO_BUCKET_FLAG")[0] == '1';   // (A/B switch)
-    sh.flag = avail - 1 >= DISP_MIN && !no_flag;
-    sh.disp = std::min(8, avail - (sh.flag ? 1 : 0));
-    return sh;
-  };
-  auto grow = [&](uint64_t nb) { const int q = ceil_log2_u64(nb); return nb == (1ULL << q) ? nb * 2 : (1ULL << q); };
+  // (a record that finds no cell within reach of its displacement field all the same makes the table grow: grow_table)
   const uint64_t cells_needed = (uint64_t)((double)expected / lf) + CELLS;
-  Shape sh = shape_of((cells_needed + CELLS - 1) / CELLS);
-  while (sh.disp < DISP_MIN && sh.nb < (1ULL << 33)) sh = shape_of(grow(sh.nb));
-  // A table whose cells leave a short displacement field (mid-size tables under wide taxon ids) is made larger until the field is
-  // long enough for the load the table will then have: the chains of full buckets grow with the load (measured maxima at 1e5..1e10
-  // records: load 0.55: 14 buckets, 0.70: 32, 0.80: over 63), and a record that finds no cell within reach is an error
-  // (SLK_E_CAPACITY; a soak of random tables at given loads of 0.70-0.80 with 4-bit fields hit it in 7 of 200).
-  auto need_bits = [](double load) { return load <= 0.50 ? 4 : load <= 0.62 ? 5 : load <= 0.72 ? 6 : load <= 0.80 ? 7 : 8; };
-  while (sh.nb < (1ULL << 32) && sh.disp < std::max(DISP_MIN, need_bits((double)expected / ((double)sh.nb * CELLS)))) sh = shape_of(grow(sh.nb));
-  if (sh.nb > (1ULL << 32) || sh.disp < DISP_MIN) { delete ix; return fail(SLK_E_CAPACITY, "a table of %llu buckets is too large", (unsigned long long)sh.nb); }
+  bool shape_ok = false;
+  const TableShape sh = settle_shape((cells_needed + CELLS - 1) / CELLS, expected, tb, &shape_ok);
+  if (!shape_ok) { delete ix; return fail(SLK_E_CAPACITY, "a table of %llu buckets is too large", (unsigned long long)sh.nb); }
   ix->bucket_bits = sh.q;
   ix->taxon_bits = tb;
   ix->disp_bits = sh.disp;
@@ -201,12 +208,9 @@ static int32_t read_build_counters(slk_index *ix) {
   ix->records = c[0];
   ix->dups = c[1];
   ix->max_disp = md;
+  ix->unplaced = c[2];
   if (c[2] != 0 && ix->W > 1) return fail(SLK_E_CAPACITY, "%llu records found no free slot: raise expected_records", c[2]);
-  if (c[2] != 0)
-    return fail(SLK_E_CAPACITY,
-                "%llu records could not be placed within %d buckets of their home bucket: raise expected_records "
-                "or lower load_factor", c[2], (1 << ix->disp_bits) - 1);
-  return SLK_OK;
+  return SLK_OK;   // (one-word table: records that found no cell within reach are the caller's to settle -- insert_growing)
 }
 
 static TableBuild build_view(slk_index *ix) {
@@ -221,6 +225,152 @@ static TableBuild build_view(slk_index *ix) {
   t.n_duplicate = ix->d_counters + 1;
   t.n_overflow = ix->d_counters + 2;
   return t;
+}
+
+// A record that found no cell within reach of its cells' displacement field -- a chain of full buckets longer than the field can
+// count; the sizing keeps that from happening at the loads it chooses, a load_factor given by the caller or a library that outgrew
+// its expected_records may not -- does NOT fail the load (a library is hours of Parquet streaming by then): the table moves to
+// the next larger geometry (twice the buckets: the load halves and the remainder gives a bit to the displacement), piece by piece
+// through a bounded staging buffer -- on the device while both tables fit its memory, through host memory otherwise --, and the
+// insert that hit the limit runs again (records it had placed are found again as duplicates of themselves: the caller corrects
+// the count).  Replaces KeyValueIndex.loadRecords' "it is a table scan: any size works" (S/slacken/KeyValueIndex.scala:150-159).
+static int32_t grow_table(slk_index *ix) {
+  bool ok = false;
+  const TableShape sh = settle_shape(grow_buckets(ix->nbuckets), std::max<uint64_t>(ix->records, 1), ix->taxon_bits, &ok);
+  if (!ok) return fail(SLK_E_CAPACITY, "the table cannot grow beyond %llu buckets", (unsigned long long)ix->nbuckets);
+  const size_t new_bytes = (size_t)sh.nb * CELLS * 8;
+  const uint64_t CH = (uint64_t)1 << 24;   // buckets per piece (at most 2^27 records: 1.5 GB of staging)
+  DevBuf dk, dt, dc;
+  HIPCHK(dc.ensure(8));
+  uint64_t *new_cells = nullptr;
+  // (SLK_GROW_VIA_HOST=1: take the host route although both tables would fit the device -- how the tests reach it)
+  const char *via_host = getenv("SLK_GROW_VIA_HOST");
+  const bool on_device = !(via_host && via_host[0] == '1') && hipMalloc((void **)&new_cells, new_bytes) == hipSuccess;
+  if (!on_device) (void)hipGetLastError();
+  const uint64_t cap = std::min<uint64_t>(CH, ix->nbuckets) * CELLS;
+  HIPCHK(dk.ensure(cap * 8));
+  HIPCHK(dt.ensure(cap * 4));
+  // scratch counters for the move (the index's own keep counting the caller's records); the new maximum displacement is the move's
+  unsigned long long *d_scratch = nullptr;
+  HIPCHK(hipMalloc((void **)&d_scratch, 3 * sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(d_scratch, 0, 3 * sizeof(unsigned long long), ix->build_stream));
+  std::vector<int64_t> h_keys;
+  std::vector<int32_t> h_taxa;
+  const TableView old_view = [&] { TableView v = ix->view(); v.to_orig = nullptr; return v; }();
+  const uint64_t old_nb = ix->nbuckets;
+  uint64_t *old_cells = ix->cells;
+  auto adopt = [&](uint64_t *cells) {
+    ix->cells = cells; ix->nbuckets = sh.nb; ix->bucket_bits = sh.q; ix->disp_bits = sh.disp; ix->bucket_flag = sh.flag;
+  };
+  auto insert_piece = [&](const int64_t *k, const int32_t *t, uint64_t n) -> int32_t {
+    TableBuild nb = build_view(ix);
+    nb.shard = 0; nb.n_shards = 0;   // (what is in the table is this shard's already)
+    nb.n_inserted = d_scratch; nb.n_duplicate = d_scratch + 1; nb.n_overflow = d_scratch + 2;
+    launch_table_insert(nb, k, t, n, ix->build_stream);
+    HIPCHK(hipGetLastError());
+    return SLK_OK;
+  };
+  if (on_device) {
+    HIPCHK(hipMemsetAsync(new_cells, 0, new_bytes, ix->build_stream));
+    HIPCHK(hipMemsetAsync(ix->d_max_disp, 0, sizeof(int32_t), ix->build_stream));
+    adopt(new_cells);
+    for (uint64_t b0 = 0; b0 < old_nb; b0 += CH) {
+      const uint64_t b1 = std::min(old_nb, b0 + CH);
+      unsigned long long n = 0;
+      HIPCHK(hipMemsetAsync(dc.p, 0, 8, ix->build_stream));
+      launch_export_range(old_view, b0, b1, dk.as<int64_t>(), dt.as<int32_t>(), cap, dc.as<unsigned long long>(), ix->build_stream);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(&n, dc.p, 8, hipMemcpyDeviceToHost, ix->build_stream));
+      HIPCHK(hipStreamSynchronize(ix->build_stream));
+      int32_t rc = insert_piece(dk.as<int64_t>(), dt.as<int32_t>(), n);
+      if (rc) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(ix->build_stream));
+    HIPCHK(hipFree(old_cells));
+  } else {
+    // both tables do not fit the device: the records wait in host memory (12 bytes each) while the old table makes room
+    for (uint64_t b0 = 0; b0 < old_nb; b0 += CH) {
+      const uint64_t b1 = std::min(old_nb, b0 + CH);
+      unsigned long long n = 0;
+      HIPCHK(hipMemsetAsync(dc.p, 0, 8, ix->build_stream));
+      launch_export_range(old_view, b0, b1, dk.as<int64_t>(), dt.as<int32_t>(), cap, dc.as<unsigned long long>(), ix->build_stream);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(&n, dc.p, 8, hipMemcpyDeviceToHost, ix->build_stream));
+      HIPCHK(hipStreamSynchronize(ix->build_stream));
+      const size_t at = h_keys.size();
+      h_keys.resize(at + n); h_taxa.resize(at + n);
+      if (n) {
+        HIPCHK(hipMemcpy(h_keys.data() + at, dk.p, n * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(h_taxa.data() + at, dt.p, n * 4, hipMemcpyDeviceToHost));
+      }
+    }
+    HIPCHK(hipFree(old_cells));
+    ix->cells = nullptr;
+    if (hipMalloc((void **)&new_cells, new_bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(d_scratch);
+      return fail(SLK_E_HIP, "hipMalloc of %zu table bytes failed while the table was growing (the records are lost: load the library again "
+                  "with a larger slk_table_config.expected_records)", new_bytes);
+    }
+    HIPCHK(hipMemsetAsync(new_cells, 0, new_bytes, ix->build_stream));
+    HIPCHK(hipMemsetAsync(ix->d_max_disp, 0, sizeof(int32_t), ix->build_stream));
+    adopt(new_cells);
+    for (uint64_t o = 0; o < h_keys.size(); o += cap) {
+      const uint64_t n = std::min<uint64_t>(cap, h_keys.size() - o);
+      HIPCHK(hipMemcpyAsync(dk.p, h_keys.data() + o, n * 8, hipMemcpyHostToDevice, ix->build_stream));
+      HIPCHK(hipMemcpyAsync(dt.p, h_taxa.data() + o, n * 4, hipMemcpyHostToDevice, ix->build_stream));
+      int32_t rc = insert_piece(dk.as<int64_t>(), dt.as<int32_t>(), n);
+      if (rc) return rc;
+      HIPCHK(hipStreamSynchronize(ix->build_stream));
+    }
+  }
+  unsigned long long c[3] = {0, 0, 0};
+  HIPCHK(hipMemcpy(c, d_scratch, sizeof(c), hipMemcpyDeviceToHost));
+  (void)hipFree(d_scratch);
+  dk.release(); dt.release(); dc.release();
+  if (c[2] != 0 || c[1] != 0) return fail(SLK_E_HIP, "moving the table to a larger one lost records (%llu unplaced, %llu collided)", c[2], c[1]);
+  ix->grown++;
+  static const bool verbose = getenv("SLK_DEBUG_GROW") != nullptr;
+  if (verbose) fprintf(stderr, "[slk] table grown to %llu buckets (%d displacement bits), %llu records moved %s\n", (unsigned long long)sh.nb, sh.disp,
+                       c[0], on_device ? "on the device" : "through host memory");
+  return SLK_OK;
+}
+
+// Runs `insert` (which queues one batch of records on the build stream; re-runnable) until every record of the batch has a cell,
+// moving the table to a larger one in between if need be.  counts_dups: the insert counts keys that are present already (the plain
+// record insert; the library builder merges them instead): a re-run then counts the records the first run placed as duplicates of
+// themselves, which is taken out again.
+static int32_t insert_growing(slk_index *ix, bool counts_dups, const std::function<int32_t()> &insert) {
+  int32_t rc = read_build_counters(ix);   // (the state before this batch)
+  if (rc) return rc;
+  const uint64_t ins0 = ix->records, dup0 = ix->dups;
+  for (int attempt = 0;; attempt++) {
+    const uint64_t ins_before = ix->records;
+    rc = insert();
+    if (rc) return rc;
+    rc = read_build_counters(ix);
+    if (rc) return rc;
+    if (ix->unplaced == 0) {
+      if (counts_dups && attempt > 0) {
+        // this run saw every record of the batch: new ones it inserted, all others it counted -- among them the (ins_before - ins0)
+        // records earlier runs had placed
+        const uint64_t dups = dup0 + (ix->dups - dup0) - (ins_before - ins0);
+        const unsigned long long v = dups;
+        HIPCHK(hipMemcpy(ix->d_counters + 1, &v, sizeof(v), hipMemcpyHostToDevice));
+        ix->dups = dups;
+      }
+      return SLK_OK;
+    }
+    if (ix->W > 1) return fail(SLK_E_CAPACITY, "%llu records found no free slot: raise expected_records", (unsigned long long)ix->unplaced);
+    if (attempt >= 6) return fail(SLK_E_CAPACITY, "%llu records could not be placed after the table had grown %d times", (unsigned long long)ix->unplaced, attempt);
+    rc = grow_table(ix);
+    if (rc) return rc;
+    // the next run starts from this batch's beginning: its duplicate count too
+    const unsigned long long z[2] = {dup0, 0};
+    HIPCHK(hipMemcpy(ix->d_counters + 1, &z[0], sizeof(unsigned long long), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ix->d_counters + 2, &z[1], sizeof(unsigned long long), hipMemcpyHostToDevice));
+    ix->dups = dup0;
+  }
 }
 
 // Table-sharded libraries (BASELINE configs[3]): the index keeps the records whose key falls to `shard` of `n_shards`
@@ -241,10 +391,16 @@ int32_t slk_index_append_device(slk_index *ix, const int64_t *d_keys, const int3
   if (ix->finalized) return fail(SLK_E_STATE, "index is finalized");
   int32_t rc = set_device(ix);
   if (rc) return rc;
-  if (ix->W > 1) launch_wide_insert(ix->wt, ix->W, d_keys, d_taxa, n, ix->d_counters, ix->build_stream);
-  else launch_table_insert(build_view(ix), d_keys, d_taxa, n, ix->build_stream);
-  HIPCHK(hipGetLastError());
-  return read_build_counters(ix);
+  if (ix->W > 1) {
+    launch_wide_insert(ix->wt, ix->W, d_keys, d_taxa, n, ix->d_counters, ix->build_stream);
+    HIPCHK(hipGetLastError());
+    return read_build_counters(ix);
+  }
+  return insert_growing(ix, true, [&]() -> int32_t {
+    launch_table_insert(build_view(ix), d_keys, d_taxa, n, ix->build_stream);
+    HIPCHK(hipGetLastError());
+    return SLK_OK;
+  });
 }
 
 int32_t slk_index_append(slk_index *ix, const int64_t *keys, const int32_t *taxa, uint64_t n) {
@@ -282,10 +438,12 @@ int32_t slk_index_append(slk_index *ix, const int64_t *keys, const int32_t *taxa
     rc = copy_in(&ix->staging, ix->build_stream, ix->stage_keys.p, keys + o, c * 8);
     if (!rc) rc = copy_in(&ix->staging, ix->build_stream, ix->stage_taxa.p, taxa + o, c * 4);
     if (rc) return rc;
-    launch_table_insert(build_view(ix), ix->stage_keys.as<int64_t>(), ix->stage_taxa.as<int32_t>(), c,
-                        ix->build_stream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ix->build_stream));
+    rc = insert_growing(ix, true, [&]() -> int32_t {
+      launch_table_insert(build_view(ix), ix->stage_keys.as<int64_t>(), ix->stage_taxa.as<int32_t>(), c, ix->build_stream);
+      HIPCHK(hipGetLastError());
+      return SLK_OK;
+    });
+    if (rc) return rc;
   }
   return read_build_counters(ix);
 }
@@ -490,10 +648,14 @@ static int32_t add_sequences(slk_index *ix, const uint8_t *bases, const uint64_t
       if (!rc) rc = copy_in(&ix->staging, ix->build_stream, d_len.p, clen.data(), nc * 4);
       if (!rc) rc = copy_in(&ix->staging, ix->build_stream, d_tax.p, ctax.data(), nc * 4);
       if (rc) return rc;
-      launch_build(ix->sp, build_view(ix), ix->d_parents, ix->T, src, gbytes, d_start.as<uint64_t>(),
-                   d_len.as<uint32_t>(), d_tax.as<int32_t>(), nc, ix->build_stream);
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipStreamSynchronize(ix->build_stream));
+      // (re-runnable: the merge by LCA is idempotent, so a group that ran into the table's limit is simply scanned again)
+      rc = insert_growing(ix, false, [&]() -> int32_t {
+        launch_build(ix->sp, build_view(ix), ix->d_parents, ix->T, src, gbytes, d_start.as<uint64_t>(),
+                     d_len.as<uint32_t>(), d_tax.as<int32_t>(), nc, ix->build_stream);
+        HIPCHK(hipGetLastError());
+        return SLK_OK;
+      });
+      if (rc) return rc;
     }
     i = j;
   }
@@ -691,7 +853,8 @@ void slk_stream_destroy(slk_stream *st) {
   (void)hipStreamSynchronize(st->s);
   DevBuf *bufs[] = {&st->span_keys, &st->span_meta, &st->span_taxon, &st->span_count, &st->bases, &st->offsets,
                     &st->mate_bases, &st->mate_offsets, &st->out_taxon, &st->out_cls, &st->out_nd, &st->out_tk,
-                    &st->out_nh, &st->out_offsets, &st->out_items, &st->defer_list};
+                    &st->out_nh, &st->out_offsets, &st->out_items, &st->defer_list, &st->pk_codes, &st->pk_valid, &st->pk_mate_codes,
+                    &st->pk_mate_valid};
   for (DevBuf *b : bufs) b->release();
   if (st->d_status) (void)hipFree(st->d_status);
   if (st->h_status) (void)hipHostFree(st->h_status);
@@ -700,6 +863,7 @@ void slk_stream_destroy(slk_stream *st) {
   for (hipEvent_t e : st->up_ev) (void)hipEventDestroy(e);
   if (st->cs) (void)hipStreamDestroy(st->cs);
   if (st->s2) { (void)hipStreamSynchronize(st->s2); (void)hipStreamDestroy(st->s2); }
+  if (st->ev_unpack) (void)hipEventDestroy(st->ev_unpack);
   if (st->ev_fork) (void)hipEventDestroy(st->ev_fork);
   if (st->ev_join) (void)hipEventDestroy(st->ev_join);
   for (int i = 0; i < 4; i++) if (st->ev[i]) (void)hipEventDestroy(st->ev[i]);
@@ -1358,17 +1522,49 @@ int32_t slk_spans_batch_wide(slk_index *ix, slk_stream *st, const uint8_t *bases
   return spans_batch(ix, st, bases, offsets, mate_bases, mate_offsets, R, out_span_offsets, out_spans, out_keys, spans_capacity);
 }
 
-int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, const uint64_t *offsets,
-                           const uint8_t *mate_bases, const uint64_t *mate_offsets, uint64_t R,
-                           int32_t min_hit_groups, const double *thresholds, int32_t C, int32_t *out_taxon,
-                           uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers,
-                           uint64_t *out_hit_offsets, slk_hit *out_hits, uint64_t hits_capacity) {
+// The reads of a host call: ASCII (bases / mate_bases) or the engine's 3-bit form (host/pack.hpp: 2-bit codes and validity bits,
+// 16 bases per word, positions as in the ASCII concatenation).  Packed reads are unpacked on the device, behind their upload, into
+// the stream's ASCII buffers -- 6 bytes over the link per 16 bases instead of 16 --, so every kernel of the path reads them as it
+// reads text.
+struct ReadSource {
+  const uint8_t *bases = nullptr, *mate_bases = nullptr;
+  const uint32_t *codes = nullptr, *mate_codes = nullptr;
+  const uint16_t *valid = nullptr, *mate_valid = nullptr;
+  bool packed() const { return codes != nullptr; }
+};
+
+// bases [p0, p1) of one mate from the caller's memory to dst (+ the device-side unpack on `run` for packed reads), ordered on `up`
+static int32_t upload_range(slk_stream *st, Staging *g, hipStream_t up, hipStream_t run, hipEvent_t ev, bool packed, const uint8_t *bases,
+                            const uint32_t *codes, const uint16_t *valid, DevBuf &d_codes, DevBuf &d_valid, uint8_t *dst, uint64_t p0, uint64_t p1) {
+  if (p1 <= p0) return SLK_OK;
+  if (!packed) return copy_in(g, up, dst + p0, bases + p0, p1 - p0);
+  const uint64_t w0 = p0 / 16, w1 = (p1 + 15) / 16;
+  int32_t rc = copy_in(g, up, d_codes.as<uint32_t>() + w0, codes + w0, (w1 - w0) * 4);
+  if (!rc) rc = copy_in(g, up, d_valid.as<uint16_t>() + w0, valid + w0, (w1 - w0) * 2);
+  if (rc) return rc;
+  if (up != run) {
+    HIPCHK(hipEventRecord(ev, up));
+    HIPCHK(hipStreamWaitEvent(run, ev, 0));
+  }
+  // (whole words: a word that straddles two ranges is unpacked by both, to the same bytes, in stream order)
+  launch_unpack_bases(d_codes.as<uint32_t>(), d_valid.as<uint16_t>(), w0, w1, dst, run);
+  HIPCHK(hipGetLastError());
+  return SLK_OK;
+}
+
+static int32_t classify_batch_host(slk_index *ix, slk_stream *st, const ReadSource &src, const uint64_t *offsets, const uint64_t *mate_offsets,
+                                   uint64_t R, int32_t min_hit_groups, const double *thresholds, int32_t C, int32_t *out_taxon,
+                                   uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers, uint64_t *out_hit_offsets,
+                                   slk_hit *out_hits, uint64_t hits_capacity) {
   int32_t rc = check_ready(ix, st, true);
   if (rc) return rc;
-  if (!offsets || (R && (!bases || !out_taxon || !out_classified))) return fail(SLK_E_INVALID, "null argument");
+  const bool pk = src.packed();
+  if (!offsets || (R && ((!pk && !src.bases) || (pk && !src.valid) || !out_taxon || !out_classified))) return fail(SLK_E_INVALID, "null argument");
   if (C < 1 || C > MAX_THRESHOLDS || !thresholds) return fail(SLK_E_INVALID, "need 1..%d thresholds", MAX_THRESHOLDS);
-  if ((mate_bases == nullptr) != (mate_offsets == nullptr))
-    return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
+  const bool paired = mate_offsets != nullptr;
+  if (paired != (pk ? (src.mate_codes != nullptr && src.mate_valid != nullptr) : src.mate_bases != nullptr) ||
+      (!paired && (src.mate_codes || src.mate_valid || src.mate_bases)))
+    return fail(SLK_E_INVALID, "the second mates' bases and mate_offsets must be given together");
   rc = set_device(ix);
   if (rc) return rc;
   if (out_hit_offsets) out_hit_offsets[0] = 0;
@@ -1377,29 +1573,38 @@ int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, 
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tp[6] = {now(), 0, 0, 0, 0, 0};
   uint64_t total = 0, mate_total = 0;
-  const bool paired = mate_offsets != nullptr;
   const bool want_hits = out_hit_offsets != nullptr && out_hits != nullptr;
   HIPCHK(st->out_taxon.ensure((size_t)C * R * 4));
   HIPCHK(st->out_cls.ensure((size_t)C * R));
   HIPCHK(st->out_nd.ensure(R * 4));
   HIPCHK(st->out_tk.ensure(R * 4));
   HIPCHK(st->out_nh.ensure(R * 4));
+  rc = validate_reads(offsets, mate_offsets, R);
+  if (rc) return rc;
+  total = offsets[R];
+  mate_total = paired ? mate_offsets[R] : 0;
+  // (packed reads are unpacked in whole words of 16 bases: the ASCII buffers hold the last word in full)
+  HIPCHK(st->bases.ensure((total + 15) / 16 * 16));
+  HIPCHK(st->offsets.ensure((R + 1) * 8));
+  if (paired) {
+    HIPCHK(st->mate_bases.ensure((mate_total + 15) / 16 * 16));
+    HIPCHK(st->mate_offsets.ensure((R + 1) * 8));
+  }
+  if (pk) {
+    HIPCHK(st->pk_codes.ensure((total + 15) / 16 * 4 + 4));
+    HIPCHK(st->pk_valid.ensure((total + 15) / 16 * 2 + 2));
+    if (paired) {
+      HIPCHK(st->pk_mate_codes.ensure((mate_total + 15) / 16 * 4 + 4));
+      HIPCHK(st->pk_mate_valid.ensure((mate_total + 15) / 16 * 2 + 2));
+    }
+    if (!st->ev_unpack) HIPCHK(hipEventCreateWithFlags(&st->ev_unpack, hipEventDisableTiming));
+  }
   // A large call is cut into sub-batches: the reads of sub-batch i+1 go up (on a second stream) while the kernels of
   // sub-batch i run, so the call costs its upload plus ONE sub-batch of kernel time.  (Calls that want the hit lists
   // keep the one-piece route: their cost is the download of the lists.)
   const char *sub_env = getenv("SLK_HOST_SUBBATCH");  // (read per call, so that tests can move it)
   const uint64_t SUB = sub_env ? (uint64_t)std::max(1L, atol(sub_env)) : (uint64_t)1 << 18;
   if (!want_hits && use_fused(ix) && R >= 2 * SUB) {
-    rc = validate_reads(offsets, mate_offsets, R);
-    if (rc) return rc;
-    total = offsets[R];
-    mate_total = paired ? mate_offsets[R] : 0;
-    HIPCHK(st->bases.ensure(total));
-    HIPCHK(st->offsets.ensure((R + 1) * 8));
-    if (paired) {
-      HIPCHK(st->mate_bases.ensure(mate_total));
-      HIPCHK(st->mate_offsets.ensure((R + 1) * 8));
-    }
     if (!st->cs) HIPCHK(hipStreamCreateWithFlags(&st->cs, hipStreamNonBlocking));
     const uint64_t nsub = (R + SUB - 1) / SUB;
     while (st->up_ev.size() < nsub) {
@@ -1412,10 +1617,11 @@ int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, 
     if (rc) return rc;
     for (uint64_t i = 0; i < nsub; i++) {
       const uint64_t r0 = i * SUB, r1 = std::min(R, r0 + SUB), n = r1 - r0;
-      rc = copy_in(&st->staging_c, st->cs, st->bases.as<uint8_t>() + offsets[r0], bases + offsets[r0], offsets[r1] - offsets[r0]);
+      rc = upload_range(st, &st->staging_c, st->cs, st->s, st->ev_unpack, pk, src.bases, src.codes, src.valid, st->pk_codes, st->pk_valid,
+                        st->bases.as<uint8_t>(), offsets[r0], offsets[r1]);
       if (!rc && paired)
-        rc = copy_in(&st->staging_c, st->cs, st->mate_bases.as<uint8_t>() + mate_offsets[r0], mate_bases + mate_offsets[r0],
-                     mate_offsets[r1] - mate_offsets[r0]);
+        rc = upload_range(st, &st->staging_c, st->cs, st->s, st->ev_unpack, pk, src.mate_bases, src.mate_codes, src.mate_valid, st->pk_mate_codes,
+                          st->pk_mate_valid, st->mate_bases.as<uint8_t>(), mate_offsets[r0], mate_offsets[r1]);
       if (rc) return rc;
       HIPCHK(hipEventRecord(st->up_ev[i], st->cs));
       HIPCHK(hipStreamWaitEvent(st->s, st->up_ev[i], 0));
@@ -1431,7 +1637,14 @@ int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, 
     HIPCHK(hipStreamSynchronize(st->cs));  // (the caller's buffers are free from here on)
     if (call_timing) tp[1] = now();
   } else {
-    rc = upload_reads(st, bases, offsets, mate_bases, mate_offsets, R, &total, &mate_total);
+    rc = upload_range(st, &st->staging, st->s, st->s, st->ev_unpack, pk, src.bases, src.codes, src.valid, st->pk_codes, st->pk_valid,
+                      st->bases.as<uint8_t>(), 0, total);
+    if (!rc) rc = copy_in(st, st->offsets.p, offsets, (R + 1) * 8);
+    if (!rc && paired) {
+      rc = upload_range(st, &st->staging, st->s, st->s, st->ev_unpack, pk, src.mate_bases, src.mate_codes, src.mate_valid, st->pk_mate_codes,
+                        st->pk_mate_valid, st->mate_bases.as<uint8_t>(), 0, mate_total);
+      if (!rc) rc = copy_in(st, st->mate_offsets.p, mate_offsets, (R + 1) * 8);
+    }
     if (rc) return rc;
     if (call_timing) { (void)hipStreamSynchronize(st->s); tp[1] = now(); }
     rc = run_classify(ix, st, st->bases.as<uint8_t>(), st->offsets.as<uint64_t>(), paired ? st->mate_bases.as<uint8_t>() : nullptr,
@@ -1467,9 +1680,52 @@ int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, 
   }
   HIPCHK(hipStreamSynchronize(st->s));
   if (call_timing)
-    fprintf(stderr, "slk_classify_batch R=%llu: upload %.2f ms, kernels %.2f, results %.2f, hit lists %.2f\n", (unsigned long long)R,
-            tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], now() - tp[3]);
+    fprintf(stderr, "slk_classify_batch%s R=%llu: upload %.2f ms, kernels %.2f, results %.2f, hit lists %.2f\n", pk ? "_packed" : "",
+            (unsigned long long)R, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], now() - tp[3]);
   return check_status(st);
+}
+
+int32_t slk_classify_batch(slk_index *ix, slk_stream *st, const uint8_t *bases, const uint64_t *offsets,
+                           const uint8_t *mate_bases, const uint64_t *mate_offsets, uint64_t R,
+                           int32_t min_hit_groups, const double *thresholds, int32_t C, int32_t *out_taxon,
+                           uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers,
+                           uint64_t *out_hit_offsets, slk_hit *out_hits, uint64_t hits_capacity) {
+  if ((mate_bases == nullptr) != (mate_offsets == nullptr)) return fail(SLK_E_INVALID, "mate_bases and mate_offsets must be given together");
+  ReadSource src;
+  src.bases = bases; src.mate_bases = mate_bases;
+  return classify_batch_host(ix, st, src, offsets, mate_offsets, R, min_hit_groups, thresholds, C, out_taxon, out_classified, out_num_distinct,
+                             out_total_kmers, out_hit_offsets, out_hits, hits_capacity);
+}
+
+// The same call with the reads in the engine's 3-bit form (host/pack.hpp; slk_pack_bases makes it): 6 bytes per 16 bases over the
+// link instead of 16.  InputFragment.nucleotides (S/kmers/minimizer/MinSplitter.scala:31-32) already encoded as
+// BitRepresentation.charToTwobit would (S/kmers/util/BitRepresentation.scala:127-135), with the isValid test (:140-143) as a bit.
+int32_t slk_classify_batch_packed(slk_index *ix, slk_stream *st, const uint32_t *codes, const uint16_t *valid, const uint64_t *offsets,
+                                  const uint32_t *mate_codes, const uint16_t *mate_valid, const uint64_t *mate_offsets, uint64_t R,
+                                  int32_t min_hit_groups, const double *thresholds, int32_t C, int32_t *out_taxon,
+                                  uint8_t *out_classified, int32_t *out_num_distinct, int32_t *out_total_kmers,
+                                  uint64_t *out_hit_offsets, slk_hit *out_hits, uint64_t hits_capacity) {
+  if (R && (!codes || !valid)) return fail(SLK_E_INVALID, "null argument");
+  if ((mate_codes == nullptr) != (mate_offsets == nullptr) || (mate_valid == nullptr) != (mate_offsets == nullptr))
+    return fail(SLK_E_INVALID, "mate_codes, mate_valid and mate_offsets must be given together");
+  ReadSource src;
+  src.codes = codes; src.valid = valid; src.mate_codes = mate_codes; src.mate_valid = mate_valid;
+  if (R == 0) { static const uint32_t z = 0; src.codes = &z; }   // (an empty batch is a packed one all the same)
+  return classify_batch_host(ix, st, src, offsets, mate_offsets, R, min_hit_groups, thresholds, C, out_taxon, out_classified, out_num_distinct,
+                             out_total_kmers, out_hit_offsets, out_hits, hits_capacity);
+}
+
+// n bases -> codes[ceil(n / 16)], valid[ceil(n / 16)] (host/pack.hpp), on the library's copy threads.  Host arithmetic: no GPU.
+int32_t slk_pack_bases(const uint8_t *bases, uint64_t n, uint32_t *codes, uint16_t *valid) {
+  if (n && (!bases || !codes || !valid)) return fail(SLK_E_INVALID, "null argument");
+  const uint64_t SLICE = (uint64_t)1 << 22;   // (a multiple of 32 bases: slices start on word borders)
+  const uint64_t parts = (n + SLICE - 1) / SLICE;
+  if (parts <= 1) { pack_bases(bases, n, codes, valid); return SLK_OK; }
+  host_pool().parallel_for(parts, [&](size_t i) {
+    const uint64_t a = i * SLICE, b = std::min(n, a + SLICE);
+    pack_bases(bases + a, b - a, codes + a / 16, valid + a / 16);
+  });
+  return SLK_OK;
 }
 
 }  // extern "C"

@@ -311,6 +311,8 @@ void launch_build(const ScanParams &P, const TableBuild &T, const int32_t *paren
                   hipStream_t s);
 void launch_export(const TableView &T, uint64_t nbuckets, int64_t *keys, int32_t *taxa, uint64_t capacity,
                    unsigned long long *counter, hipStream_t s);
+void launch_export_range(const TableView &T, uint64_t bucket0, uint64_t bucket1, int64_t *keys, int32_t *taxa, uint64_t capacity,
+                         unsigned long long *counter, hipStream_t s);
 void launch_table_lookup(const TableView &t, const int64_t *keys, uint64_t n, int32_t *out, hipStream_t s);
 void launch_scan(const ScanParams &P, const uint8_t *bases, const uint64_t *offsets, const uint8_t *mate_bases,
                  const uint64_t *mate_offsets, uint64_t R, uint64_t *span_keys, int32_t *span_meta, int32_t *span_count,
@@ -327,5 +329,7 @@ void launch_gather_spans(const uint64_t *offsets, const uint64_t *mate_offsets, 
                          const int32_t *span_meta, const uint64_t *out_offsets, void *out, hipStream_t s);
 void launch_gather_hits(const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, const int32_t *span_meta,
                         const int32_t *span_taxon, const uint64_t *out_offsets, void *out, hipStream_t s);
+// words [w0, w1) of a packed read stream (host/pack.hpp) -> out[16 w0 .. 16 w1): "ACGT" by code, 'N' where the validity bit is clear
+void launch_unpack_bases(const uint32_t *codes, const uint16_t *valid, uint64_t w0, uint64_t w1, uint8_t *out, hipStream_t s);
 
 }  // namespace slk

@@ -206,6 +206,8 @@ struct slk_index {
   bool finalized = false;
   int32_t max_disp = 0;
   uint64_t records = 0, dups = 0;
+  uint64_t unplaced = 0;           // records of the last insert that found no cell within reach of the displacement field (capi.hip: insert_growing)
+  uint32_t grown = 0;              // times the table was moved to a larger one because of that
   hipStream_t build_stream = nullptr;
   DevBuf stage_keys, stage_taxa;
   Staging staging;    // host -> HBM copies of the build calls
@@ -250,6 +252,8 @@ struct slk_stream {
   DevBuf span_keys, span_meta, span_taxon, span_count;  // per-batch scratch (sparse per-read regions)
   DevBuf bases, offsets, mate_bases, mate_offsets;      // staging for the host-pointer entry points
   DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items, defer_list;
+  DevBuf pk_codes, pk_valid, pk_mate_codes, pk_mate_valid;   // slk_classify_batch_packed: the reads as they arrive (3 bits per base)
+  hipEvent_t ev_unpack = nullptr;
   hipStream_t s2 = nullptr;                 // the segment pass runs here, beside the long-lane and wave passes on s
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int32_t *d_status = nullptr;     // device error bits of the fused kernels

@@ -583,4 +583,35 @@ void launch_gather_hits(const uint64_t *offsets, const uint64_t *mate_offsets, u
                      span_taxon, out_offsets, (HitOut *)out);
 }
 
+// Reads that arrive in the engine's 3-bit form (slk_classify_batch_packed; host/pack.hpp): back to one character per base -- "ACGT"
+// by code where the validity bit is set, 'N' elsewhere -- so that every kernel of the classify path reads them as it reads ASCII.
+// One thread per word of 16 bases, one 16-byte store; words [w0, w1).  The classify kernels see valid / invalid and the code of a
+// base, nothing else of a character, so the results are those of the original text.  Streaming: 6 B in, 16 B out per word.
+__global__ void __launch_bounds__(256) unpack_bases_kernel(const uint32_t *__restrict__ codes, const uint16_t *__restrict__ valid, uint64_t w0,
+                                                           uint64_t w1, uint8_t *__restrict__ out) {
+  for (uint64_t w = w0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < w1; w += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = codes[w];
+    const uint32_t v = valid[w];
+    uint32_t o[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      uint32_t x = 0;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int j = 4 * d + b;
+        const uint32_t code = (c >> (2 * j)) & 3u;
+        const uint32_t ch = ((v >> j) & 1u) ? ((0x54474341u >> (8 * code)) & 0xFFu) : (uint32_t)'N';   // "ACGT"
+        x |= ch << (8 * b);
+      }
+      o[d] = x;
+    }
+    *(uint4 *)(out + w * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+void launch_unpack_bases(const uint32_t *codes, const uint16_t *valid, uint64_t w0, uint64_t w1, uint8_t *out, hipStream_t s) {
+  if (w1 <= w0) return;
+  const uint64_t blocks = std::min<uint64_t>((w1 - w0 + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(unpack_bases_kernel, dim3((unsigned)blocks), dim3(256), 0, s, codes, valid, w0, w1, out);
+}
+
 }  // namespace slk

@@ -218,6 +218,30 @@ __device__ __forceinline__ int probe_batch(LaneLds *L, uint32_t *ocnt, const Tab
   return requeued;
 }
 
+// The lists of the table-sharded mode are streams: written once, read once, a step later, 12 GB of them per 10 M reads, beside a
+// table whose lines are not reused either and a taxonomy that IS (resolve_lane's node records).  SLK_STREAM_NT=1 marks their loads
+// and stores nontemporal.
+#ifndef SLK_STREAM_NT
+#define SLK_STREAM_NT 0
+#endif
+#ifndef SLK_APPLY_ROWS
+#define SLK_APPLY_ROWS 4
+#endif
+template <class T> __device__ __forceinline__ T SLK_STREAM_LOAD(const T *p) {
+#if SLK_STREAM_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+template <class T> __device__ __forceinline__ void SLK_STREAM_STORE(T *p, T v) {
+#if SLK_STREAM_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 // ---- table-sharded mode (engine.h: ShardIO, ApplyJob) -------------------------------------------------------------------
 // The step kernel runs the local kernel's scan, so it forms the same probe batches in the same order; instead of probing them it
 // appends a batch's keys to the send regions of their owners and logs where each owner's group went.  Nothing but 8-byte keys,
@@ -233,7 +257,7 @@ __device__ __forceinline__ uint32_t shard_owner(uint64_t key, uint32_t ns) {  //
 // One key of an earlier batch's lookups per lane, loaded a batch ahead of its use (engine.h: ShardIO.side_*)
 __device__ __forceinline__ uint64_t side_load(const ShardIO &S, uint64_t batch, int lane) {
   const uint64_t i = batch * 64 + (uint64_t)lane;
-  return i < S.side_n ? (uint64_t)S.side_keys[i] : 0;
+  return i < S.side_n ? (uint64_t)SLK_STREAM_LOAD(&S.side_keys[i]) : 0;
 }
 // LOOKUP job: 64 of the keys this rank received for an earlier batch, probed with probe_batch's access shape (LPB lanes per bucket,
 // all of the batch's loads in flight before the first compare); a key whose bucket is full, flagged and does not hold it goes on
@@ -294,56 +318,77 @@ __device__ __forceinline__ void side_probe(LaneLds *L, const TableView &T, const
       if (has_empty || closed) break;
     }
   }
-  if (in) S.side_out[i] = ext_taxon(T, taxon);
+  if (in) SLK_STREAM_STORE(&S.side_out[i], ext_taxon(T, taxon));
   lane_wave_sync();
 }
 
-// APPLY job, one row of the log: lane i takes the i-th entry of a logged probe batch in (owner, rank) order, reads its span
-// metadata from this rank's meta region and its taxon from the owners' answers (which lie where the keys lay), and folds it into the
-// owner lane's map exactly as the local kernel does.
+// APPLY job: the tile's rows of the log, four at a time -- lane i takes the i-th entry of a logged probe batch in (owner, rank)
+// order, reads its span metadata from this rank's meta region and its taxon from the owners' answers (which lie where the keys
+// lay), and folds it into the owner lane's map exactly as the local kernel does.  The rows' loads are independent of each other
+// (log entry -> meta and taxon), so four rows' worth are in flight before the first fold: a row at a time the replay is two
+// dependent round trips per 64 probes, which is what it cost when it rode along batch by batch (15.3 ms per step against 12.9
+// without it; profiles/r04_table_sharded_v3_first.json).
 template <bool HITS>
-__device__ __forceinline__ void apply_row(LaneLds *L, const ApplyJob &J, int lane, uint64_t row) {
+__device__ __forceinline__ void apply_rows(LaneLds *L, const ApplyJob &J, int lane, uint64_t row0, uint32_t nrows) {
   const uint32_t ns = (uint32_t)J.n_shards;
-  uint32_t off = 0;
-  bool in = false;
-  uint64_t at = 0;
-  for (uint32_t sh = 0; sh < ns; sh++) {
-    const uint4 e = J.batch_log[row * ns + sh];                        // (wave-uniform loads)
-    const uint32_t cnt = e.z;
-    if (cnt == 0) continue;
-    if ((uint32_t)lane >= off && (uint32_t)lane < off + cnt) {
-      in = true;
-      const uint32_t i = (uint32_t)lane - off;
-      at = (uint64_t)sh * J.cap + (i < e.w ? e.x + i : e.y + (i - e.w));
+  constexpr int U = SLK_APPLY_ROWS;
+  for (uint32_t b = 0; b < nrows; b += U) {
+    uint64_t at[U];
+    bool in[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      in[u] = false;
+      at[u] = 0;
+      if (b + u < nrows) {
+        uint32_t off = 0;
+        for (uint32_t sh = 0; sh < ns; sh++) {
+          const uint4 e = J.batch_log[(row0 + b + u) * ns + sh];        // (wave-uniform loads)
+          const uint32_t cnt = e.z;
+          if (cnt == 0) continue;
+          if ((uint32_t)lane >= off && (uint32_t)lane < off + cnt) {
+            in[u] = true;
+            const uint32_t i = (uint32_t)lane - off;
+            at[u] = (uint64_t)sh * J.cap + (i < e.w ? e.x + i : e.y + (i - e.w));
+          }
+          off += cnt;
+        }
+      }
     }
-    off += cnt;
-  }
-  uint32_t meta = 0;
-  int32_t taxon = 0;
-  if (in) {
-    meta = J.send_meta[at];
-    taxon = J.taxa[at];
-    if (HITS) {   // the un-merged hit list, as probe_batch writes it (the owners answer in the caller's ids)
-      const uint64_t hat = L->rb[meta & 63] + (meta >> 20);
-      J.A.span_taxon[hat] = taxon;
-      J.A.span_meta[hat] = pack_meta((int32_t)((meta >> 7) & 0x1FFF), 1, (meta >> 6) & 1);
+    uint32_t meta[U];
+    int32_t taxon[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      meta[u] = in[u] ? SLK_STREAM_LOAD(&J.send_meta[at[u]]) : 0u;
+      taxon[u] = in[u] ? SLK_STREAM_LOAD(&J.taxa[at[u]]) : 0;
     }
-    if (J.to_dense != nullptr && taxon > 0) taxon = taxon < J.n_to_dense ? J.to_dense[taxon] : 0;  // (owners answer in the caller's ids)
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (b + u < nrows) {   // (wave-uniform)
+        int32_t t = taxon[u];
+        if (in[u]) {
+          if (HITS) {   // the un-merged hit list, as probe_batch writes it (the owners answer in the caller's ids)
+            const uint64_t hat = L->rb[meta[u] & 63] + (meta[u] >> 20);
+            J.A.span_taxon[hat] = t;
+            J.A.span_meta[hat] = pack_meta((int32_t)((meta[u] >> 7) & 0x1FFF), 1, (meta[u] >> 6) & 1);
+          }
+          if (J.to_dense != nullptr && t > 0) t = t < J.n_to_dense ? J.to_dense[t] : 0;  // (owners answer in the caller's ids)
+        }
+        fold_hit<false>(L, nullptr, in[u], meta[u], t);
+      }
+    }
+    lane_wave_sync();
   }
-  fold_hit<false>(L, nullptr, in, meta, taxon);
-  lane_wave_sync();
 }
 
 // EMIT job, one probe batch: its minimizers go to their owners' send regions, the span metadata the APPLY needs (owner lane,
 // distinct, k-mers) to a region of the same shape, which stays on this rank.  Lane sh keeps the chunk of owner sh's region this wave
 // is filling (ch_pos .. ch_end); a batch whose keys for that owner do not fit what is left of it takes the rest of the chunk AND the
 // head of a freshly reserved one (one atomic per chunk and owner), so the regions have no holes but the chunk tails at the kernel's
-// end.  Between the atomic and the use of its answer run the batch's side jobs -- 64 lookups of an earlier batch, one row of a yet
-// earlier batch's log -- so the cursor's round trip, the lookups' and the replay's loads share one wait.
+// end.  Between the atomic and the use of its answer runs the batch's side job -- 64 lookups of an earlier batch -- so the cursor's
+// round trip and the lookups' share one wait.
 template <bool HITS>
 __device__ __forceinline__ void emit_batch(LaneLds *L, const FusedArgs &A, const ShardIO &S, const ApplyJob &J, int qhead, int cnt, int lane,
-                                           uint64_t row, uint64_t tile, uint32_t &ch_pos, uint32_t &ch_end, uint32_t &side_j, uint64_t &side_key,
-                                           uint32_t &ap_done, uint32_t ap_rows, uint64_t ap_row0) {
+                                           uint64_t row, uint64_t tile, uint32_t &ch_pos, uint32_t &ch_end, uint32_t &side_j, uint64_t &side_key) {
   const bool in = lane < cnt;
   const int qi = (qhead + lane) & (QCAP - 1);
   const uint64_t key = L->q_key[qi];
@@ -351,7 +396,7 @@ __device__ __forceinline__ void emit_batch(LaneLds *L, const FusedArgs &A, const
   //  ordinal -- a fragment this kernel takes has fewer than 1000 spans -- for the APPLY to write the hit where it belongs)
   const uint32_t meta = L->q_meta[qi] | (HITS ? (uint32_t)L->q_ord[qi] << 20 : 0u);
   const uint32_t ns = (uint32_t)S.n_shards;
-  const uint32_t g = shard_owner(key, ns);
+  const uint32_t g = ns == 1 ? 0u : shard_owner(key, ns);
   uint32_t mycount = 0, rank = 0;
   for (uint32_t sh = 0; sh < ns; sh++) {
     const uint64_t m = __ballot(in && g == sh);
@@ -369,7 +414,6 @@ __device__ __forceinline__ void emit_batch(LaneLds *L, const FusedArgs &A, const
     if (side_j < S.side_per_tile) side_key = side_load(S, batch + 1, lane);   // (in flight while this batch is probed)
     side_probe(L, A.T, S, lane, batch, k_now);
   }
-  if (ap_done < ap_rows) { apply_row<HITS>(L, J, lane, ap_row0 + ap_done); ap_done++; }   // APPLY job: one row of the log
   uint32_t fresh = 0xFFFFFFFFu;
   if (need) {
     if (got + S.chunk <= S.cap) fresh = (uint32_t)got;
@@ -385,8 +429,8 @@ __device__ __forceinline__ void emit_batch(LaneLds *L, const FusedArgs &A, const
     const bool tail = rank >= groom;                  // beyond what the old chunk had left: the fresh one
     if (!tail || gfresh != 0xFFFFFFFFu) {
       const uint64_t at = (uint64_t)g * S.cap + (tail ? gfresh + (rank - groom) : gpos + rank);
-      S.send_keys[at] = (int64_t)key;
-      S.send_meta[at] = meta;
+      SLK_STREAM_STORE(&S.send_keys[at], (int64_t)key);
+      SLK_STREAM_STORE(&S.send_meta[at], meta);
     }
   }
   lane_wave_sync();
@@ -729,17 +773,6 @@ __device__ __forceinline__ void lane_body(const FusedArgs &A, const ShardIO &S, 
     if (MODE == LANE_EMIT && tile < etiles) row = row0 = (span_region(A.offsets, A.mate_offsets, tile * 64) >> 6) + tile;
     const uint64_t rbase = (HITS && have) ? span_region(A.offsets, A.mate_offsets, r) : 0;
     if (HITS && MODE != LANE_EMIT) L->rb[lane] = rbase;
-    // EMIT: the APPLY job's tile of the same number -- its rows of the log, and for hit lists its fragments' span regions
-    uint32_t ap_rows = 0, ap_done = 0;
-    uint64_t ap_row0 = 0;
-    const uint64_t r2 = tile * 64 + lane;
-    bool have2 = false;
-    if (MODE == LANE_EMIT && tile < atiles) {
-      const uint2 tr = Jp->tile_rows[tile];   // (wave-uniform load)
-      ap_row0 = tr.x; ap_rows = tr.y;
-      have2 = r2 < Jp->A.R;
-      if (HITS) L->rb[lane] = have2 ? span_region(Jp->A.offsets, Jp->A.mate_offsets, r2) : 0;
-    }
     // ---- per-lane LDS state ----
 #pragma unroll
     for (int s = 0; s < OMAP; s++) L->omap[s * 64 + lane] = 0;
@@ -748,6 +781,32 @@ __device__ __forceinline__ void lane_body(const FusedArgs &A, const ShardIO &S, 
       for (int s = 0; s < OMAP; s++) ocnt[s * 64 + lane] = 0;
     }
     L->o_flags[lane] = 0;
+    if (MODE == LANE_EMIT && tile < atiles) {
+      // APPLY job first: the earlier batch's tile of the same number is replayed and classified before this tile's scan starts.  The
+      // replay is bound by memory latency, the scan by instruction issue; the waves of a CU are at different points of their tiles,
+      // so the one hides behind the other ACROSS waves, where riding along batch by batch made every wave wait three times per batch.
+      const uint64_t r2 = tile * 64 + lane;
+      const bool have2 = r2 < Jp->A.R;
+      const uint2 tr = Jp->tile_rows[tile];   // (wave-uniform load) {first row of the tile in the log, rows}
+      if (HITS) L->rb[lane] = have2 ? span_region(Jp->A.offsets, Jp->A.mate_offsets, r2) : 0;
+      lane_wave_sync();                       // (the map's reset above and the span regions are seen by every lane)
+      apply_rows<HITS>(L, *Jp, lane, tr.x, tr.y);
+      const bool dfr2 = have2 && (Jp->defer[r2] != 0 || (L->o_flags[lane] & 0x80000000u));   // not taken by its EMIT, or its map overflowed just now
+      const uint64_t DM = __ballot(dfr2);
+      if (DM != 0 && lane == 0) atomicAdd(Jp->n_deferred, (unsigned long long)__popcll(DM));
+      if (have2) {
+        if (dfr2) {
+          // (the caller routes this fragment through the staged kernels; until then it has no spans on file)
+          Jp->defer[r2] = 1;
+          if (Jp->A.out_nh) Jp->A.out_nh[r2] = 0;
+          if (HITS) Jp->A.span_count[r2] = 0;
+        } else {
+          const int2 ri = Jp->read_info[r2];
+          resolve_lane<HITS, false>(L, nullptr, Jp->A, lane, r2, L->o_flags[lane], ri.x, ri.y, 0, dbg);
+        }
+      }
+      lane_wave_sync();                       // (resolve_lane's intervals lay over the queue and the read stream's slots: the scan below stages its first bytes there)
+    }
     // ---- scan state ----
     uint32_t pos = 0;
     int mate = 0;
@@ -818,7 +877,6 @@ __device__ __forceinline__ void lane_body(const FusedArgs &A, const ShardIO &S, 
     int tphase = 0;   // generic window: step mod w (wave-uniform)
 
     const uint32_t VM = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20) | (1u << 21);  // A C G T U, either case
-    if (MODE == LANE_EMIT) lane_wave_sync();   // (the map's reset above is seen by the APPLY job's atomics)
     while (__ballot(!fin) != 0) {
       // One event per lane per step: a character, or the end of a mate.  Straight-line predicated code: the per-read
       // control flow (Supermers.splitByAmbiguity :150-178, MinSplitter.splitRead :133-172) is data, not branches.
@@ -975,7 +1033,7 @@ __device__ __forceinline__ void lane_body(const FusedArgs &A, const ShardIO &S, 
         while (qn >= 64) {
           lane_wave_sync();
           int back = 0;
-          if (MODE == LANE_EMIT) emit_batch<HITS>(L, A, S, *Jp, qhead, 64, lane, row++, tile, ch_pos, ch_end, side_j, side_key, ap_done, ap_rows, ap_row0);
+          if (MODE == LANE_EMIT) emit_batch<HITS>(L, A, S, *Jp, qhead, 64, lane, row++, tile, ch_pos, ch_end, side_j, side_key);
           else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS, LONG>(L, ocnt, A.T, qhead, qn, 64, lane, dbg, A.span_meta, A.span_taxon);
           qhead = (qhead + 64) & (QCAP - 1);
           qn += back - 64;
@@ -986,7 +1044,7 @@ __device__ __forceinline__ void lane_body(const FusedArgs &A, const ShardIO &S, 
       lane_wave_sync();
       const int cnt = min(qn, 64);
       int back = 0;
-      if (MODE == LANE_EMIT) emit_batch<HITS>(L, A, S, *Jp, qhead, cnt, lane, row++, tile, ch_pos, ch_end, side_j, side_key, ap_done, ap_rows, ap_row0);
+      if (MODE == LANE_EMIT) emit_batch<HITS>(L, A, S, *Jp, qhead, cnt, lane, row++, tile, ch_pos, ch_end, side_j, side_key);
       else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS, LONG>(L, ocnt, A.T, qhead, qn, cnt, lane, dbg, A.span_meta, A.span_taxon);
       qhead = (qhead + cnt) & (QCAP - 1);
       qn += back - cnt;
@@ -997,8 +1055,8 @@ __device__ __forceinline__ void lane_body(const FusedArgs &A, const ShardIO &S, 
         if (have) S.read_info[r] = make_int2(total, nhits);
         if (lane == 0) S.tile_rows[tile] = make_uint2((uint32_t)row0, (uint32_t)(row - row0));
       }
-      // a tile that sent off fewer batches than it owns of the LOOKUP job, or than its APPLY twin logged rows, finishes its
-      // share now (a few at most: the shares are dealt out by the batch's average, and neighbouring batches resemble each other)
+      // a tile that sent off fewer batches than it owns of the LOOKUP job finishes its share now (a few at most: the shares are
+      // dealt out by the batch's average)
       while (side_j < S.side_per_tile) {
         const uint64_t batch = tile * S.side_per_tile + side_j;
         const uint64_t k_now = side_key;
@@ -1006,7 +1064,6 @@ __device__ __forceinline__ void lane_body(const FusedArgs &A, const ShardIO &S, 
         if (side_j < S.side_per_tile) side_key = side_load(S, batch + 1, lane);
         side_probe(L, A.T, S, lane, batch, k_now);
       }
-      for (; ap_done < ap_rows; ap_done++) apply_row<HITS>(L, *Jp, lane, ap_row0 + ap_done);
     }
 
     // ---- per-read classification (one lane per read) ------------------------------------------------------------------
@@ -1019,21 +1076,6 @@ __device__ __forceinline__ void lane_body(const FusedArgs &A, const ShardIO &S, 
       if (have && !dfr) resolve_lane<HITS, LONG>(L, ocnt, A, lane, r, oflags, total, nhits, np, dbg);
     } else {
       if (have && too_long) defer[r] = 1;   // EMIT job: fragments this kernel does not take (the caller routes them)
-      const bool dfr2 = have2 && (Jp->defer[r2] != 0 || (L->o_flags[lane] & 0x80000000u));   // not taken by its EMIT, or its map overflowed just now
-      const uint64_t DM = __ballot(dfr2);
-      if (DM != 0 && lane == 0) atomicAdd(Jp->n_deferred, (unsigned long long)__popcll(DM));
-      if (have2) {                          // APPLY job: this tile's fragments of the earlier batch
-        const uint32_t oflags = L->o_flags[lane];
-        if (dfr2) {
-          // (the caller routes this fragment through the staged kernels; until then it has no spans on file)
-          Jp->defer[r2] = 1;
-          if (Jp->A.out_nh) Jp->A.out_nh[r2] = 0;
-          if (HITS) Jp->A.span_count[r2] = 0;
-        } else {
-          const int2 ri = Jp->read_info[r2];
-          resolve_lane<HITS, false>(L, nullptr, Jp->A, lane, r2, oflags, ri.x, ri.y, 0, dbg);
-        }
-      }
     }
     lane_wave_sync();
   }

@@ -21,6 +21,7 @@
 
 #include "../../include/slacken_amd.h"
 #include "output.hpp"
+#include "pack.hpp"
 #include "parquet_source.hpp"
 #include "seqio.hpp"
 #include "taxonomy.hpp"
@@ -292,6 +293,9 @@ struct ClassifyOpts {
   std::string library, rank = "species";
   int min_count = -1, min_distinct = -1, reads = -1;
   double init_confidence = 0.15;
+  // GoldSetOptions (Dynamic.scala:62): a user-supplied taxon set to compare the detected set with, or to build the library from
+  std::string gold_set, promote_rank;
+  bool classify_with_gold = false;
 };
 
 static ClassifyOpts parse_classify_opts(int argc, char **argv, bool two_step) {
@@ -333,8 +337,11 @@ static ClassifyOpts parse_classify_opts(int argc, char **argv, bool two_step) {
     else if (two_step && (a == "-D" || a == "--min-distinct")) o.min_distinct = std::stoi(next());
     else if (two_step && (a == "-R" || a == "--reads")) o.reads = std::stoi(next());
     else if (two_step && a == "--init-confidence") o.init_confidence = std::stod(next());
-    else if (two_step && (a == "--bracken-length" || a == "--index-reports" || a == "-g" || a == "--gold-set" || a == "--classify-with-gold" || a == "--promote-gold-set"))
-      die(a + " is not supported by this engine (Bracken weights, index reports and gold sets are outside the classify path)");
+    else if (two_step && (a == "-g" || a == "--gold-set")) o.gold_set = next();
+    else if (two_step && a == "--classify-with-gold") o.classify_with_gold = true;
+    else if (two_step && a == "--promote-gold-set") o.promote_rank = next();
+    else if (two_step && (a == "--bracken-length" || a == "--index-reports"))
+      die(a + " is not supported by this engine (Bracken weights and index reports are outside the classify path)");
     else if (!a.empty() && a[0] == '@') { std::ifstream lf(a.substr(1)); std::string l; while (std::getline(lf, l)) if (!trim(l).empty()) o.files.push_back(trim(l)); }
     else if (!a.empty() && a[0] == '-') die("unknown option " + a);
     else o.files.push_back(a);
@@ -342,6 +349,8 @@ static ClassifyOpts parse_classify_opts(int argc, char **argv, bool two_step) {
   if (o.index.empty() || o.output.empty() || o.files.empty() || (two_step && o.library.empty()))
     die(two_step ? "usage: classify2 -i INDEX -o OUTPUT --library DIR [--rank R] [-R N | -C N | -D N] [--init-confidence X] [classify options] FILES"
                  : "usage: classify -i INDEX -o OUTPUT [-p] [-c T...] [--min-hits N] [--sample-regex RE] FILES");
+  if (two_step && o.gold_set.empty() && (o.classify_with_gold || !o.promote_rank.empty()))
+    die("--classify-with-gold and --promote-gold-set qualify a gold set: give one with -g FILE");
   if (o.thresholds.empty()) o.thresholds.push_back(0.0);
   for (double t : o.thresholds) if (t < 0 || t > 1) die("confidence must be in [0, 1]");
   if (o.paired && o.files.size() % 2 != 0)
@@ -507,8 +516,12 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
   std::exception_ptr failure;
   std::atomic<bool> failed{false};
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  // SLK_CLI_PACKED=0: reads always cross the link as text (A/B switch)
+  const bool packed_calls = !(getenv("SLK_CLI_PACKED") && getenv("SLK_CLI_PACKED")[0] == '0');
   auto work = [&](slk_index *wix, slk_stream *st) {
     std::vector<int32_t> nd, tk;
+    std::vector<uint32_t> pk_codes, pk_mcodes;
+    std::vector<uint16_t> pk_valid, pk_mvalid;
     double w_input = 0, w_device = 0, w_hand_over = 0;
     try {
       for (;;) {
@@ -539,8 +552,22 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
         if (want_hits) b->reserve_hits(cap);
         const uint8_t *mb = fb.paired ? fb.mate_bases.data() : nullptr;
         const uint64_t *mo = fb.paired ? fb.mate_offs.data() : nullptr;
-        SLK_CALL(slk_classify_batch(wix, st, fb.bases.data(), fb.offs.data(), mb, mo, n, min_hits, thresholds.data(), C,
-                                    b->taxon.data(), b->classified.data(), nd.data(), tk.data(), b->hit_offs.data(), want_hits ? b->hits.get() : nullptr, cap));
+        if (!want_hits && packed_calls) {
+          // reports only: nothing but the reads crosses the link, so they cross it in the engine's 3-bit form -- packed here, on the
+          // worker's own time (pack.hpp: AVX2 + BMI2), 6 bytes per 16 bases instead of 16
+          pk_codes.resize((fb.bases.size() + 15) / 16 + 1); pk_valid.resize(pk_codes.size());
+          slk::pack_bases(fb.bases.data(), fb.bases.size(), pk_codes.data(), pk_valid.data());
+          if (fb.paired) {
+            pk_mcodes.resize((fb.mate_bases.size() + 15) / 16 + 1); pk_mvalid.resize(pk_mcodes.size());
+            slk::pack_bases(fb.mate_bases.data(), fb.mate_bases.size(), pk_mcodes.data(), pk_mvalid.data());
+          }
+          SLK_CALL(slk_classify_batch_packed(wix, st, pk_codes.data(), pk_valid.data(), fb.offs.data(), fb.paired ? pk_mcodes.data() : nullptr,
+                                             fb.paired ? pk_mvalid.data() : nullptr, mo, n, min_hits, thresholds.data(), C, b->taxon.data(),
+                                             b->classified.data(), nd.data(), tk.data(), b->hit_offs.data(), nullptr, cap));
+        } else {
+          SLK_CALL(slk_classify_batch(wix, st, fb.bases.data(), fb.offs.data(), mb, mo, n, min_hits, thresholds.data(), C,
+                                      b->taxon.data(), b->classified.data(), nd.data(), tk.data(), b->hit_offs.data(), want_hits ? b->hits.get() : nullptr, cap));
+        }
         if (want_spans) {
           b->span_offs.resize(n + 1);
           b->spans.resize(cap);
@@ -1003,6 +1030,76 @@ static void find_fna(const fs::path &dir, std::vector<std::string> &out) {  // H
   std::sort(out.begin(), out.end());
 }
 
+// "%.2f%%".format(d * 100) (Helpers.formatPerc, S/kmers/package.scala:60) with java.util.Formatter's rounding
+static std::string format_perc(double d) {
+  if (std::isnan(d)) return "NaN%";
+  std::string v = java_format_6_2f(d * 100);
+  return v.substr(v.find_first_not_of(' ')) + "%";
+}
+static std::string rank_name(int rank_index_) {   // a Rank's toString: the case object's name (Taxonomy.scala:39-48)
+  if (rank_index_ == NO_RANK) return "null";
+  std::string t = rank_titles(rank_index_);
+  if (!t.empty()) t[0] = (char)toupper((unsigned char)t[0]);
+  return t;
+}
+
+// Dynamic.readGoldSet (Dynamic.scala:284-310): the taxa of the file (one per line, first CSV column; secondary ids mapped to their
+// primaries by merged.dmp), those without sequence in the library replaced by -- in the reference's words "promoted to" -- their
+// nearest ancestor that has, everything filtered at the reclassification rank; the promoted ones are kept down to
+// --promote-gold-set RANK if that is given.  in_library: GenomeLibrary.taxonSet (:35-44), the labelled taxa with their ancestors.
+// The messages are the reference's (println: standard output).
+static std::vector<Taxon> read_gold_set(const Taxonomy &tax, const std::string &file, const std::string &promote_rank, int rank_depth,
+                                        const std::string &rank_title, const std::vector<uint8_t> &in_library) {
+  std::ifstream f(file);
+  if (!f) die("cannot open the gold set " + file);
+  std::set<Taxon> gold;
+  std::string l;
+  while (std::getline(f, l)) {
+    if (!l.empty() && l.back() == '\r') l.pop_back();
+    if (l.empty()) continue;   // (spark.read.csv drops empty lines)
+    std::string c0 = l.substr(0, l.find(','));
+    if (c0.size() >= 2 && c0.front() == '"' && c0.back() == '"') c0 = c0.substr(1, c0.size() - 2);
+    size_t used = 0;
+    int t = 0;
+    try { t = std::stoi(c0, &used); } catch (...) { used = 0; }
+    if (used != c0.size() || c0.empty()) die("gold set " + file + ": not a taxon id: " + l);   // (x.getString(0).toInt throws)
+    if (t < 0 || t >= (int)tax.primary.size()) die("gold set " + file + ": taxon " + c0 + " is outside the taxonomy");
+    gold.insert(tax.primary[t]);
+  }
+  std::cout << "Gold set contained " << gold.size() << " taxa" << std::endl;
+  auto in_lib = [&](Taxon t) { return t >= 0 && t < (Taxon)in_library.size() && in_library[t]; };
+  std::set<Taxon> not_found, promoted;
+  for (Taxon t : gold) if (!in_lib(t)) not_found.insert(t);
+  for (Taxon t : not_found)
+    for (Taxon p = t; p != NONE; p = (p >= 0 && p < tax.size()) ? tax.parents[p] : NONE)   // Taxonomy.pathToRoot :204-215
+      if (in_lib(p)) { promoted.insert(p); break; }
+  std::cout << not_found.size() << " taxa from gold set not found in library, promoted to " << promoted.size() << " taxa." << std::endl;
+  {
+    std::map<int, int> by_depth;   // (depth -> taxa; Rank orders by depth)
+    for (Taxon t : promoted) by_depth[tax.depth(t)]++;
+    std::cout << "Promoted to levels: ArrayBuffer(";
+    bool first = true;
+    for (auto &kv : by_depth) {
+      std::cout << (first ? "" : ", ") << "(" << rank_name(kv.first >= 0 && kv.first <= 8 ? kv.first + 1 : NO_RANK) << "," << kv.second << ")";
+      first = false;
+    }
+    std::cout << ")" << std::endl;
+  }
+  std::set<Taxon> kept;
+  if (!promote_rank.empty()) {
+    const int pr = rank_index(promote_rank);
+    if (pr == NO_RANK) die("unknown rank " + promote_rank);
+    for (Taxon t : promoted) if (tax.depth(t) >= pr - 1) kept.insert(t);
+    std::cout << "Keeping " << kept.size() << " taxa at rank " << rank_name(pr) << " and below from promoted set" << std::endl;
+  }
+  std::set<Taxon> total = gold;
+  total.insert(promoted.begin(), promoted.end());
+  std::set<Taxon> filtered = kept;
+  for (Taxon t : total) if (tax.depth(t) >= rank_depth) filtered.insert(t);
+  std::cout << "Initial adjusted gold set size " << total.size() << ", filtered at " << rank_title << " to " << filtered.size() << std::endl;
+  return std::vector<Taxon>(filtered.begin(), filtered.end());
+}
+
 static int cmd_classify2(int argc, char **argv) {
   ClassifyOpts o = parse_classify_opts(argc, argv, true);
   int rank = rank_index(o.rank);  // Taxonomy.rankOrNull
@@ -1012,6 +1109,20 @@ static int cmd_classify2(int argc, char **argv) {
   Taxonomy tax;
   std::vector<std::pair<Taxon, long>> counts;  // (inputs: getInputFragments(withAmbiguous = true), Dynamic.scala:323)
   int32_t max_taxon;
+  // GenomeLibrary.getTaxonLabels: TSV header \t taxon
+  std::vector<std::pair<std::string, Taxon>> all_labels;
+  {
+    std::ifstream lf(o.library + "/seqid2taxid.map");
+    if (!lf) die("cannot open " + o.library + "/seqid2taxid.map");
+    std::string l;
+    while (std::getline(lf, l)) {
+      size_t tab = l.find('\t');
+      if (tab == std::string::npos) continue;
+      all_labels.emplace_back(l.substr(0, tab), (Taxon)std::stoi(l.substr(tab + 1)));
+    }
+  }
+  std::vector<Taxon> gold;          // readGoldSet's result, if a gold set was given
+  const bool with_gold = !o.gold_set.empty() && o.classify_with_gold;   // makeRecords :366-369: the library is built from it, nothing is detected
   {
     DeviceIndex base;
     base.devices = o.devices;
@@ -1019,9 +1130,18 @@ static int cmd_classify2(int argc, char **argv) {
     slk_index_info info;
     SLK_CALL(slk_index_get_info(base.ix, &info));
     max_taxon = info.taxonomy_size - 1;
+    if (!o.gold_set.empty()) {
+      // GenomeLibrary.taxonSet (:35-44): the labelled taxa and their ancestors (Taxonomy.taxaWithAncestors :306-310)
+      std::vector<uint8_t> in_library((size_t)tax.size(), 0);
+      for (auto &lb : all_labels)
+        for (Taxon p = lb.second; p > 0 && p < tax.size() && !in_library[p]; p = tax.parents[p]) in_library[p] = 1;
+      gold = read_gold_set(tax, o.gold_set, o.promote_rank, rank_depth, rank_name(rank), in_library);
+    }
     // step 1: per-taxon support in the sample (Dynamic.findTaxonSet :213-243)
     std::map<Taxon, long> m;
-    if (o.min_count >= 0 || o.min_distinct >= 0) {
+    if (with_gold) {
+      // (no detection pass)
+    } else if (o.min_count >= 0 || o.min_distinct >= 0) {
       // MinimizerTotalCount / MinimizerDistinctCount: hits with a true taxon at depth >= rank (minimizersInSubjects :73-86)
       std::vector<std::pair<Taxon, int64_t>> pairs;
       classify_stream(base, o.files, o.paired, o.min_hits, {0.0}, o.min_distinct >= 0, true, [&](std::shared_ptr<const ClassifiedBatch> b) {
@@ -1072,27 +1192,32 @@ static int cmd_classify2(int argc, char **argv) {
   std::vector<Taxon> keep;
   for (auto &kv : agg.taxonCounts)
     if (tax.depth(kv.first) >= rank_depth && agg.clade(kv.first) >= threshold) keep.push_back(kv.first);
-  {
+  if (with_gold) {
+    keep = gold;   // Dynamic.makeRecords :366-369: taxonomy.taxaWithDescendants(goldSet); no _taxonSet.txt, nothing was detected
+  } else {
     std::ofstream ts(o.output + "_taxonSet.txt");  // HDFSUtil.writeTextLines, Dynamic.scala:224-225 (BitSet order = ascending)
     for (Taxon t : keep) ts << t << "\n";
+  }
+  if (!o.gold_set.empty() && !with_gold) {
+    // findTaxonSet :262-274: the detected set against the gold set
+    std::set<Taxon> g(gold.begin(), gold.end());
+    size_t tp = 0;
+    for (Taxon t : keep) tp += g.count(t);
+    const size_t fp = keep.size() - tp, fn = g.size() - tp;
+    std::cout << "Comparing detected set with supplied gold set. True Positives: " << tp << ", False Positives: " << fp << ", False Negatives: " << fn
+              << ", Precision: " << format_perc((double)tp / (double)(tp + fp)) << ", Recall: " << format_perc((double)tp / (double)g.size()) << std::endl;
   }
   std::vector<uint8_t> in_set = tax.withDescendants(keep);
   size_t n_set = 0;
   for (uint8_t b : in_set) n_set += b;
-  std::cerr << "Detected set: initial scan produced " << keep.size() << " taxa at rank " << o.rank << ", expanded with descendants to " << n_set << std::endl;
+  if (with_gold) std::cerr << "Gold set: " << keep.size() << " taxa at rank " << o.rank << ", expanded with descendants to " << n_set << std::endl;
+  else std::cerr << "Detected set: initial scan produced " << keep.size() << " taxa at rank " << o.rank << ", expanded with descendants to " << n_set << std::endl;
 
   // step 2: KeyValueIndex.makeRecords(library, Some(taxonSet)) :100-122 -- sequences whose label is in the set
-  std::unordered_map<std::string, Taxon> labels;  // GenomeLibrary.getTaxonLabels: TSV header \t taxon
-  {
-    std::ifstream lf(o.library + "/seqid2taxid.map");
-    if (!lf) die("cannot open " + o.library + "/seqid2taxid.map");
-    std::string l;
-    while (std::getline(lf, l)) {
-      size_t tab = l.find('\t');
-      if (tab == std::string::npos) continue;
-      Taxon t = (Taxon)std::stoi(l.substr(tab + 1));
-      if (t >= 0 && t < tax.size() && in_set[t] && tax.isDefined(t)) labels[l.substr(0, tab)] = t;
-    }
+  std::unordered_map<std::string, Taxon> labels;
+  for (auto &lb : all_labels) {
+    const Taxon t = lb.second;
+    if (t >= 0 && t < tax.size() && in_set[t] && tax.isDefined(t)) labels[lb.first] = t;
   }
   std::vector<std::string> fna;
   find_fna(fs::path(o.library) / "library", fna);
@@ -1144,7 +1269,10 @@ static const char *HELP =
     "  -c, --confidence T...  confidence thresholds in [0, 1] (default 0.0)\n"
     "      --min-hits N       distinct minimizer hits needed to classify (default 2)\n"
     "  -p, --paired           FILES are pairs (file_1 file_2 ...), joined by read id without /1 /2\n"
-    "      --sample-regex RE  group 1 of the first match in the read id names the sample\n"
+    "      --sample-regex RE  group 1 of the first match in the read id names the sample (\"other\" without a match).  The dialect is\n"
+    "                         std::regex's ECMAScript, not java.util.regex: no possessive quantifiers, look-behind, \\p{..} or named\n"
+    "                         groups; character classes, alternation, greedy and lazy quantifiers, look-ahead and back-references\n"
+    "                         behave alike.  A match in which group 1 took no part names the sample \"null\", as the reference does\n"
     "      --[no]unclassified keep (default) or drop unclassified reads\n"
     "      --[no]detailed     per-read output (default) or reports only\n"
     "      --devices LIST     GPUs that share the reads, `all` or e.g. 0,1,2,3 (default 0); the library is replicated on each\n"
@@ -1153,6 +1281,9 @@ static const char *HELP =
     "  FILES                  FASTA / FASTQ, plain, .gz or .bz2; @list.txt names a file of file names\n"
     "options of classify2 (Slacken.scala:199-260): --library DIR (DIR/library/**/*.fna, DIR/seqid2taxid.map), --rank RANK (species),\n"
     "  -R, --reads N (100) | -C, --min-count N | -D, --min-distinct N, --init-confidence X (0.15)\n"
+    "  -g, --gold-set FILE (a taxon per line: the detected set is compared with it), --classify-with-gold (the dynamic library is built\n"
+    "  from the gold set instead of a detected one), --promote-gold-set RANK (gold taxa without sequence in the library: keep the\n"
+    "  ancestors they are promoted to down to RANK)\n"
     "host-only helpers: report TAXONOMY_DIR COUNTS_TSV | parse FILE [MATE_FILE] | props INDEX | records INDEX | repeated [-p] FILES\n"
     "environment: SLK_HOST_THREADS (formatting/decoding threads), SLK_INPUT_STREAMS (input files read side by side, default 8),\n"
     "             SLK_PARSE_THREADS (threads parsing one plain input file, default min(8, cores/2)), SLK_GZIP_LEVEL (1..9, default zlib's),\n"

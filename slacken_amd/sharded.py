@@ -12,6 +12,8 @@ Host plumbing only: torch for device buffers and the collectives, the engine for
           fragments are scanned once; takes fragments of up to 1000 bases with at most 12 distinct taxa;
   staged  slk_scan_device / slk_lookup_device / slk_classify_hits_device with the exchange lists built by torch ops: takes
           everything, and the fragments the fast route hands back (`defer`)."""
+import sys
+
 import numpy as np
 
 _C1 = 0xff51afd7ed558ccd - (1 << 64)
@@ -412,16 +414,26 @@ class ShardedClassifier:
             for k in ("recv_keys", "found", "send_keys"):
                 b.pop(k, None)
 
+        import os
+        import time
+        trace = os.environ.get("SLK_SHARDED_TRACE") == "1"     # (tuning aid: where the host's time goes, per step)
+        tw = time.perf_counter()
         try:
             for t in range(n + 4):
+                t0 = time.perf_counter()
                 launch(t)
+                t1 = time.perf_counter()
                 if t == 0 and self._any_rank(unsupported):
                     states.clear()
                     return None
                 if 1 <= t <= n:
                     exchange_keys(t - 1)
+                t2 = time.perf_counter()
                 if 3 <= t <= n + 2:
                     exchange_taxa(t - 3)
+                if trace:
+                    print(f"[sharded] step {t}: launch {1e3 * (t1 - t0):.2f} ms, wait + keys {1e3 * (t2 - t1):.2f}, taxa {1e3 * (time.perf_counter() - t2):.2f}",
+                          file=sys.stderr, flush=True)
         except BaseException:
             states.clear()     # (nothing of a batch may outlive this call: see close())
             raise
@@ -442,6 +454,8 @@ class ShardedClassifier:
             self.stage_ms = {k: float(np.mean(v)) for k, v in acc.items()}
             self.step_ms = [e0.elapsed_time(e1) for _, e0, e1 in steps]
         cur.wait_stream(ext)
+        if trace:
+            print(f"[sharded] pipeline of {n} batches: {1e3 * (time.perf_counter() - tw):.2f} ms", file=sys.stderr, flush=True)
         for i, (b, batch) in enumerate(zip(states, batches)):
             d_bases, d_offsets, R, total_bases, mates = batch
             if b["failed"]:      # the whole batch through the staged route

@@ -127,6 +127,14 @@ def check_classify(orc, world, reads, mates=None, thresholds=(0.0, 0.07, 0.15, 0
                              with_hits=False, with_num_hits=True)
     for key in ("taxon", "classified", "num_distinct", "total_kmers", "num_hits"):
         assert np.array_equal(fast[key], want[key]), "hot path: " + key
+    # the same reads in the engine's 3-bit form (slk_pack_bases -> slk_classify_batch_packed): identical in everything, hit lists too
+    pk = st.classify_batch(bases, offsets, mb, mo, min_hit_groups=min_hit_groups, thresholds=thresholds, packed=True)
+    for key in ("taxon", "classified", "num_distinct", "total_kmers", "num_hits", "hit_offsets", "hits"):
+        assert np.array_equal(pk[key], got[key]), "packed: " + key
+    pkf = st.classify_batch(bases, offsets, mb, mo, min_hit_groups=min_hit_groups, thresholds=thresholds, with_hits=False,
+                            with_num_hits=True, packed=True)
+    for key in ("taxon", "classified", "num_distinct", "total_kmers", "num_hits"):
+        assert np.array_equal(pkf[key], want[key]), "packed, hot path: " + key
     # un-merged hit lists (what hitDetails / lengthString are formatted from)
     ho = got["hit_offsets"].astype(np.int64)
     for i in range(0, len(reads), max(1, len(reads) // 300)):
@@ -540,3 +548,130 @@ def test_tiles_staged_by_the_whole_wave(orc, world):
     # the same fragments shifted through the tiles: every alignment of a fragment's start within a word, tiles that mix the two routes
     for shift in (1, 7, 33):
         check_classify(orc, world, reads[shift:] + reads[:shift], thresholds=(0.0,))
+
+
+def test_packed_reads_any_text(orc, world):
+    """slk_classify_batch_packed on text with everything a FASTQ line can hold -- lowercase, U / u, IUPAC codes, N runs shorter than,
+    equal to and longer than k, '-', digits, bytes above 127 --, packed by slk_pack_bases and, for comparison, by a plain Python
+    restatement of the 3-bit form; single reads and pairs, in one piece and through the sub-batch pipeline (words of 16 bases
+    straddle the sub-batches' borders), from pinned and from pageable buffers."""
+    from slacken_amd import capi
+    rng = np.random.default_rng(404)
+    reads = synth.make_reads(world["lib"], 2500, rng, vary_length=True, n_single=0.2, n_run=0.1, short=0.05)
+    junk = np.frombuffer(b"acgtuURYKMSWBDHVNn-.*0123\x80\xff", np.uint8)
+    for i in rng.integers(0, len(reads), 600):
+        r = reads[i].copy()
+        if len(r):
+            at = rng.integers(0, len(r), max(1, len(r) // 12))
+            r[at] = rng.choice(junk, len(at))
+            if i % 3 == 0:
+                r = np.frombuffer(r.tobytes().lower(), np.uint8)
+            reads[i] = r
+    mates = synth.make_reads(world["lib"], 2500, rng, vary_length=True, short=0.1)
+    bases, offsets = synth.pack(reads)
+    mb, mo = synth.pack(mates)
+
+    def py_pack(b):
+        lut = np.full(256, 255, np.uint8)
+        for ch, code in zip(b"ACGTUacgtu", [0, 1, 2, 3, 3, 0, 1, 2, 3, 3]):
+            lut[ch] = code
+        x = lut[b]
+        ok = x != 255
+        pad = (-len(b)) % 16
+        xx = np.concatenate([np.where(ok, x, 0), np.zeros(pad, np.uint8)]).reshape(-1, 16).astype(np.uint32)
+        codes = (xx << (2 * np.arange(16, dtype=np.uint32))).sum(1).astype(np.uint32)
+        valid = (np.concatenate([ok, np.zeros(pad, bool)]).reshape(-1, 16).astype(np.uint32) << np.arange(16, dtype=np.uint32)).sum(1).astype(np.uint16)
+        return codes, valid
+
+    for b in (bases, mb):
+        c, v = capi.pack_bases(b)
+        pc, pv = py_pack(b)
+        assert np.array_equal(c[:len(pc)], pc) and np.array_equal(v[:len(pv)], pv)
+    thr = (0.0, 0.2)
+    old = os.environ.get("SLK_HOST_SUBBATCH")
+    try:
+        for m_b, m_o in ((None, None), (mb, mo)):
+            want = orc.classify_batch(world["p"], world["oix"], world["parents"], bases, offsets, m_b, m_o, thresholds=thr)
+            for sub in ("300", "1000", "1000000"):
+                os.environ["SLK_HOST_SUBBATCH"] = sub
+                for pinned in (False, True):
+                    pk = capi.pack_bases(bases, pinned=pinned) + (capi.pack_bases(m_b, pinned=pinned) if m_b is not None else ())
+                    got = world["st"].classify_batch(None, offsets, None, m_o, thresholds=thr, with_hits=False, with_num_hits=True, packed=pk)
+                    for k in ("taxon", "classified", "num_distinct", "total_kmers", "num_hits"):
+                        assert np.array_equal(got[k], want[k]), (sub, pinned, k)
+    finally:
+        if old is None:
+            os.environ.pop("SLK_HOST_SUBBATCH", None)
+        else:
+            os.environ["SLK_HOST_SUBBATCH"] = old
+    empty = world["st"].classify_batch(None, np.zeros(1, np.uint64), packed=(np.zeros(1, np.uint32), np.zeros(1, np.uint16)))
+    assert empty["taxon"].shape == (1, 0)
+
+
+def test_a_library_that_outgrows_its_table_makes_it_grow(orc):
+    """expected_records far below what is appended: the load passes what the cells' displacement field can count, and records find
+    no cell within reach.  That used to fail the load (SLK_E_CAPACITY, after hours of Parquet streaming for a real library); now
+    the table moves to a larger geometry and the insert that hit the limit runs again.  Every record present, every lookup exact,
+    duplicate keys counted once each -- also those in the batch that ran twice --, the export equal to the input; with records and
+    with sequences (the library builder), on the device and (SLK_TEST_HOST_GROW) through host memory."""
+    import slacken_amd
+    rng = np.random.default_rng(808)
+    n = 400_000
+    keys = np.unique(rng.integers(-2**62, 2**62, n, dtype=np.int64) & ~np.int64(0x33333333))
+    taxa = rng.integers(1, 2000, len(keys)).astype(np.int32)
+    dup_at = rng.choice(len(keys) // 2, 700, replace=False)
+    for via_host in ("0", "1"):
+        os.environ["SLK_GROW_VIA_HOST"] = via_host
+        try:
+            _grow_with_records(keys, taxa, dup_at, rng)
+        finally:
+            os.environ.pop("SLK_GROW_VIA_HOST", None)
+    _grow_with_sequences(orc, rng)
+
+
+def _grow_with_records(keys, taxa, dup_at, rng):
+    import slacken_amd
+    ix = slacken_amd.Index(expected_records=len(keys) // 5, max_taxon=2047)
+    b0 = ix.info().buckets
+    cuts = [0, len(keys) // 3, len(keys) // 2, len(keys)]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        k, t = keys[a:b], taxa[a:b]
+        if a == cuts[2]:     # the last call repeats 700 keys of the first half (with other taxa: the first stays)
+            k, t = np.concatenate([k, keys[dup_at]]), np.concatenate([t, np.full(700, 7, np.int32)])
+            order = rng.permutation(len(k))
+            k, t = k[order], t[order]
+        ix.append(k, t)
+    info = ix.info()
+    assert info.buckets > b0, "the table did not have to grow: the test no longer tests anything"
+    assert info.records == len(keys) and info.duplicate_keys == 700
+    parents = np.zeros(2048, np.int32)
+    parents[2:] = 1
+    ix.set_taxonomy(parents)
+    ix.finalize()
+    assert np.array_equal(ix.lookup(keys), taxa)
+    assert not ix.lookup(np.setdiff1d(keys[:5000] ^ np.int64(1 << 40), keys)).any()
+    gk, gt = ix.export()
+    assert np.array_equal(gk, keys) and np.array_equal(gt, taxa)
+    ix.close()
+
+
+def _grow_with_sequences(orc, rng):
+    """the library builder: sequences whose minimizers outnumber expected_records several times"""
+    import slacken_amd
+    p = orc.params()
+    parents = taxgen.taxonomy(8 * 16, rng)
+    leaves = np.array(taxgen.defined_taxa(parents))[-20:]
+    genomes = [synth.random_dna(30000, rng) for _ in range(12)]
+    gt_ = rng.choice(leaves, len(genomes)).astype(np.int32)
+    bases, offsets = synth.pack(genomes)
+    want_k, want_t = orc.build_records(p, parents, bases, offsets, gt_)
+    ix = slacken_amd.Index(expected_records=len(want_k) // 6, max_taxon=len(parents) - 1)
+    b0 = ix.info().buckets
+    ix.set_taxonomy(parents)
+    ix.add_sequences(bases[:int(offsets[5])], offsets[:6], gt_[:5])
+    ix.add_sequences(bases[int(offsets[5]):], offsets[5:] - offsets[5], gt_[5:])
+    assert ix.info().buckets > b0
+    ix.finalize()
+    gk, gtx = ix.export()
+    assert np.array_equal(gk, want_k) and np.array_equal(gtx, want_t)
+    ix.close()

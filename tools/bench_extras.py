@@ -75,6 +75,24 @@ def main():
     out["host_entry_pinned"] = dict(reads=R, seconds=round(dt, 4), M_reads_per_s=round(R / dt / 1e6, 1),
                                     GB_per_s_up=round((rb.nbytes + ro.nbytes) / dt / 1e9, 1),
                                     note="the same call with input and output buffers from slk_host_alloc: direct DMA, one call (best of 3)")
+    # the same reads in the engine's 3-bit form (slk_classify_batch_packed): 6 bytes per 16 bases over the link
+    t0 = time.perf_counter()
+    pk_codes, pk_valid = capi.pack_bases(rb, pinned=True)
+    out["pack_bases"] = dict(bases=int(rb.size), seconds=round(time.perf_counter() - t0, 4),
+                             note="slk_pack_bases (AVX2 + BMI2, the library's copy threads) incl. first touch of the pinned output")
+    t0 = time.perf_counter()
+    capi.lib().slk_pack_bases(rb.ctypes.data, rb.size, pk_codes.ctypes.data, pk_valid.ctypes.data)
+    dtp = time.perf_counter() - t0
+    out["pack_bases"].update(seconds_warm=round(dtp, 4), GB_per_s=round(rb.size / dtp / 1e9, 1))
+    dt = timed(lambda: st.classify_batch(None, pro, with_hits=False, out=pout, packed=(pk_codes, pk_valid)))
+    assert np.array_equal(pout["taxon"], res["taxon"])
+    out["host_entry_packed_pinned"] = dict(reads=R, seconds=round(dt, 4), M_reads_per_s=round(R / dt / 1e6, 1),
+                                           GB_per_s_up=round((pk_codes.nbytes + pk_valid.nbytes + ro.nbytes) / dt / 1e9, 1),
+                                           bytes_per_read_up=round((pk_codes.nbytes + pk_valid.nbytes + ro.nbytes) / R, 1),
+                                           note="slk_classify_batch_packed, reads packed beforehand into buffers of slk_host_alloc: one call (best of 3)")
+    dt = timed(lambda: st.classify_batch(None, ro, with_hits=False, packed=(np.array(pk_codes), np.array(pk_valid))))
+    out["host_entry_packed_pageable"] = dict(reads=R, seconds=round(dt, 4), M_reads_per_s=round(R / dt / 1e6, 1),
+                                             note="the same from pageable buffers (staged by the library's copy threads)")
     # several caller threads, one stream each (the intended use: one slk_stream per Spark task thread)
     for nthreads, pinned_bufs in ((3, False), (3, True)):
         streams = [ix.stream() for _ in range(nthreads)]
