@@ -33,9 +33,13 @@ constexpr int SPAN_CAP = 128;  // buffered spans per wave before a flush
 constexpr int MAP_CAP = 128;   // taxon map slots per wave (power of two)
 constexpr int32_t MAP_EMPTY = -1;  // AMBIGUOUS_SPAN is never inserted, so -1 is free
 
+// the wave-per-fragment scan's staged bases (fused_kernel only: the segment kernel's lanes stream their bases themselves)
+struct __attribute__((aligned(16))) RingLds {
+  uint32_t fwd_ring[32 + 4];     // 2-bit bases, MSB first inside each dword, ring of 512 bases (two 256-base blocks); words 32..34
+                                 // repeat words 0..2, so that the three words an m-mer straddles are read without wrapping around
+  uint32_t rc_ring[32 + 4];      // complement of base p at ring position 511 - p
+};
 struct __attribute__((aligned(16))) WaveLds {
-  uint32_t fwd_ring[32];         // 2-bit bases, MSB first inside each dword, ring of 512 bases (two 256-base blocks)
-  uint32_t rc_ring[32];          // complement of base p at ring position 511 - p
   uint64_t span_key[SPAN_CAP];
   int32_t span_meta[SPAN_CAP];
   uint64_t stash[128];           // probe: (bucket byte offset, tag) per span of the chunk; resolveTree: dense (taxon,count)
@@ -54,15 +58,16 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
   uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
   return ((uint64_t)hi << 32) | lo;
 }
-// lane i <- lane i+1 / lane i-1 (DPP wave shifts; the vacated end lane reads 0)
+// lane i <- lane i+1 / lane i-1 (DPP wave shifts; the vacated end lane reads 0 -- bound_ctrl, so that no register has to be
+// zeroed for it beforehand)
 __device__ __forceinline__ uint64_t from_next(uint64_t v) {
-  uint32_t lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x130, 0xF, 0xF, false);
-  uint32_t hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x130, 0xF, 0xF, false);
+  uint32_t lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x130, 0xF, 0xF, true);
+  uint32_t hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x130, 0xF, 0xF, true);
   return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ uint64_t from_prev(uint64_t v) {
-  uint32_t lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x138, 0xF, 0xF, false);
-  uint32_t hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, false);
+  uint32_t lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x138, 0xF, 0xF, true);
+  uint32_t hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, true);
   return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {  // src wave-uniform; result wave-uniform
@@ -98,7 +103,7 @@ __device__ __forceinline__ uint64_t next_unit(unsigned long long *counter) {
 
 // ---- staging: 256 characters -> 2-bit codes in the two rings ----------------------------------------------------------
 // returns true in lanes that saw a character outside ACGTUacgtu (BitRepresentation.isValid, BitRepresentation.scala:140-143)
-__device__ __forceinline__ bool stage_block(WaveLds *L, const uint8_t *seq, uint32_t n, uint32_t blk, int lane) {
+__device__ __forceinline__ bool stage_block(RingLds *L, const uint8_t *seq, uint32_t n, uint32_t blk, int lane) {
   uint32_t pos = blk * 256 + lane * 4;
   uint32_t nchars = pos < n ? min(4u, n - pos) : 0u;
   uint32_t v = 0x41414141u;  // missing characters read as 'A' (never used by a window, never "bad")
@@ -118,33 +123,40 @@ __device__ __forceinline__ bool stage_block(WaveLds *L, const uint8_t *seq, uint
   t ^= (t >> 1) & 0x01010101u;
   uint32_t pack = (t * 0x40100401u) >> 24;  // code0<<6 | code1<<4 | code2<<2 | code3
   uint32_t g = (blk * 64 + lane) & 127;     // group of 4 bases within the 512-base ring
-  ((uint8_t *)L->fwd_ring)[(g & ~3u) | (3u - (g & 3u))] = (uint8_t)pack;  // MSB-first inside each dword
+  const uint32_t fi = (g & ~3u) | (3u - (g & 3u));                        // MSB-first inside each dword
+  ((uint8_t *)L->fwd_ring)[fi] = (uint8_t)pack;
+  if (fi < 12u) ((uint8_t *)L->fwd_ring)[fi + 128u] = (uint8_t)pack;      // (the ring's first three words again behind its end)
   // reverse complement of the group: complement, reverse the four 2-bit codes
   uint32_t x = __brev(~pack) >> 24;                         // bit-reversed byte
   x = ((x >> 1) & 0x55u) | ((x & 0x55u) << 1);              // swap the bits of each pair back
   uint32_t gr = 127 - g;
-  ((uint8_t *)L->rc_ring)[(gr & ~3u) | (3u - (gr & 3u))] = (uint8_t)x;
+  const uint32_t ri = (gr & ~3u) | (3u - (gr & 3u));
+  ((uint8_t *)L->rc_ring)[ri] = (uint8_t)x;
+  if (ri < 12u) ((uint8_t *)L->rc_ring)[ri + 128u] = (uint8_t)x;
   return bad;
 }
 
 // 64 bits of a ring starting at base position p (mod 512), left-aligned
 __device__ __forceinline__ uint64_t ring_bits(const uint32_t *ring, uint32_t p) {
-  uint32_t i = (p >> 4) & 31, s = (p & 15) * 2;
-  uint32_t w0 = ring[i], w1 = ring[(i + 1) & 31], w2 = ring[(i + 2) & 31];
+  const uint32_t *w = ring + ((p >> 4) & 31);   // (words 32..34 repeat 0..2: no wrap-around inside the three)
+  const uint32_t s = (p & 15) * 2;
+  const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
   uint32_t hi = (uint32_t)(((((uint64_t)w0 << 32) | w1) << s) >> 32);
   uint32_t lo = (uint32_t)(((((uint64_t)w1 << 32) | w2) << s) >> 32);
   return ((uint64_t)hi << 32) | lo;
 }
 
 // left-aligned key of the m-mer starting at base q (NTBitArray layout; SpacedSeed(RandomXOR) priority)
-__device__ __forceinline__ uint64_t key_at(const WaveLds *L, const ScanParams &P, uint32_t q) {
-  uint64_t fwd = ring_bits(L->fwd_ring, q) & P.keep;
+// (keep / xmask / smask: the splitter's masks, which the caller holds in VECTOR registers although they are wave-uniform -- the
+//  kernel's scalar registers are oversubscribed, and as scalars these six were spilled and read back lane by lane every round)
+__device__ __forceinline__ uint64_t key_at(const RingLds *L, const ScanParams &P, uint32_t q, uint64_t keep, uint64_t xmask, uint64_t smask) {
+  uint64_t fwd = ring_bits(L->fwd_ring, q) & keep;
   uint64_t canon = fwd;
   if (P.canonical) {
-    uint64_t rc = ring_bits(L->rc_ring, 512u - ((q + P.m) & 511u)) & P.keep;
+    uint64_t rc = ring_bits(L->rc_ring, 512u - ((q + P.m) & 511u)) & keep;
     canon = umin64(fwd, rc);  // NTBitArray.writeCanonical :258-266 == unsigned minimum of the two orientations
   }
-  return (canon ^ P.xmask) & P.smask;
+  return (canon ^ xmask) & smask;
 }
 
 __device__ __forceinline__ void put_span(WaveLds *L, int slot, uint64_t key, int32_t kmers, int32_t flag, bool distinct) {
@@ -456,14 +468,19 @@ enum { PH_START = 0, PH_FAST = 1, PH_RUNS = 2, PH_NEXT = 3 };
 #define FUSED_BOUNDS __launch_bounds__(FW * 64)
 #endif
 
-template <int MODE>
+// W5: the window of the default splitter (k = 35, m = 31: five m-mers), its minimum as a fixed network of lane shifts
+template <int MODE, bool W5>
 __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
   __shared__ WaveLds lds[FW];
+  __shared__ RingLds rings[FW];
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps per-read state in SGPRs
   WaveLds *L = &lds[wib];
+  RingLds *G = &rings[wib];
   const ScanParams &P = A.P;
-  const int w = P.w;
+  uint64_t v_keep = P.keep, v_xmask = P.xmask, v_smask = P.smask;
+  asm volatile("" : "+v"(v_keep), "+v"(v_xmask), "+v"(v_smask));   // (vector registers: see key_at)
+  const int w = W5 ? 5 : P.w;
   const uint32_t STEP = 64 - (w - 1);  // k-mer windows resolved per round
   const uint64_t nwaves = (uint64_t)gridDim.x * FW;
   // Work list: every fragment, or (work_list) the fragments the lane kernel deferred -- it appends them to the list itself --
@@ -512,7 +529,7 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
           // end up holding blocks 0 and 1
           bool bad = false;
           uint32_t nblk = (n + 255) / 256;
-          for (uint32_t b = nblk; b-- > 0;) bad |= stage_block(L, seq, n, b, lane);
+          for (uint32_t b = nblk; b-- > 0;) bad |= stage_block(G, seq, n, b, lane);
           if (__ballot(bad) != 0) {
             // Supermers.splitByAmbiguity :150-178: the mate is a sequence of runs of valid and of other characters; a valid run
             // of >= k characters is scanned like a whole clean mate, another run of >= k characters is one ambiguous span
@@ -541,19 +558,26 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
             continue;
           }
           uint32_t need = min(n, i0 + 64 + P.m - 1);
-          while (staged < need) { stage_block(L, seq, n, blk, lane); blk++; staged += 256; }
+          while (staged < need) { stage_block(G, seq, n, blk, lane); blk++; staged += 256; }
           wave_sync();
           uint32_t q = i0 + lane;
-          uint64_t key = (q + P.m <= fast_n) ? key_at(L, P, q) : ~0ULL;
+          uint64_t key = (q + P.m <= fast_n) ? key_at(G, P, q, v_keep, v_xmask, v_smask) : ~0ULL;
           // minimum over lanes [l, l+w): doubling, then one overlapping step (PosRankWindow's observable result)
-          uint64_t cur = key;
-          int covered = 1;
-          if (w >= 2) { cur = umin64(cur, from_next(cur)); covered = 2; }
-          for (; covered * 2 <= w; covered *= 2) cur = umin64(cur, shfl64(cur, lane + covered));
-          uint64_t res = cur;
-          if (covered < w) {
-            int d = w - covered;
-            res = umin64(cur, d == 1 ? from_next(cur) : shfl64(cur, lane + d));
+          uint64_t res;
+          if (W5) {
+            const uint64_t c2 = umin64(key, from_next(key));                  // lanes l, l + 1
+            const uint64_t c4 = umin64(c2, from_next(from_next(c2)));         // l .. l + 3
+            res = umin64(c4, from_next(c4));                                  // l .. l + 4
+          } else {
+            uint64_t cur = key;
+            int covered = 1;
+            if (w >= 2) { cur = umin64(cur, from_next(cur)); covered = 2; }
+            for (; covered * 2 <= w; covered *= 2) cur = umin64(cur, shfl64(cur, lane + covered));
+            res = cur;
+            if (covered < w) {
+              int d = w - covered;
+              res = umin64(cur, d == 1 ? from_next(cur) : shfl64(cur, lane + d));
+            }
           }
           int nw = (int)min(STEP, nwin - i0);
           i0 += STEP;
@@ -1122,9 +1146,10 @@ void launch_fused(int mode, const FusedArgs &A, hipStream_t s) {
   const uint64_t cap = (A.work_list || bpc <= 0) ? 256 * 8 : (uint64_t)256 * bpc;
   if (blocks > cap) blocks = cap;
   dim3 g((unsigned)blocks), b(FW * 64);
-  if (mode == MODE_SPANS) hipLaunchKernelGGL(fused_kernel<MODE_SPANS>, g, b, 0, s, A);
-  else if (mode == MODE_HITS) hipLaunchKernelGGL(fused_kernel<MODE_HITS>, g, b, 0, s, A);
-  else hipLaunchKernelGGL(fused_kernel<MODE_CLASSIFY>, g, b, 0, s, A);
+  const bool w5 = A.P.w == 5;
+  if (mode == MODE_SPANS) { if (w5) hipLaunchKernelGGL((fused_kernel<MODE_SPANS, true>), g, b, 0, s, A); else hipLaunchKernelGGL((fused_kernel<MODE_SPANS, false>), g, b, 0, s, A); }
+  else if (mode == MODE_HITS) { if (w5) hipLaunchKernelGGL((fused_kernel<MODE_HITS, true>), g, b, 0, s, A); else hipLaunchKernelGGL((fused_kernel<MODE_HITS, false>), g, b, 0, s, A); }
+  else { if (w5) hipLaunchKernelGGL((fused_kernel<MODE_CLASSIFY, true>), g, b, 0, s, A); else hipLaunchKernelGGL((fused_kernel<MODE_CLASSIFY, false>), g, b, 0, s, A); }
 }
 
 }  // namespace slk

@@ -247,10 +247,29 @@ class OutputSink {
   // Reports only (--nodetailed): the reference takes the SQL route, ifnull(regexp_extract(title, re, 1), "other")
   // (SQLClassifier, Classifier.scala:297-300) -- and regexp_extract yields "" rather than null without a match, so there the
   // unmatched titles form the sample "" (report file "_kreport.txt").  Mirrored as is.
+  //
+  // A match in which group 1 took no part: Regex.Match.group(1) is null there, and so is ClassifiedRead.sampleId.  What becomes of
+  // it is Spark's doing (org.apache.spark:spark-sql_2.12:3.5.6, not under /root/reference; parity unpinned): the per-read rows are
+  // written with partitionBy("sample") (Classifier.scala:207-211), whose directory for a null OR EMPTY value is
+  // sample=__HIVE_DEFAULT_PARTITION__ and which %-escapes the characters a path cannot hold (ExternalCatalogUtils.
+  // getPartitionPathString / escapePathName), and the report's name is read back from that directory's name
+  // (makeReportsFromClassifications :232-241).  The reports-only route's regexp_extract gives "" for such a group as for no match.
+  // (std::regex is ECMAScript, not java.util.regex: see --help.)
+  static std::string spark_partition_value(const std::string &v, bool is_null) {
+    if (is_null || v.empty()) return "__HIVE_DEFAULT_PARTITION__";
+    std::string out;
+    for (unsigned char c : v) {
+      const bool esc = (c >= 0x01 && c <= 0x1F) || c == 0x7F || strchr("\"#%'*/:=?\\{[]^", c) != nullptr;
+      if (esc) { char b[8]; snprintf(b, sizeof b, "%%%02X", c); out += b; }
+      else out.push_back((char)c);
+    }
+    return out;
+  }
   std::string sample_of(std::string_view title) const {
     if (o_.sample_regex.empty()) return "all";
     std::cmatch m;
-    if (std::regex_search(title.data(), title.data() + title.size(), m, re_) && m.size() > 1) return m[1].str();
+    if (std::regex_search(title.data(), title.data() + title.size(), m, re_) && m.size() > 1)
+      return o_.detailed ? spark_partition_value(m[1].str(), !m[1].matched) : m[1].str();
     return o_.detailed ? "other" : "";
   }
   // ClassifiedRead.outputLine, Classifier.scala:41-44

@@ -129,6 +129,35 @@ def with_descendants(tax, taxa):
     return out
 
 
+def read_gold_set(tax, lines, primary, in_library, rank_depth, promote_depth=None):
+    """Dynamic.readGoldSet (S/slacken/Dynamic.scala:284-310): the file's taxa mapped to their primaries; those without sequence in
+    the library replaced by the nearest ancestor that has; filtered at the reclassification rank, the promoted ones kept down to
+    promote_depth if given.  in_library: the labelled taxa with their ancestors (GenomeLibrary.taxonSet).  -> sorted list"""
+    gold = {primary.get(int(l.split(",")[0]), int(l.split(",")[0])) for l in lines if l.strip()}
+    not_found = {t for t in gold if t not in in_library}
+    promoted = set()
+    for t in not_found:
+        p = t
+        while p != 0:
+            if p in in_library:
+                promoted.add(p)
+                break
+            p = tax.parents[p]
+    kept = {t for t in promoted if depth(tax, t) >= promote_depth} if promote_depth is not None else set()
+    total = gold | promoted
+    return sorted({t for t in total if depth(tax, t) >= rank_depth} | kept), dict(gold=len(gold), not_found=len(not_found),
+                                                                                 promoted=len(promoted), kept=len(kept), total=len(total))
+
+
+def with_ancestors(tax, taxa):
+    out = set()
+    for t in taxa:
+        while t != 0 and t not in out:
+            out.add(t)
+            t = tax.parents[t]
+    return out
+
+
 # ---- regrouping by title: Classifier.spansToGroupedHits (S/slacken/Classifier.scala:77-96) + classifyHits (:124-147) ----
 def merge_by_title(fragments):
     """fragments: [(title, hits, distinct)] in input order, hits = [(taxon, count)...] in ordinal order (a fragment without

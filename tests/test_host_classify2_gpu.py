@@ -251,3 +251,74 @@ def test_classify2_repeated_titles_count_once_in_the_detection_pass(tmp_path, or
         want.append(orc.output_line(res["classified"], title, res["taxon"], hits, 35))
     got = read_out(f"{out}_c0.0")
     assert sorted(got) == sorted(want) and sum(l.split("\t")[1] == "dup_title" for l in got) == 1
+
+
+def test_classify2_gold_set(tmp_path, orc):
+    """-g FILE: the detected set is compared with a gold set (Dynamic.findTaxonSet :262-274) -- read through merged.dmp's
+    primaries, taxa without sequence in the library promoted to their nearest ancestor that has (readGoldSet :284-310),
+    --promote-gold-set keeping those down to a rank -- and --classify-with-gold builds the dynamic library from the gold set
+    instead of a detected one (makeRecords :362-374): no detection pass, no _taxonSet.txt.  Messages and files against a Python
+    restatement driven by the oracle."""
+    S = setup(tmp_path, orc, seed=12)
+    tax, parents = S["tax"], S["parents"]
+    ls = (len(parents) - 2) // taxgen.N_RANKS
+    species = list(range(7 * ls + 2, 8 * ls + 2))
+    genus = list(range(6 * ls + 2, 7 * ls + 2))
+    lab = sorted(set(S["seq_taxa"]) | {5})                      # (seqid2taxid.map also labels NC_missing.1 with taxon 5)
+    in_library = hostmodel.with_ancestors(tax, lab)
+    # a merged.dmp: secondary id 900 -> the first labelled species
+    sec = len(parents) + 50
+    with open(S["loc"] + "_taxonomy/merged.dmp", "w") as f:
+        f.write(f"{sec}\t|\t{species[0]}\t|\n")
+    not_in_lib = [t for t in species if t not in in_library][:2]  # species without sequence: promoted to an ancestor that has
+    gold_ids = [sec, species[1], genus[1]] + not_in_lib
+    gold_file = tmp_path / "gold.txt"
+    gold_file.write_text("".join(f"{t}\n" for t in gold_ids) + "\n")
+    gold, st = hostmodel.read_gold_set(tax, [str(t) for t in gold_ids], {sec: species[0]}, in_library, 8)
+    assert st["not_found"] == len(not_in_lib) > 0 and species[0] in gold and genus[1] not in gold
+    # (1) compare only: same files as without -g, plus the comparison line
+    out = tmp_path / "cmp"
+    r = subprocess.run([CLI, "classify2", "-i", S["loc"], "-o", str(out), "--library", S["lib"], "-R", "50", "-g", str(gold_file), S["fq"]],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    keep, lines, _ = restate(orc, S, "reads", 50)
+    assert [int(l) for l in open(f"{out}_taxonSet.txt").read().split()] == keep
+    assert read_out(f"{out}_c0.0") == lines[0.0]
+    tp = len(set(keep) & set(gold))
+    fp, fn = len(keep) - tp, len(gold) - tp
+    perc = lambda x: hostmodel.fmt_6_2f(100 * x).strip() + "%"
+    assert f"Gold set contained {st['gold']} taxa" in r.stdout
+    assert f"{st['not_found']} taxa from gold set not found in library, promoted to {st['promoted']} taxa." in r.stdout
+    assert f"Initial adjusted gold set size {st['total']}, filtered at Species to {len(gold)}" in r.stdout
+    assert (f"Comparing detected set with supplied gold set. True Positives: {tp}, False Positives: {fp}, False Negatives: {fn}, "
+            f"Precision: {perc(tp / (tp + fp))}, Recall: {perc(tp / len(gold))}") in r.stdout
+    # (2) --promote-gold-set genus: the promoted ancestors at genus and below stay in the set although they are above the species rank
+    gold_p, st_p = hostmodel.read_gold_set(tax, [str(t) for t in gold_ids], {sec: species[0]}, in_library, 8, promote_depth=7)
+    r = subprocess.run([CLI, "classify2", "-i", S["loc"], "-o", str(tmp_path / "cmp2"), "--library", S["lib"], "-R", "50", "-g", str(gold_file),
+                        "--promote-gold-set", "genus", S["fq"]], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert f"Keeping {st_p['kept']} taxa at rank Genus and below from promoted set" in r.stdout
+    assert f"filtered at Species to {len(gold_p)}" in r.stdout
+    # (3) --classify-with-gold: the library of the gold set's clades, whatever the sample holds
+    out3 = tmp_path / "withgold"
+    r = subprocess.run([CLI, "classify2", "-i", S["loc"], "-o", str(out3), "--library", S["lib"], "-g", str(gold_file), "--classify-with-gold",
+                        "--promote-gold-set", "genus", S["fq"]], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert not os.path.exists(f"{out3}_taxonSet.txt") and "Comparing detected set" not in r.stdout
+    full = hostmodel.with_descendants(tax, gold_p)
+    sel = [i for i, t in enumerate(S["seq_taxa"]) if t in full]
+    b = np.frombuffer("".join(S["seqs"][i] for i in sel).encode(), np.uint8)
+    o = np.zeros(len(sel) + 1, np.uint64)
+    np.cumsum([len(S["seqs"][i]) for i in sel], out=o[1:])
+    dk, dt = orc.build_records(S["p"], parents, b, o, [S["seq_taxa"][i] for i in sel])
+    assert f"dynamic index: {len(dk)} records" in r.stderr
+    dyn = orc.Index(1, dk, dt)
+    want = []
+    for title, sq in S["reads"]:
+        res, hits = orc.classify_read(S["p"], dyn, parents, sq, None, 2, 0.0)
+        if hits:
+            want.append(orc.output_line(res["classified"], title, res["taxon"], hits, 35))
+    assert read_out(f"{out3}_c0.0") == want
+    # options that qualify a gold set need one
+    r = subprocess.run([CLI, "classify2", "-i", S["loc"], "-o", str(out3), "--library", S["lib"], "--classify-with-gold", S["fq"]], capture_output=True, text=True)
+    assert r.returncode != 0 and "gold set" in r.stderr

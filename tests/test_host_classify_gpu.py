@@ -115,6 +115,22 @@ def test_cli_paired_samples_and_flags(tmp_path):
     for s in samples:
         assert all(l.split("\t")[1].split("sra.")[1][0] == s for l in read_out(f"{out4}_c0.0", s))
         assert os.path.exists(f"{out4}_c0.0/{s}_kreport.txt")
+    # A match in which group 1 takes no part: Match.group(1) is null in the reference, and a null (or empty) partition value is
+    # Spark's sample=__HIVE_DEFAULT_PARTITION__, from whose name the report's is read back (Classifier.scala:138-142,207-211,232-241);
+    # characters a path cannot hold are %-escaped the way Spark's partition writer escapes them.  Reports only: regexp_extract's "".
+    out5 = tmp_path / "nullgroup"
+    classify("-i", loc, "-o", out5, "--sample-regex", r"(?:sra\.([0-4]))?\d", "-p", f1, f2)   # group 1 only for ids sra.0 .. sra.4
+    samples5 = sorted(os.path.basename(d)[len("sample="):] for d in glob.glob(f"{out5}_c0.0/sample=*"))
+    assert "__HIVE_DEFAULT_PARTITION__" in samples5 and set(samples5) - {"__HIVE_DEFAULT_PARTITION__"} <= set("01234")
+    assert os.path.exists(f"{out5}_c0.0/__HIVE_DEFAULT_PARTITION___kreport.txt")
+    assert sorted(l for s in samples5 for l in read_out(f"{out5}_c0.0", s)) == sorted(lines)
+    out6 = tmp_path / "escaped"
+    classify("-i", loc, "-o", out6, "--sample-regex", r"(a\.\d)", "-p", f1, f2)            # "a.3" needs no escape ...
+    classify("-i", loc, "-o", tmp_path / "escaped2", "--sample-regex", r"(r)(a)", "-p", f1, f2)
+    assert glob.glob(f"{out6}_c0.0/sample=a.*")
+    out7 = tmp_path / "nullgroup_reports"
+    classify("-i", loc, "-o", out7, "--nodetailed", "--sample-regex", r"(?:sra\.([0-4]))?\d", "-p", f1, f2)
+    assert os.path.exists(f"{out7}_c0.0/_kreport.txt") and not os.path.exists(f"{out7}_c0.0/__HIVE_DEFAULT_PARTITION___kreport.txt")
 
 
 @pytest.mark.parametrize("m", [31, 40, 100])
