@@ -76,7 +76,8 @@ typedef struct {
   uint64_t expected_records; /* upper bound on records that will be appended */
   int32_t max_taxon;         /* largest taxon id that will be appended (0 = derive from nothing: 2^22-1) */
   float load_factor;         /* target cells-used fraction, 0 = default: 0.55 while the table then takes at most 55 % of the device's
-                                memory, more for larger libraries (0.80 at most); less for tables whose cells leave a short displacement field */
+                                FREE memory, more for larger libraries (0.85 at most); less for tables whose cells leave a short
+                                displacement field */
 } slk_table_config;
 
 typedef struct {
@@ -91,6 +92,10 @@ typedef struct {
   int32_t dense_taxa;       /* > 0: taxon ids beyond 22 bits were renumbered internally at slk_index_finalize (the number of
                                taxonomy nodes); every taxon that crosses this ABI is still the caller's id */
   int32_t bucket_cells;     /* 8-byte cells per bucket: 8 (64-byte buckets; a build option makes it 16) */
+  float load_factor;        /* the load the table was sized for: slk_table_config.load_factor, or what the default chose from the
+                               device's free memory (runs on parts with different memory are comparable by this) */
+  int32_t grown;            /* times the table moved to a larger geometry because a record found no cell within reach
+                               (more records than expected_records: the load never fails for that) */
 } slk_index_info;
 
 /* OrdinalSpan (S/slacken/package.scala:61-62) without the title; ordinal = position in the read's span list.

@@ -35,7 +35,8 @@ class IndexInfo(C.Structure):
     _fields_ = [("records", C.c_uint64), ("buckets", C.c_uint64), ("table_bytes", C.c_uint64),
                 ("bucket_bits", C.c_int32), ("taxon_bits", C.c_int32), ("disp_bits", C.c_int32),
                 ("max_displacement", C.c_int32), ("duplicate_keys", C.c_uint64), ("taxonomy_size", C.c_int32),
-                ("device", C.c_int32), ("dense_taxa", C.c_int32), ("bucket_cells", C.c_int32)]
+                ("device", C.c_int32), ("dense_taxa", C.c_int32), ("bucket_cells", C.c_int32), ("load_factor", C.c_float),
+                ("grown", C.c_int32)]
 
 
 class _ShardBatch(C.Structure):

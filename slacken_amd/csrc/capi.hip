@@ -163,9 +163,11 @@ int32_t slk_index_create(const slk_params *p, const slk_table_config *cfg, int32
   const uint64_t expected = std::max<uint64_t>(cfg->expected_records, 1);
   double lf = cfg->load_factor;
   if (default_lf) {
+    // (the memory that is FREE now, not the part's total: several tables may share a device -- `--shard-table --devices 0,0`, a
+    //  dynamic library beside its base -- and each then takes its share of what the earlier ones left)
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) { (void)hipGetLastError(); total_b = (size_t)288 << 30; }
-    const double cell_bytes = (double)expected * 8.0, t = (double)total_b;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) { (void)hipGetLastError(); free_b = total_b = (size_t)288 << 30; }
+    const double cell_bytes = (double)expected * 8.0, t = (double)std::min(total_b, free_b + ((size_t)2 << 30));
     if (cell_bytes / 0.55 <= 0.55 * t) lf = 0.55;
     else if (cell_bytes / 0.70 <= 0.55 * t) lf = cell_bytes / (0.55 * t);
     else if (cell_bytes / 0.70 <= 0.80 * t) lf = 0.70;
@@ -177,6 +179,7 @@ int32_t slk_index_create(const slk_params *p, const slk_table_config *cfg, int32
   bool shape_ok = false;
   const TableShape sh = settle_shape((cells_needed + CELLS - 1) / CELLS, expected, tb, &shape_ok);
   if (!shape_ok) { delete ix; return fail(SLK_E_CAPACITY, "a table of %llu buckets is too large", (unsigned long long)sh.nb); }
+  ix->load_target = (float)lf;
   ix->bucket_bits = sh.q;
   ix->taxon_bits = tb;
   ix->disp_bits = sh.disp;
@@ -778,6 +781,8 @@ int32_t slk_index_get_info(const slk_index *ix, slk_index_info *out) {
   out->device = ix->device;
   out->dense_taxa = ix->D;
   out->bucket_cells = ix->W > 1 ? 1 : CELLS;
+  out->load_factor = ix->load_target;
+  out->grown = (int32_t)ix->grown;
   return SLK_OK;
 }
 
@@ -861,7 +866,9 @@ void slk_stream_destroy(slk_stream *st) {
   st->staging.release();
   st->staging_c.release();
   for (hipEvent_t e : st->up_ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : st->dn_ev) (void)hipEventDestroy(e);
   if (st->cs) (void)hipStreamDestroy(st->cs);
+  if (st->ds) { (void)hipStreamSynchronize(st->ds); (void)hipStreamDestroy(st->ds); }
   if (st->s2) { (void)hipStreamSynchronize(st->s2); (void)hipStreamDestroy(st->s2); }
   if (st->ev_unpack) (void)hipEventDestroy(st->ev_unpack);
   if (st->ev_fork) (void)hipEventDestroy(st->ev_fork);
@@ -942,6 +949,7 @@ int32_t check_status(slk_stream *st) {  // call after the stream has been synchr
         int32_t rc = run_unbounded(st, L);
         if (rc) return rc;
       }
+      st->reran = true;
       return SLK_OK;
     }
     if (v & 2) return fail(SLK_E_CAPACITY, "a send region of slk_shard_step_device's EMIT job overflowed its capacity_per_owner");
@@ -1574,6 +1582,7 @@ static int32_t classify_batch_host(slk_index *ix, slk_stream *st, const ReadSour
   double tp[6] = {now(), 0, 0, 0, 0, 0};
   uint64_t total = 0, mate_total = 0;
   const bool want_hits = out_hit_offsets != nullptr && out_hits != nullptr;
+  bool early_down = false;
   HIPCHK(st->out_taxon.ensure((size_t)C * R * 4));
   HIPCHK(st->out_cls.ensure((size_t)C * R));
   HIPCHK(st->out_nd.ensure(R * 4));
@@ -1603,20 +1612,36 @@ static int32_t classify_batch_host(slk_index *ix, slk_stream *st, const ReadSour
   // sub-batch i run, so the call costs its upload plus ONE sub-batch of kernel time.  (Calls that want the hit lists
   // keep the one-piece route: their cost is the download of the lists.)
   const char *sub_env = getenv("SLK_HOST_SUBBATCH");  // (read per call, so that tests can move it)
-  const uint64_t SUB = sub_env ? (uint64_t)std::max(1L, atol(sub_env)) : (uint64_t)1 << 18;
+  // (2^19 reads: measured from pinned memory, 4 M reads of 150 bp -- packed 353 / 576 / 643 / 623 / 403 M reads/s at 2^17 .. 2^21, text
+  //  313 / 324 / 327 / 315 / 246: smaller pieces pay per copy -- a sub-batch is five to nine DMAs --, larger ones leave the last
+  //  piece's kernels exposed; profiles/r04_packed_entry.json)
+  const uint64_t SUB = sub_env ? (uint64_t)std::max(1L, atol(sub_env)) : (uint64_t)1 << 19;
   if (!want_hits && use_fused(ix) && R >= 2 * SUB) {
     if (!st->cs) HIPCHK(hipStreamCreateWithFlags(&st->cs, hipStreamNonBlocking));
+    if (!st->ds) HIPCHK(hipStreamCreateWithFlags(&st->ds, hipStreamNonBlocking));
     const uint64_t nsub = (R + SUB - 1) / SUB;
     while (st->up_ev.size() < nsub) {
       hipEvent_t e;
       HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       st->up_ev.push_back(e);
     }
-    rc = copy_in(&st->staging_c, st->cs, st->offsets.p, offsets, (R + 1) * 8);
-    if (!rc && paired) rc = copy_in(&st->staging_c, st->cs, st->mate_offsets.p, mate_offsets, (R + 1) * 8);
-    if (rc) return rc;
+    while (st->dn_ev.size() < nsub) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      st->dn_ev.push_back(e);
+    }
+    // Result buffers the library can DMA into take their rows sub-batch by sub-batch, beside the next sub-batch's kernels (the link
+    // is full duplex: the rows come down while the reads go up); pageable ones are filled at the end, through the staging buffers.
+    early_down = pinned().covers(out_taxon, (size_t)C * R * 4) && pinned().covers(out_classified, (size_t)C * R) &&
+                 (!out_num_distinct || pinned().covers(out_num_distinct, R * 4)) && (!out_total_kmers || pinned().covers(out_total_kmers, R * 4));
+    st->reran = false;
     for (uint64_t i = 0; i < nsub; i++) {
       const uint64_t r0 = i * SUB, r1 = std::min(R, r0 + SUB), n = r1 - r0;
+      // (the offsets travel with their sub-batch: 8 bytes per read are a tenth of a packed batch, and the first kernels should not
+      //  wait for all of them)
+      rc = copy_in(&st->staging_c, st->cs, st->offsets.as<uint64_t>() + r0, offsets + r0, (n + 1) * 8);
+      if (!rc && paired) rc = copy_in(&st->staging_c, st->cs, st->mate_offsets.as<uint64_t>() + r0, mate_offsets + r0, (n + 1) * 8);
+      if (rc) return rc;
       rc = upload_range(st, &st->staging_c, st->cs, st->s, st->ev_unpack, pk, src.bases, src.codes, src.valid, st->pk_codes, st->pk_valid,
                         st->bases.as<uint8_t>(), offsets[r0], offsets[r1]);
       if (!rc && paired)
@@ -1633,6 +1658,16 @@ static int32_t classify_batch_host(slk_index *ix, slk_stream *st, const ReadSour
                         st->out_cls.as<uint8_t>() + r0, st->out_nd.as<int32_t>() + r0, st->out_tk.as<int32_t>() + r0,
                         st->out_nh.as<int32_t>() + r0, nullptr, false, R);
       if (rc) return rc;
+      if (early_down) {
+        HIPCHK(hipEventRecord(st->dn_ev[i], st->s));
+        HIPCHK(hipStreamWaitEvent(st->ds, st->dn_ev[i], 0));
+        for (int32_t c = 0; c < C; c++) {
+          HIPCHK(hipMemcpyAsync(out_taxon + (size_t)c * R + r0, st->out_taxon.as<int32_t>() + (size_t)c * R + r0, n * 4, hipMemcpyDeviceToHost, st->ds));
+          HIPCHK(hipMemcpyAsync(out_classified + (size_t)c * R + r0, st->out_cls.as<uint8_t>() + (size_t)c * R + r0, n, hipMemcpyDeviceToHost, st->ds));
+        }
+        if (out_num_distinct) HIPCHK(hipMemcpyAsync(out_num_distinct + r0, st->out_nd.as<int32_t>() + r0, n * 4, hipMemcpyDeviceToHost, st->ds));
+        if (out_total_kmers) HIPCHK(hipMemcpyAsync(out_total_kmers + r0, st->out_tk.as<int32_t>() + r0, n * 4, hipMemcpyDeviceToHost, st->ds));
+      }
     }
     HIPCHK(hipStreamSynchronize(st->cs));  // (the caller's buffers are free from here on)
     if (call_timing) tp[1] = now();
@@ -1659,11 +1694,14 @@ static int32_t classify_batch_host(slk_index *ix, slk_stream *st, const ReadSour
   tp[2] = now();
   rc = check_status(st);  // (re-runs the batch through the unbounded path if a taxon map overflowed)
   if (rc) return rc;
-  rc = copy_out(st, out_taxon, st->out_taxon.p, (size_t)C * R * 4);
-  if (!rc) rc = copy_out(st, out_classified, st->out_cls.p, (size_t)C * R);
-  if (!rc && out_num_distinct) rc = copy_out(st, out_num_distinct, st->out_nd.p, R * 4);
-  if (!rc && out_total_kmers) rc = copy_out(st, out_total_kmers, st->out_tk.p, R * 4);
-  if (rc) return rc;
+  if (early_down) HIPCHK(hipStreamSynchronize(st->ds));
+  if (!early_down || st->reran) {   // (rows that came down early are stale if the batch was classified again)
+    rc = copy_out(st, out_taxon, st->out_taxon.p, (size_t)C * R * 4);
+    if (!rc) rc = copy_out(st, out_classified, st->out_cls.p, (size_t)C * R);
+    if (!rc && out_num_distinct) rc = copy_out(st, out_num_distinct, st->out_nd.p, R * 4);
+    if (!rc && out_total_kmers) rc = copy_out(st, out_total_kmers, st->out_tk.p, R * 4);
+    if (rc) return rc;
+  }
   if (call_timing) { (void)hipStreamSynchronize(st->s); tp[3] = now(); }
   if (out_hit_offsets) {
     rc = counts_to_offsets(st, st->out_nh.as<int32_t>(), R, out_hit_offsets, out_hits ? hits_capacity : ~0ULL);

@@ -522,6 +522,13 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
     while (true) {
       // ================= producer: fill the span buffer =================
       while (!done && nbuf <= SPAN_CAP - 66) {
+        // (wave-uniform state, said so: the compiler's analysis loses that through the state machine's merges and then runs the
+        //  machine as divergent control flow, with lane masks and register copies at every join)
+        phase = __builtin_amdgcn_readfirstlane(phase); nbuf = __builtin_amdgcn_readfirstlane(nbuf);
+        carry_run = __builtin_amdgcn_readfirstlane(carry_run);
+        i0 = __builtin_amdgcn_readfirstlane(i0); nwin = __builtin_amdgcn_readfirstlane(nwin);
+        staged = __builtin_amdgcn_readfirstlane(staged); blk = __builtin_amdgcn_readfirstlane(blk);
+        fast_n = __builtin_amdgcn_readfirstlane(fast_n); n = __builtin_amdgcn_readfirstlane(n);
         if (phase == PH_START) {
           if (mate == 0) { uint64_t o = A.offsets[r]; seq = A.bases + o; n = (uint32_t)(A.offsets[r + 1] - o); }
           else { uint64_t o = A.mate_offsets[r]; seq = A.mate_bases + o; n = (uint32_t)(A.mate_offsets[r + 1] - o); }
@@ -549,13 +556,16 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
             phase = PH_NEXT;  // an all-valid mate shorter than k yields nothing (Supermers.scala:116)
           }
         } else if (phase == PH_FAST) {
+         // rounds of STEP windows, one after the other while the span buffer has room (a loop of its own: the state machine around
+         // it is not consulted between two rounds of one stretch)
+         do {
           if (i0 >= nwin) {  // the segment's last super-mer
             if (lane == 0)
               put_span(L, nbuf, carry_val, carry_run, 1, seg_first ? (first || !have_last || carry_val != last_key) : true);
             nbuf += 1;
             first = false; have_last = true; last_key = carry_val;
             phase = runs_mode ? PH_RUNS : PH_NEXT;
-            continue;
+            break;
           }
           uint32_t need = min(n, i0 + 64 + P.m - 1);
           while (staged < need) { stage_block(G, seq, n, blk, lane); blk++; staged += 256; }
@@ -604,6 +614,7 @@ __global__ void FUSED_BOUNDS fused_kernel(FusedArgs A) {
           nbuf += emitted;
           carry_val = readlane64(res, lastl);
           carry_run = nw - lastl;
+         } while (nbuf <= SPAN_CAP - 66);
         } else if (phase == PH_RUNS) {
           if (rpos >= n) { phase = PH_NEXT; continue; }
           // the run that starts at rpos: its class and its end (512 characters per step, 8 per lane)

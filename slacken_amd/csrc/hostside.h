@@ -208,6 +208,7 @@ struct slk_index {
   uint64_t records = 0, dups = 0;
   uint64_t unplaced = 0;           // records of the last insert that found no cell within reach of the displacement field (capi.hip: insert_growing)
   uint32_t grown = 0;              // times the table was moved to a larger one because of that
+  float load_target = 0;           // the load factor the table was sized for (given, or chosen by the free memory: slk_index_create)
   hipStream_t build_stream = nullptr;
   DevBuf stage_keys, stage_taxa;
   Staging staging;    // host -> HBM copies of the build calls
@@ -265,6 +266,10 @@ struct slk_stream {
   hipStream_t cs = nullptr;
   Staging staging_c;
   std::vector<hipEvent_t> up_ev;
+  // ... and the results of sub-batch i come down on a third stream while sub-batch i + 1 runs (pinned result buffers only)
+  hipStream_t ds = nullptr;
+  std::vector<hipEvent_t> dn_ev;
+  bool reran = false;           // check_status classified queued calls again (a taxon map had overflowed): results on the host are stale
   bool timed = false;
   bool last_used_lane = false;  // the last classify call ran the lane kernel (defer_list[0] is its deferral count)
   // The arguments of every classify call queued since the stream was last synchronised, for the unbounded re-run

@@ -262,7 +262,7 @@ __device__ __forceinline__ uint64_t side_load(const ShardIO &S, uint64_t batch, 
 // LOOKUP job: 64 of the keys this rank received for an earlier batch, probed with probe_batch's access shape (LPB lanes per bucket,
 // all of the batch's loads in flight before the first compare); a key whose bucket is full, flagged and does not hold it goes on
 // alone (as in shard.hip's lookup_coop_kernel).  `key` was loaded a batch ago (side_load).
-__device__ __forceinline__ void side_probe(LaneLds *L, const TableView &T, const ShardIO &S, int lane, uint64_t batch, uint64_t key) {
+__device__ __forceinline__ void side_probe(LaneLds *L, const TableView &T, const ShardIO &S, int lane, uint64_t batch, uint64_t key, int dbg) {
   const uint64_t base = batch * 64;
   if (base >= S.side_n) return;
   const uint64_t i = base + (uint64_t)lane;
@@ -282,7 +282,11 @@ __device__ __forceinline__ void side_probe(LaneLds *L, const TableView &T, const
   const char *cellbase = (const char *)T.cells + c * 16;
   ulonglong2 cell[LPB];
 #pragma unroll
-  for (int s = 0; s < LPB; s++) cell[s] = SLK_PROBE_LOAD((const ulonglong2 *)(cellbase + ((uint64_t)((const uint4 *)L->stash)[s * PG + g].x << BUCKET_SHIFT)));
+  for (int s = 0; s < LPB; s++) {
+    uint32_t bkt = ((const uint4 *)L->stash)[s * PG + g].x;
+    SLK_TUNE(if (dbg & 4) bkt &= 1023u;)                                  // (timing experiment 4: every probe hits the L2)
+    cell[s] = SLK_PROBE_LOAD((const ulonglong2 *)(cellbase + ((uint64_t)bkt << BUCKET_SHIFT)));
+  }
   uint32_t unresolved = 0;
 #pragma unroll
   for (int s = 0; s < LPB; s++) {
@@ -318,7 +322,7 @@ __device__ __forceinline__ void side_probe(LaneLds *L, const TableView &T, const
       if (has_empty || closed) break;
     }
   }
-  if (in) SLK_STREAM_STORE(&S.side_out[i], ext_taxon(T, taxon));
+  if (in && !SLK_TUNE_ON(128)) SLK_STREAM_STORE(&S.side_out[i], ext_taxon(T, taxon));   // (128: timing experiment, the answers are not written)
   lane_wave_sync();
 }
 
@@ -388,7 +392,7 @@ __device__ __forceinline__ void apply_rows(LaneLds *L, const ApplyJob &J, int la
 // round trip and the lookups' share one wait.
 template <bool HITS>
 __device__ __forceinline__ void emit_batch(LaneLds *L, const FusedArgs &A, const ShardIO &S, const ApplyJob &J, int qhead, int cnt, int lane,
-                                           uint64_t row, uint64_t tile, uint32_t &ch_pos, uint32_t &ch_end, uint32_t &side_j, uint64_t &side_key) {
+                                           uint64_t row, uint64_t tile, uint32_t &ch_pos, uint32_t &ch_end, uint32_t &side_j, uint64_t &side_key, int dbg) {
   const bool in = lane < cnt;
   const int qi = (qhead + lane) & (QCAP - 1);
   const uint64_t key = L->q_key[qi];
@@ -412,7 +416,7 @@ __device__ __forceinline__ void emit_batch(LaneLds *L, const FusedArgs &A, const
     const uint64_t k_now = side_key;
     side_j++;
     if (side_j < S.side_per_tile) side_key = side_load(S, batch + 1, lane);   // (in flight while this batch is probed)
-    side_probe(L, A.T, S, lane, batch, k_now);
+    side_probe(L, A.T, S, lane, batch, k_now, dbg);
   }
   uint32_t fresh = 0xFFFFFFFFu;
   if (need) {
@@ -427,7 +431,7 @@ __device__ __forceinline__ void emit_batch(LaneLds *L, const FusedArgs &A, const
   const uint32_t gpos = (uint32_t)__shfl((int)pos, (int)g), groom = (uint32_t)__shfl((int)room, (int)g), gfresh = (uint32_t)__shfl((int)fresh, (int)g);
   if (in) {
     const bool tail = rank >= groom;                  // beyond what the old chunk had left: the fresh one
-    if (!tail || gfresh != 0xFFFFFFFFu) {
+    if ((!tail || gfresh != 0xFFFFFFFFu) && !SLK_TUNE_ON(32)) {   // (32: timing experiment, keys and metadata are not written)
       const uint64_t at = (uint64_t)g * S.cap + (tail ? gfresh + (rank - groom) : gpos + rank);
       SLK_STREAM_STORE(&S.send_keys[at], (int64_t)key);
       SLK_STREAM_STORE(&S.send_meta[at], meta);
@@ -1033,7 +1037,7 @@ __device__ __forceinline__ void lane_body(const FusedArgs &A, const ShardIO &S, 
         while (qn >= 64) {
           lane_wave_sync();
           int back = 0;
-          if (MODE == LANE_EMIT) emit_batch<HITS>(L, A, S, *Jp, qhead, 64, lane, row++, tile, ch_pos, ch_end, side_j, side_key);
+          if (MODE == LANE_EMIT) emit_batch<HITS>(L, A, S, *Jp, qhead, 64, lane, row++, tile, ch_pos, ch_end, side_j, side_key, dbg);
           else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS, LONG>(L, ocnt, A.T, qhead, qn, 64, lane, dbg, A.span_meta, A.span_taxon);
           qhead = (qhead + 64) & (QCAP - 1);
           qn += back - 64;
@@ -1044,7 +1048,7 @@ __device__ __forceinline__ void lane_body(const FusedArgs &A, const ShardIO &S, 
       lane_wave_sync();
       const int cnt = min(qn, 64);
       int back = 0;
-      if (MODE == LANE_EMIT) emit_batch<HITS>(L, A, S, *Jp, qhead, cnt, lane, row++, tile, ch_pos, ch_end, side_j, side_key);
+      if (MODE == LANE_EMIT) emit_batch<HITS>(L, A, S, *Jp, qhead, cnt, lane, row++, tile, ch_pos, ch_end, side_j, side_key, dbg);
       else if (!SLK_TUNE_ON(1)) back = probe_batch<HITS, LONG>(L, ocnt, A.T, qhead, qn, cnt, lane, dbg, A.span_meta, A.span_taxon);
       qhead = (qhead + cnt) & (QCAP - 1);
       qn += back - cnt;
@@ -1062,7 +1066,7 @@ __device__ __forceinline__ void lane_body(const FusedArgs &A, const ShardIO &S, 
         const uint64_t k_now = side_key;
         side_j++;
         if (side_j < S.side_per_tile) side_key = side_load(S, batch + 1, lane);
-        side_probe(L, A.T, S, lane, batch, k_now);
+        side_probe(L, A.T, S, lane, batch, k_now, dbg);
       }
     }
 
@@ -1166,7 +1170,12 @@ static void launch_step_mode(const FusedArgs &A, const ShardIO &S, const ApplyJo
   static const int bpc = getenv("SLK_STEP_BLOCKS_PER_CU") ? atoi(getenv("SLK_STEP_BLOCKS_PER_CU")) : 0;  // (tuning experiment)
   if (bpc > 0) nb = bpc;
   const uint64_t blocks = std::min<uint64_t>((tiles + LW - 1) / LW, (uint64_t)cus * nb);
-  hipLaunchKernelGGL((lane_step_kernel<W5, HITS>), dim3((unsigned)blocks), dim3(LW * 64), lds, s, A, S, J, defer, max_len, 0);
+#ifdef SLK_TUNING
+  static const int dbg = getenv("SLK_DEBUG_ABLATE") ? atoi(getenv("SLK_DEBUG_ABLATE")) : 0;  // timing experiments only (4, 32, 128: see side_probe / emit_batch)
+#else
+  const int dbg = 0;
+#endif
+  hipLaunchKernelGGL((lane_step_kernel<W5, HITS>), dim3((unsigned)blocks), dim3(LW * 64), lds, s, A, S, J, defer, max_len, dbg);
 }
 void launch_lane_step(const FusedArgs &A, const ShardIO &S, const ApplyJob &J, int32_t *defer, uint32_t max_len, hipStream_t s) {
   const bool hits = A.R ? A.span_taxon != nullptr : J.A.span_taxon != nullptr;

@@ -602,6 +602,10 @@ int32_t launch_step(Pipe &P, int t, const std::vector<std::vector<uint64_t>> &re
       if (received[rl][g]) {
         Big &bg = mb.big[rl % NBIG];
         lk.d_keys = bg.recv_keys.as<int64_t>(); lk.n = received[rl][g]; lk.d_out_taxa = bg.found.as<int32_t>();
+        if (W == 1) {   // a set of one: nothing travels -- the keys are answered where they were written, the answers land where the replay reads them
+          lk.d_keys = bg.send_keys.as<int64_t>();
+          lk.d_out_taxa = mb.slot[rl % NSLOT].taxa.as<int32_t>();
+        }
         lookup = &lk;
       }
     }
@@ -685,9 +689,12 @@ int32_t exchange_after_step(Pipe &P, int t, std::vector<std::vector<uint64_t>> &
       received[r][g] = lay.received[g];
     }
     set->cnt = sent[r];
-    int32_t rc = exchange(set, src, dst, sent[r], 8, ncclInt64, str, ev,
-                          [&](int a, int b) { return (uint64_t)b * set->m[a].slot[r % NSLOT].lists.capacity_per_owner; },
-                          [&](int b, int a) { return lay.roff[b][a]; });
+    int32_t rc = SLK_OK;
+    if (W > 1)
+      rc = exchange(set, src, dst, sent[r], 8, ncclInt64, str, ev,
+                    [&](int a, int b) { return (uint64_t)b * set->m[a].slot[r % NSLOT].lists.capacity_per_owner; },
+                    [&](int b, int a) { return lay.roff[b][a]; });
+    else { rc = use(set->m[0]); if (!rc) HIPCHK(hipStreamWaitEvent(str[0], ev[0], 0)); }
     if (rc) return rc;
     for (int g = 0; g < W; g++) {
       int32_t rc2 = use(set->m[g]);
@@ -704,8 +711,11 @@ int32_t exchange_after_step(Pipe &P, int t, std::vector<std::vector<uint64_t>> &
     std::vector<const void *> src(W);
     std::vector<void *> dst(W);
     for (int g = 0; g < W; g++) { src[g] = set->m[g].big[rb % NBIG].found.p; dst[g] = set->m[g].slot[rb % NSLOT].taxa.p; }
-    int32_t rc = exchange(set, src, dst, back, 4, ncclInt32, str, ev, [&](int b, int a) { return lay.roff[b][a]; },
-                          [&](int a, int b) { return (uint64_t)b * set->m[a].slot[rb % NSLOT].lists.capacity_per_owner; });
+    int32_t rc = SLK_OK;
+    if (W > 1)
+      rc = exchange(set, src, dst, back, 4, ncclInt32, str, ev, [&](int b, int a) { return lay.roff[b][a]; },
+                    [&](int a, int b) { return (uint64_t)b * set->m[a].slot[rb % NSLOT].lists.capacity_per_owner; });
+    else { rc = use(set->m[0]); if (!rc) HIPCHK(hipStreamWaitEvent(str[0], ev[0], 0)); }
     if (rc) return rc;
     for (int g = 0; g < W; g++) {
       int32_t rc2 = use(set->m[g]);

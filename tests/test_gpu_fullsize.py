@@ -128,8 +128,9 @@ def test_lane_and_wave_kernels_agree(big):
 
 
 def test_host_entry_at_its_default_subbatch_size(big):
-    """1.5 M reads through slk_classify_batch -- cut into sub-batches of 2^18 whose upload overlaps the kernels of the one before --
-    from pageable and from pinned caller buffers: the same answers as the device entry on the resident copy of the reads."""
+    """1.5 M reads through slk_classify_batch and slk_classify_batch_packed -- cut into sub-batches of 2^19 whose upload overlaps the
+    kernels of the one before and whose rows come down beside the next one's -- from pageable and from pinned caller buffers: the
+    same answers as the device entry on the resident copy of the reads."""
     from slacken_amd import capi
     R = min(big["R"], 1_500_000)
     host_b = big["bases"][:R * 150].cpu().numpy()
@@ -141,7 +142,10 @@ def test_host_entry_at_its_default_subbatch_size(big):
     out = dict(taxon=capi.pinned_array((2, R), np.int32), classified=capi.pinned_array((2, R), np.uint8),
                num_distinct=capi.pinned_array((R,), np.int32), total_kmers=capi.pinned_array((R,), np.int32))
     big["st"].classify_batch(pb, po, thresholds=(0.0, 0.1), with_hits=False, out=out)
-    for res in (got, out):
+    out2 = dict(taxon=capi.pinned_array((2, R), np.int32), classified=capi.pinned_array((2, R), np.uint8),
+                num_distinct=capi.pinned_array((R,), np.int32), total_kmers=capi.pinned_array((R,), np.int32))
+    big["st"].classify_batch(None, po, thresholds=(0.0, 0.1), with_hits=False, out=out2, packed=capi.pack_bases(host_b, pinned=True))
+    for res in (got, out, out2):
         assert np.array_equal(res["taxon"].reshape(-1), dev["taxon"].cpu().numpy())
         assert np.array_equal(res["classified"].reshape(-1), dev["cls"].cpu().numpy())
         assert np.array_equal(res["num_distinct"], dev["nd"].cpu().numpy())

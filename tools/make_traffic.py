@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/make_traffic.py <profile dir> <bench json of the same command> -> profiles/r03_traffic.json
+"""tools/make_traffic.py <profile dir> <bench json of the same command> -> profiles/r04_traffic.json
 HBM traffic of the dominant kernel from the FETCH_SIZE / WRITE_SIZE passes of tools/profile.sh (separate rocprofv3 --pmc runs,
 per-dispatch means), stamped with the hash of the kernel sources it was measured on: bench.py quotes it only on a match."""
 import csv
@@ -55,5 +55,5 @@ doc = {
     "genomes": [cfg["genomes"], cfg["genome_len"]],
 }
 doc["records"] = int(float(os.environ.get("SLK_BENCH_RECORDS", "1e10")))
-json.dump(doc, open(os.path.join(ROOT, "profiles", "r03_traffic.json"), "w"), indent=1)
+json.dump(doc, open(os.path.join(ROOT, "profiles", "r04_traffic.json"), "w"), indent=1)
 print(json.dumps(doc, indent=1))
