@@ -111,6 +111,65 @@ JNIEXPORT void JNICALL Java_com_jnpersson_slacken_gpu_Native_classifyBatch(
   if (rc != SLK_OK) throw_state(e);
 }
 
+/* Classifier.classify for one batch whose reads are PACKED -- 2-bit codes and validity bits, 16 bases per word, both in ONE direct
+ * buffer of slk_host_alloc memory: codes (4 bytes per 16 bases) from byte 0, validity (2 bytes per 16 bases) from byte
+ * validOffset -- so that 64 instead of 158 bytes per 150-base read cross the PCIe link (slk_classify_batch_packed: 643 against
+ * 327 M reads/s).  Reports-only shape: no hit lists.  packBases below fills such a buffer from text; a caller that copies its reads
+ * out of JVM strings anyway packs while it does (GpuClassifier.packInto). */
+JNIEXPORT void JNICALL Java_com_jnpersson_slacken_gpu_Native_classifyBatchPacked(
+    JNIEnv *e, jclass c, jlong h, jlong s, jobject packed, jlong validOffset, jlongArray offsets, jint R, jint minHitGroups,
+    jdoubleArray thresholds, jintArray outTaxon, jbyteArray outClassified, jintArray outNumDistinct, jintArray outTotalKmers,
+    jlongArray outHitOffsets) {
+  (void)c;
+  const uint8_t *buf = (const uint8_t *)(*e)->GetDirectBufferAddress(e, packed);
+  jsize C = (*e)->GetArrayLength(e, thresholds);
+  jdouble thr[16];
+  if (C > 16) C = 16;
+  (*e)->GetDoubleArrayRegion(e, thresholds, 0, C, thr);
+  jlong *o = (*e)->GetLongArrayElements(e, offsets, NULL);
+  jint *t = (*e)->GetIntArrayElements(e, outTaxon, NULL);
+  jbyte *cl = (*e)->GetByteArrayElements(e, outClassified, NULL);
+  jint *nd = (*e)->GetIntArrayElements(e, outNumDistinct, NULL);
+  jint *tk = (*e)->GetIntArrayElements(e, outTotalKmers, NULL);
+  jlong *ho = outHitOffsets ? (*e)->GetLongArrayElements(e, outHitOffsets, NULL) : NULL;   /* span counts only: a read without a span has no row */
+  int32_t rc = slk_classify_batch_packed(H(h), S(s), (const uint32_t *)buf, (const uint16_t *)(buf + validOffset), (const uint64_t *)o, NULL, NULL,
+                                         NULL, (uint64_t)R, minHitGroups, thr, C, (int32_t *)t, (uint8_t *)cl, (int32_t *)nd, (int32_t *)tk,
+                                         (uint64_t *)ho, NULL, 0);
+  if (ho) (*e)->ReleaseLongArrayElements(e, outHitOffsets, ho, 0);
+  (*e)->ReleaseIntArrayElements(e, outTotalKmers, tk, 0);
+  (*e)->ReleaseIntArrayElements(e, outNumDistinct, nd, 0);
+  (*e)->ReleaseByteArrayElements(e, outClassified, cl, 0);
+  (*e)->ReleaseIntArrayElements(e, outTaxon, t, 0);
+  (*e)->ReleaseLongArrayElements(e, offsets, o, JNI_ABORT);
+  if (rc != SLK_OK) throw_state(e);
+}
+
+/* slk_pack_bases: text (direct buffer) -> the packed form in another direct buffer (layout as above) */
+JNIEXPORT void JNICALL Java_com_jnpersson_slacken_gpu_Native_packBases(JNIEnv *e, jclass c, jobject text, jlong n, jobject packed, jlong validOffset) {
+  (void)c;
+  uint8_t *buf = (uint8_t *)(*e)->GetDirectBufferAddress(e, packed);
+  if (slk_pack_bases((const uint8_t *)(*e)->GetDirectBufferAddress(e, text), (uint64_t)n, (uint32_t *)buf, (uint16_t *)(buf + validOffset)) != SLK_OK)
+    throw_state(e);
+}
+
+/* slk_spans_batch: OrdinalSpan per fragment (KeyValueIndex.getSpans :163-173) -- here for the `distinct` flags of fragments whose title
+ * repeats (GpuClassifier.regroup).  outSpans: direct buffer of slk_span {long key; int kmers; byte flag; byte distinct; short pad} */
+JNIEXPORT void JNICALL Java_com_jnpersson_slacken_gpu_Native_spansBatch(JNIEnv *e, jclass c, jlong h, jlong s, jobject bases, jlongArray offsets,
+                                                                       jobject mateBases, jlongArray mateOffsets, jint R, jlongArray outSpanOffsets,
+                                                                       jobject outSpans, jlong capacity) {
+  (void)c;
+  jlong *o = (*e)->GetLongArrayElements(e, offsets, NULL);
+  jlong *mo = mateOffsets ? (*e)->GetLongArrayElements(e, mateOffsets, NULL) : NULL;
+  jlong *so = (*e)->GetLongArrayElements(e, outSpanOffsets, NULL);
+  int32_t rc = slk_spans_batch(H(h), S(s), (const uint8_t *)(*e)->GetDirectBufferAddress(e, bases), (const uint64_t *)o,
+                               mateBases ? (const uint8_t *)(*e)->GetDirectBufferAddress(e, mateBases) : NULL, (const uint64_t *)mo, (uint64_t)R,
+                               (uint64_t *)so, (slk_span *)(*e)->GetDirectBufferAddress(e, outSpans), (uint64_t)capacity);
+  (*e)->ReleaseLongArrayElements(e, outSpanOffsets, so, 0);
+  if (mo) (*e)->ReleaseLongArrayElements(e, mateOffsets, mo, JNI_ABORT);
+  (*e)->ReleaseLongArrayElements(e, offsets, o, JNI_ABORT);
+  if (rc != SLK_OK) throw_state(e);
+}
+
 /* slk_classify_hits: hit lists merged by the caller (fragments that share a title, Classifier.scala:92,136) */
 JNIEXPORT void JNICALL Java_com_jnpersson_slacken_gpu_Native_classifyHits(JNIEnv *e, jclass c, jlong h, jlong s, jint r, jlongArray hitOffsets,
                                                                           jobject hits, jbyteArray distinct, jint minHitGroups,

@@ -533,6 +533,29 @@ def test_cli_shard_table_gives_the_same_files(tmp_path):
     bad = subprocess.run([CLI, "classify2", "-i", loc, "-o", str(tmp_path / "x"), "--library", str(tmp_path), "--shard-table", str(fq)],
                          capture_output=True, text=True)
     assert bad.returncode != 0 and "--shard-table is for classify" in bad.stderr
+    # Batches that are all long reads (the send lists used to be sized from every base of a batch, long fragments
+    # included, against a hard limit of 2^25 entries per list -- a batch of 512 MB of long reads aborted; the regions are now sized
+    # below 2^32 entries and the long fragments emit nothing).  40 Mbp of 25-50 kbp reads among short ones, one big batch.
+    lf = tmp_path / "long.fq"
+    genome = "".join(s for _, s in reads)
+    with open(lf, "w") as f:
+        n = 0
+        while n < 40_000_000:
+            L = int(rng.integers(25_000, 50_000))
+            reps = -(-L // len(genome))
+            s = (genome * reps)[:L]
+            f.write(f"@L{n}\n{s}\n+\n{'I' * L}\n")
+            n += L
+        for t, s in reads[:50]:
+            f.write(f"@{t}.s\n{s}\n+\n{'I' * len(s)}\n")
+    outs = {}
+    for name, extra in (("rep", []), ("sh2", ["--devices", "0,0", "--shard-table"])):
+        out = tmp_path / f"long_{name}"
+        r = subprocess.run([CLI, "classify", "-i", loc, "-o", str(out), *extra, str(lf)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = out
+    a, b = (gzip.open(f"{outs[n]}_c0.0/sample=all/part-00000.txt.gz", "rb").read() for n in ("rep", "sh2"))
+    assert a == b and a.count(b"\n") > 800
 
 
 @pytest.mark.gpu
