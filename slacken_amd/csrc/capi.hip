@@ -1014,7 +1014,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
       st->last_used_lane = true;
       // Hot path: one lane per fragment.  What that kernel does not take -- fragments over 1000 bases, taxon maps that overflow --
       // it appends to the hand-on list of the kernel that does (engine.h: FusedArgs.hand_*): four length classes for its own long
-      // variant (1001 .. 4999 bases), the lane-per-segment kernel (unpaired, from 16 000 bases, w = 5), the
+      // variant (1001 .. 4999 bases), the lane-per-segment kernel (unpaired, from 250 000 bases, w = 5), the
       // wave-per-fragment kernel (the rest, and what the long variant hands on in turn).  The passes run behind it on this stream;
       // the segment pass, which depends on nothing but the first pass, on a second stream beside the other two.
       const size_t hdr_bytes = 16 * sizeof(uint64_t);
@@ -1024,14 +1024,15 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
       A.hand_lists = (uint32_t *)((char *)st->defer_list.p + hdr_bytes);
       A.hand_stride = R;
       // SLK_LANE_LONG_MAX moves the long variant's limit (at most 8191: queue entries carry 13-bit k-mer counts; 0: no such pass),
-      // SLK_SEG_MIN_LEN the segment kernel's (16 000: the wave kernel is the faster one up to there -- 104 against 90 Gbp/s at
-      // 5 kbp, level at 15-20 kbp, 79 against 92 at 100 kbp, 55 against 74 at 300 kbp, profiles/r03_long_routes.txt; it was 5 000
-      // until round 3, when both kernels were last measured side by side below 10 kbp; 0: wave kernel only).  Read per call, so
-      // that tests can move them.
+      // SLK_SEG_MIN_LEN the segment kernel's (250 000 since round 4's diet of the wave kernel, which is now the faster one up to
+      // there -- 115 against 101 Gbp/s at 15 kbp, 111 / 100 at 30 kbp, 91 / 92 at 100 kbp, 90 / 74 at 200 kbp, 70 / 75 at 300 kbp,
+      // profiles/r04_long_routes.txt: what is left to the segment kernel are batches of so few and so long fragments that a wave per
+      // fragment leaves the part idle at the end; it was 16 000 in round 3 and 5 000 before; 0: wave kernel only).  Read per call,
+      // so that tests can move them.
       const char *long_env = getenv("SLK_LANE_LONG_MAX");
       const int long_max = std::min(long_env ? atoi(long_env) : 4999, 8191);
       const char *seg_env = getenv("SLK_SEG_MIN_LEN");
-      const int seg_min = seg_env ? atoi(seg_env) : 16000;
+      const int seg_min = seg_env ? atoi(seg_env) : 250000;
       // (hit lists: the segment kernel can put them together -- SLK_SEG_HITS=1 --, but the queues that take its spans to memory
       //  in order cost it half its resident waves, and it measured 51-53 Gbp/s against the wave kernel's 68-79 on the same reads:
       //  profiles/r03_long_hits_*.json; so per-read lines of long reads keep the wave kernel unless asked otherwise)

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def segments_from_1001_bases(monkeypatch):
-    # the engine's default hands fragments of 16 000 bases and more to the segment kernel (those of 1001..4999 to the lane kernel's
+    # the engine's default hands fragments of 250 000 bases and more to the segment kernel (those of 1001..4999 to the lane kernel's
     # long variant, those in between to the wave kernel); here everything over 1000 goes to the segment kernel, which makes the segments short (64 windows) and the
     # borders many
     monkeypatch.setenv("SLK_SEG_MIN_LEN", "1001")
@@ -87,7 +87,7 @@ def check(orc, world, reads, thresholds=(0.0, 0.1, 0.5), min_hit_groups=2):
         assert bad.size == 0, (key, bad[:5].tolist(), [len(reads[i]) for i in bad[:5]],
                                np.atleast_2d(got[key])[:, bad[:5]].tolist(), np.atleast_2d(want[key])[:, bad[:5]].tolist())
     # the same batch with every handed-on fragment on the wave kernel, and with the engine's default routes (1001..4999 bases: the
-    # lane kernel's long variant, from 16 000: the segment kernel, the rest and map overflows: the wave kernel)
+    # lane kernel's long variant, from 250 000: the segment kernel, the rest and map overflows: the wave kernel)
     saved = {v: os.environ.get(v) for v in ("SLK_SEG_MIN_LEN", "SLK_LANE_LONG_MAX")}
     try:
         for name, env in (("wave kernel", dict(SLK_SEG_MIN_LEN="0", SLK_LANE_LONG_MAX="0")), ("default routes", {})):
@@ -206,7 +206,7 @@ def test_very_long_read(orc, world):
 
 
 def test_default_threshold_splits_the_work_between_the_two_kernels(orc, world, monkeypatch):
-    """Default threshold (16 000 bases): shorter long fragments, clean or with characters outside ACGTU (which the wave kernel takes
+    """Default threshold (250 000 bases): shorter long fragments, clean or with characters outside ACGTU (which the wave kernel takes
     run by run), stay on the wave kernel or the lane kernel's long variant, longer ones go to the segment kernel, short ones to the
     lane kernel -- one batch."""
     monkeypatch.delenv("SLK_SEG_MIN_LEN")
@@ -221,7 +221,7 @@ def test_default_threshold_splits_the_work_between_the_two_kernels(orc, world, m
     reads += synth.make_reads(world["lib"], 200, rng, vary_length=True)
     reads += [long_read(world["lib"], rng, int(rng.integers(5000, 16000))) for _ in range(12)]
     reads += [long_read(world["lib"], rng, int(rng.integers(16000, 40000))) for _ in range(12)]
-    reads += [long_read(world["lib"], rng, n) for n in (15999, 16000, 16001)]
+    reads += [long_read(world["lib"], rng, n) for n in (249999, 250000, 250001, 400000)]
     bases, offsets = synth.pack(reads)
     got = world["st"].classify_batch(bases, offsets, thresholds=(0.0, 0.2), with_hits=False, with_num_hits=True)
     want = orc.classify_batch(world["p"], world["oix"], world["parents"], bases, offsets, None, None, min_hit_groups=2,

@@ -105,6 +105,12 @@ def test_cli_paired_samples_and_flags(tmp_path):
     classify("-i", loc, "-o", out3, "-p", "--nodetailed", f1, f2)
     assert not glob.glob(f"{out3}_c0.0/sample=*")
     assert open(f"{out3}_c0.0/all_kreport.txt").read() == open(f"{out}_c0.0/all_kreport.txt").read()
+    # SLK_CLI_PACKED=1: the reports-only calls send the reads at 3 bits per base (slk_classify_batch_packed, pairs too): same report
+    out3p = tmp_path / "paired3_packed"
+    r = subprocess.run([CLI, "classify", "-i", loc, "-o", str(out3p), "-p", "--nodetailed", str(f1), str(f2)], capture_output=True, text=True,
+                       env=dict(os.environ, SLK_CLI_PACKED="1"))
+    assert r.returncode == 0, r.stderr
+    assert open(f"{out3p}_c0.0/all_kreport.txt").read() == open(f"{out}_c0.0/all_kreport.txt").read()
     # --sample-regex: group 1 of the first match is the sample id (Classifier.scala:138-142); unmatched -> "other"
     out4 = tmp_path / "multi"
     classify("-i", loc, "-o", out4, "--sample-regex", r"sra\.(\d)", "-p", f1, f2)
