@@ -1014,25 +1014,37 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
       st->last_used_lane = true;
       // Hot path: one lane per fragment.  What that kernel does not take -- fragments over 1000 bases, taxon maps that overflow --
       // it appends to the hand-on list of the kernel that does (engine.h: FusedArgs.hand_*): four length classes for its own long
-      // variant (1001 .. 4999 bases), the lane-per-segment kernel (unpaired, from 250 000 bases, w = 5), the
-      // wave-per-fragment kernel (the rest, and what the long variant hands on in turn).  The passes run behind it on this stream;
-      // the segment pass, which depends on nothing but the first pass, on a second stream beside the other two.
-      const size_t hdr_bytes = 16 * sizeof(uint64_t);
-      HIPCHK(st->defer_list.ensure(hdr_bytes + 6 * (size_t)R * sizeof(uint32_t)));
+      // variant (1001 .. 4999 bases), the lane-per-segment kernel (unpaired, w = 5, the fragments that are long for their batch), the
+      // wave-per-fragment kernel (the rest, and what the long variant hands on in turn).
+      const size_t hdr_bytes = HandOn::WORDS * sizeof(uint64_t);
+      const uint64_t long_cap = std::min<uint64_t>(R, (total_bases + total_mate_bases) / 1001 + 1);
+      // SLK_LANE_LONG_MAX moves the long variant's limit (at most 8191: queue entries carry 13-bit k-mer counts; 0: no such pass)
+      const char *long_env = getenv("SLK_LANE_LONG_MAX");
+      const int long_max = std::min(long_env ? atoi(long_env) : 4999, 8191);
+      // A batch whose fragments average more than 1000 bases gets a routing kernel instead of a first pass (engine.h:
+      // FusedArgs.hand_short; SLK_ROUTE_FIRST=0 / 1 says so either way)
+      const char *route_env = getenv("SLK_ROUTE_FIRST");
+      const bool route_first = long_max > 1000 && (route_env ? route_env[0] == '1' : (total_bases + total_mate_bases) / 1000 > R);
+      HIPCHK(st->defer_list.ensure(hdr_bytes + HandOn::entries(R, long_cap, route_first) * sizeof(uint32_t)));
       HIPCHK(hipMemsetAsync(st->defer_list.p, 0, hdr_bytes, st->s));
       A.hand_hdr = (unsigned long long *)st->defer_list.p;
       A.hand_lists = (uint32_t *)((char *)st->defer_list.p + hdr_bytes);
       A.hand_stride = R;
-      // SLK_LANE_LONG_MAX moves the long variant's limit (at most 8191: queue entries carry 13-bit k-mer counts; 0: no such pass),
-      // SLK_SEG_MIN_LEN the segment kernel's (250 000 since round 4's diet of the wave kernel, which is now the faster one up to
-      // there -- 115 against 101 Gbp/s at 15 kbp, 111 / 100 at 30 kbp, 91 / 92 at 100 kbp, 90 / 74 at 200 kbp, 70 / 75 at 300 kbp,
-      // profiles/r04_long_routes.txt: what is left to the segment kernel are batches of so few and so long fragments that a wave per
-      // fragment leaves the part idle at the end; it was 16 000 in round 3 and 5 000 before; 0: wave kernel only).  Read per call,
-      // so that tests can move them.
-      const char *long_env = getenv("SLK_LANE_LONG_MAX");
-      const int long_max = std::min(long_env ? atoi(long_env) : 4999, 8191);
+      A.hand_long_cap = long_cap;
+      A.route_first = route_first ? 1 : 0;
+      // SLK_SEG_MIN_LEN moves the segment kernel's limit (0: wave kernel only).  Read per call, like the others, so that tests can
+      // move them.
+      // Wave or segment kernel: on batches of ONE length the wave kernel is the faster one up to ~250 000 bases since round 4's diet
+      // (115 against 101 Gbp/s at 15 kbp, 111 / 100 at 30 kbp, 91 / 92 at 100 kbp, 90 / 74 at 200 kbp, 70 / 75 at 300 kbp,
+      // profiles/r04_long_routes.txt) -- but it takes a fragment per wave at ~15 Mbp/s, so a fragment that is long for its batch is
+      // what the batch then waits for.  So the default follows the batch: the segment kernel takes what a single wave would need
+      // about half the batch's time for -- fragments of more than 1/16384 of the batch's bases --, never under 16 000 bases (below
+      // that its lanes have too little each) and always from 250 000; and the wave kernel starts its long fragments longest first
+      // (engine.h: hand_hdr).  Nanopore-like mix, 200 .. 50 000 bases, 1 Gbp: 90-94 Gbp/s with the threshold at 12-16 000, 93-99 at
+      // 30 000, 97-101 at 64 000 (none on the segment kernel).
       const char *seg_env = getenv("SLK_SEG_MIN_LEN");
-      const int seg_min = seg_env ? atoi(seg_env) : 250000;
+      const uint64_t seg_auto = std::min<uint64_t>(250000, std::max<uint64_t>(16000, (total_bases + total_mate_bases) >> 14));
+      const int seg_min = seg_env ? atoi(seg_env) : (int)seg_auto;
       // (hit lists: the segment kernel can put them together -- SLK_SEG_HITS=1 --, but the queues that take its spans to memory
       //  in order cost it half its resident waves, and it measured 51-53 Gbp/s against the wave kernel's 68-79 on the same reads:
       //  profiles/r03_long_hits_*.json; so per-read lines of long reads keep the wave kernel unless asked otherwise)
@@ -1045,25 +1057,44 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
         for (int i = 0; i < 3; i++) A.long_bound[i] = (uint32_t)(1000.0 * pow(ratio, i + 1));
       }
       A.seg_min_len = seg_on ? (uint32_t)std::max(seg_min, (int)std::max<uint32_t>(A.long_max, 1000) + 1) : 0;
-      launch_lane(A, nullptr, 1000, st->s);  // (the one-word map entries carry 10-bit k-mer counts)
+      A.wave_min = std::max<uint32_t>(A.long_max, 1000) + 1;   // (the wave kernel's eight length classes: 1.75^7 = 50 times the shortest)
+      A.wave_ratio_q10 = 1792;
+      if (route_first) launch_route(A, st->s);
+      else launch_lane(A, nullptr, 1000, st->s);  // (the one-word map entries carry 10-bit k-mer counts)
+      // The passes over the hand-on lists depend on the first pass only, and the long variant runs BESIDE the other two (which
+      // follow each other on a second stream): with a few hundred thousand long fragments in a batch the long variant is a handful
+      // of waves per CU working through 5 000 lockstep steps, the segment pass not much more, and the wave kernel behind them on one
+      // stream waited for both (nanopore-like mix: 1.1 + 4.9 + 5.8 ms one after the other, 77-84 Gbp/s; 95-101 this way;
+      // profiles/r04_long_mixed_trace.txt).  Segment pass before wave pass: the wave kernel is bound by instruction issue and holds
+      // every wave slot until it is through, the other two are chains of dependent steps that share a CU well.  What the long
+      // variant hands on in turn (map overflows) goes to a list of its own that a second launch of the wave kernel takes when
+      // both streams are through.
+      if (!st->s2) {
+        HIPCHK(hipStreamCreateWithFlags(&st->s2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming));
+      }
+      HIPCHK(hipEventRecord(st->ev_fork, st->s));
+      if (A.long_max) launch_lane_long(A, A.long_max, st->s);   // (first: its chain of steps is the longest, whoever comes first gets the CUs)
+      HIPCHK(hipStreamWaitEvent(st->s2, st->ev_fork, 0));
       if (seg_on) {
-        if (!st->s2) {
-          HIPCHK(hipStreamCreateWithFlags(&st->s2, hipStreamNonBlocking));
-          HIPCHK(hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming));
-          HIPCHK(hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming));
-        }
-        HIPCHK(hipEventRecord(st->ev_fork, st->s));
-        HIPCHK(hipStreamWaitEvent(st->s2, st->ev_fork, 0));
         FusedArgs B = A;
         if (want_hits) B.span_keys = st->span_keys.as<uint64_t>();   // (scratch of the hit lists: the spans' places before the borders are settled)
-        B.work_list = A.hand_lists + 4 * A.hand_stride; B.work_count = A.hand_hdr + 4; B.work_draw = A.hand_hdr + 7;
+        B.work_list = A.hand_lists + HandOn::list_at(HandOn::SEG, R, long_cap); B.work_count = A.hand_hdr + HandOn::SEG; B.work_draw = A.hand_hdr + HandOn::SEG_DRAW;
         launch_segments(B, st->s2);
-        HIPCHK(hipEventRecord(st->ev_join, st->s2));
       }
-      if (A.long_max) launch_lane_long(A, A.long_max, st->s);
-      A.work_list = A.hand_lists + 5 * A.hand_stride; A.work_count = A.hand_hdr + 5; A.work_draw = A.hand_hdr + 8;
-      launch_fused(want_hits ? MODE_HITS : MODE_CLASSIFY, A, st->s);
-      if (seg_on) HIPCHK(hipStreamWaitEvent(st->s, st->ev_join, 0));
+      {
+        FusedArgs W = A;
+        launch_order_wave_list(W, st->s2);
+        W.work_list = A.hand_lists + HandOn::ordered_at(R, long_cap); W.work_count = A.hand_hdr + HandOn::ORDERED; W.work_draw = A.hand_hdr + HandOn::WAVE_DRAW;
+        launch_fused(want_hits ? MODE_HITS : MODE_CLASSIFY, W, st->s2);
+      }
+      HIPCHK(hipEventRecord(st->ev_join, st->s2));
+      HIPCHK(hipStreamWaitEvent(st->s, st->ev_join, 0));
+      if (A.long_max) {
+        A.work_list = A.hand_lists + HandOn::list_at(HandOn::LATE, R, long_cap); A.work_count = A.hand_hdr + HandOn::N_LATE; A.work_draw = A.hand_hdr + HandOn::LATE_DRAW;
+        launch_fused(want_hits ? MODE_HITS : MODE_CLASSIFY, A, st->s);
+      }
     } else {
       launch_fused(want_hits ? MODE_HITS : MODE_CLASSIFY, A, st->s);
     }
@@ -1386,7 +1417,7 @@ int32_t slk_stream_last_deferred(slk_stream *st, uint64_t *out_count) {
   *out_count = 0;
   HIPCHK(hipStreamSynchronize(st->s));
   if (st->defer_list.p && st->last_used_lane)   // (word 9 of the hand-on header: what the first pass handed on)
-    HIPCHK(hipMemcpy(out_count, (const uint64_t *)st->defer_list.p + 9, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_count, (const uint64_t *)st->defer_list.p + HandOn::HANDED, sizeof(uint64_t), hipMemcpyDeviceToHost));
   return SLK_OK;
 }
 

@@ -192,6 +192,31 @@ __host__ __device__ __forceinline__ bool shard_keeps(const TableBuild &t, uint64
 constexpr int MAX_THRESHOLDS = 16;
 struct Thresholds { double v[MAX_THRESHOLDS]; };
 
+// Layout of the hand-on lists and their header (FusedArgs.hand_*)
+struct HandOn {
+  enum { SEG = 4, REST = 5, WAVE0 = 6, WAVE_CLASSES = 8, LATE = WAVE0 + WAVE_CLASSES, SHORT = LATE + 1, LISTS = SHORT + 1 };
+  // header words: [l] = entries of list l for l < 6, then
+  enum { LONG_DRAW = 6, SEG_DRAW = 7, WAVE_DRAW = 8,  // tile / unit draws of the long, segment and wave pass
+         HANDED = 9,                                  // fragments handed on by the first pass (or: routed to another list than 15)
+         ORDERED = 10,                                // entries of the wave pass's list as launch_order_wave_list put it together
+         N_LATE = 11, LATE_DRAW = 12, N_SHORT = 13, N_WAVE0 = 16, WORDS = 32 };
+  static __host__ __device__ __forceinline__ int count_word(int l) {
+    return l < WAVE0 ? l : l < LATE ? N_WAVE0 + (l - WAVE0) : l == LATE ? N_LATE : N_SHORT;
+  }
+  // where list l starts (entries from hand_lists); lists 0..5 and SHORT hold up to `stride` entries, the others `long_cap`
+  static __host__ __device__ __forceinline__ uint64_t list_at(int l, uint64_t stride, uint64_t long_cap) {
+    return l < WAVE0 ? (uint64_t)l * stride : l < LATE ? WAVE0 * stride + (uint64_t)(l - WAVE0) * long_cap
+           : l == LATE ? (WAVE0 + 1) * stride + WAVE_CLASSES * long_cap : (WAVE0 + 1) * stride + (WAVE_CLASSES + 1) * long_cap;
+  }
+  static __host__ __device__ __forceinline__ uint64_t ordered_at(uint64_t stride, uint64_t long_cap) {   // (`stride` entries)
+    return WAVE0 * stride + WAVE_CLASSES * long_cap;
+  }
+  static __host__ __device__ __forceinline__ uint64_t entries(uint64_t stride, uint64_t long_cap, bool with_short) {
+    return (WAVE0 + 1 + (with_short ? 1 : 0)) * stride + (WAVE_CLASSES + 1) * long_cap;
+  }
+};
+
+
 // arguments of the fused wave-per-read kernels (fused.hip)
 struct FusedArgs {
   ScanParams P;
@@ -218,13 +243,24 @@ struct FusedArgs {
   int32_t *span_taxon;   // MODE_HITS output
   int32_t *span_count;   // MODE_SPANS / MODE_HITS output
   int32_t *status;       // device error bits: 1 = taxon map overflow
-  // Hand-on lists.  The lane kernel's first pass sorts the fragments it does not take by the kernel that will: lists 0..3 = the
-  // four length classes of its own long variant (tiles of similar length: the 64 lanes of a wave run in lockstep), 4 = the
-  // lane-per-segment kernel, 5 = the wave kernel (also what the long variant hands on in turn).  uint32 fragment indices.
-  unsigned long long *hand_hdr;          // 16 words: [l] = entries of list l; [6] tile draw of the long pass, [7] / [8] unit draws of
-                                         // the segment / wave pass; [9] = fragments handed on by the first pass
-  uint32_t *hand_lists;                  // [6][hand_stride]
-  uint64_t hand_stride;
+  // Hand-on lists (uint32 fragment indices; HandOn below is their layout).  The lane kernel's first pass sorts the fragments it does
+  // not take by the kernel that will: lists 0..3 = the four length classes of its own long variant (tiles of similar length: the 64
+  // lanes of a wave run in lockstep), 4 = the lane-per-segment kernel, 5 = the wave kernel's short ones (map overflows), 6..13 = the
+  // wave kernel's long fragments in eight length classes, longest first: that kernel takes a fragment per wave, so a long fragment
+  // started late is what the whole pass then waits for, and it walks 6, 7, .., 13, 5 -- longest first, whatever the order of the
+  // batch.  (A small kernel strings the lists together before the pass, launch_order_wave_list: the wave kernel itself, tuned to
+  // its registers, walks one list as before -- drawing from four inside it cost it a tenth of its rate.)  14 = what the long
+  // variant hands on in turn (map overflows; a second launch of the wave kernel takes them).
+  // A batch of mostly long fragments has no first pass: its few short fragments, spread over all the tiles, would keep every tile
+  // going for up to 1000 steps with a tenth of its lanes (1.1 of the 10.3 ms of a nanopore-like batch).  A routing kernel fills the
+  // lists instead (launch_route), the fragments of at most 1000 bases go to list 15, and the long variant takes them as a fifth
+  // class, the last to start.
+  unsigned long long *hand_hdr;          // HandOn::WORDS words
+  uint32_t *hand_lists;
+  uint64_t hand_stride;                  // entries of a list that may hold every fragment (= R)
+  uint64_t hand_long_cap;                // entries of a list of fragments over 1000 bases (a batch holds at most total bases / 1001)
+  uint32_t route_first;                  // 1: the routing kernel stands for the first pass (list 15 exists)
+  uint32_t wave_min, wave_ratio_q10;     // wave classes: 13 = up to wave_min * ratio, 12 = up to wave_min * ratio^2, ...
   uint32_t long_max;                     // the long variant takes fragments of up to this many bases (0: there is no such pass)
   uint32_t long_bound[3];                // borders of its length classes
   uint32_t seg_min_len;                  // unpaired fragments of at least this many bases belong to the lane-per-segment kernel
@@ -295,11 +331,15 @@ void launch_remap_cells(uint64_t *cells, uint64_t ncells, int32_t taxon_bits, co
 
 enum { MODE_SPANS = 0, MODE_CLASSIFY = 1, MODE_HITS = 2 };
 void launch_fused(int mode, const FusedArgs &A, hipStream_t s);
+// strings the wave pass's hand-on lists together, long fragments first (FusedArgs.hand_hdr); behind the passes that fill them
+void launch_order_wave_list(const FusedArgs &A, hipStream_t s);
 // list[0 .. *count) = the indices r < R with flags[r] != 0 (in no particular order); *count must be zero beforehand
 void launch_segments(const FusedArgs &A, hipStream_t s);
 // lane-per-fragment classify kernel (lane.hip); fragments it cannot take are flagged in defer[] for launch_fused
 void launch_lane(const FusedArgs &A, int32_t *defer, uint32_t max_len, hipStream_t s);
 void launch_lane_long(const FusedArgs &A, uint32_t max_len, hipStream_t s);
+// instead of a first pass (FusedArgs.route_first): every fragment goes to the hand-on list of the kernel that takes it
+void launch_route(const FusedArgs &A, hipStream_t s);
 
 // launchers (kernels.hip)
 void launch_table_insert(const TableBuild &t, const int64_t *keys, const int32_t *taxa, uint64_t n, hipStream_t s);

@@ -255,7 +255,7 @@ struct slk_stream {
   DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items, defer_list;
   DevBuf pk_codes, pk_valid, pk_mate_codes, pk_mate_valid;   // slk_classify_batch_packed: the reads as they arrive (3 bits per base)
   hipEvent_t ev_unpack = nullptr;
-  hipStream_t s2 = nullptr;                 // the segment pass runs here, beside the long-lane and wave passes on s
+  hipStream_t s2 = nullptr;                 // the segment pass and the wave pass run here, beside the long-lane pass on s
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int32_t *d_status = nullptr;     // device error bits of the fused kernels
   int32_t *h_status = nullptr;     // pinned copy, refreshed after every classify launch

@@ -608,6 +608,32 @@ __global__ void __launch_bounds__(256) unpack_bases_kernel(const uint32_t *__res
     *(uint4 *)(out + w * 16) = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }
+// The wave pass's work list: the hand-on lists of its long fragments, longest class first, then list 5, one behind the other
+// (engine.h: FusedArgs.hand_hdr).  A few hundred thousand entries at most; the counts are only known on the device.
+__global__ void order_wave_list_kernel(unsigned long long *hdr, uint32_t *lists, uint64_t stride, uint64_t long_cap) {
+  uint64_t start[HandOn::WAVE_CLASSES + 2];   // of list WAVE0 + j (j = WAVE_CLASSES: list REST) in the output
+  start[0] = 0;
+#pragma unroll
+  for (int j = 0; j < HandOn::WAVE_CLASSES; j++) start[j + 1] = start[j] + hdr[HandOn::N_WAVE0 + j];
+  start[HandOn::WAVE_CLASSES + 1] = start[HandOn::WAVE_CLASSES] + hdr[HandOn::REST];
+  const uint64_t n = start[HandOn::WAVE_CLASSES + 1];
+  uint32_t *const out = lists + HandOn::ordered_at(stride, long_cap);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q <= HandOn::WAVE_CLASSES; q++) j += i >= start[q];
+    const uint64_t from = HandOn::list_at(j < HandOn::WAVE_CLASSES ? HandOn::WAVE0 + j : (int)HandOn::REST, stride, long_cap);
+    uint64_t st = 0;
+#pragma unroll
+    for (int q = 0; q <= HandOn::WAVE_CLASSES; q++) if (q == j) st = start[q];
+    out[i] = lists[from + (i - st)];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) hdr[HandOn::ORDERED] = n;
+}
+void launch_order_wave_list(const FusedArgs &A, hipStream_t s) {
+  order_wave_list_kernel<<<256, 256, 0, s>>>(A.hand_hdr, A.hand_lists, A.hand_stride, A.hand_long_cap);
+}
+
 void launch_unpack_bases(const uint32_t *codes, const uint16_t *valid, uint64_t w0, uint64_t w1, uint8_t *out, hipStream_t s) {
   if (w1 <= w0) return;
   const uint64_t blocks = std::min<uint64_t>((w1 - w0 + 255) / 256, 256 * 32);

@@ -534,28 +534,85 @@ __device__ __forceinline__ uint2 packed_take(const uint32_t *pcodes, const uint1
 
 // A wave of the first pass (or of the long variant) hands fragments on: straight into the hand-on list of the kernel that takes such
 // a fragment (the order inside a list does not matter); one atomic per wave and list that gets something.
-__device__ __attribute__((noinline)) void hand_on(unsigned long long *hdr, uint32_t *lists, uint64_t stride, uint32_t long_max, uint32_t b0,
-                                                  uint32_t b1, uint32_t b2, uint32_t seg_min_len, const uint64_t *offsets,
-                                                  const uint64_t *mate_offsets, bool dfr, bool too_long, uint64_t r, int lane, bool from_long) {
+// hand-on list of a fragment the first pass does not take for its length (engine.h: FusedArgs.hand_hdr)
+__device__ __forceinline__ int route_by_length(uint64_t len, uint32_t long_max, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t seg_min_len,
+                                               uint32_t wave_min, uint32_t wave_ratio_q10) {
+  if (long_max != 0 && len <= long_max) return (len > b0) + (len > b1) + (len > b2);
+  if (seg_min_len != 0 && len >= seg_min_len) return HandOn::SEG;
+  int c = HandOn::WAVE_CLASSES - 1;                         // the wave kernel's long fragments, by length: a geometric ladder
+  for (uint64_t b = ((uint64_t)wave_min * wave_ratio_q10) >> 10; c > 0 && len >= b; b = (b * wave_ratio_q10) >> 10) c--;
+  return HandOn::WAVE0 + c;
+}
+__device__ __attribute__((noinline)) void hand_on(unsigned long long *hdr, uint32_t *lists, uint64_t stride, uint64_t long_cap, uint32_t long_max,
+                                                  uint32_t b0, uint32_t b1, uint32_t b2, uint32_t seg_min_len, uint32_t wave_min,
+                                                  uint32_t wave_ratio_q10, const uint64_t *offsets, const uint64_t *mate_offsets, bool dfr,
+                                                  bool too_long, uint64_t r, int lane, bool from_long) {
   const uint64_t DM = __ballot(dfr);
-  int route = 5;                                            // map overflow (of either pass): the wave kernel
+  int route = from_long ? HandOn::LATE : HandOn::REST;      // map overflow (of the long variant | of the first pass): the wave kernel
   if (!from_long && dfr && too_long) {
     uint64_t len = offsets[r + 1] - offsets[r];
     if (mate_offsets) len += mate_offsets[r + 1] - mate_offsets[r];
-    if (long_max != 0 && len <= long_max) route = (len > b0) + (len > b1) + (len > b2);
-    else if (seg_min_len != 0 && len >= seg_min_len) route = 4;
+    route = route_by_length(len, long_max, b0, b1, b2, seg_min_len, wave_min, wave_ratio_q10);
   }
-  if (!from_long && lane == 0) atomicAdd(&hdr[9], (unsigned long long)__popcll(DM));
-  for (int l = from_long ? 5 : 0; l < 6; l++) {
+  if (!from_long && lane == 0) atomicAdd(&hdr[HandOn::HANDED], (unsigned long long)__popcll(DM));
+  for (int l = from_long ? HandOn::LATE : 0; l <= HandOn::LATE; l++) {
     const uint64_t M = __ballot(dfr && route == l);
     if (M == 0) continue;
     const int leader = __ffsll((long long)M) - 1;
     unsigned long long at = 0;
-    if (lane == leader) at = atomicAdd(&hdr[l], (unsigned long long)__popcll(M));
+    if (lane == leader) at = atomicAdd(&hdr[HandOn::count_word(l)], (unsigned long long)__popcll(M));
     at = lane_readlane64(at, leader);
     if (dfr && route == l)
-      lists[(uint64_t)l * stride + at + __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0))] = (uint32_t)r;
+      lists[HandOn::list_at(l, stride, long_cap) + at + __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0))] = (uint32_t)r;
   }
+}
+
+// The routing kernel (engine.h: FusedArgs.route_first): what a first pass does with the fragments it does not take, for all of
+// them.  A block sorts 2048 fragments at a time: places inside the block from LDS counters, one atomic per list and block on the
+// header (a wave at a time, like hand_on, the 3 500 waves of a 224 k-fragment batch queued up at eight addresses for 0.26 ms).
+__global__ void __launch_bounds__(256) route_kernel(FusedArgs A) {
+  constexpr int PER = 8, NL = HandOn::LISTS;
+  __shared__ uint32_t cnt[NL];
+  __shared__ unsigned long long base[NL];
+  const uint64_t chunk = 256 * PER, chunks = (A.R + chunk - 1) / chunk;
+  for (uint64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+    if (threadIdx.x < NL) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    int route[PER];
+    uint32_t rank[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      const uint64_t r = c * chunk + (uint64_t)j * 256 + threadIdx.x;
+      route[j] = -1;
+      rank[j] = 0;
+      if (r < A.R) {
+        uint64_t len = A.offsets[r + 1] - A.offsets[r];
+        if (A.mate_offsets) len += A.mate_offsets[r + 1] - A.mate_offsets[r];
+        route[j] = len <= 1000 ? (int)HandOn::SHORT : route_by_length(len, A.long_max, A.long_bound[0], A.long_bound[1], A.long_bound[2],
+                                                                      A.seg_min_len, A.wave_min, A.wave_ratio_q10);
+        rank[j] = atomicAdd(&cnt[route[j]], 1u);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < NL && cnt[threadIdx.x] != 0)
+      base[threadIdx.x] = atomicAdd(&A.hand_hdr[HandOn::count_word((int)threadIdx.x)], (unsigned long long)cnt[threadIdx.x]);
+    if (threadIdx.x == 0) {
+      uint32_t handed = 0;
+      for (int l = 0; l < NL; l++) if (l != HandOn::SHORT) handed += cnt[l];
+      if (handed) atomicAdd(&A.hand_hdr[HandOn::HANDED], (unsigned long long)handed);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; j++)
+      if (route[j] >= 0)
+        A.hand_lists[HandOn::list_at(route[j], A.hand_stride, A.hand_long_cap) + base[route[j]] + rank[j]] =
+            (uint32_t)(c * chunk + (uint64_t)j * 256 + threadIdx.x);
+    __syncthreads();
+  }
+}
+void launch_route(const FusedArgs &A, hipStream_t s) {
+  if (A.R == 0) return;
+  hipLaunchKernelGGL(route_kernel, dim3((unsigned)std::min<uint64_t>((A.R + 2047) / 2048, 2048)), dim3(256), 0, s, A);
 }
 
 // Per-read classification, one lane per read: the map the probe batches (or the APPLY job's replay) folded for the lane's fragment
@@ -703,13 +760,18 @@ __device__ __forceinline__ void lane_body(const FusedArgs &A, const ShardIO &S, 
   const bool paired = A.mate_bases != nullptr;
   const bool scans = MODE != LANE_EMIT || A.R != 0;   // (a step may carry side jobs only)
   const uint64_t bases_end = scans ? A.offsets[A.R] : 0, mates_end = (scans && paired) ? A.mate_offsets[A.R] : 0;  // (wave-uniform loads)
-  // LONG: tiles of the four class lists one after the other (a tile never mixes classes); the first pass has finished (same stream)
-  uint64_t cls_n[4] = {0, 0, 0, 0}, cls_tiles[4] = {0, 0, 0, 0};
+  // LONG: tiles of the four class lists one after the other (a tile never mixes classes; class 0 here: list 15, the fragments
+  // of at most 1000 bases of a batch without a first pass); the first pass / the routing kernel has finished (same stream)
+  uint64_t cls_n[5] = {0, 0, 0, 0, 0}, cls_tiles[5] = {0, 0, 0, 0, 0};
   uint64_t ntiles = (A.R + 63) / 64;
   if (LONG) {
     ntiles = 0;
 #pragma unroll
-    for (int c = 0; c < 4; c++) { cls_n[c] = A.hand_hdr[c]; cls_tiles[c] = (cls_n[c] + 63) / 64; ntiles += cls_tiles[c]; }
+    for (int c = 0; c < 5; c++) {
+      cls_n[c] = c == 0 ? (A.route_first ? A.hand_hdr[HandOn::N_SHORT] : 0ULL) : A.hand_hdr[c - 1];
+      cls_tiles[c] = (cls_n[c] + 63) / 64;
+      ntiles += cls_tiles[c];
+    }
   }
   const uint64_t nwaves = (uint64_t)gridDim.x * LW;
   // EMIT: tiles of the scan and tiles of the APPLY job (an earlier batch: its tile t rides with the scan's tile t; whichever batch
@@ -731,7 +793,7 @@ __device__ __forceinline__ void lane_body(const FusedArgs &A, const ShardIO &S, 
       // (A wave's first tile is the one of its own number: fewer tiles than waves -- usually none -- cost no atomics.)
       if (it) {
         unsigned long long t = 0;
-        if (lane == 0) t = atomicAdd(&A.hand_hdr[6], 1ULL);
+        if (lane == 0) t = atomicAdd(&A.hand_hdr[HandOn::LONG_DRAW], 1ULL);
         tile = nwaves + lane_readlane64(t, 0);
       }
     } else if (MODE == LANE_EMIT) {
@@ -750,12 +812,13 @@ __device__ __forceinline__ void lane_body(const FusedArgs &A, const ShardIO &S, 
     uint64_t r = unit;
     if (LONG) {
       uint64_t local = tile;   // (the longest class first: the last tiles to start are the shortest)
-      int c = 3;
+      int c = 4;
 #pragma unroll
-      for (int i = 3; i > 0; i--) if (c == i && local >= cls_tiles[i]) { local -= cls_tiles[i]; c = i - 1; }
+      for (int i = 4; i > 0; i--) if (c == i && local >= cls_tiles[i]) { local -= cls_tiles[i]; c = i - 1; }
       unit = local * 64 + lane;
       have = unit < cls_n[c];
-      r = have ? (uint64_t)A.hand_lists[(uint64_t)c * A.hand_stride + unit] : 0;
+      const uint32_t *const cl = A.hand_lists + HandOn::list_at(c == 0 ? (int)HandOn::SHORT : c - 1, A.hand_stride, A.hand_long_cap);
+      r = have ? (uint64_t)cl[unit] : 0;
     }
     // ---- fragment descriptor ----
     const uint8_t *seq = A.bases;
@@ -1075,8 +1138,8 @@ __device__ __forceinline__ void lane_body(const FusedArgs &A, const ShardIO &S, 
       const uint32_t oflags = have ? L->o_flags[lane] : 0u;
       const bool dfr = have && (too_long || (oflags & 0x80000000u));  // re-done by the wave-per-read / segment kernels
       if (__ballot(dfr) != 0)   // (rare, and kept out of line: the hot loop's registers and schedule are not to know about it)
-        hand_on(A.hand_hdr, A.hand_lists, A.hand_stride, A.long_max, A.long_bound[0], A.long_bound[1], A.long_bound[2], A.seg_min_len,
-                A.offsets, A.mate_offsets, dfr, too_long, r, lane, LONG);
+        hand_on(A.hand_hdr, A.hand_lists, A.hand_stride, A.hand_long_cap, A.long_max, A.long_bound[0], A.long_bound[1], A.long_bound[2],
+                A.seg_min_len, A.wave_min, A.wave_ratio_q10, A.offsets, A.mate_offsets, dfr, too_long, r, lane, LONG);
       if (have && !dfr) resolve_lane<HITS, LONG>(L, ocnt, A, lane, r, oflags, total, nhits, np, dbg);
     } else {
       if (have && too_long) defer[r] = 1;   // EMIT job: fragments this kernel does not take (the caller routes them)

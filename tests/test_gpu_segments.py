@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def segments_from_1001_bases(monkeypatch):
-    # the engine's default hands fragments of 250 000 bases and more to the segment kernel (those of 1001..4999 to the lane kernel's
+    # the engine's default hands the fragments that are long for their batch to the segment kernel (those of 1001..4999 to the lane kernel's
     # long variant, those in between to the wave kernel); here everything over 1000 goes to the segment kernel, which makes the segments short (64 windows) and the
     # borders many
     monkeypatch.setenv("SLK_SEG_MIN_LEN", "1001")
@@ -87,10 +87,14 @@ def check(orc, world, reads, thresholds=(0.0, 0.1, 0.5), min_hit_groups=2):
         assert bad.size == 0, (key, bad[:5].tolist(), [len(reads[i]) for i in bad[:5]],
                                np.atleast_2d(got[key])[:, bad[:5]].tolist(), np.atleast_2d(want[key])[:, bad[:5]].tolist())
     # the same batch with every handed-on fragment on the wave kernel, and with the engine's default routes (1001..4999 bases: the
-    # lane kernel's long variant, from 250 000: the segment kernel, the rest and map overflows: the wave kernel)
-    saved = {v: os.environ.get(v) for v in ("SLK_SEG_MIN_LEN", "SLK_LANE_LONG_MAX")}
+    # lane kernel's long variant, the long ones of the batch: the segment kernel, the rest and map overflows: the wave kernel)
+    # -- the latter with a first pass of the lane kernel and with the routing kernel in its place (the engine's choice follows the
+    # batch's mean fragment length), where the fragments of up to 1000 bases are a fifth class of the long variant
+    saved = {v: os.environ.get(v) for v in ("SLK_SEG_MIN_LEN", "SLK_LANE_LONG_MAX", "SLK_ROUTE_FIRST")}
     try:
-        for name, env in (("wave kernel", dict(SLK_SEG_MIN_LEN="0", SLK_LANE_LONG_MAX="0")), ("default routes", {})):
+        for name, env in (("wave kernel", dict(SLK_SEG_MIN_LEN="0", SLK_LANE_LONG_MAX="0")), ("default routes", {}),
+                          ("default routes behind a first pass", dict(SLK_ROUTE_FIRST="0")),
+                          ("default routes behind the routing kernel", dict(SLK_ROUTE_FIRST="1"))):
             for v in saved:
                 os.environ.pop(v, None)
             os.environ.update(env)
@@ -119,13 +123,23 @@ def check_hits(orc, world, reads, every=1):
         _, hits = orc.classify_read(world["p"], world["oix"], world["parents"], reads[i].tobytes(), None, 2, 0.0)
         g = got["hits"][ho[i]:ho[i + 1]]
         assert [(int(t), int(c)) for t, c in zip(g["taxon"], g["count"])] == hits, (i, len(reads[i]))
-    saved = os.environ.get("SLK_SEG_MIN_LEN")
-    os.environ["SLK_SEG_MIN_LEN"] = "0"
+    saved = {v: os.environ.get(v) for v in ("SLK_SEG_MIN_LEN", "SLK_LANE_LONG_MAX", "SLK_ROUTE_FIRST")}
     try:
-        wave = world["st"].classify_batch(bases, offsets, thresholds=(0.0, 0.2), with_hits=True)
+        # the wave kernel alone; the default routes behind a first pass and behind the routing kernel (long variant with hit lists)
+        for name, env in (("wave kernel", dict(SLK_SEG_MIN_LEN="0", SLK_LANE_LONG_MAX="0")),
+                          ("first pass", dict(SLK_ROUTE_FIRST="0")), ("routing kernel", dict(SLK_ROUTE_FIRST="1"))):
+            for v in saved:
+                os.environ.pop(v, None)
+            os.environ.update(env)
+            other = world["st"].classify_batch(bases, offsets, thresholds=(0.0, 0.2), with_hits=True)
+            assert np.array_equal(other["hit_offsets"], got["hit_offsets"]) and np.array_equal(other["hits"], got["hits"]), name
+            for key in ("total_kmers", "num_hits", "num_distinct", "taxon", "classified"):
+                assert np.array_equal(other[key], got[key]), name + ": " + key
     finally:
-        os.environ["SLK_SEG_MIN_LEN"] = saved
-    assert np.array_equal(wave["hit_offsets"], got["hit_offsets"]) and np.array_equal(wave["hits"], got["hits"])
+        for v, x in saved.items():
+            os.environ.pop(v, None)
+            if x is not None:
+                os.environ[v] = x
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SLK_SEG_SEEDS", 4))))   # (SLK_SEG_SEEDS: soak runs)
@@ -206,9 +220,10 @@ def test_very_long_read(orc, world):
 
 
 def test_default_threshold_splits_the_work_between_the_two_kernels(orc, world, monkeypatch):
-    """Default threshold (250 000 bases): shorter long fragments, clean or with characters outside ACGTU (which the wave kernel takes
-    run by run), stay on the wave kernel or the lane kernel's long variant, longer ones go to the segment kernel, short ones to the
-    lane kernel -- one batch."""
+    """Default routes: the segment kernel's threshold follows the batch (1/16384 of its bases, at least 16 000 -- which is what a batch
+    of this size gets --, at most 250 000); shorter long fragments, clean or with characters outside ACGTU (which the wave kernel
+    takes run by run), stay on the wave kernel (three lists by length, longest first) or the lane kernel's long variant, short ones
+    on the lane kernel -- one batch."""
     monkeypatch.delenv("SLK_SEG_MIN_LEN")
     monkeypatch.delenv("SLK_LANE_LONG_MAX")
     rng = np.random.default_rng(12)
@@ -221,7 +236,7 @@ def test_default_threshold_splits_the_work_between_the_two_kernels(orc, world, m
     reads += synth.make_reads(world["lib"], 200, rng, vary_length=True)
     reads += [long_read(world["lib"], rng, int(rng.integers(5000, 16000))) for _ in range(12)]
     reads += [long_read(world["lib"], rng, int(rng.integers(16000, 40000))) for _ in range(12)]
-    reads += [long_read(world["lib"], rng, n) for n in (249999, 250000, 250001, 400000)]
+    reads += [long_read(world["lib"], rng, n) for n in (9999, 10000, 10001, 15999, 16000, 16001, 250001)]
     bases, offsets = synth.pack(reads)
     got = world["st"].classify_batch(bases, offsets, thresholds=(0.0, 0.2), with_hits=False, with_num_hits=True)
     want = orc.classify_batch(world["p"], world["oix"], world["parents"], bases, offsets, None, None, min_hit_groups=2,
