@@ -393,6 +393,7 @@ __device__ __forceinline__ void apply_rows(LaneLds *L, const ApplyJob &J, int la
 template <bool HITS>
 __device__ __forceinline__ void emit_batch(LaneLds *L, const FusedArgs &A, const ShardIO &S, const ApplyJob &J, int qhead, int cnt, int lane,
                                            uint64_t row, uint64_t tile, uint32_t &ch_pos, uint32_t &ch_end, uint32_t &side_j, uint64_t &side_key, int dbg) {
+  SLK_TUNE(if (dbg & 256) return;)                        // (timing experiment 256: the scan alone, its keys dropped)
   const bool in = lane < cnt;
   const int qi = (qhead + lane) & (QCAP - 1);
   const uint64_t key = L->q_key[qi];

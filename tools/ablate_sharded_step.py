@@ -44,8 +44,11 @@ sc.close()
 ''' % (ROOT, ROOT)
 
 out = {}
-for name, abl in (("all on", "0"), ("lookups from the L2 (4)", "4"), ("no key / meta stores (32)", "32"), ("no answer stores (128)", "128"),
-                  ("no list stores at all (160)", "160"), ("L2 lookups, no stores (164)", "164")):
+SETS = (("all on", "0"), ("lookups from the L2 (4)", "4"), ("no key / meta stores (32)", "32"), ("no answer stores (128)", "128"),
+        ("no list stores at all (160)", "160"), ("L2 lookups, no stores (164)", "164"), ("no EMIT at all: the scan drops its keys (256)", "256"))
+if len(sys.argv) > 1:   # only the experiments named (by their number)
+    SETS = tuple(x for x in SETS if x[1] in sys.argv[1:])
+for name, abl in SETS:
     env = dict(os.environ, SLACKEN_AMD_LIB=os.path.join(ROOT, "build_ab", "lib_tuning.so"), SLK_DEBUG_ABLATE=abl)
     r = subprocess.run([sys.executable, "-c", CODE], capture_output=True, text=True, env=env, timeout=600)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
