@@ -318,3 +318,51 @@ def test_hit_lists_of_long_reads_with_ambiguous_runs(orc, world, paired):
                                     None if mates is None else mates[i].tobytes(), 2, 0.0)
         g = got["hits"][ho[i]:ho[i + 1]]
         assert [(int(t), int(c)) for t, c in zip(g["taxon"], g["count"])] == hits, i
+
+
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("with_hits", [False, True])
+def test_batches_of_mostly_long_fragments_have_no_first_pass(orc, world, monkeypatch, paired, with_hits):
+    """A batch whose fragments average over 1000 bases is sorted by a routing kernel instead of a first pass of the lane kernel, and
+    its fragments of up to 1000 bases -- empty ones, ones shorter than k, ones of exactly 1000 -- are a fifth class of the lane
+    kernel's long variant (capi.hip: route_first; engine.h: HandOn): the engine's default routes on such a batch, pairs too (a pair
+    counts with both mates' bases), against the oracle, and the same with a first pass."""
+    for v in ("SLK_SEG_MIN_LEN", "SLK_LANE_LONG_MAX", "SLK_SEG_HITS"):
+        monkeypatch.delenv(v)
+    rng = np.random.default_rng(77 + 2 * paired + with_hits)
+    lib = world["lib"]
+    reads = [long_read(lib, rng, int(n)) for n in np.exp(rng.uniform(np.log(1001), np.log(40000), 140)).astype(np.int64)]
+    reads += [long_read(lib, rng, n) for n in (1000, 1001, 4999, 5000, 5001, 8750, 8751, 999)]
+    reads += synth.make_reads(lib, 60, rng, vary_length=True)                              # short ones among them
+    reads += [np.zeros(0, np.uint8), synth.random_dna(34, rng), synth.random_dna(35, rng), np.full(1000, ord("N"), np.uint8)]
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    mates = mb = mo = None
+    if paired:
+        mates = [long_read(lib, rng, int(rng.integers(1, 2500))) if rng.random() < 0.8 else np.zeros(0, np.uint8) for _ in reads]
+        mb, mo = synth.pack(mates)
+    bases, offsets = synth.pack(reads)
+    assert (len(bases) + (len(mb) if paired else 0)) // 1000 > len(reads)                  # (the engine's criterion)
+    want = orc.classify_batch(world["p"], world["oix"], world["parents"], bases, offsets, mb, mo, min_hit_groups=2, thresholds=(0.0, 0.2))
+    first = None
+    for route_first in (None, "1", "0"):
+        if route_first is None:
+            monkeypatch.delenv("SLK_ROUTE_FIRST", raising=False)
+        else:
+            monkeypatch.setenv("SLK_ROUTE_FIRST", route_first)
+        got = world["st"].classify_batch(bases, offsets, mb, mo, thresholds=(0.0, 0.2), min_hit_groups=2, with_hits=with_hits,
+                                         with_num_hits=True)
+        for key in ("total_kmers", "num_hits", "num_distinct", "taxon", "classified"):
+            bad = np.nonzero(np.atleast_2d(got[key] != want[key]).any(axis=0))[0]
+            assert bad.size == 0, (route_first, key, bad[:5].tolist(), [len(reads[i]) for i in bad[:5]])
+        if with_hits:
+            if first is None:
+                first = got
+                ho = got["hit_offsets"].astype(np.int64)
+                for i in range(0, len(reads), 7):
+                    _, hits = orc.classify_read(world["p"], world["oix"], world["parents"], reads[i].tobytes(),
+                                                None if mates is None else mates[i].tobytes(), 2, 0.0)
+                    g = got["hits"][ho[i]:ho[i + 1]]
+                    assert [(int(t), int(c)) for t, c in zip(g["taxon"], g["count"])] == hits, (i, len(reads[i]))
+            else:
+                assert np.array_equal(got["hit_offsets"], first["hit_offsets"]) and np.array_equal(got["hits"], first["hits"]), route_first
