@@ -1735,23 +1735,28 @@ static int32_t classify_batch_host(slk_index *ix, slk_stream *st, const ReadSour
     if (rc) return rc;
   }
   if (call_timing) { (void)hipStreamSynchronize(st->s); tp[3] = now(); }
+  double th[3] = {0, 0, 0};
   if (out_hit_offsets) {
     rc = counts_to_offsets(st, st->out_nh.as<int32_t>(), R, out_hit_offsets, out_hits ? hits_capacity : ~0ULL);
     if (rc) return rc;
+    if (call_timing) th[0] = now();
     uint64_t n = out_hit_offsets[R];
     if (n && out_hits) {
       HIPCHK(st->out_items.ensure(n * sizeof(slk_hit)));
       launch_gather_hits(d_off, d_moff, R, st->span_meta.as<int32_t>(), st->span_taxon.as<int32_t>(),
                          st->out_offsets.as<uint64_t>(), st->out_items.p, st->s);
       HIPCHK(hipGetLastError());
+      if (call_timing) { (void)hipStreamSynchronize(st->s); th[1] = now(); }
       rc = copy_out(st, out_hits, st->out_items.p, n * sizeof(slk_hit));
       if (rc) return rc;
+      if (call_timing) th[2] = now();
     }
   }
   HIPCHK(hipStreamSynchronize(st->s));
   if (call_timing)
-    fprintf(stderr, "slk_classify_batch%s R=%llu: upload %.2f ms, kernels %.2f, results %.2f, hit lists %.2f\n", pk ? "_packed" : "",
-            (unsigned long long)R, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], now() - tp[3]);
+    fprintf(stderr, "slk_classify_batch%s R=%llu: upload %.2f ms, kernels %.2f, results %.2f, hit lists %.2f (offsets %.2f, gather %.2f, download %.2f)\n",
+            pk ? "_packed" : "", (unsigned long long)R, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], now() - tp[3], th[0] ? th[0] - tp[3] : 0.0,
+            th[1] ? th[1] - th[0] : 0.0, th[2] ? th[2] - th[1] : 0.0);
   return check_status(st);
 }
 
