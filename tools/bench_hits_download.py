@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""One CLI-sized batch (53 600 reads x 150 bp) through slk_classify_batch with hit lists, into a buffer that has been written before
+(as the CLI's recycled result buffers have), alone on the machine: with SLK_DEBUG_CALL_TIMING=1 the library prints where a call's time
+goes.  GPU box."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
