@@ -17,7 +17,7 @@ ix.set_taxonomy(parents)
 ix.add_sequences(bases, np.arange(G + 1, dtype=np.uint64) * np.uint64(L), rng.choice(taxa[len(taxa) // 2:], G).astype(np.int32))
 ix.finalize()
 st = ix.stream()
-R = 53600
+R = int(os.environ.get("R", 53600))
 starts = rng.integers(0, G * L - 150, R)
 rb = bases[(starts[:, None] + np.arange(150)[None, :])].reshape(-1).copy()
 offs = np.arange(0, (R + 1) * 150, 150, dtype=np.uint64)
