@@ -858,7 +858,7 @@ void slk_stream_destroy(slk_stream *st) {
   (void)hipStreamSynchronize(st->s);
   DevBuf *bufs[] = {&st->span_keys, &st->span_meta, &st->span_taxon, &st->span_count, &st->bases, &st->offsets,
                     &st->mate_bases, &st->mate_offsets, &st->out_taxon, &st->out_cls, &st->out_nd, &st->out_tk,
-                    &st->out_nh, &st->out_offsets, &st->out_items, &st->defer_list, &st->pk_codes, &st->pk_valid, &st->pk_mate_codes,
+                    &st->out_nh, &st->out_offsets, &st->out_items, &st->defer_list, &st->scan_tmp, &st->pk_codes, &st->pk_valid, &st->pk_mate_codes,
                     &st->pk_mate_valid};
   for (DevBuf *b : bufs) b->release();
   if (st->d_status) (void)hipFree(st->d_status);
@@ -1475,16 +1475,18 @@ int32_t upload_reads(slk_stream *st, const uint8_t *bases, const uint64_t *offse
 // counts (device, int32[R]) -> out_offsets (host, u64[R+1]); uploads the offsets for a gather kernel
 int32_t counts_to_offsets(slk_stream *st, const int32_t *d_counts, uint64_t R, uint64_t *out_offsets,
                                  uint64_t capacity) {
-  std::vector<int32_t> counts(R);
-  int32_t rc = copy_out(st, counts.data(), d_counts, R * 4);
-  if (rc) return rc;
   out_offsets[0] = 0;
-  for (uint64_t r = 0; r < R; r++) out_offsets[r + 1] = out_offsets[r] + (uint64_t)counts[r];
+  if (R == 0) return SLK_OK;
+  HIPCHK(st->out_offsets.ensure((R + 1) * 8));
+  HIPCHK(st->scan_tmp.ensure((R / 2048 + 2) * 8));
+  launch_counts_to_offsets(d_counts, R, st->out_offsets.as<uint64_t>(), st->scan_tmp.as<uint64_t>(), st->s);   // (kernels.hip)
+  HIPCHK(hipGetLastError());
+  int32_t rc = copy_out(st, out_offsets, st->out_offsets.p, (R + 1) * 8);
+  if (rc) return rc;
   if (out_offsets[R] > capacity)
     return fail(SLK_E_CAPACITY, "output needs %llu entries, capacity is %llu", (unsigned long long)out_offsets[R],
                 (unsigned long long)capacity);
-  HIPCHK(st->out_offsets.ensure((R + 1) * 8));
-  return copy_in(st, st->out_offsets.p, out_offsets, (R + 1) * 8);
+  return SLK_OK;
 }
 
 // slk_spans_batch / slk_spans_batch_wide: out_keys (nullable) receives the spans' id1..idW rows
