@@ -22,6 +22,8 @@ object Native {
   @native def addSequences(h: Long, bases: ByteBuffer, offsets: Array[Long], taxa: Array[Int], n: Int): Unit
   @native def streamCreate(h: Long): Long
   @native def streamDestroy(s: Long): Unit
+  /** slk_stream_set_merged_hits: hit lists come back as TaxonCounts.fromHits would merge them (for output lines only) */
+  @native def streamSetMergedHits(s: Long, on: Boolean): Unit
   @native def classifyBatch(h: Long, s: Long, bases: ByteBuffer, offsets: Array[Long], mateBases: ByteBuffer,
                             mateOffsets: Array[Long], r: Int, minHitGroups: Int, thresholds: Array[Double], outTaxon: Array[Int],
                             outClassified: Array[Byte], outNumDistinct: Array[Int], outTotalKmers: Array[Int],

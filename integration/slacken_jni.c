@@ -73,6 +73,11 @@ JNIEXPORT jlong JNICALL Java_com_jnpersson_slacken_gpu_Native_streamCreate(JNIEn
   return (jlong)(intptr_t)st;
 }
 JNIEXPORT void JNICALL Java_com_jnpersson_slacken_gpu_Native_streamDestroy(JNIEnv *e, jclass c, jlong s) { slk_stream_destroy(S(s)); }
+/* slk_stream_set_merged_hits: the hit lists of classifyBatch / classifyBatchPacked as TaxonCounts.fromHits merges them (what
+ * outputLine prints), a sixth of the bytes on the way back; not for lists that are regrouped by title afterwards */
+JNIEXPORT void JNICALL Java_com_jnpersson_slacken_gpu_Native_streamSetMergedHits(JNIEnv *e, jclass c, jlong s, jboolean on) {
+  if (slk_stream_set_merged_hits(S(s), on ? 1 : 0) != SLK_OK) throw_state(e);
+}
 
 /* Classifier.classify for one batch.  bases / mateBases: direct ByteBuffers (mateBases null for single-end); offsets,
  * mateOffsets: long[R+1]; thresholds: double[C]; outputs are caller-owned arrays: outTaxon int[C*R], outClassified byte[C*R],

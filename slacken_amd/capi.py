@@ -77,7 +77,7 @@ EXPORTS = ["slk_device_count", "slk_last_error", "slk_version", "slk_host_alloc"
            "slk_stream_hip_stream", "slk_stream_destroy", "slk_spans_batch", "slk_spans_batch_wide", "slk_classify_batch",
            "slk_classify_batch_packed", "slk_pack_bases",
            "slk_classify_batch_device", "slk_classify_hits", "slk_stream_last_stage_ms", "slk_scan_device", "slk_lookup_device",
-           "slk_shard_of", "slk_classify_hits_device", "slk_shard_batch_rows", "slk_shard_chunk", "slk_shard_step_device",
+           "slk_shard_of", "slk_stream_set_merged_hits", "slk_classify_hits_device", "slk_shard_batch_rows", "slk_shard_chunk", "slk_shard_step_device",
            "slk_stream_last_deferred", "slk_table_slot", "slk_table_hash_of",
            "slk_shardset_create", "slk_shardset_classify", "slk_shardset_classify_rounds", "slk_shardset_exchange_mode", "slk_shardset_destroy"]
 
@@ -130,6 +130,7 @@ def lib():
     L.slk_index_destroy.restype = None
     L.slk_stream_create.argtypes = [vp, C.POINTER(vp)]
     L.slk_stream_synchronize.argtypes = [vp]
+    L.slk_stream_set_merged_hits.argtypes = [vp, C.c_int32]
     L.slk_stream_hip_stream.argtypes = [vp]
     L.slk_stream_hip_stream.restype = C.c_void_p
     L.slk_stream_destroy.argtypes = [vp]
@@ -466,6 +467,11 @@ class Stream:
 
     def synchronize(self):
         _check(lib().slk_stream_synchronize(self.h))
+
+    def set_merged_hits(self, on=True):
+        """hit lists of classify_batch as TaxonCounts.fromHits merges them (adjacent hits of one taxon summed); `num_hits` then counts
+        the merged entries"""
+        _check(lib().slk_stream_set_merged_hits(self.h, 1 if on else 0))
 
     def last_deferred(self):
         n = C.c_uint64(0)

@@ -850,6 +850,12 @@ int32_t slk_stream_synchronize(slk_stream *st) {
   return check_status(st);
 }
 
+int32_t slk_stream_set_merged_hits(slk_stream *st, int32_t on) {
+  if (!st) return fail(SLK_E_INVALID, "null handle");
+  st->merged_hits = on != 0;
+  return SLK_OK;
+}
+
 void *slk_stream_hip_stream(slk_stream *st) { return st ? (void *)st->s : nullptr; }
 
 void slk_stream_destroy(slk_stream *st) {
@@ -1739,14 +1745,24 @@ static int32_t classify_batch_host(slk_index *ix, slk_stream *st, const ReadSour
   if (call_timing) { (void)hipStreamSynchronize(st->s); tp[3] = now(); }
   double th[3] = {0, 0, 0};
   if (out_hit_offsets) {
-    rc = counts_to_offsets(st, st->out_nh.as<int32_t>(), R, out_hit_offsets, out_hits ? hits_capacity : ~0ULL);
+    const bool merged = st->merged_hits && want_hits;
+    if (merged) {   // (the merged lists' lengths first: span_count is free once the kernels are through)
+      launch_merged_hits(true, d_off, d_moff, R, st->span_meta.as<int32_t>(), st->span_taxon.as<int32_t>(), st->out_nh.as<int32_t>(), nullptr,
+                         st->span_count.as<int32_t>(), nullptr, st->s);
+      HIPCHK(hipGetLastError());
+    }
+    rc = counts_to_offsets(st, merged ? st->span_count.as<int32_t>() : st->out_nh.as<int32_t>(), R, out_hit_offsets, out_hits ? hits_capacity : ~0ULL);
     if (rc) return rc;
     if (call_timing) th[0] = now();
     uint64_t n = out_hit_offsets[R];
     if (n && out_hits) {
       HIPCHK(st->out_items.ensure(n * sizeof(slk_hit)));
-      launch_gather_hits(d_off, d_moff, R, st->span_meta.as<int32_t>(), st->span_taxon.as<int32_t>(),
-                         st->out_offsets.as<uint64_t>(), st->out_items.p, st->s);
+      if (merged)
+        launch_merged_hits(false, d_off, d_moff, R, st->span_meta.as<int32_t>(), st->span_taxon.as<int32_t>(), st->out_nh.as<int32_t>(),
+                           st->out_offsets.as<uint64_t>(), nullptr, st->out_items.p, st->s);
+      else
+        launch_gather_hits(d_off, d_moff, R, st->span_meta.as<int32_t>(), st->span_taxon.as<int32_t>(),
+                           st->out_offsets.as<uint64_t>(), st->out_items.p, st->s);
       HIPCHK(hipGetLastError());
       if (call_timing) { (void)hipStreamSynchronize(st->s); th[1] = now(); }
       rc = copy_out(st, out_hits, st->out_items.p, n * sizeof(slk_hit));

@@ -369,6 +369,9 @@ void launch_gather_spans(const uint64_t *offsets, const uint64_t *mate_offsets, 
                          const int32_t *span_meta, const uint64_t *out_offsets, void *out, hipStream_t s);
 // out[i] = counts[0] + .. + counts[i - 1] for i = 0 .. n (n + 1 values); tmp holds n / 2048 + 2 words
 void launch_counts_to_offsets(const int32_t *counts, uint64_t n, uint64_t *out, uint64_t *tmp, hipStream_t s);
+// the hit lists merged as TaxonCounts.fromHits merges them: count = true -> merged[r] = entries of fragment r; else -> out[moffs[r] ..)
+void launch_merged_hits(bool count, const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, const int32_t *span_meta, const int32_t *span_taxon,
+                        const int32_t *nh, const uint64_t *moffs, int32_t *merged, void *out, hipStream_t s);
 void launch_gather_hits(const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, const int32_t *span_meta,
                         const int32_t *span_taxon, const uint64_t *out_offsets, void *out, hipStream_t s);
 // words [w0, w1) of a packed read stream (host/pack.hpp) -> out[16 w0 .. 16 w1): "ACGT" by code, 'N' where the validity bit is clear

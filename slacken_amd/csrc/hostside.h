@@ -253,6 +253,7 @@ struct slk_stream {
   DevBuf span_keys, span_meta, span_taxon, span_count;  // per-batch scratch (sparse per-read regions)
   DevBuf bases, offsets, mate_bases, mate_offsets;      // staging for the host-pointer entry points
   DevBuf out_taxon, out_cls, out_nd, out_tk, out_nh, out_offsets, out_items, defer_list, scan_tmp;
+  bool merged_hits = false;                 // slk_stream_set_merged_hits: hit lists as TaxonCounts.fromHits merges them
   DevBuf pk_codes, pk_valid, pk_mate_codes, pk_mate_valid;   // slk_classify_batch_packed: the reads as they arrive (3 bits per base)
   hipEvent_t ev_unpack = nullptr;
   hipStream_t s2 = nullptr;                 // the segment pass and the wave pass run here, beside the long-lane pass on s

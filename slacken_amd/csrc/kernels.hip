@@ -493,6 +493,74 @@ __global__ void __launch_bounds__(256) gather_hits_kernel(const uint64_t *__rest
   }
 }
 
+// The hit lists as TaxonCounts.fromHits merges them (S/slacken/TaxonCounts.scala:31-48): adjacent entries of one taxon become one entry
+// with the sum of their k-mer counts -- what ClassifiedRead.outputLine prints (pairsInOrderString :94-110), and a fifth to a tenth of
+// the bytes the un-merged lists send over the link (slk_stream_set_merged_hits).  A wave per fragment, 64 entries at a time; the run
+// that is open at the end of a 64 is carried (taxon, sum) and written when the next 64 close it or the fragment ends.
+// COUNT: merged[r] = entries of fragment r's merged list; otherwise the entries go to out[moffs[r] ..).
+template <bool COUNT>
+__global__ void __launch_bounds__(256) merged_hits_kernel(const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ mate_offsets, uint64_t R,
+                                                          const int32_t *__restrict__ span_meta, const int32_t *__restrict__ span_taxon,
+                                                          const int32_t *__restrict__ nh, const uint64_t *__restrict__ moffs,
+                                                          int32_t *__restrict__ merged, HitOut *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (uint64_t r = wave; r < R; r += nwaves) {
+    const uint64_t base = span_region(offsets, mate_offsets, r);
+    const int32_t n = nh[r];
+    const uint64_t o = COUNT ? 0 : moffs[r];
+    int32_t carry_t = 0, carry_c = 0;
+    bool have_carry = false;
+    uint32_t runs = 0;   // runs begun so far; the open one is run runs - 1
+    for (int32_t j0 = 0; j0 < n; j0 += 64) {
+      const int32_t j = j0 + lane;
+      const bool valid = j < n;
+      const int32_t t = valid ? span_taxon[base + j] : 0;
+      int32_t left = __shfl_up(t, 1);
+      if (lane == 0) left = carry_t;
+      const bool start = valid && ((lane == 0 && !have_carry) || t != left);
+      const uint64_t S = __ballot(start);
+      const int nvalid = min(64, n - j0);
+      const int nstart = __popcll(S);
+      const int last = nvalid - 1;
+      if (COUNT) {
+        runs += (uint32_t)nstart;
+        have_carry = true;
+        carry_t = __shfl(t, last);
+        continue;
+      }
+      const int32_t c = valid ? meta_kmers(span_meta[base + j]) : 0;
+      int32_t P = c;   // inclusive prefix sums of the counts over the lanes
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int32_t q = __shfl_up(P, d);
+        if (lane >= d) P += q;
+      }
+      const int first = S ? __ffsll((long long)S) - 1 : nvalid;   // lanes [0, first) continue the carried run
+      if (first > 0) carry_c += __shfl(P, first - 1);
+      if (S != 0) {
+        if (have_carry && lane == 0) { HitOut h; h.taxon = carry_t; h.count = carry_c; out[o + runs - 1] = h; }
+        // a run begun at lane i ends before the next start (or with the 64): its sum from the prefix sums
+        const uint64_t later = lane < 63 ? (S >> (lane + 1)) : 0;
+        const int e = later ? lane + 1 + (__ffsll((long long)later) - 1) : nvalid;
+        const int32_t Pe = __shfl(P, e - 1), Pb = __shfl_up(P, 1);
+        const int32_t seg = Pe - (lane == 0 ? 0 : Pb);
+        const int L = 63 - __clzll((long long)S);                 // the last start: its run stays open
+        if (start && lane != L) {
+          HitOut h; h.taxon = t; h.count = seg;
+          out[o + runs + (uint32_t)__popcll(S & ((1ULL << lane) - 1))] = h;
+        }
+        carry_t = __shfl(t, L);
+        carry_c = __shfl(seg, L);
+        runs += (uint32_t)nstart;
+        have_carry = true;
+      }
+    }
+    if (COUNT) { if (lane == 0) merged[r] = (int32_t)runs; }
+    else if (have_carry && lane == 0) { HitOut h; h.taxon = carry_t; h.count = carry_c; out[o + runs - 1] = h; }
+  }
+}
+
 // ---- launchers (called from capi.hip) ----
 // slk_index_finalize, dense taxon ids: the taxon field of every cell becomes to_dense[taxon] (cells whose taxon has no dense
 // id -- not a node of the taxonomy -- are counted; the caller first counts, and rewrites only if there are none)
@@ -639,6 +707,13 @@ void launch_counts_to_offsets(const int32_t *counts, uint64_t n, uint64_t *out, 
   hipLaunchKernelGGL(scan_fill_kernel, dim3((unsigned)nb), dim3(SCAN_T), 0, s, counts, n, tmp, out);
 }
 
+void launch_merged_hits(bool count, const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, const int32_t *span_meta, const int32_t *span_taxon,
+                        const int32_t *nh, const uint64_t *moffs, int32_t *merged, void *out, hipStream_t s) {
+  if (R == 0) return;
+  const uint64_t blocks = std::min<uint64_t>((R + 3) / 4, 8192);
+  if (count) hipLaunchKernelGGL(merged_hits_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, offsets, mate_offsets, R, span_meta, span_taxon, nh, moffs, merged, (HitOut *)out);
+  else hipLaunchKernelGGL(merged_hits_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, offsets, mate_offsets, R, span_meta, span_taxon, nh, moffs, merged, (HitOut *)out);
+}
 void launch_gather_hits(const uint64_t *offsets, const uint64_t *mate_offsets, uint64_t R, const int32_t *span_meta,
                         const int32_t *span_taxon, const uint64_t *out_offsets, void *out, hipStream_t s) {
   if (R == 0) return;

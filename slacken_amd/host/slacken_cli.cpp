@@ -465,7 +465,9 @@ struct DeviceIndex {
 template <class F>
 static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &files, bool paired, int min_hits,
                             const std::vector<double> &thresholds, bool want_spans, bool want_hits, F f, RepeatedTitles *rep = nullptr,
-                            const std::function<void(const FragmentBatch &)> &pre = nullptr) {
+                            const std::function<void(const FragmentBatch &)> &pre = nullptr, bool merged_hits = false) {
+  // merged_hits: the hit lists come merged as TaxonCounts.fromHits merges them (slk_stream_set_merged_hits) -- for a consumer that only
+  // prints them (OutputSink), a sixth of the bytes on the way back; never with spans (their lists go by position) nor on a shard set
   // Several input files (or pairs) are read side by side, each on its own threads (a gzip file on the cores' share of it, pargz.hpp), and
   // their batches are taken in turn: the order of the output is deterministic, though interleaved between files at batch
   // granularity (the reference's output order is whatever Spark's partitions give).
@@ -507,6 +509,9 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
   for (size_t i = 0; i < n_workers; i++) stream_ix[i] = dev.ixs[i % dev.ixs.size()];
   streams[0] = dev.st;
   for (size_t i = 1; i < n_workers && !dev.sharded; i++) SLK_CALL(slk_stream_create(stream_ix[i], &streams[i]));
+  static const bool no_merge = getenv("SLK_CLI_MERGED_HITS") && getenv("SLK_CLI_MERGED_HITS")[0] == '0';   // (A/B switch)
+  const bool merge = merged_hits && want_hits && !want_spans && !dev.sharded && !no_merge;
+  for (size_t i = 0; i < n_workers && !dev.sharded; i++) SLK_CALL(slk_stream_set_merged_hits(streams[i], merge ? 1 : 0));
   std::atomic<size_t> total{0}, n_batches{0};
   const bool timing = getenv("SLK_HOST_TIMING") != nullptr;  // where the wall clock of the workers goes, by stage
   std::mutex mu_in, mu_out, mu_stat;
@@ -679,6 +684,7 @@ static void classify_stream(DeviceIndex &dev, const std::vector<std::string> &fi
     for (auto &t : workers) t.join();
   }
   for (size_t i = 1; i < n_workers; i++) slk_stream_destroy(streams[i]);
+  if (!dev.sharded) (void)slk_stream_set_merged_hits(dev.st, 0);   // (the device's own stream serves other callers: un-merged lists again)
   if (failure) std::rethrow_exception(failure);
   if (timing)
     std::cerr << "host timing: " << n_batches << " batches on " << n_workers << " classify thread(s) over " << dev.ixs.size() << " device table(s); summed over them: waiting for input "
@@ -939,7 +945,7 @@ static void classify_and_write(DeviceIndex &dev, const IndexParams &ip, const Ta
   Timer t("Classify reads");
   OutputSink sink(oo, tax, host_threads());
   classify_stream(dev, o.files, o.paired, o.min_hits, o.thresholds, false, o.detailed,   // (hit lists only feed the per-read lines)
-                  [&](std::shared_ptr<const ClassifiedBatch> b) { sink.submit(std::move(b)); }, &sink.repeated());
+                  [&](std::shared_ptr<const ClassifiedBatch> b) { sink.submit(std::move(b)); }, &sink.repeated(), nullptr, true);
   sink.drain();
   sink.repeated().settle_unmatched([&](uint64_t h) { return sink.has_title(h); });
   if (!sink.repeated().empty()) resolve_repeated_titles(dev, ip, o, sink);

@@ -111,6 +111,24 @@ def test_reference_kat_on_gpu():
            ["AATTT", "ATTTA", "TTTACTTT", "CTTTA", "TTTAGTTA", "GTTAC"]
 
 
+def merged_lists(hit_offsets, hits):
+    """TaxonCounts.fromHits (TaxonCounts.scala:31-48) over every fragment's list: adjacent entries of one taxon become one, counts summed"""
+    ho = hit_offsets.astype(np.int64)
+    n = len(hits)
+    if n == 0:
+        return np.zeros(len(ho), np.uint64), hits[:0]
+    first_of_read = np.zeros(n, bool)
+    first_of_read[ho[:-1][ho[:-1] < n]] = True
+    start = first_of_read.copy()
+    start[1:] |= hits["taxon"][1:] != hits["taxon"][:-1]
+    run = np.cumsum(start) - 1
+    out = np.zeros(int(run[-1]) + 1, hits.dtype)
+    out["taxon"] = hits["taxon"][start]
+    out["count"] = np.bincount(run, weights=hits["count"].astype(np.float64)).astype(np.int64)
+    runs_before = np.concatenate([[0], np.cumsum(start)])            # runs begun before entry i
+    return runs_before[ho].astype(np.uint64), out
+
+
 def check_classify(orc, world, reads, mates=None, thresholds=(0.0, 0.07, 0.15, 0.5, 1.0), min_hit_groups=2):
     p, st = world["p"], world["st"]
     bases, offsets = synth.pack(reads)
@@ -135,6 +153,18 @@ def check_classify(orc, world, reads, mates=None, thresholds=(0.0, 0.07, 0.15, 0
                             with_num_hits=True, packed=True)
     for key in ("taxon", "classified", "num_distinct", "total_kmers", "num_hits"):
         assert np.array_equal(pkf[key], want[key]), "packed, hot path: " + key
+    # the same lists merged on the device as TaxonCounts.fromHits merges them (slk_stream_set_merged_hits), text and packed
+    want_off, want_hits = merged_lists(got["hit_offsets"], got["hits"])
+    st.set_merged_hits(True)
+    try:
+        for packed in (False, True):
+            mg = st.classify_batch(bases, offsets, mb, mo, min_hit_groups=min_hit_groups, thresholds=thresholds, packed=packed)
+            for key in ("taxon", "classified", "num_distinct", "total_kmers"):
+                assert np.array_equal(mg[key], want[key]), "merged lists: " + key
+            assert np.array_equal(mg["hit_offsets"], want_off), "merged lists: offsets"
+            assert np.array_equal(mg["hits"]["taxon"], want_hits["taxon"]) and np.array_equal(mg["hits"]["count"], want_hits["count"]), "merged lists"
+    finally:
+        st.set_merged_hits(False)
     # un-merged hit lists (what hitDetails / lengthString are formatted from)
     ho = got["hit_offsets"].astype(np.int64)
     for i in range(0, len(reads), max(1, len(reads) // 300)):
