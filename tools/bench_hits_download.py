@@ -29,6 +29,8 @@ taxon = np.zeros((1, R), np.int32); cls = np.zeros((1, R), np.uint8); nd = np.ze
 hit_off = np.zeros(R + 1, np.uint64)
 hits = np.ones(cap, capi.HIT_DTYPE)          # (touched: a recycled buffer of the CLI)
 thr = (C.c_double * 1)(0.0)
+if os.environ.get("MERGED") == "1":
+    st.set_merged_hits(True)
 for i in range(10):
     t = time.perf_counter()
     rc = lib.slk_classify_batch(ix.h, st.h, capi._ptr(rb), capi._ptr(offs), None, None, R, 2, thr, 1, capi._ptr(taxon), capi._ptr(cls),
