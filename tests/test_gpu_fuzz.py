@@ -77,6 +77,16 @@ def test_differential(orc, seed, monkeypatch):
                                     mhg, thresholds[0])
         g = full["hits"][ho[i]:ho[i + 1]]
         assert [(int(t), int(c)) for t, c in zip(g["taxon"], g["count"])] == hits, (int(i), ctx)
+    # the lists merged on the device (slk_stream_set_merged_hits) against TaxonCounts.fromHits over the un-merged ones
+    from test_gpu_parity import merged_lists
+    m_off, m_hits = merged_lists(full["hit_offsets"], full["hits"])
+    st.set_merged_hits(True)
+    try:
+        mg = st.classify_batch(bases, offsets, mb, mo, min_hit_groups=mhg, thresholds=thresholds, with_hits=True)
+    finally:
+        st.set_merged_hits(False)
+    assert np.array_equal(mg["hit_offsets"], m_off) and np.array_equal(mg["hits"]["taxon"], m_hits["taxon"]) and \
+        np.array_equal(mg["hits"]["count"], m_hits["count"]), ("merged lists", ctx)
     # spans (kernel-1-only entry) on a subset
     off, sp = st.spans_batch(bases[:int(offsets[200])], offsets[:201])
     for i in range(0, 200, 7):
