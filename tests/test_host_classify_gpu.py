@@ -300,11 +300,13 @@ def test_cli_long_reads_all_routes_agree(tmp_path, orc):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [dict(SLK_CLASSIFY_THREADS="1", SLK_PARSE_THREADS="1"),
                                  dict(SLK_CLASSIFY_THREADS="6", SLK_PARSE_THREADS="8", SLK_IO_CHUNK="4096", SLK_HOST_THREADS="3"),
-                                 dict(SLK_CLASSIFY_THREADS="3", SLK_IO_CHUNK="777", SLK_GZIP_IMPL="zlib", SLK_GZIP_LEVEL="1")],
-                         ids=["serial", "many-small-batches", "tiny-segments-zlib"])
+                                 dict(SLK_CLASSIFY_THREADS="3", SLK_IO_CHUNK="777", SLK_GZIP_IMPL="zlib", SLK_GZIP_LEVEL="1"),
+                                 dict(SLK_CLI_MERGED_HITS="0")],
+                         ids=["serial", "many-small-batches", "tiny-segments-zlib", "un-merged-hit-lists"])
 def test_cli_output_does_not_depend_on_the_host_pipeline_shape(tmp_path, env):
-    """Segment size of the parallel parser, number of parsing / classifying / formatting threads, the gzip implementation: the
-    per-read lines (in input order) and the report are the same as with the defaults."""
+    """Segment size of the parallel parser, number of parsing / classifying / formatting threads, the gzip implementation, hit lists
+    merged on the device (the default of the first pass) or by the formatter: the per-read lines (in input order) and the report are
+    the same as with the defaults."""
     g, loc, tax, reads = make_library(tmp_path, convert=False)
     rng = np.random.default_rng(5)
     fq = tmp_path / "r.fq"
