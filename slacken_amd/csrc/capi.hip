@@ -925,14 +925,13 @@ static bool force_wave() {  // SLK_FORCE_WAVE=1: A/B switch, classify with the w
 static int32_t run_unbounded(slk_stream *st, const slk_stream::LastCall &L) {
   slk_index *ix = st->ix;
   const bool paired = L.mate_bases != nullptr;
-  int32_t rc = ensure_scratch(st, span_slots(L.total, L.mate_total, L.R, paired), L.R);
+  int32_t rc = ensure_scratch(st, span_slots(L.total, L.mate_total, L.R, paired) + L.span_shift, L.R);
   if (rc) return rc;
-  launch_scan(ix->sp, L.bases, L.offsets, L.mate_bases, L.mate_offsets, L.R, st->span_keys.as<uint64_t>(),
-              st->span_meta.as<int32_t>(), st->span_count.as<int32_t>(), st->s);
-  launch_probe(ix->view(), L.offsets, L.mate_offsets, L.R, st->span_keys.as<uint64_t>(), st->span_meta.as<int32_t>(),
-               st->span_count.as<int32_t>(), st->span_taxon.as<int32_t>(), st->s);
-  launch_classify(ix->d_parents, ix->d_nodes_orig, ix->T, L.offsets, L.mate_offsets, L.R, st->span_meta.as<int32_t>(),
-                  st->span_taxon.as<int32_t>(), st->span_count.as<int32_t>(), st->span_keys.as<uint64_t>(),
+  uint64_t *const keys = st->span_keys.as<uint64_t>() + L.span_shift;   // (fused path only: one key word per span)
+  int32_t *const meta = st->span_meta.as<int32_t>() + L.span_shift, *const taxa = st->span_taxon.as<int32_t>() + L.span_shift;
+  launch_scan(ix->sp, L.bases, L.offsets, L.mate_bases, L.mate_offsets, L.R, keys, meta, st->span_count.as<int32_t>(), st->s);
+  launch_probe(ix->view(), L.offsets, L.mate_offsets, L.R, keys, meta, st->span_count.as<int32_t>(), taxa, st->s);
+  launch_classify(ix->d_parents, ix->d_nodes_orig, ix->T, L.offsets, L.mate_offsets, L.R, meta, taxa, st->span_count.as<int32_t>(), keys,
                   L.min_hit_groups, L.thr, L.C, L.out_stride, L.out_taxon, L.out_cls, L.out_nd, L.out_tk, L.out_nh, L.out_np, st->s);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st->s));
@@ -974,14 +973,18 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
                             uint64_t total_bases, uint64_t total_mate_bases, int32_t min_hit_groups,
                             const double *thresholds, int32_t C, int32_t *d_out_taxon, uint8_t *d_out_classified,
                             int32_t *d_out_num_distinct, int32_t *d_out_total_kmers, int32_t *d_out_num_hits,
-                            int32_t *d_out_num_probes, bool want_hits, uint64_t out_stride = 0) {
+                            int32_t *d_out_num_probes, bool want_hits, uint64_t out_stride = 0, uint64_t span_shift = 0) {
+  // span_shift (a sub-batch of a larger host call, hit lists wanted): its fragments' span regions are addressed by their ABSOLUTE
+  // offsets but by the fragment's number INSIDE the sub-batch (span_region: offsets[r] + mate_offsets[r] + r for pairs), so the
+  // arrays are handed over moved by the sub-batch's first fragment number -- the regions then are the ones the whole batch has,
+  // and sub-batches do not overlap.  The caller has sized the scratch for the whole batch.
   if (out_stride == 0) out_stride = R;
   bool paired = d_mate_bases != nullptr;
   bool fused = use_fused(ix);
   int32_t rc;
   st->last_used_lane = false;
   if (!fused || want_hits) {
-    rc = ensure_scratch(st, span_slots(total_bases, total_mate_bases, R, paired), R);
+    rc = ensure_scratch(st, span_slots(total_bases, total_mate_bases, R, paired) + span_shift, R);
     if (rc) return rc;
   }
   Thresholds thr{};
@@ -998,7 +1001,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
     L.valid = fused; L.want_hits = want_hits; L.thr = thr;
     L.bases = d_bases; L.offsets = d_offsets; L.mate_bases = d_mate_bases; L.mate_offsets = d_mate_offsets;
     L.R = R; L.total = total_bases; L.mate_total = total_mate_bases; L.min_hit_groups = min_hit_groups; L.C = C;
-    L.out_stride = out_stride;
+    L.out_stride = out_stride; L.span_shift = span_shift;
     L.out_taxon = d_out_taxon; L.out_cls = d_out_classified; L.out_nd = d_out_num_distinct; L.out_tk = d_out_total_kmers;
     L.out_nh = d_out_num_hits; L.out_np = d_out_num_probes;
   }
@@ -1011,8 +1014,8 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
     A.out_taxon = d_out_taxon; A.out_classified = d_out_classified;
     A.out_nd = d_out_num_distinct; A.out_tk = d_out_total_kmers; A.out_nh = d_out_num_hits; A.out_np = d_out_num_probes;
     A.span_keys = nullptr;
-    A.span_meta = want_hits ? st->span_meta.as<int32_t>() : nullptr;
-    A.span_taxon = want_hits ? st->span_taxon.as<int32_t>() : nullptr;
+    A.span_meta = want_hits ? st->span_meta.as<int32_t>() + span_shift : nullptr;
+    A.span_taxon = want_hits ? st->span_taxon.as<int32_t>() + span_shift : nullptr;
     A.span_count = want_hits ? st->span_count.as<int32_t>() : nullptr;
     A.status = st->d_status;
     A.work_list = nullptr; A.work_count = nullptr; A.work_draw = nullptr;
@@ -1085,7 +1088,7 @@ static int32_t run_classify(slk_index *ix, slk_stream *st, const uint8_t *d_base
       HIPCHK(hipStreamWaitEvent(st->s2, st->ev_fork, 0));
       if (seg_on) {
         FusedArgs B = A;
-        if (want_hits) B.span_keys = st->span_keys.as<uint64_t>();   // (scratch of the hit lists: the spans' places before the borders are settled)
+        if (want_hits) B.span_keys = st->span_keys.as<uint64_t>() + span_shift;   // (scratch of the hit lists: the spans' places before the borders are settled)
         B.work_list = A.hand_lists + HandOn::list_at(HandOn::SEG, R, long_cap); B.work_count = A.hand_hdr + HandOn::SEG; B.work_draw = A.hand_hdr + HandOn::SEG_DRAW;
         launch_segments(B, st->s2);
       }
@@ -1649,14 +1652,18 @@ static int32_t classify_batch_host(slk_index *ix, slk_stream *st, const ReadSour
     if (!st->ev_unpack) HIPCHK(hipEventCreateWithFlags(&st->ev_unpack, hipEventDisableTiming));
   }
   // A large call is cut into sub-batches: the reads of sub-batch i+1 go up (on a second stream) while the kernels of
-  // sub-batch i run, so the call costs its upload plus ONE sub-batch of kernel time.  (Calls that want the hit lists
-  // keep the one-piece route: their cost is the download of the lists.)
+  // sub-batch i run, so the call costs its upload plus ONE sub-batch of kernel time.  With hit lists too: the sub-batches leave
+  // their spans in the batch's span arrays (run_classify: span_shift) and the lists are put together for the whole batch at the end.
   const char *sub_env = getenv("SLK_HOST_SUBBATCH");  // (read per call, so that tests can move it)
   // (2^19 reads: measured from pinned memory, 4 M reads of 150 bp -- packed 353 / 576 / 643 / 623 / 403 M reads/s at 2^17 .. 2^21, text
   //  313 / 324 / 327 / 315 / 246: smaller pieces pay per copy -- a sub-batch is five to nine DMAs --, larger ones leave the last
   //  piece's kernels exposed; profiles/r04_packed_entry.json)
   const uint64_t SUB = sub_env ? (uint64_t)std::max(1L, atol(sub_env)) : (uint64_t)1 << 19;
-  if (!want_hits && use_fused(ix) && R >= 2 * SUB) {
+  if (use_fused(ix) && R >= 2 * SUB) {
+    if (want_hits) {   // (once, for the whole batch: a sub-batch must not move the arrays under the kernels of the one before)
+      rc = ensure_scratch(st, span_slots(total, mate_total, R, paired), R);
+      if (rc) return rc;
+    }
     if (!st->cs) HIPCHK(hipStreamCreateWithFlags(&st->cs, hipStreamNonBlocking));
     if (!st->ds) HIPCHK(hipStreamCreateWithFlags(&st->ds, hipStreamNonBlocking));
     const uint64_t nsub = (R + SUB - 1) / SUB;
@@ -1696,7 +1703,7 @@ static int32_t classify_batch_host(slk_index *ix, slk_stream *st, const ReadSour
                         paired ? st->mate_offsets.as<uint64_t>() + r0 : nullptr, n, offsets[r1],
                         paired ? mate_offsets[r1] : 0, min_hit_groups, thresholds, C, st->out_taxon.as<int32_t>() + r0,
                         st->out_cls.as<uint8_t>() + r0, st->out_nd.as<int32_t>() + r0, st->out_tk.as<int32_t>() + r0,
-                        st->out_nh.as<int32_t>() + r0, nullptr, false, R);
+                        st->out_nh.as<int32_t>() + r0, nullptr, want_hits, R, want_hits && paired ? r0 : 0);
       if (rc) return rc;
       if (early_down) {
         HIPCHK(hipEventRecord(st->dn_ev[i], st->s));

@@ -281,6 +281,7 @@ struct slk_stream {
     const uint8_t *bases = nullptr, *mate_bases = nullptr;
     const uint64_t *offsets = nullptr, *mate_offsets = nullptr;
     uint64_t R = 0, total = 0, mate_total = 0, out_stride = 0;
+    uint64_t span_shift = 0;   // slots the span arrays are moved by for this call (a sub-batch of a larger host call: run_classify)
     int32_t min_hit_groups = 0, C = 0;
     int32_t *out_taxon = nullptr, *out_nd = nullptr, *out_tk = nullptr, *out_nh = nullptr, *out_np = nullptr;
     uint8_t *out_cls = nullptr;

@@ -291,6 +291,16 @@ def test_many_taxa_per_read_take_the_deferred_path(orc):
     got = check_classify(orc, world2, big, thresholds=(0.0, 0.1, 0.5))
     assert got["num_distinct"][0] > 128 and got["num_distinct"][2] > 128
     check_classify(orc, world2, big[:25], big[25:50], thresholds=(0.0,))
+    # ... and as sub-batches of one host call (each sub-batch is classified again, into its own part of the batch's span arrays)
+    old_sub = os.environ.get("SLK_HOST_SUBBATCH")
+    os.environ["SLK_HOST_SUBBATCH"] = "7"
+    try:
+        check_classify(orc, world2, big, thresholds=(0.0, 0.5))
+        check_classify(orc, world2, big[:25], big[25:50], thresholds=(0.0,))
+    finally:
+        os.environ.pop("SLK_HOST_SUBBATCH", None)
+        if old_sub is not None:
+            os.environ["SLK_HOST_SUBBATCH"] = old_sub
     # the same stream keeps working on ordinary batches afterwards
     check_classify(orc, world2, reads[:100], thresholds=(0.0,))
     import torch
@@ -499,11 +509,26 @@ def test_host_entry_subbatches_and_pinned_buffers(orc, world):
         want = orc.classify_batch(world["p"], world["oix"], world["parents"], bases, offsets, m_b, m_o, thresholds=thr)
         old = os.environ.get("SLK_HOST_SUBBATCH")
         try:
+            os.environ["SLK_HOST_SUBBATCH"] = "1000000"
+            whole = world["st"].classify_batch(bases, offsets, m_b, m_o, thresholds=thr, with_hits=True)   # (in one piece)
+            m_off, m_hits = merged_lists(whole["hit_offsets"], whole["hits"])
             for sub in ("256", "1000", "1500"):   # 12, 4 and 3 sub-batches (the last ones ragged)
                 os.environ["SLK_HOST_SUBBATCH"] = sub
                 got = world["st"].classify_batch(bases, offsets, m_b, m_o, thresholds=thr, with_hits=False, with_num_hits=True)
                 for k in keys + ("num_hits",):
                     assert np.array_equal(got[k], want[k]), (sub, k)
+                # with hit lists: the sub-batches' spans lie in the batch's span arrays (pairs: regions by fragment number), the lists
+                # are put together at the end -- as they come, merged, and from packed reads
+                for packed in (False, True):
+                    got = world["st"].classify_batch(bases, offsets, m_b, m_o, thresholds=thr, with_hits=True, packed=packed)
+                    for k in keys + ("num_hits", "hit_offsets", "hits"):
+                        assert np.array_equal(got[k], whole[k] if k in ("hit_offsets", "hits") else want[k]), (sub, packed, k)
+                world["st"].set_merged_hits(True)
+                try:
+                    got = world["st"].classify_batch(bases, offsets, m_b, m_o, thresholds=thr, with_hits=True)
+                finally:
+                    world["st"].set_merged_hits(False)
+                assert np.array_equal(got["hit_offsets"], m_off) and np.array_equal(got["hits"], m_hits), (sub, "merged")
             # pinned input and output buffers, pipelined and in one piece
             pb = capi.pinned_array(bases.shape, np.uint8); pb[:] = bases
             po = capi.pinned_array(offsets.shape, np.uint64); po[:] = offsets
