@@ -189,6 +189,15 @@ class ShardedClassifier:
         if torch.cuda.is_available():
             torch.cuda.synchronize(self.device)
             torch.cuda.empty_cache()
+            # (the pinned-memory allocator too keeps events on the streams its blocks were used on; this classifier's own pinned
+            #  buffers are the library's, but a caller may have copied results with non_blocking=True on one of these streams)
+            host_empty = getattr(torch._C, "_host_emptyCache", None)
+            if host_empty is not None:
+                try:
+                    host_empty()
+                except Exception:
+                    pass
+        self.__dict__.pop("_cursor_pool", None)
         self._ext = self._xext = None     # (the ExternalStream wrappers: Stream.close refuses while one is alive)
         for st in (self._xst, self.st):
             if st is not None:
@@ -288,8 +297,26 @@ class ShardedClassifier:
                             mo.data_ptr() if mo is not None else None, R, total_bases, mtotal, W, 0, cap, t["send_keys"].data_ptr(), t["send_meta"].data_ptr(),
                             t["cursors"].data_ptr(), t["log"].data_ptr(), t["tile_rows"].data_ptr(), t["read_info"].data_ptr(),
                             t["defer"].data_ptr(), None, None, None)
-        h = torch.empty(W + 3, dtype=torch.int64, pin_memory=True)
+        # (pinned by the LIBRARY, not by torch: torch's pinned-memory allocator keeps an event per block on the stream that used it
+        #  and asks for it at some later allocation -- by then the engine's stream that the event was recorded on may be gone:
+        #  "operation not permitted on an event last recorded in a capturing stream" in the first pinned allocation of a later
+        #  classifier, once in 3 000 tests.  Memory torch does not own has no such afterlife.)
+        h = torch.from_numpy(self._cursor_buffer(W + 3))
         return dict(R=R, cap=cap, lists=L, h_cursors=h, prof=[] if profile else None, failed=False, batch=batch, **t)
+
+    def _cursor_buffer(self, n):
+        """a pinned int64 array of n words from this classifier's small pool (slk_host_alloc; a pipeline has at most six batches in flight)"""
+        from slacken_amd import capi
+        pool = self.__dict__.setdefault("_cursor_pool", [])
+        at = self.__dict__.get("_cursor_next", 0)
+        if len(pool) < 8:
+            pool.append(capi.pinned_array((n,), np.int64))
+            self._cursor_next = 0
+            return pool[-1]
+        self._cursor_next = (at + 1) % len(pool)
+        if pool[at].size < n:
+            pool[at] = capi.pinned_array((n,), np.int64)
+        return pool[at][:n]
 
     def classify_many(self, batches, thresholds=(0.0,), min_hit_groups=2, profile=False):
         """The fast route over several batches [(d_bases, d_offsets, R, total_bases, mates or None)], pipelined (see above).
