@@ -626,7 +626,7 @@ def main():
     barrier()
     # Dominant kernel: HIP events recorded on the ENGINE's stream (torch sees it as an external stream) bracket every timed
     # step's launches -- no host synchronisation inside the timed region; read back after it.  A step's bracket holds the
-    # lane kernel and the near-empty deferral launches behind it (segment_kernel, fused_kernel<1>: a few microseconds).
+    # lane kernel and the near-empty launches behind it (the passes over its hand-on lists: a few microseconds each).
     ext = torch.cuda.ExternalStream(st.hip_stream, device=device)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t_start = time.perf_counter()
@@ -650,8 +650,8 @@ def main():
     fused = float(stage_ms[1]) < 0.05 and float(stage_ms[2]) < 0.05  # one fused launch: [fused, 0, ~0]
     # hot path: mean device time of a step's launches over the K timed steps; staged path (other splitters): the probe kernel
     dom_ms = float(step_dev_ms.mean()) if fused else float(stage_ms[1])
-    dom_name = ("slk::lane_kernel<true> (scan+probe+LCA fused, lane per read; followed by the near-empty deferral "
-                "launches of segment_kernel and fused_kernel<1>)") if fused else "slk::probe_kernel"
+    dom_name = ("slk::lane_kernel<true> (scan+probe+LCA fused, lane per read; followed by the near-empty launches of the passes "
+                "over its hand-on lists: lane_kernel<LONG>, segment_kernel, order_wave_list_kernel, fused_kernel<1> twice)") if fused else "slk::probe_kernel"
     achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9
     path_achieved = bytes_per_launch / (float(stage_ms.sum()) * 1e-3) / 1e9
 
