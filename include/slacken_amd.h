@@ -187,7 +187,8 @@ int32_t slk_stream_synchronize(slk_stream *st);
  * alone) become one entry whose count is the sum of theirs -- and out_hit_offsets index the merged entries.  It is the list
  * ClassifiedRead.outputLine prints (pairsInOrderString :94-110, lengthString) at a fifth to a tenth of the bytes over the link;
  * ordinals and `distinct` of single spans are no longer implied by position, so lists that will be regrouped by title
- * (slk_classify_hits) or counted per minimizer must stay un-merged (the default). */
+ * (slk_classify_hits) or counted per minimizer must stay un-merged (the default).  A call that asks for the offsets alone
+ * (out_hits == NULL) still counts the single spans. */
 int32_t slk_stream_set_merged_hits(slk_stream *st, int32_t on);
 void *slk_stream_hip_stream(slk_stream *st); /* the hipStream_t, for event timing by the caller */
 void slk_stream_destroy(slk_stream *st);
