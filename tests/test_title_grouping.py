@@ -120,3 +120,34 @@ def test_host_finds_the_titles_to_regroup(tmp_path):
         assert want == ["p200", "p5", "p9"]
         got = _repeated(tmp_path, [(h + "/1", q) for h, q in r1], [(h + "/2", q) for h, q in r2])
         assert set(want) <= set(got) <= set(want) | {"dup_no_mate"}, (trial, got)
+
+
+def test_the_merged_list_helper_of_the_gpu_tests_is_from_hits():
+    """tests/test_gpu_parity.py: merged_lists (numpy) is what the GPU tests hold the device-merged hit lists against; here it is held
+    against TaxonCounts.fromHits (TaxonCounts.scala:31-48) written out plainly: adjacent hits of one taxon become one entry with
+    the sum of their counts -- per fragment, borders (-2) and ambiguous spans (-1) like any other taxon."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gpu_parity_helpers", os.path.join(os.path.dirname(__file__), "test_gpu_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    dt = np.dtype([("taxon", np.int32), ("count", np.int32)])
+    rng = np.random.default_rng(31)
+    for _ in range(50):
+        lists = []
+        for _r in range(int(rng.integers(1, 40))):
+            n = int(rng.integers(0, 12)) if rng.random() < 0.8 else 0
+            lists.append([(int(rng.choice([-2, -1, 0, 5, 5, 5, 9, 9, 12])), int(rng.integers(1, 30))) for _ in range(n)])
+        offs = np.cumsum([0] + [len(h) for h in lists]).astype(np.uint64)
+        flat = np.array([h for hs in lists for h in hs], dt) if offs[-1] else np.zeros(0, dt)
+        m_off, m_hits = mod.merged_lists(offs, flat)
+        want = []
+        for hs in lists:
+            out = []
+            for t, c in hs:
+                if out and out[-1][0] == t:
+                    out[-1] = (t, out[-1][1] + c)
+                else:
+                    out.append((t, c))
+            want.append(out)
+        assert m_off.tolist() == np.cumsum([0] + [len(h) for h in want]).tolist()
+        assert [(int(t), int(c)) for t, c in zip(m_hits["taxon"], m_hits["count"])] == [h for hs in want for h in hs]
