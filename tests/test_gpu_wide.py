@@ -83,6 +83,15 @@ def test_wide_classify_parity(orc, k, m, spaces, canonical):
             _, hits = orc.classify_read(p, oix, parents, reads[i].tobytes(), None if mb is None else mates[i].tobytes(), 2, 0.0)
             g = full["hits"][ho[i]:ho[i + 1]]
             assert [(int(t), int(c)) for t, c in zip(g["taxon"], g["count"])] == hits
+        # the lists merged on the device (slk_stream_set_merged_hits) on the staged route of the wide minimizers too
+        from test_gpu_parity import merged_lists
+        m_off, m_hits = merged_lists(full["hit_offsets"], full["hits"])
+        st.set_merged_hits(True)
+        try:
+            mg = st.classify_batch(bases, offsets, mb, mo, thresholds=(0.0,), with_hits=True)
+        finally:
+            st.set_merged_hits(False)
+        assert np.array_equal(mg["hit_offsets"], m_off) and np.array_equal(mg["hits"], m_hits)
     assert want["classified"][0].mean() > 0.05
 
 
