@@ -127,6 +127,78 @@ def test_lane_and_wave_kernels_agree(big):
     assert np.array_equal(wave["num_hits"], lane["nh"].cpu().numpy())
 
 
+def test_long_reads_of_mixed_lengths_all_routes_agree(big, orc, monkeypatch):
+    """A batch of ~1 Gbp of fragments of 200 .. 50 000 bases (log-normal, as a nanopore run's) takes the routing kernel, the long
+    variant of the lane kernel, the wave kernel in length order and -- when its threshold is moved down -- the segment kernel, three of
+    them side by side on two streams: at that size the passes really overlap.  Every arrangement of the routes must give the same rows
+    (integer work: exact), and a sample of the fragments is classified by the oracle through point lookups of the big table."""
+    torch = big["torch"]
+    dev = big["dev"]
+    full = os.environ.get("SLK_FULLSIZE", "1") == "1"
+    rng = np.random.default_rng(41)
+    target = 1_000_000_000 if full else 200_000_000
+    lens = np.clip(rng.lognormal(np.log(3000), 0.9, 2_000_000), 200, 50000).astype(np.int64)
+    lens = lens[:np.searchsorted(np.cumsum(lens), target)]
+    lens[:8] = (1000, 1001, 4999, 5000, 35, 34, 8750, 50000)
+    R = len(lens)
+    offs = np.zeros(R + 1, np.int64)
+    np.cumsum(lens, out=offs[1:])
+    total = int(offs[-1])
+    # the fragments are stretches of the 150-base reads' buffer (reads of the library's genomes and random ones, some with Ns), cut
+    # anywhere: a long fragment then runs over several source reads -- several taxa, N runs, misses
+    src_len = big["R"] * 150
+    starts = torch.from_numpy(rng.integers(0, src_len - 50001, R)).to(dev)
+    d_offs = torch.from_numpy(offs).to(dev)
+    pos = torch.arange(total, device=dev)
+    rid = torch.searchsorted(d_offs, pos, right=True) - 1
+    d_b = big["bases"][starts[rid] + (pos - d_offs[rid])].contiguous()
+    del pos, rid
+
+    def classify(env):
+        for v in ("SLK_SEG_MIN_LEN", "SLK_LANE_LONG_MAX", "SLK_ROUTE_FIRST", "SLK_FORCE_WAVE"):
+            monkeypatch.delenv(v, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = dict(taxon=torch.zeros(2 * R, dtype=torch.int32, device=dev), cls=torch.zeros(2 * R, dtype=torch.uint8, device=dev),
+                   nd=torch.zeros(R, dtype=torch.int32, device=dev), tk=torch.zeros(R, dtype=torch.int32, device=dev),
+                   nh=torch.zeros(R, dtype=torch.int32, device=dev))
+        big["st"].classify_batch_device(d_b.data_ptr(), d_offs.data_ptr(), R, total, out["taxon"].data_ptr(), out["cls"].data_ptr(),
+                                        out["nd"].data_ptr(), out["tk"].data_ptr(), out["nh"].data_ptr(), thresholds=(0.0, 0.1))
+        big["st"].synchronize()
+        return out
+
+    keys = ("taxon", "cls", "nd", "tk", "nh")
+    base = classify({})                                             # default routes: routing kernel first
+    again = classify({})
+    assert same(base, again, keys)
+    for name, env in (("first pass instead of the routing kernel", dict(SLK_ROUTE_FIRST="0")),
+                      ("segment kernel from 12 000 bases", dict(SLK_SEG_MIN_LEN="12000")),
+                      ("wave kernel for everything over 1000 bases", dict(SLK_SEG_MIN_LEN="0", SLK_LANE_LONG_MAX="0")),
+                      ("no long variant, segment kernel from 5 000", dict(SLK_LANE_LONG_MAX="0", SLK_SEG_MIN_LEN="5000"))):
+        other = classify(env)
+        for k in keys:
+            bad = torch.nonzero(other[k][:R] != base[k][:R]).flatten()[:5].cpu().tolist()
+            assert not bad and bool((other[k] == base[k]).all()), (name, k, bad, [int(lens[i]) for i in bad])
+    # a sample against the oracle (its minimizers looked up in the big table by the point-lookup kernel)
+    pick = np.unique(np.concatenate([np.arange(8), rng.choice(R, 300, replace=False)]))
+    h_reads = [d_b[int(offs[i]):int(offs[i + 1])].cpu().numpy() for i in pick]
+    p = orc.params()
+    mk = np.unique(np.concatenate([orc.minimizer_keys(p, r.tobytes()) for r in h_reads if len(r) >= 35] or [np.zeros(0, np.int64)]))
+    taxa = big["ix"].lookup(mk)
+    oix = orc.Index(1, mk[taxa != 0], taxa[taxa != 0])
+    sb = np.concatenate(h_reads)
+    so = np.cumsum([0] + [len(r) for r in h_reads]).astype(np.uint64)
+    want = orc.classify_batch(p, oix, big["parents"], sb, so, thresholds=(0.0, 0.1))
+    idx = torch.from_numpy(pick).to(dev)
+    for c in range(2):
+        assert np.array_equal(base["taxon"][c * R + idx].cpu().numpy(), want["taxon"][c])
+        assert np.array_equal(base["cls"][c * R + idx].cpu().numpy(), want["classified"][c])
+    assert np.array_equal(base["nd"][idx].cpu().numpy(), want["num_distinct"])
+    assert np.array_equal(base["tk"][idx].cpu().numpy(), want["total_kmers"])
+    assert np.array_equal(base["nh"][idx].cpu().numpy(), want["num_hits"])
+    assert int((want["num_distinct"] > 1).sum()) > 50          # (fragments over several source reads: several taxa each)
+
+
 def test_host_entry_at_its_default_subbatch_size(big):
     """1.5 M reads through slk_classify_batch and slk_classify_batch_packed -- cut into sub-batches of 2^19 whose upload overlaps the
     kernels of the one before and whose rows come down beside the next one's -- from pageable and from pinned caller buffers: the
