@@ -225,6 +225,38 @@ def test_host_entry_at_its_default_subbatch_size(big):
     assert np.array_equal(got["num_hits"], dev["nh"].cpu().numpy())
 
 
+@pytest.mark.parametrize("paired", [False, True])
+def test_host_entry_with_hit_lists_at_its_default_subbatch_size(big, monkeypatch, paired):
+    """1.3 M fragments with hit lists through slk_classify_batch, un-merged and merged on the device (slk_stream_set_merged_hits): the
+    sub-batches of 2^19 leave their spans in the batch's span arrays (pairs: regions by the fragment's number in the BATCH) and the
+    lists are put together at the end -- the same rows and lists as the call in one piece, and the rows of the device entry."""
+    from test_gpu_parity import merged_lists
+    R = min(big["R"] // 2, 1_300_000)
+    host_b = big["bases"][:R * 150].cpu().numpy()
+    host_o = np.arange(0, (R + 1) * 150, 150, dtype=np.uint64)
+    mb = mo = None
+    if paired:   # (mates of 100 bases: stretches of the second half of the reads)
+        mb = big["bases"][R * 150:R * 150 + R * 100].cpu().numpy()
+        mo = np.arange(0, (R + 1) * 100, 100, dtype=np.uint64)
+    st = big["st"]
+    monkeypatch.setenv("SLK_HOST_SUBBATCH", "100000000")
+    whole = st.classify_batch(host_b, host_o, mb, mo, thresholds=(0.0, 0.1), with_hits=True)
+    monkeypatch.delenv("SLK_HOST_SUBBATCH")
+    parts = st.classify_batch(host_b, host_o, mb, mo, thresholds=(0.0, 0.1), with_hits=True)
+    for k in ("taxon", "classified", "num_distinct", "total_kmers", "hit_offsets", "hits"):
+        assert np.array_equal(parts[k], whole[k]), k
+    m_off, m_hits = merged_lists(whole["hit_offsets"], whole["hits"])
+    st.set_merged_hits(True)
+    try:
+        mg = st.classify_batch(host_b, host_o, mb, mo, thresholds=(0.0, 0.1), with_hits=True)
+    finally:
+        st.set_merged_hits(False)
+    assert np.array_equal(mg["hit_offsets"], m_off) and np.array_equal(mg["hits"], m_hits)
+    if not paired:
+        dev = run(big, big["bases"], big["offsets"][:R + 1], R)
+        assert np.array_equal(parts["taxon"].reshape(-1), dev["taxon"].cpu().numpy()) and np.array_equal(parts["num_hits"], dev["nh"].cpu().numpy())
+
+
 def test_poly_a_known_answer(big):
     torch = big["torch"]
     R = 4096
