@@ -257,6 +257,37 @@ def test_host_entry_with_hit_lists_at_its_default_subbatch_size(big, monkeypatch
         assert np.array_equal(parts["taxon"].reshape(-1), dev["taxon"].cpu().numpy()) and np.array_equal(parts["num_hits"], dev["nh"].cpu().numpy())
 
 
+def test_sharded_pipeline_of_several_batches_against_the_local_kernel(big):
+    """Seven batches of 1.4 M reads (the last one short) through the table-sharded pipeline at world = 1 -- one step kernel per batch
+    carrying EMIT(t), LOOKUP(t - 2) and APPLY(t - 4), batches of different sizes in flight at once -- against the local kernel's rows
+    for the same reads in the 1.0e10-record table."""
+    from slacken_amd.sharded import ShardedClassifier
+    torch = big["torch"]
+    R = big["R"]
+    thr = (0.0, 0.1)
+    local = run(big, big["bases"], big["offsets"], R, thresholds=thr)
+    per = 1_400_000 if R >= 9_000_000 else R // 7 + 1
+    cuts = list(range(0, R, per)) + [R]
+    batches = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        n = b - a
+        d_o = torch.arange(0, (n + 1) * 150, 150, dtype=torch.int64, device=big["dev"])
+        batches.append((big["bases"][a * 150:b * 150 if b < R else None], d_o, n, n * 150, None))
+    sc = ShardedClassifier(big["ix"], 0, 1, None, big["dev"])
+    try:
+        outs = sc.classify_many(batches, thresholds=thr)
+        assert outs is not None and len(outs) == len(batches)
+        for (a, b), o in zip(zip(cuts[:-1], cuts[1:]), outs):
+            n = b - a
+            assert int(o["deferred"]) == 0 if "deferred" in o else True
+            for c in range(2):
+                assert bool((o["taxon"][c * n:(c + 1) * n] == local["taxon"][c * R + a:c * R + b]).all()), (a, c)
+                assert bool((o["classified"][c * n:(c + 1) * n] == local["cls"][c * R + a:c * R + b]).all()), (a, c)
+            assert bool((o["num_distinct"][:n] == local["nd"][a:b]).all()) and bool((o["total_kmers"][:n] == local["tk"][a:b]).all())
+    finally:
+        sc.close()
+
+
 def test_poly_a_known_answer(big):
     torch = big["torch"]
     R = 4096
