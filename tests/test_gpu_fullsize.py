@@ -33,6 +33,7 @@ def big():
     genome_taxa = rng.choice(leaves, size=G, replace=False).astype(np.int32)
     genome_cat = bench.make_genomes_device(torch, G, GL, 225, dev)
     ix = slacken_amd.Index(expected_records=n_records, max_taxon=bench.TAX_EXTENT - 1)
+    ix.set_shard(0, 1)      # (shard 0 of 1 = the whole library: lets the C-ABI shard set take this index as its one member)
     ix.set_taxonomy(parents)
     ix.add_sequences_device(genome_cat.data_ptr(), np.arange(0, (G + 1) * GL, GL, dtype=np.uint64), genome_taxa)
     n_genome = int(ix.info().records)
@@ -286,6 +287,41 @@ def test_sharded_pipeline_of_several_batches_against_the_local_kernel(big):
             assert bool((o["num_distinct"][:n] == local["nd"][a:b]).all()) and bool((o["total_kmers"][:n] == local["tk"][a:b]).all())
     finally:
         sc.close()
+
+
+def test_shard_set_rounds_against_the_local_kernel(big):
+    """The C-ABI route of the table-sharded mode (slk_shardset_classify_rounds, device-resident batches, one member): seven rounds of
+    different sizes in one pipelined call against the local kernel's rows."""
+    from slacken_amd import capi
+    torch = big["torch"]
+    R = big["R"]
+    thr = (0.0, 0.1)
+    local = run(big, big["bases"], big["offsets"], R, thresholds=thr)
+    per = 1_400_000 if R >= 9_000_000 else R // 7 + 1
+    cuts = list(range(0, R, per)) + [R]
+    rounds, keep = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        n = b - a
+        d_o = torch.arange(0, (n + 1) * 150, 150, dtype=torch.int64, device=big["dev"])
+        d_b = big["bases"][a * 150:b * 150].contiguous()          # (exactly offsets[n] bytes)
+        out = dict(taxon=torch.zeros(2 * n, dtype=torch.int32, device=big["dev"]), cls=torch.zeros(2 * n, dtype=torch.uint8, device=big["dev"]),
+                   nd=torch.zeros(n, dtype=torch.int32, device=big["dev"]), tk=torch.zeros(n, dtype=torch.int32, device=big["dev"]))
+        keep.append((d_b, d_o, out))
+        rounds.append([dict(bases=d_b.data_ptr(), offsets=d_o.data_ptr(), R=n, out_taxon=out["taxon"].data_ptr(), out_classified=out["cls"].data_ptr(),
+                            out_num_distinct=out["nd"].data_ptr(), out_total_kmers=out["tk"].data_ptr())])
+    torch.cuda.synchronize()
+    ss = capi.ShardSet([big["ix"]])
+    try:
+        ss.classify_rounds_device(rounds, thresholds=thr)
+        torch.cuda.synchronize()
+        for (a, b), (_, _, o) in zip(zip(cuts[:-1], cuts[1:]), keep):
+            n = b - a
+            for c in range(2):
+                assert bool((o["taxon"][c * n:(c + 1) * n] == local["taxon"][c * R + a:c * R + b]).all()), (a, c)
+                assert bool((o["cls"][c * n:(c + 1) * n] == local["cls"][c * R + a:c * R + b]).all()), (a, c)
+            assert bool((o["nd"] == local["nd"][a:b]).all()) and bool((o["tk"] == local["tk"][a:b]).all())
+    finally:
+        ss.close() if hasattr(ss, "close") else None
 
 
 def test_poly_a_known_answer(big):
