@@ -200,6 +200,46 @@ def test_long_reads_of_mixed_lengths_all_routes_agree(big, orc, monkeypatch):
     assert int((want["num_distinct"] > 1).sum()) > 50          # (fragments over several source reads: several taxa each)
 
 
+def test_pairs_lane_and_wave_kernels_agree_and_a_sample_against_the_oracle(big, orc):
+    """2 x 150-base pairs at full table size: the device entry (lane kernel, both mates in one lane) against the host entry with hit
+    lists (wave kernel) pair for pair, and a sample of the pairs classified by the oracle through point lookups of the big table."""
+    torch = big["torch"]
+    dev = big["dev"]
+    R = min(big["R"] // 2, 400_000)
+    d_b1 = big["bases"][:R * 150]
+    d_b2 = big["bases"][R * 150:2 * R * 150].contiguous()
+    d_o = big["offsets"][:R + 1]
+    thr = (0.0, 0.1)
+    out = dict(taxon=torch.zeros(2 * R, dtype=torch.int32, device=dev), cls=torch.zeros(2 * R, dtype=torch.uint8, device=dev),
+               nd=torch.zeros(R, dtype=torch.int32, device=dev), tk=torch.zeros(R, dtype=torch.int32, device=dev),
+               nh=torch.zeros(R, dtype=torch.int32, device=dev))
+    big["st"].classify_batch_device(d_b1.data_ptr(), d_o.data_ptr(), R, R * 150, out["taxon"].data_ptr(), out["cls"].data_ptr(),
+                                    out["nd"].data_ptr(), out["tk"].data_ptr(), out["nh"].data_ptr(), d_mate_bases=d_b2.data_ptr(),
+                                    d_mate_offsets=d_o.data_ptr(), total_mate_bases=R * 150, thresholds=thr)
+    big["st"].synchronize()
+    h1, h2 = d_b1.cpu().numpy(), d_b2.cpu().numpy()
+    ho = np.arange(0, (R + 1) * 150, 150, dtype=np.uint64)
+    wave = big["st"].classify_batch(h1, ho, h2, ho, thresholds=thr, with_hits=True)
+    assert np.array_equal(wave["taxon"].reshape(-1), out["taxon"].cpu().numpy())
+    assert np.array_equal(wave["classified"].reshape(-1), out["cls"].cpu().numpy())
+    assert np.array_equal(wave["num_distinct"], out["nd"].cpu().numpy()) and np.array_equal(wave["total_kmers"], out["tk"].cpu().numpy())
+    assert np.array_equal(wave["num_hits"], out["nh"].cpu().numpy())
+    rng = np.random.default_rng(8)
+    pick = np.sort(rng.choice(R, 3000, replace=False))
+    r1 = h1.reshape(R, 150)[pick]
+    r2 = h2.reshape(R, 150)[pick]
+    p = orc.params()
+    mk = np.unique(np.concatenate([orc.minimizer_keys(p, bytes(x)) for x in r1] + [orc.minimizer_keys(p, bytes(x)) for x in r2]))
+    taxa = big["ix"].lookup(mk)
+    oix = orc.Index(1, mk[taxa != 0], taxa[taxa != 0])
+    so = np.arange(0, (len(pick) + 1) * 150, 150, dtype=np.uint64)
+    want = orc.classify_batch(p, oix, big["parents"], r1.reshape(-1), so, r2.reshape(-1), so, thresholds=thr)
+    for c in range(2):
+        assert np.array_equal(wave["taxon"][c][pick], want["taxon"][c]) and np.array_equal(wave["classified"][c][pick], want["classified"][c])
+    assert np.array_equal(wave["num_distinct"][pick], want["num_distinct"]) and np.array_equal(wave["total_kmers"][pick], want["total_kmers"])
+    assert np.array_equal(wave["num_hits"][pick], want["num_hits"])
+
+
 def test_host_entry_at_its_default_subbatch_size(big):
     """1.5 M reads through slk_classify_batch and slk_classify_batch_packed -- cut into sub-batches of 2^19 whose upload overlaps the
     kernels of the one before and whose rows come down beside the next one's -- from pageable and from pinned caller buffers: the
