@@ -126,6 +126,21 @@ def measure_request_ceiling(torch, device, table_bytes):
         return None
 
 
+def sharded_traffic(world, records_per_rank, reads_per_step):
+    """`traffic` of the table-sharded line: HBM bytes of a full step from the counters on file (profiles/r04_traffic_sharded.json),
+    quoted only for the kernel sources and the workload they were taken from -- else null, as the contract allows."""
+    path = os.path.join(ROOT, "profiles", "r04_traffic_sharded.json")
+    try:
+        tj = json.load(open(path))
+    except (OSError, ValueError):
+        return {"traffic": None}
+    if tj.get("kernel_source_hash") == kernel_source_hash() and tj.get("world") == world and \
+            tj.get("records_per_rank") == records_per_rank and tj.get("reads_per_step") == reads_per_step:
+        return {"traffic": tj["hbm_bytes_per_step"], "traffic_source": "profiles/r04_traffic_sharded.json (a full step; same kernel sources, same workload)",
+                "l2_miss_requests_per_step": int(tj["l2_miss_requests_per_step"])}
+    return {"traffic": None, "traffic_source": "profiles/r04_traffic_sharded.json is for other kernel sources or another workload: not quoted"}
+
+
 def kernel_source_hash():
     """sha256 over the sources of the dominant kernel (lane.hip and the structures it shares, engine.h): a counter-derived
     figure on file is only quoted for the code it was taken from."""
@@ -482,7 +497,7 @@ def table_sharded(args, rank, world, local_rank):
         "roofline": {"bound": "hbm", "kernel": "the sharded pipeline: lane_step_kernel (EMIT of batch t, LOOKUP of batch t - 2 and APPLY of batch t - 4 in one launch) "
                                                "beside the exchanges; K batches take K + 4 steps", "achieved": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9, 1),
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                     "traffic": None, "algorithmic_bytes_per_launch": bytes_per_step, "kernel_ms": round(ms_per_step, 3),
+                     **sharded_traffic(world, per_rank, n_reads), "algorithmic_bytes_per_launch": bytes_per_step, "kernel_ms": round(ms_per_step, 3),
                      "lookup_stage_Grequests_per_s": None if lookup_rate is None else round(lookup_rate, 2),
                      "random_line_ceiling_Glines_per_s": ceiling, "random_line_ceiling_source": ceiling_src,
                      "lookup_stage_frac_of_request_rate_ceiling": None if lookup_rate is None else round(lookup_rate / ceiling, 3)},
