@@ -66,6 +66,7 @@ def lib():
         L.orc_char_to_twobit.argtypes = [C.c_int]
         L.orc_priority.argtypes = [C.POINTER(Params), u64p, u64p]
         L.orc_priority.restype = None
+        L.orc_all_matches.argtypes = [C.POINTER(Params), C.c_char_p, C.c_int, u64p, C.POINTER(C.c_uint8)]
         L.orc_encode.argtypes = [C.c_char_p, C.c_int, u64p]
         L.orc_encode.restype = None
         L.orc_reverse_complement.argtypes = [u64p, C.c_int, u64p]
@@ -152,6 +153,17 @@ def priority(p, words):
     out = (C.c_uint64 * MAXW)()
     lib().orc_priority(C.byref(p), a, out)
     return list(out)[:p.W]
+
+
+def all_matches(p, seq):
+    """ShiftScanner.allMatches (ShiftScanner.scala:90-159): [(key words, valid)] per valid character of seq, or None on an invalid one"""
+    b = _b(seq)
+    keys = (C.c_uint64 * (max(len(b), 1) * MAXW))()
+    valid = (C.c_uint8 * max(len(b), 1))()
+    n = lib().orc_all_matches(C.byref(p), b, len(b), keys, valid)
+    if n < 0:
+        return None
+    return [(tuple(keys[i * p.W + j] for j in range(p.W)), bool(valid[i])) for i in range(n)]
 
 
 def split_encode(p, seq):

@@ -214,6 +214,12 @@ static int all_matches(const orc_params *p, const char *seq, int n, uint64_t *ke
   return validSize;
 }
 
+/* The scanner's matches by themselves (what ShiftScannerProps.scala:28-58 looks at): keys[i * W ..] / valid[i] for the i-th VALID
+ * character of seq; the caller's arrays hold n entries.  Returns their number, -1 on an invalid character. */
+int orc_all_matches(const orc_params *p, const char *seq, int n, uint64_t *keys, uint8_t *valid) {
+  return all_matches(p, seq, n, keys, valid);
+}
+
 /* PosRankWindow, S/kmers/minimizer/PosRankWindow.scala:33-97 */
 typedef struct {
   int m, k, W, length;

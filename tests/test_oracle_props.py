@@ -215,3 +215,23 @@ def test_four_word_minimizers_match_the_python_model(orc, c):
     got = orc.split_encode(p, x)
     want = [(pymodel.left_align(v, p.m), s, l) for v, s, l in pymodel.supermers(x, k, **pri)]
     assert got == want
+
+
+@SET
+@given(st.integers(1, 40).flatmap(lambda m: st.tuples(st.just(m), st.text(alphabet="ACTGactg", min_size=m, max_size=200))))
+def test_scanner_finds_all_mmers(orc, c):  # ShiftScannerProps.scala:28-58 "Find all m-mers", :60-68 "Encoding of NT sequence"
+    """With a priority that is the identity on the encoded m-mer (no toggle mask, no spaces, forward orientation only -- the reference
+    test uses a table that permits every m-mer) the scanner's match at every position from m - 1 on IS the m-mer that ends there,
+    upper case; the first m - 1 positions carry no match; and with the canonical orientation it is the smaller of the m-mer and its
+    reverse complement (the scan of the reverse strand that the reference test makes separately)."""
+    m, x = c
+    p = orc.params(k=m, m=m, spaces=0, xor_mask=0, canonical=False)
+    got = orc.all_matches(p, x)
+    assert len(got) == len(x) and all(not v for _, v in got[:m - 1]) and all(v for _, v in got[m - 1:])
+    up = x.upper()
+    assert [orc.decode(list(k), m) for k, _ in got[m - 1:]] == [up[i:i + m] for i in range(len(x) - m + 1)]
+    pc = orc.params(k=m, m=m, spaces=0, xor_mask=0, canonical=True)
+    can = orc.all_matches(pc, x)
+    assert [orc.decode(list(k), m) for k, _ in can[m - 1:]] == \
+        [min(up[i:i + m], revcomp(up[i:i + m]), key=lambda s: orc.encode(s)) for i in range(len(x) - m + 1)]
+    assert orc.all_matches(p, x[:m // 2] + "#" + x[m // 2:]) is None            # (InvalidNucleotideException, ShiftScanner.scala:101)
