@@ -95,3 +95,37 @@ def test_build_records_lca_merge(orc):
     np.cumsum([len(seqs[i]) for i in perm], out=o2[1:])
     k2, t2 = orc.build_records(p, parents, b2, o2, [tx[i] for i in perm])
     assert np.array_equal(k2, keys) and np.array_equal(t2, rt)
+
+
+import pytest
+
+
+@pytest.mark.parametrize("k,m,spaces,canonical,xor", [(35, 31, 7, True, 0xe37e28c4271b5a2d), (15, 15, 0, True, 0), (40, 22, 5, False, 0x1234567),
+                                                       (61, 32, 10, True, 0xe37e28c4271b5a2d), (28, 17, 3, True, 0xdeadbeefcafe)])
+def test_reads_classify_to_their_genome_or_an_ancestor(orc, k, m, spaces, canonical, xor):
+    """The reference's one end-to-end property of the classify path, ClassifierTest.scala:74-117 ("Classify with random genomes"):
+    random genomes of 1 000 .. 10 000 bases at the leaves of a generated taxonomy (Testing.taxonomies(800)), the library
+    makeRecords builds from them, 1 000 reads of 200 bases cut from them, minHitGroups = 1, confidence 0: every read that is
+    classified is classified to its genome's taxon or one of its ancestors.  Here on the oracle; tests/test_gpu_build.py holds the
+    engine to the same."""
+    rng = np.random.default_rng(k * 1000 + m)
+    parents = taxgen.taxonomy(100 * 8, rng)
+    has_child = np.zeros(len(parents), bool)
+    has_child[parents[parents > 0]] = True
+    leaves = [t for t in taxgen.defined_taxa(parents) if not has_child[t] and t != 1]
+    genomes = [synth.random_dna(int(rng.integers(1000, 10001)), rng) for _ in leaves]
+    bases = np.concatenate(genomes)
+    offsets = np.cumsum([0] + [len(g) for g in genomes]).astype(np.uint64)
+    p = orc.params(k=k, m=m, spaces=spaces, xor_mask=xor, canonical=canonical)
+    keys, tx = orc.build_records(p, parents, bases, offsets, np.array(leaves, np.int32))
+    oix = orc.Index(1, keys, tx)
+    which = rng.integers(0, len(genomes), 1000)
+    reads = []
+    for g in which:
+        a = int(rng.integers(0, len(genomes[g]) - 200))
+        reads.append(genomes[g][a:a + 200])
+    rb, ro = synth.pack(reads)
+    res = orc.classify_batch(p, oix, parents, rb, ro, min_hit_groups=1, thresholds=(0.0,))
+    wrong = [i for i in range(1000) if res["classified"][0][i] and int(res["taxon"][0][i]) not in taxgen.path_to_root(parents, leaves[which[i]])]
+    assert not wrong, wrong[:5]
+    assert res["classified"][0].mean() > 0.95       # (not in the reference's test: a read of 200 bases of its genome does classify)
